@@ -1,0 +1,152 @@
+/*
+ * sdfr.h -- C ABI of libsdfr_hip.so: the MI355X (gfx950) differentiable SDF renderer hot path.
+ *
+ * The upstream reference (TRI-ML/sdflabel) exposes this path only as Python/PyTorch objects
+ * (SURVEY.md 8b); there is no upstream FFI.  Each entry point below therefore names the reference
+ * Python interface whose arithmetic it replaces (file:line relative to the reference root).  The
+ * host-side mirror of those Python interfaces lives in sdflabel_amd/ and binds this library with
+ * ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the name starts with h_.
+ *   - all floating-point data is float32, row-major, densely packed.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is enqueued on it;
+ *     no entry point synchronises except sdfr_decoder_create/destroy.
+ *   - ragged per-crop data uses the layout [B][cap][...] with a device-side count per crop (`cnt`, int32[B]).
+ *     cnt == NULL means "every crop holds exactly cap items".
+ *   - return value: 0 on success, negative SDFR_E_* on error; sdfr_last_error() gives a message.
+ */
+#ifndef SDFR_H
+#define SDFR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDFR_OK 0
+#define SDFR_E_INVALID (-1)   /* bad argument (shape, NULL pointer, unsupported architecture spec) */
+#define SDFR_E_HIP (-2)       /* a HIP runtime call failed */
+#define SDFR_E_UNSUPPORTED (-3)
+
+#define SDFR_MAX_LAYERS 16
+
+int sdfr_version(void);
+const char* sdfr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * DeepSDF decoder  --  replaces Decoder.forward (sdfrenderer/deepsdf/networks/deep_sdf_decoder_scale.py:78-107)
+ * and the autograd backward of it w.r.t. its input (the normals hook of sdfrenderer/grid.py:11-12,55-56 and
+ * the latent gradient of pipelines/optimizer.py:156).
+ *
+ * The decoder is described by its EFFECTIVE linear layers (weight-norm g*v/||v|| already folded, as
+ * nn.utils.weight_norm recomputes on every call, deep_sdf_decoder_scale.py:51-52):
+ *   n_lin         number of nn.Linear layers (9 for the 8x512 DeepSDF decoder); the last one must have out_dim 1
+ *   in_dim[l]     input width of layer l INCLUDING any re-injected input columns
+ *   out_dim[l]    output width of layer l
+ *   inj_n[l]      number of input columns concatenated to the activations BEFORE layer l
+ *                 (L+3 when l is in latent_in, :90-91; 3 when xyz_in_all, :92-93; else 0); inj_n[0] must be 0
+ *   inj_off[l]    first input column that is concatenated (0 for latent_in, L for xyz_in_all)
+ *   h_W[l]        HOST pointer, float32 [out_dim[l]][in_dim[l]] row-major (torch nn.Linear.weight layout)
+ *   h_b[l]        HOST pointer, float32 [out_dim[l]]
+ *   n_inputs      width of an input row (L+3)
+ *   use_tanh      apply tanh to the last linear before the final tanh (:96-97); the final tanh (:106-107) is always applied
+ * Hidden widths up to 512 are supported.  LayerNorm decoders (weight_norm=False with norm_layers) are not.
+ */
+typedef struct sdfr_decoder sdfr_decoder;
+
+int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_dim, const int* out_dim,
+                        const int* inj_n, const int* inj_off, const float* const* h_W, const float* const* h_b,
+                        int n_inputs, int use_tanh, int device);
+int sdfr_decoder_destroy(sdfr_decoder* dec);
+/* algorithmic multiply-accumulates per evaluated point (sum of in_dim*out_dim) */
+int64_t sdfr_decoder_macs(const sdfr_decoder* dec);
+
+/* sdf[i] = Decoder(inputs[i,:]) for i < n.   inputs [n][n_inputs], sdf [n].
+ * Reference: pred_sdf_grid, _ = dsdf(inputs)  (pipelines/optimizer.py:99-101). */
+int sdfr_mlp_forward(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, void* stream);
+
+/* Input Jacobian of the decoder at selected rows:
+ *   for crop b < B, slot s < cnt[b]:  r = row_base + b*rows_per_crop + idx[b*cap+s]
+ *     J[b][s][:]      = d sdf(inputs[r,:]) / d inputs[r,:]      (n_inputs values)
+ *     sdf_sel[b][s]   = sdf(inputs[r,:])                         (may be NULL)
+ * J must be zero-filled by the caller's stream order is handled internally (the call memsets J).
+ * Reference: the xyz columns are what grid.py:55-56 captures through its hook for the band points; the latent
+ * columns give d sdf/d latent, which autograd recomputes at optimizer.py:156. */
+int sdfr_mlp_jacobian(const sdfr_decoder* dec, const float* inputs, int64_t rows_per_crop, int B,
+                      const int32_t* idx, int cap, const int32_t* cnt, float* J, float* sdf_sel, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Zero-isosurface projection  --  replaces Grid3D.get_surface_points (sdfrenderer/grid.py:43-71)
+ */
+
+/* Order-preserving selection of the band |sdf| < thr (grid.py:64-66), per crop:
+ *   idx[b][0..cnt[b])  = ascending local row indices g in [0,G) with |sdf[b*G+g]| < thr
+ *   slot[b*G+g]        = position of g in idx[b] or -1          (may be NULL)
+ * If a crop holds more than cap band points the surplus is dropped and cnt[b] is set to the TRUE count
+ * (callers compare against cap).  scratch: int32[B * ceil(G/256)]. */
+int sdfr_band_select(const float* sdf, int64_t G, int B, float thr, int32_t* idx, int cap, int32_t* cnt,
+                     int32_t* slot, int32_t* scratch, void* stream);
+
+/* points[b][s] = x - sdf * n_hat, n_hat = J_xyz/||J_xyz||, nocs = (points+1)/2   (grid.py:57-67)
+ *   inputs [B*G][n_inputs] (xyz = last 3 columns), J [B][cap][n_inputs] from sdfr_mlp_jacobian, or
+ *   (when Jstride == 3) raw normals d sum(sdf)/d xyz gathered by the caller.
+ *   outputs points, nocs, normals: [B][cap][3]. */
+int sdfr_surface_project(const float* xyz, int xyz_stride, const float* sdf, int64_t G, int B,
+                         const int32_t* idx, int cap, const int32_t* cnt, const float* J, int Jstride, int Joff,
+                         float* points, float* nocs, float* normals, void* stream);
+
+/* Backward of the projection (n_hat is a constant, grid.py:56-58):
+ *   g_sdf[b*G + idx] = -(g_points + g_nocs/2) . n_hat ; g_xyz[b*G+idx][:] = g_points + g_nocs/2   (others 0; buffers are
+ *   fully overwritten).  g_nocs, g_xyz may be NULL. */
+int sdfr_surface_project_bwd(const float* g_points, const float* g_nocs, const float* normals, int64_t G, int B,
+                             const int32_t* idx, int cap, const int32_t* cnt, float* g_sdf, float* g_xyz, void* stream);
+
+/* g_inputs[r][:] = g_sdf[r] * J[slot[r]][:]  for rows with slot[r] >= 0, else 0   (DeepSDF backward through the
+ * cached band Jacobian).  n_uncached (device int32, may be NULL) receives the number of rows with g_sdf != 0 and
+ * slot < 0, i.e. rows the cache does not cover. */
+int sdfr_sdf_input_grad(const float* g_sdf, const int32_t* slot, const float* J, int n_inputs, int64_t G, int B, int cap,
+                        float* g_inputs, int32_t* n_uncached, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Projection to the camera frame  --  replaces project_in_2D (sdfrenderer/renderer/projection.py:7-101), rot='dcm'
+ *   pose [B][16] row-major 4x4 (only the top 3 rows are used, :34); K [B][9]
+ *   in : points, normals, colors [B][cap][3]  (colors ignored when output_nocs: c = p*(-1,1,1), :53-55)
+ *   out: p_cam, n_cam, col [B][cap][3]; uv [B][cap][2] (clamped, :88-93; may be NULL)
+ *        front-facing filter n_cam.p_cam < 0 (:61-70): fidx [B][cap] ascending slots, fcnt [B]
+ *        (fidx/fcnt may be NULL).
+ */
+int sdfr_project_dcm(const float* pose, const float* K, const float* points, const float* normals, const float* colors,
+                     int B, int cap, const int32_t* cnt, int output_nocs, int res_x, int res_y,
+                     float* p_cam, float* n_cam, float* col, float* uv, int32_t* fidx, int32_t* fcnt, void* stream);
+
+/* Backward: g_points, g_normals, g_colors [B][cap][3] (g_colors NULL when output_nocs), g_pose [B][16]. */
+int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* normals,
+                         const float* g_p_cam, const float* g_n_cam, const float* g_col,
+                         int B, int cap, const int32_t* cnt, int output_nocs,
+                         float* g_points, float* g_normals, float* g_colors, float* g_pose, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Surfel splat + depth-softmax composite  --  replaces inside_surfel(diam=0.04, softclamp=False, add_bg=False)
+ * (sdfrenderer/renderer/primitives.py:165-242) and the compositing of Rasterer.forward
+ * (sdfrenderer/renderer/rasterer.py:113-144) without ever forming the N x P tensors.
+ *   Kinv [B][9] = inverse(K.float()) (primitives.py:204), K [B][9] (used only for conservative tile binning)
+ *   p_cam, n_cam, attr [B][cap][3]   attr is the composited colour attribute AFTER the (c+1)/2 mapping
+ *   images: color [B][3][H][W], mask [B][H][W], depth [B][H][W], normals [B][3][H][W] (any may be NULL)
+ *   aux [B][H*W][4]: per-pixel state for the backward (nu, max logit, softmax denominator, clamp gates)
+ */
+int sdfr_splat_forward(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
+                       int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant,
+                       float* color, float* mask, float* depth, float* normals, float* aux, void* stream);
+
+/* Backward w.r.t. p_cam, n_cam, attr given the gradients of the four images (any may be NULL). */
+int sdfr_splat_backward(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
+                        int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant,
+                        const float* aux, const float* g_color, const float* g_mask, const float* g_depth,
+                        const float* g_normals, float* g_p_cam, float* g_n_cam, float* g_attr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFR_H */

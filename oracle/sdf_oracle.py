@@ -1,0 +1,516 @@
+"""CPU oracle for the sdflabel differentiable-SDF-renderer hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-numpy restatement of the reference's algorithm (dense N x P
+formulation, the same operation order as the reference's ATen graph), each
+function citing the reference file:line it follows (paths relative to
+/root/reference).  It exists so that the HIP kernels have an independent checker
+on the GPU box, where the Python reference cannot travel.
+
+  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+    import this module, and only as the checker / the timed CPU baseline.  The
+    product package (sdflabel_amd/) never imports it and has no CPU fallback.
+  * Parity pinning: the reference ships no tests or golden vectors for this path
+    (SURVEY.md §4).  The oracle is pinned against golden vectors generated IN
+    THE BUILD CONTAINER by importing the reference itself
+    (tools/make_golden.py -> tests/golden/*.npz); tests/test_oracle_golden.py
+    checks every function below against them.
+  * The backward functions restate what torch autograd computes for the
+    reference graph (detach points: primitives.py:226,228; in-place eps
+    assignment primitives.py:210; clamp sub-gradients) and are pinned against
+    autograd gradients captured from the reference (golden G7).
+
+All functions take/return numpy arrays; `dtype` follows the inputs (float32 for
+parity, float64 for threshold-margin analysis).
+"""
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# Grid  (sdfrenderer/grid.py)
+# --------------------------------------------------------------------------------------
+
+
+def generate_point_grid(density):
+    """grid.py:22-41 -- staggered D^3 sample grid, z fastest, odd flat indices shifted in x,y by 1/D."""
+    c = density * 1j
+    X, Y, Z = np.mgrid[-1:1:c, -1:1:c, -1:1:c]
+    g = np.concatenate((X[..., None], Y[..., None], Z[..., None]), axis=-1).reshape((-1, 3))
+    g[1::2, :2] += ((X.max() - X.min()) / density / 2)
+    return g.astype(np.float32)
+
+
+def get_surface_points(points, sdf, grad_points, threshold=0.03):
+    """grid.py:43-71 -- zero-isosurface projection.
+
+    points (G,3), sdf (G,1), grad_points (G,3) = d(sum sdf)/d points (what the
+    autograd hook grid.py:11-12,20 captures).  Returns points_masked (N,3),
+    nocs (N,3), normals_masked (N,3), band index (N,), n_hat (G,3).
+    """
+    dt = sdf.dtype
+    nrm = np.sqrt(np.sum(grad_points * grad_points, axis=1)).astype(dt)          # grid.py:57
+    with np.errstate(invalid="ignore", divide="ignore"):
+        n_hat = (grad_points / nrm[:, None]).astype(dt)                           # grid.py:58
+    proj = (points - sdf * n_hat).astype(dt)                                      # grid.py:61
+    mask = (np.abs(sdf) < dt.type(threshold))[:, 0]                               # grid.py:64
+    idx = np.nonzero(mask)[0]
+    pm = proj[idx]                                                                # grid.py:65
+    nm = n_hat[idx]                                                               # grid.py:66
+    nocs = ((pm + dt.type(1)) / dt.type(2)).astype(dt)                            # grid.py:67
+    return pm, nocs, nm, idx, n_hat
+
+
+def get_surface_points_backward(sdf, n_hat, idx, g_points_masked, g_nocs=None):
+    """Autograd of grid.py:61-67 w.r.t. sdf and grid points (n_hat is a constant: it comes from a
+    .grad tensor, grid.py:56-58).  Returns g_sdf (G,1), g_gridpoints (G,3)."""
+    dt = sdf.dtype
+    g = g_points_masked.astype(dt).copy()
+    if g_nocs is not None:
+        g = g + g_nocs.astype(dt) / dt.type(2)
+    g_sdf = np.zeros_like(sdf)
+    g_pts = np.zeros((sdf.shape[0], 3), dt)
+    g_pts[idx] = g
+    g_sdf[idx, 0] = -np.sum(g * n_hat[idx], axis=1)
+    return g_sdf, g_pts
+
+
+# --------------------------------------------------------------------------------------
+# DeepSDF decoder  (sdfrenderer/deepsdf/networks/deep_sdf_decoder_scale.py)
+# --------------------------------------------------------------------------------------
+
+
+def fold_weight_norm(v, g):
+    """torch.nn.utils.weight_norm(dim=0) as used at deep_sdf_decoder_scale.py:51-52: w = v * (g / ||v||_row)."""
+    nrm = np.sqrt(np.sum(v.astype(np.float32) ** 2, axis=1, keepdims=True)).astype(np.float32)
+    return (v * (g.reshape(-1, 1) / nrm)).astype(np.float32)
+
+
+def decoder_layers_from_state(state, spec):
+    """Build the effective per-layer (W[out,in], b[out], ln) list from a reference state dict
+    (keys lin{l}.weight | lin{l}.weight_g/_v | lin{l}.bias | bn{l}.weight/bias), float32."""
+    n_lin = len(spec["dims"]) + 1
+    layers = []
+    for l in range(n_lin):
+        p = "lin%d." % l
+        if p + "weight_v" in state:
+            W = fold_weight_norm(np.asarray(state[p + "weight_v"], np.float32), np.asarray(state[p + "weight_g"], np.float32))
+        else:
+            W = np.asarray(state[p + "weight"], np.float32)
+        b = np.asarray(state[p + "bias"], np.float32)
+        ln = None
+        if ("bn%d.weight" % l) in state:
+            ln = (np.asarray(state["bn%d.weight" % l], np.float32), np.asarray(state["bn%d.bias" % l], np.float32))
+        layers.append((W, b, ln))
+    return layers
+
+
+def decoder_forward(layers, spec, inputs, want_cache=False):
+    """deep_sdf_decoder_scale.py:78-107 (eval mode: dropout inactive :103-104).
+
+    inputs (G, L+3) = [latent, xyz].  Returns sdf (G,1) (and the per-layer cache for the backward).
+    spec keys used: latent_in, xyz_in_all, use_tanh (norm handled through `ln` in layers).
+    """
+    dt = inputs.dtype
+    latent_in = tuple(spec.get("latent_in", ()))
+    xyz_in_all = bool(spec.get("xyz_in_all", False))
+    use_tanh = bool(spec.get("use_tanh", False))
+    n_lin = len(layers)
+    xyz = inputs[:, -3:]
+    x = inputs
+    cache = []
+    for l in range(n_lin):
+        W, b, ln = layers[l]
+        if l in latent_in:
+            x = np.concatenate([x, inputs], axis=1)                                # :90-91
+        elif l != 0 and xyz_in_all:
+            x = np.concatenate([x, xyz], axis=1)                                   # :92-93
+        xin = x
+        x = (x @ W.astype(dt).T + b.astype(dt)).astype(dt)                         # :94
+        pre_tanh = None
+        if l == n_lin - 1 and use_tanh:
+            pre_tanh = x
+            x = np.tanh(x)                                                         # :96-97
+        lnc = None
+        pre_relu = None
+        if l < n_lin - 1:
+            if ln is not None:                                                     # :99-101 LayerNorm variant
+                mu = x.mean(axis=1, keepdims=True)
+                var = ((x - mu) ** 2).mean(axis=1, keepdims=True)
+                rstd = 1.0 / np.sqrt(var + dt.type(1e-5))
+                xh = (x - mu) * rstd
+                lnc = (xh, rstd)
+                x = (xh * ln[0].astype(dt) + ln[1].astype(dt)).astype(dt)
+            pre_relu = x
+            x = np.maximum(x, dt.type(0))                                          # :102
+        if want_cache:
+            cache.append((xin.shape[1], pre_relu, lnc, pre_tanh))
+    out_pre = x
+    x = np.tanh(x).astype(dt)                                                      # :106-107 (self.th always present)
+    if want_cache:
+        return x, (cache, out_pre)
+    return x
+
+
+def decoder_backward_inputs(layers, spec, inputs, cache, g_out):
+    """Autograd of decoder_forward w.r.t. `inputs` only (weights frozen: optimizer.py:34-38 optimises
+    yaw/trans/scale/latent).  g_out (G,1) -> g_inputs (G, L+3).  With g_out = 1 this is what the
+    grid hook captures for the xyz columns (grid.py:55-56)."""
+    dt = inputs.dtype
+    latent_in = tuple(spec.get("latent_in", ()))
+    xyz_in_all = bool(spec.get("xyz_in_all", False))
+    n_lin = len(layers)
+    caches, out_pre = cache
+    th = np.tanh(out_pre)
+    g = (g_out * (dt.type(1) - th * th)).astype(dt)                                # d tanh
+    g_inputs = np.zeros_like(inputs)
+    n_in0 = inputs.shape[1]
+    for l in range(n_lin - 1, -1, -1):
+        W, b, ln = layers[l]
+        in_dim, pre_relu, lnc, pre_tanh = caches[l]
+        if l < n_lin - 1:
+            g = g * (pre_relu > 0)                                                 # relu'
+            if ln is not None:
+                xh, rstd = lnc
+                gy = g * ln[0].astype(dt)
+                m1 = gy.mean(axis=1, keepdims=True)
+                m2 = (gy * xh).mean(axis=1, keepdims=True)
+                g = (gy - m1 - xh * m2) * rstd
+        elif pre_tanh is not None:
+            t = np.tanh(pre_tanh)
+            g = g * (dt.type(1) - t * t)
+        g = (g @ W.astype(dt)).astype(dt)                                          # (G, in_dim)
+        if l in latent_in:
+            g_inputs += g[:, -n_in0:]
+            g = g[:, :-n_in0]
+        elif l != 0 and xyz_in_all:
+            g_inputs[:, -3:] += g[:, -3:]
+            g = g[:, :-3]
+    g_inputs += g
+    return g_inputs
+
+
+def scale_net_forward(scale_params, latent_row):
+    """deep_sdf_decoder_scale.py:69-75,112 -- 3 tiny linears with ReLU on the first row's latent."""
+    x = latent_row
+    for i, (W, b) in enumerate(scale_params):
+        x = x @ W.T + b
+        if i < len(scale_params) - 1:
+            x = np.maximum(x, 0)
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# Pose helpers  (utils/refinement.py, pipelines/optimizer.py, renderer/utils_rasterer.py)
+# --------------------------------------------------------------------------------------
+
+
+def rot_from_yaw(yaw, dtype=np.float32):
+    """utils/refinement.py:108-125."""
+    c, s = np.cos(dtype(yaw)), np.sin(dtype(yaw))
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype)
+
+
+def render_pose(yaw, trans, dtype=np.float32):
+    """pipelines/optimizer.py:87-90 -- [R_y(yaw)|t], row 1 negated BEFORE the translation is written."""
+    P = np.eye(4, dtype=dtype)
+    P[:3, :3] = rot_from_yaw(yaw, dtype)
+    P[1] *= -1
+    P[:3, 3] = np.asarray(trans, dtype)
+    return P
+
+
+def calibration_matrix(resolution_px, diagonal_mm, focal_len_mm, skew=0.0):
+    """renderer/utils_rasterer.py:59-83."""
+    rx, ry = resolution_px
+    diag = np.sqrt(rx ** 2 + ry ** 2)
+    rx_mm = rx / diag * diagonal_mm
+    ry_mm = ry / diag * diagonal_mm
+    ax = focal_len_mm * (rx / rx_mm)
+    ay = focal_len_mm * (ry / ry_mm)
+    return np.array([[ax, skew, rx / 2], [0, ay, ry / 2], [0, 0, 1]])
+
+
+def qrot(q, v):
+    """renderer/utils_rasterer.py:6-24."""
+    qvec = q[:, 1:]
+    uv = np.cross(qvec, v)
+    uuv = np.cross(qvec, uv)
+    return v + 2 * (q[:, :1] * uv + uuv)
+
+
+def pixel_grid(resolution_px):
+    """renderer/rasterer.py:25-27 -- (P,2) integer pixel coordinates, x fastest."""
+    rx, ry = resolution_px
+    yy, xx = np.mgrid[0:ry, 0:rx]
+    return np.concatenate((xx[..., None], yy[..., None]), axis=-1).reshape((-1, 2))
+
+
+# --------------------------------------------------------------------------------------
+# Projection  (sdfrenderer/renderer/projection.py)
+# --------------------------------------------------------------------------------------
+
+
+def project_in_2D(K, camera_pose, points, normals, colors, resolution_px, output_nocs=True):
+    """projection.py:7-101 (rot='dcm', filter_normals=True, filter_hpr=False)."""
+    dt = K.dtype
+    eps = np.finfo(dt).eps
+    rx, ry = resolution_px
+    RT = camera_pose[:-1, :].astype(dt)                                            # :34
+    ones = np.ones((points.shape[0], 1), dt)
+    ch = np.concatenate([points.astype(dt), ones], axis=-1).T                     # :44-46
+    normals_p = (RT[:, :3] @ normals.astype(dt).T).T                              # :49
+    if output_nocs:
+        colors = points.astype(dt).copy()                                          # :53-55
+        colors[:, 0] *= -1
+    p3 = (RT @ ch).T                                                               # :58
+    dot = np.sum(normals_p * p3, axis=1)                                           # :62 (bmm)
+    keep = dot < 0
+    fidx = np.nonzero(keep)[0]
+    out = {
+        "points_3d_filt": p3[fidx], "normals_3d_filt": normals_p[fidx], "colors_3d_filt": colors[fidx],
+        "filt_idx": fidx, "dot": dot,
+    }
+    p2h = (K @ p3.T).T                                                             # :88
+    p2 = p2h[:, :2] / (p2h[:, 2:] + eps)                                           # :89
+    out["points_3d"] = p3
+    out["normals_3d"] = normals_p
+    out["colors_3d"] = colors
+    out["points_2d"] = np.concatenate([np.clip(p2[:, 0:1], -1, rx), np.clip(p2[:, 1:2], -1, ry)], axis=-1)  # :92-93,:99
+    return out
+
+
+def project_in_2D_quat(K, camera_pose, points, normals, colors, resolution_px, output_nocs=True):
+    """projection.py:104-199 (filter_normals=False default: no *_filt keys; NOCS x not flipped :147-149)."""
+    dt = K.dtype
+    eps = np.finfo(dt).eps
+    rx, ry = resolution_px
+    q = camera_pose[:4].astype(dt)
+    t = camera_pose[4:].astype(dt)
+    qn = np.broadcast_to(q[None], (normals.shape[0], 4))
+    normals_p = qrot(qn, normals.astype(dt))                                       # :136-137
+    if output_nocs:
+        colors = points.astype(dt).copy()
+    p3 = qrot(qn, points.astype(dt)) + t[None]                                     # :152-157
+    p2h = (K @ p3.T).T
+    p2 = p2h[:, :2] / (p2h[:, 2:] + eps)
+    return {
+        "points_3d": p3, "normals_3d": normals_p, "colors_3d": colors,
+        "points_2d": np.concatenate([np.clip(p2[:, 0:1], -1, rx), np.clip(p2[:, 1:2], -1, ry)], axis=-1),
+    }
+
+
+# --------------------------------------------------------------------------------------
+# Primitive: 3-D tangent disc  (sdfrenderer/renderer/primitives.py:165-242)
+# --------------------------------------------------------------------------------------
+
+
+def pixel_rays(Kinv, grid_2d):
+    """primitives.py:203-208 -- rays K^-1 [x,y,1] for every pixel, (P,3)."""
+    dt = Kinv.dtype
+    g = np.concatenate([grid_2d.astype(dt), np.ones((grid_2d.shape[0], 1), dt)], axis=-1)
+    return (Kinv @ g.T).T.astype(dt)
+
+
+def inside_surfel(Kinv, grid_2d, vertex_3d, normals, diam=0.04, depth_constant=150, add_bg=False,
+                  chunk=8192, want_aux=False):
+    """primitives.py:165-242 with softclamp=False (the renderer's call, rasterer.py:102-104).
+
+    Kinv is K.float().inverse() (primitives.py:204), supplied by the caller.  Returns the (N[+1], P)
+    weight matrix (the reference expands it to 3 identical channels, :241).  Dense, chunked over pixels.
+    """
+    dt = vertex_3d.dtype
+    eps = np.finfo(dt).eps
+    fmin = np.finfo(dt).min
+    N = vertex_3d.shape[0]
+    P = grid_2d.shape[0]
+    rays = pixel_rays(Kinv.astype(dt), grid_2d)
+    n_v3d = np.sum(normals * vertex_3d, axis=1).astype(dt)                         # :202
+    rows = N + (1 if add_bg else 0)
+    W = np.zeros((rows, P), dt)
+    aux = {"t": None, "mask": None, "margin_disc": np.full(P, np.inf), "margin_b": np.full(P, np.inf)} if want_aux else None
+    for s in range(0, P, chunk):
+        r = rays[s:s + chunk]                                                      # (p,3)
+        b = (normals @ r.T).astype(dt)                                             # :209 (N,p)
+        if want_aux:
+            aux["margin_b"][s:s + chunk] = np.min(np.abs(np.abs(b) - 0.01), axis=0) if N else np.inf
+        small = np.abs(b) < dt.type(0.01)
+        b = np.where(small, dt.type(eps), b)                                       # :210
+        z = (n_v3d[:, None] / b).astype(dt)                                        # :211
+        g3 = r[None, :, :] * z[:, :, None]                                         # :212
+        vec = vertex_3d[:, None, :] - g3                                           # :215
+        d = np.sqrt(np.sum(vec * vec, axis=-1)).astype(dt)
+        dist = np.maximum(dt.type(diam) - d, dt.type(0))                           # :220
+        m = (dist > 0)
+        if want_aux:
+            aux["margin_disc"][s:s + chunk] = np.min(np.abs(dt.type(diam) - d), axis=0) if N else np.inf
+        mf = m.astype(dt)
+        zz = (-z * mf).astype(dt)                                                  # :227
+        zn = np.sqrt(np.sum(zz * zz, axis=0)).astype(dt)                           # :228
+        zz = (np.maximum(zz / (zn[None] + dt.type(eps)) + dt.type(1), dt.type(0)) * dt.type(depth_constant)).astype(dt)  # :229-230
+        if add_bg:
+            z2d = -vertex_3d[:, 2] * dt.type(depth_constant)                       # :234
+            zbg = np.full((1, zz.shape[1]), z2d.min() - 1, dt)                     # :235
+            zz = np.concatenate([zz, zbg], axis=0)
+            mf = np.concatenate([mf, np.ones((1, mf.shape[1]), dt)], axis=0)
+            m = np.concatenate([m, np.ones((1, m.shape[1]), bool)], axis=0)
+        zm = np.where(m, zz, dt.type(fmin))                                        # :240
+        zm = zm - zm.max(axis=0, keepdims=True)
+        e = np.exp(zm)
+        W[:, s:s + chunk] = (e / e.sum(axis=0, keepdims=True) * mf).astype(dt)
+    if want_aux:
+        return W, aux
+    return W
+
+
+# --------------------------------------------------------------------------------------
+# Rasterer  (sdfrenderer/renderer/rasterer.py:49-155)
+# --------------------------------------------------------------------------------------
+
+
+def rasterer_forward(K, Kinv, resolution_px, coords, normals, colors, camera_matrix, rot="dcm", bg=None,
+                     output_mask=True, output_depth=True, output_normals=True, output_nocs=True, chunk=8192,
+                     want_aux=False):
+    """rasterer.py:49-155 with primitives='disc'.  Returns (rendering dict, points dict, proj dict)."""
+    dt = K.dtype
+    rx, ry = resolution_px
+    if rot == "dcm":
+        proj = project_in_2D(K, camera_matrix, coords, normals, colors, resolution_px, output_nocs)
+    else:
+        proj = project_in_2D_quat(K, camera_matrix, coords, normals, colors, resolution_px, output_nocs)
+    v3 = proj["points_3d"].astype(dt)
+    nrm = proj["normals_3d"].astype(dt)
+    col = proj["colors_3d"].astype(dt)
+    grid_2d = pixel_grid(resolution_px)
+    res = inside_surfel(Kinv, grid_2d, v3, nrm, diam=0.04, add_bg=(bg is not None), chunk=chunk, want_aux=want_aux)
+    W, aux = res if want_aux else (res, None)
+    rendering = {}
+    if bg is not None:                                                             # :107-111
+        color = (W[:-1].T @ ((col + 1) / 2)).T + W[-1][None, :] * bg.reshape(3, -1).astype(dt)
+    else:
+        c_t = (col + 1) / 2 if output_nocs else col                                # :113-116
+        color = (W.T @ c_t).T
+    rendering["color"] = np.minimum(color, 1).reshape(3, ry, rx).astype(dt)        # :123-124
+    rendering["color_pre"] = color.reshape(3, ry, rx).astype(dt)
+    if output_mask:
+        msum = W.sum(axis=0)
+        rendering["mask"] = np.minimum(msum, 1).reshape(1, ry, rx).astype(dt)      # :127-131
+        rendering["mask_pre"] = msum.reshape(1, ry, rx).astype(dt)
+    if output_depth and bg is None:
+        rendering["depth"] = (W.T @ v3[:, 2]).reshape(1, ry, rx).astype(dt)        # :134-137
+    if output_normals and bg is None:
+        nsum = (W.T @ ((nrm + 1) / 2)).T
+        rendering["normals"] = np.minimum(nsum, 1).reshape(3, ry, rx).astype(dt)   # :140-144
+        rendering["normals_pre"] = nsum.reshape(3, ry, rx).astype(dt)
+    points = {"xyz": v3, "rgb": (col + 1) / 2}                                     # :147-153
+    if "points_3d_filt" in proj:
+        points["xyzf"] = proj["points_3d_filt"]
+        points["rgbf"] = (proj["colors_3d_filt"] + 1) / 2
+    if want_aux:
+        return rendering, points, proj, aux
+    return rendering, points, proj
+
+
+def splat_backward(Kinv, resolution_px, v3, nrm, c_attr, g_color, g_mask, g_depth, g_normals,
+                   diam=0.04, depth_constant=150, chunk=4096):
+    """Autograd of inside_surfel + compositing (primitives.py:202-241, rasterer.py:119-144; bg=None) w.r.t.
+    camera-frame surfel positions v3 (N,3), camera-frame normals nrm (N,3) and the composited colour
+    attribute c_attr (N,3) (= (colors+1)/2 for NOCS, `colors` otherwise).
+
+    Detached in the reference and therefore constants here: the disc mask (:226), the per-pixel norm (:228);
+    entries with |n.ray|<0.01 are overwritten in place by eps (:210) and pass no gradient to n through b.
+    clamp(max=1)/clamp(min=0) pass gradient on the closed side (x<=1 / x>=0), as ATen does.
+    g_* are gradients of the post-clamp images, shapes (3,H,W),(1,H,W),(1,H,W),(3,H,W) or None.
+    Returns g_v3, g_nrm, g_cattr.
+    """
+    dt = v3.dtype
+    eps = np.finfo(dt).eps
+    fmin = np.finfo(dt).min
+    N = v3.shape[0]
+    rx, ry = resolution_px
+    P = rx * ry
+    grid_2d = pixel_grid(resolution_px)
+    rays = pixel_rays(Kinv.astype(dt), grid_2d)
+    a = np.sum(nrm * v3, axis=1).astype(dt)
+    n_attr = ((nrm + 1) / 2).astype(dt)
+    zero3 = np.zeros((3, P), dt)
+    gC = g_color.reshape(3, P).astype(dt) if g_color is not None else zero3
+    gM = g_mask.reshape(P).astype(dt) if g_mask is not None else np.zeros(P, dt)
+    gD = g_depth.reshape(P).astype(dt) if g_depth is not None else np.zeros(P, dt)
+    gN = g_normals.reshape(3, P).astype(dt) if g_normals is not None else zero3
+    g_v3 = np.zeros((N, 3), np.float64)
+    g_n = np.zeros((N, 3), np.float64)
+    g_c = np.zeros((N, 3), np.float64)
+    g_a = np.zeros(N, np.float64)
+    for s in range(0, P, chunk):
+        r = rays[s:s + chunk]
+        b0 = (nrm @ r.T).astype(dt)
+        small = np.abs(b0) < dt.type(0.01)
+        b = np.where(small, dt.type(eps), b0)
+        t = (a[:, None] / b).astype(dt)
+        g3 = r[None] * t[:, :, None]
+        vec = v3[:, None, :] - g3
+        d = np.sqrt(np.sum(vec * vec, axis=-1)).astype(dt)
+        m = (np.maximum(dt.type(diam) - d, dt.type(0)) > 0)
+        mf = m.astype(dt)
+        zz = (-t * mf).astype(dt)
+        zn = np.sqrt(np.sum(zz * zz, axis=0)).astype(dt)
+        q = (zz / (zn[None] + dt.type(eps)) + dt.type(1)).astype(dt)
+        logit = (np.maximum(q, dt.type(0)) * dt.type(depth_constant)).astype(dt)
+        zm = np.where(m, logit, dt.type(fmin))
+        zm = zm - zm.max(axis=0, keepdims=True)
+        e = np.exp(zm)
+        sm = (e / e.sum(axis=0, keepdims=True)).astype(dt)
+        w = sm * mf
+        # composites (pre-clamp) and clamp gates
+        Cs = c_attr.T @ w
+        Ms = w.sum(axis=0)
+        Ns = n_attr.T @ w
+        gCg = gC[:, s:s + chunk] * (Cs <= 1)
+        gMg = gM[s:s + chunk] * (Ms <= 1)
+        gDg = gD[s:s + chunk]
+        gNg = gN[:, s:s + chunk] * (Ns <= 1)
+        # dL/dw (N,p)
+        dW = c_attr @ gCg + gMg[None] + v3[:, 2:3] * gDg[None] + n_attr @ gNg
+        # attribute grads
+        g_c += w @ gCg.T
+        g_n += (w @ gNg.T) * 0.5
+        g_v3[:, 2] += w @ gDg
+        # softmax backward (w = sm * mf ; masked entries have sm == 0 unless the whole column is masked)
+        dsm = dW * mf
+        dlog = sm * (dsm - np.sum(sm * dsm, axis=0, keepdims=True))
+        dlog = dlog * m                                    # masked_fill blocks the gradient
+        dq = dlog * dt.type(depth_constant) * (q >= 0)
+        dzz = dq / (zn[None] + dt.type(eps))
+        dt_ = -dzz * mf                                    # zz = -t * mask
+        da = dt_ / b
+        db = -dt_ * t / b
+        db = np.where(small, 0, db)                        # in-place eps assignment blocks grad (:210)
+        g_a += da.sum(axis=1)
+        g_n += db @ r
+    g_n += g_a[:, None] * v3
+    g_v3 += g_a[:, None] * nrm
+    return g_v3.astype(dt), g_n.astype(dt), g_c.astype(dt)
+
+
+def project_backward_dcm(camera_pose, points, normals, g_p3, g_nrm, g_col, output_nocs=True,
+                         filt_idx=None, g_p3_filt=None, g_col_filt=None):
+    """Autograd of projection.py:34-70 (rot='dcm') w.r.t. points, normals, colors and the (4,4) pose.
+    g_col is the gradient w.r.t. colors_3d (pre '(c+1)/2').  Gradients arriving through the filtered
+    outputs (points_3d_filt / colors_3d_filt) are scattered back through filt_idx."""
+    dt = points.dtype
+    R = camera_pose[:3, :3].astype(dt)
+    g_p3 = g_p3.astype(np.float64).copy()
+    g_col = g_col.astype(np.float64).copy()
+    if filt_idx is not None and g_p3_filt is not None:
+        np.add.at(g_p3, filt_idx, g_p3_filt)
+    if filt_idx is not None and g_col_filt is not None:
+        np.add.at(g_col, filt_idx, g_col_filt)
+    g_points = g_p3 @ R
+    g_normals = g_nrm.astype(np.float64) @ R
+    g_colors_in = None
+    if output_nocs:
+        g_points = g_points + g_col * np.array([-1.0, 1.0, 1.0])
+    else:
+        g_colors_in = g_col.astype(dt)
+    g_pose = np.zeros((4, 4), np.float64)
+    g_pose[:3, :3] = g_p3.T @ points + g_nrm.astype(np.float64).T @ normals
+    g_pose[:3, 3] = g_p3.sum(axis=0)
+    return g_points.astype(dt), g_normals.astype(dt), g_colors_in, g_pose.astype(dt)

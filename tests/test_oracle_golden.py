@@ -1,0 +1,168 @@
+"""Pin the numpy oracle (oracle/sdf_oracle.py) against golden vectors captured from the reference itself
+(tools/make_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import sdf_oracle as O
+from tests._util import gold, fitted_state, state_from_npz
+
+
+def test_g1_grid():
+    z = gold("g1_grid.npz")
+    for D in (4, 5, 8):
+        assert np.array_equal(O.generate_point_grid(D), z["grid_%d" % D])
+    for D in (30, 40):
+        g = O.generate_point_grid(D)
+        assert np.array_equal(g[::97], z["grid_%d_stride97" % D])
+        assert np.array_equal(g[-8:], z["grid_%d_tail" % D])
+        assert np.allclose(g.astype(np.float64).sum(0), z["grid_%d_sum64" % D], atol=1e-9)
+
+
+@pytest.mark.parametrize("tag,spec", [
+    ("wn", dict(dims=[64] * 8, latent_in=[4])),
+    ("ln", dict(dims=[64] * 8, latent_in=[4])),
+    ("x", dict(dims=[48] * 5, latent_in=[2, 4], xyz_in_all=True, use_tanh=True)),
+])
+def test_g2_decoder_small(tag, spec):
+    z = gold("g2_decoder.npz")
+    layers = O.decoder_layers_from_state(state_from_npz(z, tag + "_state_"), spec)
+    inp = z[tag + "_inputs"]
+    sdf, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+    assert np.allclose(sdf, z[tag + "_sdf"], atol=2e-6)
+    g_out = z[tag + "_gout"] if (tag + "_gout") in z.files else np.ones_like(sdf)
+    g_in = O.decoder_backward_inputs(layers, spec, inp, cache, g_out)
+    ref = z[tag + "_grad_inputs"]
+    assert np.allclose(g_in, ref, atol=2e-5 * max(1.0, np.abs(ref).max()))
+
+
+def test_g2_decoder_fitted():
+    z = gold("g2_decoder.npz")
+    st, spec = fitted_state()
+    layers = O.decoder_layers_from_state(st, spec)
+    inp = z["fit_inputs"]
+    sdf, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+    assert np.allclose(sdf, z["fit_sdf"], atol=2e-6)
+    g_in = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(sdf))
+    assert np.allclose(g_in, z["fit_grad_inputs"], atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g3_surface(tag):
+    z = gold("g3_surface.npz")
+    st, spec = fitted_state()
+    layers = O.decoder_layers_from_state(st, spec)
+    D = int(z[tag + "_D"])
+    lat = z[tag + "_latent"]
+    lat = (lat / np.sqrt((lat * lat).sum())).astype(np.float32)
+    pts = O.generate_point_grid(D)
+    inp = np.concatenate([np.broadcast_to(lat, (pts.shape[0], 3)), pts], 1).astype(np.float32)
+    sdf, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+    assert np.allclose(sdf, z[tag + "_sdf"], atol=2e-6)
+    g = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(sdf))[:, 3:]
+    pm, nocs, nm, idx, n_hat = O.get_surface_points(pts, sdf, g, 0.03)
+    assert float(z[tag + "_band_margin"]) > 1e-5       # selection is well separated from the threshold
+    assert np.array_equal(idx, z[tag + "_band_idx"])
+    assert np.allclose(pm, z[tag + "_points"], atol=2e-6)
+    assert np.allclose(nocs, z[tag + "_nocs"], atol=2e-6)
+    assert np.allclose(nm, z[tag + "_normals"], atol=2e-5)
+
+
+def test_g4_project():
+    z = gold("g4_project.npz")
+    K = z["K"]
+    for i in range(3):
+        for flag, name in ((True, "nocs"), (False, "col")):
+            t = "dcm%d_%s_" % (i, name)
+            o = O.project_in_2D(K, z[t + "pose"], z["points"], z["normals"], z["normals"], (32, 32), output_nocs=flag)
+            assert float(z[t + "filt_margin"]) > 1e-6
+            for k in ("points_3d", "normals_3d", "colors_3d", "points_2d", "points_3d_filt", "normals_3d_filt", "colors_3d_filt"):
+                assert o[k].shape == z[t + k].shape, k
+                assert np.allclose(o[k], z[t + k], atol=1e-5), k
+    o = O.project_in_2D_quat(K, z["quat_pose"], z["points"], z["normals"], z["normals"], (32, 32), output_nocs=True)
+    for k in ("points_3d", "normals_3d", "colors_3d", "points_2d"):
+        assert np.allclose(o[k], z["quat_" + k], atol=1e-5), k
+
+
+def test_g5_inside_surfel():
+    z = gold("g5_inside_surfel.npz")
+    grid = z["grid"][0]
+    assert np.array_equal(grid, O.pixel_grid(tuple(z["res"])))
+    for bg in (0, 1):
+        w = O.inside_surfel(z["Kinv"], grid, z["points"], z["normals"], diam=0.04, add_bg=bool(bg))
+        assert w.shape == z["w_bg%d" % bg].shape
+        assert np.allclose(w, z["w_bg%d" % bg], atol=2e-6)
+
+
+@pytest.mark.parametrize("res", [(32, 32), (64, 48)])
+def test_g6_rasterer(res):
+    z = gold("g6_rasterer.npz")
+    H, W = res
+    t0 = "r%dx%d_" % (H, W)
+    K, Kinv = z[t0 + "K"], z[t0 + "Kinv"]
+    for flag, name in ((True, "nocs_"), (False, "col_")):
+        rend, pts, proj = O.rasterer_forward(K, Kinv, (W, H), z["points"], z["normals"], z["colors"], z["pose"],
+                                             rot="dcm", output_nocs=flag)
+        t = t0 + name
+        for k in ("color", "mask", "depth", "normals"):
+            assert rend[k].shape == z[t + k].shape
+            assert np.abs(rend[k] - z[t + k]).max() < 1e-4, k
+        for k in ("xyz", "rgb", "xyzf", "rgbf"):
+            assert np.allclose(pts[k], z[t + "pts_" + k], atol=1e-5), k
+    rend, _, _ = O.rasterer_forward(K, Kinv, (W, H), z["points"], z["normals"], z["colors"], z["pose"], rot="dcm",
+                                    bg=z[t0 + "bg"], output_depth=False, output_normals=False, output_nocs=True)
+    for k in ("color", "mask"):
+        assert np.abs(rend[k] - z[t0 + "bg_" + k]).max() < 1e-4, k
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g7_gradients(tag):
+    """End-to-end gradients of the optimizer graph vs. reference autograd."""
+    z = gold("g7_grads.npz")
+    st, spec = fitted_state()
+    layers = O.decoder_layers_from_state(st, spec)
+    D, H, W = [int(v) for v in z[tag + "_cfg"]]
+    lat_raw = z[tag + "_latent"].astype(np.float32)
+    nrm_l = np.sqrt((lat_raw * lat_raw).sum())
+    lat = (lat_raw / nrm_l).astype(np.float32)
+    pts = O.generate_point_grid(D)
+    G = pts.shape[0]
+    inp = np.concatenate([np.broadcast_to(lat, (G, 3)), pts], 1).astype(np.float32)
+    sdf, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+    Jall = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(sdf))
+    pm, nocs, nm, idx, n_hat = O.get_surface_points(pts, sdf, Jall[:, 3:], 0.03)
+    assert np.allclose(pm, z[tag + "_pcd"], atol=2e-6)
+    yaw, trans = float(z[tag + "_yaw"][0]), z[tag + "_trans"]
+    pose = O.render_pose(yaw, trans)
+    assert np.allclose(pose, z[tag + "_pose"], atol=1e-7)
+    K, Kinv = z[tag + "_K"], z[tag + "_Kinv"]
+    rend, points, proj = O.rasterer_forward(K, Kinv, (W, H), pm, nm, nm, pose, rot="dcm", output_nocs=True)
+    for k in ("color", "mask", "depth", "normals"):
+        assert np.abs(rend[k] - z[tag + "_out_" + k]).max() < 1e-4, k
+    # backward of  sum_k <out_k, W_k> + sum <points_k, Wp_k>
+    c_attr = ((proj["colors_3d"] + 1) / 2).astype(np.float32)
+    g_v3, g_n, g_c = O.splat_backward(Kinv, (W, H), proj["points_3d"], proj["normals_3d"], c_attr,
+                                      z[tag + "_W_color"], z[tag + "_W_mask"], z[tag + "_W_depth"], z[tag + "_W_normals"])
+    g_v3 = g_v3 + z[tag + "_Wp_xyz"]
+    g_col = g_c * 0.5 + z[tag + "_Wp_rgb"] * 0.5          # colors_3d -> (c+1)/2
+    g_points, g_normals, _, g_pose = O.project_backward_dcm(
+        pose, pm, nm, g_v3, g_n, g_col, output_nocs=True, filt_idx=proj["filt_idx"],
+        g_p3_filt=z[tag + "_Wp_xyzf"], g_col_filt=z[tag + "_Wp_rgbf"] * 0.5)
+    ref_gp = z[tag + "_g_pcd"]
+    assert np.abs(g_points - ref_gp).max() < 2e-4 * max(1.0, np.abs(ref_gp).max())
+    ref_pose = z[tag + "_g_pose"]
+    assert np.abs(g_pose[:3] - ref_pose[:3]).max() < 5e-4 * max(1.0, np.abs(ref_pose).max())
+    # pose -> yaw, trans  (optimizer.py:87-90)
+    c, s = np.cos(yaw), np.sin(yaw)
+    dR = np.array([[-s, 0, c], [0, 0, 0], [-c, 0, -s]])
+    dR[1] *= -1
+    g_yaw = float((g_pose[:3, :3] * dR).sum())
+    assert abs(g_yaw - float(z[tag + "_g_yaw"][0])) < 5e-4 * max(1.0, abs(float(z[tag + "_g_yaw"][0])))
+    assert np.allclose(g_pose[:3, 3], z[tag + "_g_trans"], atol=5e-4 * max(1.0, np.abs(z[tag + "_g_trans"]).max()))
+    # points -> sdf -> latent
+    g_sdf, _ = O.get_surface_points_backward(sdf, n_hat, idx, g_points)
+    g_inp = Jall * g_sdf                                  # linearity: d sdf/d inputs scaled by upstream
+    g_lat_n = g_inp[:, :3].astype(np.float64).sum(0)
+    # F.normalize backward (optimizer.py:96)
+    g_lat = (g_lat_n - lat * (lat.astype(np.float64) @ g_lat_n)) / nrm_l
+    ref = z[tag + "_g_latent"]
+    assert np.abs(g_lat - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())

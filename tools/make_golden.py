@@ -1,0 +1,368 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (build container only).
+
+The reference (TRI-ML/sdflabel @ /root/reference) ships no tests or fixtures for the renderer hot path
+(SURVEY.md §4), so parity is pinned by vectors produced here from the reference's own code, imported
+read-only with bytecode writing disabled (tools/_ref_import.py).  Only DATA is committed: inputs, outputs,
+seeds, torch version and threshold margins -- never reference source.
+
+  G1 grid            grid.Grid3D.generate_point_grid                       (grid.py:22-41)
+  G2 decoder         Decoder.forward + d(sum sdf)/d inputs                 (deep_sdf_decoder_scale.py:78-114)
+  G3 surface         Grid3D.get_surface_points                             (grid.py:43-71)
+  G4 project         project_in_2D / project_in_2D_quat                    (projection.py:7-199)
+  G5 inside_surfel   inside_surfel weights (+bg variant)                   (primitives.py:165-242)
+  G6 rasterer        Rasterer.forward, 32x32 and 64x64, nocs T/F, bg       (rasterer.py:49-155)
+  G7 grads           autograd gradients of a fixed random functional of all outputs w.r.t.
+                     yaw, trans, latent, coords, normals                  (optimizer.py:79-123 graph)
+  G8 optimizer       10-iteration Optimizer.optimize trajectory            (optimizer.py:56-164)
+
+usage: python tools/make_golden.py [G1 G2 ...]
+"""
+import contextlib
+import io
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _ref_import  # noqa: E402
+
+_ref_import.setup()
+sys.modules["pyquaternion"].Quaternion = object  # `from pyquaternion import Quaternion` (utils/refinement.py:6)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import grid as ref_grid  # noqa: E402  (reference sdfrenderer/grid.py)
+from deepsdf.networks.deep_sdf_decoder_scale import Decoder  # noqa: E402
+import deepsdf.workspace as ref_ws  # noqa: E402
+from renderer.rasterer import Rasterer  # noqa: E402
+from renderer import projection as ref_proj  # noqa: E402
+from renderer import primitives as ref_prim  # noqa: E402
+import utils.refinement as rtools  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden")
+ASSET = os.path.join(HERE, "..", "sdflabel_amd", "assets", "deepsdf_synth.pt")
+META = dict(torch_version=str(torch.__version__), numpy_version=str(np.__version__))
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: (np.asarray(v) if not isinstance(v, str) else np.asarray(v)) for k, v in arrs.items()},
+                        **{"_" + k: np.asarray(v) for k, v in META.items()})
+    print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def state_np(mod):
+    return {k: v.detach().cpu().float().numpy() for k, v in mod.state_dict().items()}
+
+
+def load_fitted(precision=torch.float32):
+    dec, L = ref_ws.setup_dsdf(ASSET, precision=precision)
+    return dec, L
+
+
+def K_for(H, W):
+    f = 45.0 * H / 32.0
+    return torch.tensor([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1]], dtype=torch.float32)
+
+
+def build_pose(yaw, trans):
+    """pipelines/optimizer.py:86-90 executed verbatim."""
+    render_pose = torch.eye(4)
+    render_pose[:3, :3] = rtools.rot_from_yaw(yaw)
+    render_pose[1] *= -1
+    render_pose[:3, 3] = trans
+    return render_pose
+
+
+# ---------------------------------------------------------------------------------------------------------
+
+def g1():
+    arrs = {}
+    for D in (4, 5, 8, 30, 40):
+        g = ref_grid.Grid3D(D, "cpu", torch.float32).points.detach().numpy()
+        if D <= 8:
+            arrs["grid_%d" % D] = g
+        else:
+            arrs["grid_%d_stride97" % D] = g[::97]
+            arrs["grid_%d_sum64" % D] = g.astype(np.float64).sum(0)
+            arrs["grid_%d_tail" % D] = g[-8:]
+    save("g1_grid.npz", **arrs)
+
+
+def g2():
+    arrs = {}
+    torch.manual_seed(7)
+    # small seeded nets: weight-norm variant and LayerNorm variant, latent_in=[4]
+    for tag, wn in (("wn", True), ("ln", False)):
+        dec = Decoder(3, dims=[64] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)),
+                      latent_in=[4], weight_norm=wn, xyz_in_all=False, use_tanh=False, latent_dropout=False)
+        dec.eval()
+        with torch.no_grad():
+            for p in dec.parameters():      # de-trivialise biases / gains
+                p.add_(0.05 * torch.randn_like(p))
+        inp = torch.randn(300, 6) * 0.7
+        inp.requires_grad_(True)
+        sdf, scale = dec(inp)
+        sdf.sum().backward()
+        for k, v in state_np(dec).items():
+            arrs["%s_state_%s" % (tag, k)] = v
+        arrs["%s_inputs" % tag] = inp.detach().numpy()
+        arrs["%s_sdf" % tag] = sdf.detach().numpy()
+        arrs["%s_scale" % tag] = scale.detach().numpy()
+        arrs["%s_grad_inputs" % tag] = inp.grad.numpy()
+    # an extra spec: xyz_in_all + use_tanh + two latent_in layers, plain linears
+    dec = Decoder(5, dims=[48] * 5, dropout=None, norm_layers=(), latent_in=[2, 4], weight_norm=False,
+                  xyz_in_all=True, use_tanh=True)
+    dec.eval()
+    inp = (torch.randn(200, 8) * 0.6).requires_grad_(True)
+    sdf, scale = dec(inp)
+    g_out = torch.randn_like(sdf)
+    (sdf * g_out).sum().backward()
+    for k, v in state_np(dec).items():
+        arrs["x_state_%s" % k] = v
+    arrs["x_inputs"] = inp.detach().numpy()
+    arrs["x_sdf"] = sdf.detach().numpy()
+    arrs["x_gout"] = g_out.numpy()
+    arrs["x_grad_inputs"] = inp.grad.numpy()
+    # the fitted 8x512 fixture on a strided sample of the D=40 grid
+    dec, L = load_fitted()
+    g = ref_grid.Grid3D(40, "cpu", torch.float32).points.detach()[::31]
+    lat = F.normalize(torch.tensor([0.3, -0.5, 0.8]), p=2, dim=0)
+    inp = torch.cat([lat.expand(g.size(0), -1), g], 1).clone().requires_grad_(True)
+    sdf, scale = dec(inp)
+    sdf.sum().backward()
+    arrs["fit_inputs"] = inp.detach().numpy()
+    arrs["fit_sdf"] = sdf.detach().numpy()
+    arrs["fit_scale"] = scale.detach().numpy()
+    arrs["fit_grad_inputs"] = inp.grad.numpy()
+    save("g2_decoder.npz", **arrs)
+
+
+def surface_case(D, latent, dec=None):
+    dec = dec or load_fitted()[0]
+    grid = ref_grid.Grid3D(D, "cpu", torch.float32)
+    lat = torch.tensor(latent, dtype=torch.float32, requires_grad=True)
+    lat_ = F.normalize(lat, p=2, dim=0)
+    inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1)
+    sdf, _ = dec(inputs)
+    pts, nocs, nrm = grid.get_surface_points(sdf)
+    return dec, grid, lat, sdf, pts, nocs, nrm
+
+
+def g3():
+    arrs = {}
+    for tag, D, latent in (("a", 16, [0.3, -0.5, 0.8]), ("b", 21, [-0.6, 0.2, 0.1])):
+        dec, grid, lat, sdf, pts, nocs, nrm = surface_case(D, latent)
+        s = sdf.detach().numpy()
+        arrs[tag + "_D"] = D
+        arrs[tag + "_latent"] = np.asarray(latent, np.float32)
+        arrs[tag + "_sdf"] = s
+        arrs[tag + "_grad_points"] = ref_grid.grads["grid_points"].detach().numpy()  # n_hat after the in-place divide
+        arrs[tag + "_points"] = pts.detach().numpy()
+        arrs[tag + "_nocs"] = nocs.detach().numpy()
+        arrs[tag + "_normals"] = nrm.detach().numpy()
+        arrs[tag + "_band_idx"] = np.nonzero(np.abs(s[:, 0]) < 0.03)[0]
+        arrs[tag + "_band_margin"] = np.min(np.abs(np.abs(s[:, 0]) - 0.03))
+        print("G3", tag, "N =", pts.shape[0], "margin", arrs[tag + "_band_margin"])
+    save("g3_surface.npz", **arrs)
+
+
+def g4():
+    arrs = {}
+    dec, grid, lat, sdf, pts, nocs, nrm = surface_case(16, [0.3, -0.5, 0.8])
+    pts, nrm = pts.detach(), nrm.detach()
+    arrs["points"] = pts.numpy()
+    arrs["normals"] = nrm.numpy()
+    K = K_for(32, 32)
+    arrs["K"] = K.numpy()
+    for i, (yaw, trans) in enumerate((([0.6], [0.0, 0.0, 3.5]), ([-1.1], [0.2, -0.1, 2.8]), ([2.5], [-0.3, 0.15, 4.2]))):
+        pose = build_pose(torch.tensor(yaw), torch.tensor(trans))
+        for nocs_flag in (True, False):
+            o = ref_proj.project_in_2D(K, pose, pts, nrm, nrm, (32, 32), output_nocs=nocs_flag)
+            t = "dcm%d_%s_" % (i, "nocs" if nocs_flag else "col")
+            arrs[t + "pose"] = pose.numpy()
+            for k, v in o.items():
+                arrs[t + k] = v.numpy()
+            dot = (o["normals_3d"] * o["points_3d"]).sum(1)
+            arrs[t + "filt_margin"] = dot.abs().min().numpy()
+    q = F.normalize(torch.tensor([0.9, 0.1, 0.35, -0.2]), dim=0)
+    cam = torch.cat([q, torch.tensor([0.1, -0.05, 3.2])])
+    with torch.no_grad():
+        o = ref_proj.project_in_2D_quat(K, cam, pts, nrm, nrm, (32, 32), output_nocs=True)
+    arrs["quat_pose"] = cam.numpy()
+    for k, v in o.items():
+        arrs["quat_" + k] = v.detach().numpy()
+    save("g4_project.npz", **arrs)
+
+
+def g5():
+    arrs = {}
+    torch.manual_seed(3)
+    H = W = 16
+    K = K_for(H, W)
+    r = Rasterer(K, (W, H), precision=torch.float32)
+    # small synthetic surfel set in front of the camera facing it, dense enough to overlap
+    N = 64
+    p = torch.stack([torch.rand(N) * 0.5 - 0.25, torch.rand(N) * 0.5 - 0.25, 1.0 + torch.rand(N) * 0.3], 1)
+    n = F.normalize(torch.randn(N, 3) * 0.4 + torch.tensor([0, 0, -1.0]), dim=1)
+    n[:4] = F.normalize(torch.tensor([[1.0, 0.0, 0.002], [0.0, 1.0, -0.004], [0.7, 0.7, 0.003], [1.0, 0.2, 0.0]]), dim=1)  # grazing
+    p2 = torch.zeros(N, 2)
+    for bg in (False, True):
+        w = ref_prim.inside_surfel(K, r.grid, p2, p, n, diam=0.04, softclamp=False, add_bg=bg)
+        arrs["w_bg%d" % int(bg)] = w[:, 0, :].numpy()
+        assert torch.equal(w[:, 0], w[:, 1]) and torch.equal(w[:, 0], w[:, 2])
+    arrs["K"] = K.numpy()
+    arrs["Kinv"] = K.float().inverse().numpy()
+    arrs["points"] = p.numpy()
+    arrs["normals"] = n.numpy()
+    arrs["res"] = np.array([W, H])
+    arrs["grid"] = r.grid.numpy()
+    save("g5_inside_surfel.npz", **arrs)
+
+
+def g6():
+    arrs = {}
+    dec, grid, lat, sdf, pts, nocs, nrm = surface_case(16, [0.3, -0.5, 0.8])
+    pts, nrm = pts.detach(), nrm.detach()
+    arrs["points"] = pts.numpy()
+    arrs["normals"] = nrm.numpy()
+    torch.manual_seed(11)
+    colors = torch.rand(pts.size(0), 3)
+    arrs["colors"] = colors.numpy()
+    pose = build_pose(torch.tensor([0.6]), torch.tensor([0.0, 0.0, 3.5]))
+    arrs["pose"] = pose.numpy()
+    for (H, W) in ((32, 32), (64, 48)):
+        K = K_for(H, W)
+        r = Rasterer(K, (W, H), precision=torch.float32)
+        t0 = "r%dx%d_" % (H, W)
+        arrs[t0 + "K"] = K.numpy()
+        arrs[t0 + "Kinv"] = K.float().inverse().numpy()
+        for nocs_flag in (True, False):
+            rend, points = r(pts, nrm, colors, pose, rot="dcm", primitives="disc", bg=None, output_mask=True,
+                             output_depth=True, output_normals=True, output_nocs=nocs_flag, output_points=True)
+            t = t0 + ("nocs_" if nocs_flag else "col_")
+            for k, v in rend.items():
+                arrs[t + k] = v.numpy()
+            for k, v in points.items():
+                arrs[t + "pts_" + k] = v.numpy()
+        bg = torch.rand(3, H, W)
+        rend = r(pts, nrm, colors, pose, rot="dcm", primitives="disc", bg=bg, output_mask=True,
+                 output_depth=False, output_normals=False, output_nocs=True, output_points=False)
+        arrs[t0 + "bg"] = bg.numpy()
+        for k, v in rend.items():
+            arrs[t0 + "bg_" + k] = v.numpy()
+    save("g6_rasterer.npz", **arrs)
+
+
+def g7():
+    """End-to-end autograd gradients through the optimizer's graph (optimizer.py:79-123), losses replaced by a
+    fixed random linear functional of every differentiable output."""
+    arrs = {}
+    for tag, D, H, W, latent, yaw0, trans0 in (("a", 16, 32, 32, [0.3, -0.5, 0.8], 0.6, [0.0, 0.0, 3.5]),
+                                               ("b", 21, 48, 40, [-0.6, 0.2, 0.1], -0.9, [0.15, -0.1, 3.0])):
+        dec = load_fitted()[0]
+        grid = ref_grid.Grid3D(D, "cpu", torch.float32)
+        lat = torch.tensor(latent, dtype=torch.float32, requires_grad=True)
+        yaw = torch.tensor([yaw0], requires_grad=True)
+        trans = torch.tensor(trans0, requires_grad=True)
+        K = K_for(H, W)
+        renderer = Rasterer(K, (W, H), precision=torch.float32)
+        lat_ = F.normalize(lat, p=2, dim=0)
+        inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1)
+        sdf, _ = dec(inputs)
+        pcd, _, normals = grid.get_surface_points(sdf)
+        lat.grad = None
+        dec.zero_grad()
+        grid.points.grad = None
+        pcd.retain_grad()
+        pose = build_pose(yaw, trans)
+        pose.retain_grad()
+        rendering, points = renderer(pcd, normals, normals, pose, primitives="disc", rot="dcm", bg=None,
+                                     output_depth=True, output_normals=True, output_nocs=True, output_points=True,
+                                     output_mask=True)
+        gen = torch.Generator().manual_seed(5)
+        Wt = {k: torch.randn(v.shape, generator=gen) for k, v in rendering.items()}
+        Wp = {k: torch.randn(points[k].shape, generator=gen) for k in ("xyzf", "rgbf", "xyz", "rgb")}
+        loss = sum((rendering[k] * Wt[k]).sum() for k in rendering) + sum((points[k] * Wp[k]).sum() for k in Wp)
+        loss.backward()
+        arrs[tag + "_cfg"] = np.array([D, H, W])
+        arrs[tag + "_latent"] = np.asarray(latent, np.float32)
+        arrs[tag + "_yaw"] = np.asarray([yaw0], np.float32)
+        arrs[tag + "_trans"] = np.asarray(trans0, np.float32)
+        arrs[tag + "_K"] = K.numpy()
+        arrs[tag + "_Kinv"] = K.float().inverse().numpy()
+        arrs[tag + "_sdf"] = sdf.detach().numpy()
+        arrs[tag + "_pcd"] = pcd.detach().numpy()
+        arrs[tag + "_normals"] = normals.detach().numpy()
+        arrs[tag + "_pose"] = pose.detach().numpy()
+        for k, v in rendering.items():
+            arrs[tag + "_out_" + k] = v.detach().numpy()
+            arrs[tag + "_W_" + k] = Wt[k].numpy()
+        for k in Wp:
+            arrs[tag + "_pts_" + k] = points[k].detach().numpy()
+            arrs[tag + "_Wp_" + k] = Wp[k].numpy()
+        arrs[tag + "_loss"] = loss.detach().numpy()
+        arrs[tag + "_g_yaw"] = yaw.grad.numpy()
+        arrs[tag + "_g_trans"] = trans.grad.numpy()
+        arrs[tag + "_g_latent"] = lat.grad.numpy()
+        arrs[tag + "_g_pcd"] = pcd.grad.numpy()
+        arrs[tag + "_g_pose"] = pose.grad.numpy()
+        arrs[tag + "_g_gridpoints_absmax"] = grid.points.grad.abs().max().numpy()
+        print("G7", tag, "N", pcd.shape[0], "loss", float(loss), "g_yaw", yaw.grad.numpy(), "g_lat", lat.grad.numpy())
+    save("g7_grads.npz", **arrs)
+
+
+def synth_targets(dec, D, H, W, latent_gt, yaw_gt, trans_gt, scale_gt):
+    """Render the GT pose with the reference renderer to obtain a target NOCS image and a lidar-like cloud
+    (the a-harness of SURVEY.md §8: what refine_css_demo.py:107-131 would supply from the CSS net + lidar)."""
+    grid = ref_grid.Grid3D(D, "cpu", torch.float32)
+    lat_ = F.normalize(torch.tensor(latent_gt), p=2, dim=0)
+    inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1)
+    sdf, _ = dec(inputs)
+    pcd, _, normals = grid.get_surface_points(sdf)
+    pose = build_pose(torch.tensor([yaw_gt]), torch.tensor(trans_gt))
+    K = K_for(H, W)
+    renderer = Rasterer(K, (W, H), precision=torch.float32)
+    rendering, points = renderer(pcd.detach(), normals.detach(), normals.detach(), pose, primitives="disc", rot="dcm",
+                                 output_nocs=True, output_points=True, output_mask=True)
+    nocs = rendering["color"].detach()
+    lidar = (points["xyzf"].detach() * scale_gt)[::3].numpy().copy()
+    return K, nocs, lidar
+
+
+def g8():
+    from pipelines.optimizer import Optimizer
+    dec = load_fitted()[0]
+    D, H, W = 20, 32, 32
+    K, nocs, lidar = synth_targets(dec, D, H, W, [0.3, -0.5, 0.8], 0.6, [0.0, 0.0, 3.5], 2.0)
+    params = {"yaw": [0.7], "trans": [0.03, 0.02, 3.45], "scale": [2.0], "latent": [0.5, -0.3, 0.6]}
+    opt = Optimizer({k: list(v) for k, v in params.items()}, "cpu", {"2d": 0.3, "3d": 0.5})
+    grid = ref_grid.Grid3D(D, "cpu", torch.float32)
+    traj = []
+    buf = io.StringIO()
+    for it in range(10):
+        with contextlib.redirect_stdout(buf):
+            opt.optimize(1, nocs, lidar, dec, grid, K, [H, W], viz_type=None)
+        traj.append(np.concatenate([opt.params[k].detach().numpy().ravel() for k in ("yaw", "trans", "scale", "latent")]))
+    losses = [l for l in buf.getvalue().splitlines() if l.startswith("ITER")]
+    l2d, l3d = [], []
+    for l in losses:
+        parts = l.split("2D - ")[1].split(", 3D - ")
+        l2d.append(float(parts[0]))
+        l3d.append(float(parts[1].split(", Total")[0]))
+    print("G8 losses2d", l2d[:3], "...", l2d[-1], "traj yaw", [t[0] for t in traj])
+    save("g8_optimizer.npz", D=D, H=H, W=W, K=K.numpy(), nocs_target=nocs.numpy(), lidar=lidar,
+         init=np.concatenate([np.asarray(params[k], np.float32) for k in ("yaw", "trans", "scale", "latent")]),
+         traj=np.asarray(traj), loss2d_weighted=np.asarray(l2d), loss3d_weighted=np.asarray(l3d))
+
+
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(ALL)
+    for w in which:
+        ALL[w]()

@@ -112,7 +112,7 @@ int sdfr_sdf_input_grad(const float* g_sdf, const int32_t* slot, const float* J,
 /* ------------------------------------------------------------------------------------------------
  * Projection to the camera frame  --  replaces project_in_2D (sdfrenderer/renderer/projection.py:7-101), rot='dcm'
  *   pose [B][16] row-major 4x4 (only the top 3 rows are used, :34); K [B][9]
- *   in : points, normals, colors [B][cap][3]  (colors ignored when output_nocs: c = p*(-1,1,1), :53-55)
+ *   in : points, normals, colors [B][cap][3]  (colors ignored when output_nocs != 0: 1 -> c = p*(-1,1,1), :53-55; 2 -> c = p, :147-149)
  *   out: p_cam, n_cam, col [B][cap][3]; uv [B][cap][2] (clamped, :88-93; may be NULL)
  *        front-facing filter n_cam.p_cam < 0 (:61-70): fidx [B][cap] ascending slots, fcnt [B]
  *        (fidx/fcnt may be NULL).
@@ -138,13 +138,16 @@ int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* no
  */
 int sdfr_splat_forward(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
                        int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant,
+                       int32_t* bbox_ws /* workspace int32[B][cap][4]: conservative screen boxes */,
                        float* color, float* mask, float* depth, float* normals, float* aux, void* stream);
 
-/* Backward w.r.t. p_cam, n_cam, attr given the gradients of the four images (any may be NULL). */
+/* Backward w.r.t. p_cam, n_cam, attr given the gradients of the four images (any may be NULL; a non-NULL gradient
+ * needs the corresponding forward image, which carries the pre-softmax-backward sum <grad, output>). */
 int sdfr_splat_backward(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
                         int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant,
-                        const float* aux, const float* g_color, const float* g_mask, const float* g_depth,
-                        const float* g_normals, float* g_p_cam, float* g_n_cam, float* g_attr, void* stream);
+                        const float* aux, const float* color, const float* mask, const float* depth, const float* normals,
+                        const float* g_color, const float* g_mask, const float* g_depth, const float* g_normals,
+                        float* g_p_cam, float* g_n_cam, float* g_attr, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,87 @@
+"""ctypes binding of libsdfr_hip.so (the C ABI declared in include/sdfr.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails the product raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsdfr_hip.so")
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/sdfr.h one to one
+_PROTOS = {
+    "sdfr_version": (c_int, []),
+    "sdfr_last_error": (c_char_p, []),
+    "sdfr_decoder_create": (c_int, [POINTER(c_void_p), c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                    POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int]),
+    "sdfr_decoder_destroy": (c_int, [c_void_p]),
+    "sdfr_decoder_macs": (c_int64, [c_void_p]),
+    "sdfr_mlp_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "sdfr_mlp_jacobian": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_band_select": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_surface_project": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_surface_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p]),
+    "sdfr_sdf_input_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sdfr_project_dcm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_project_dcm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float,
+                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float,
+                                    c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+
+class SdfrError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise SdfrError("libsdfr_hip.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or sdflabel_amd/csrc/build.sh -- there is no CPU fallback" % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SdfrError("%s failed (%d): %s" % (what, rc, lib().sdfr_last_error().decode()))
+
+
+def ptr(t):
+    """device (or host) pointer of a torch tensor / None"""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu_f32(*tensors):
+    import torch
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise SdfrError("sdflabel_amd runs on the GPU only (got a %s tensor); there is no CPU fallback" % t.device)
+        if t.dtype != torch.float32:
+            raise SdfrError("sdflabel_amd kernels are float32 (got %s)" % t.dtype)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libsdfr_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT" "$HERE/obj"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+# the MLP uses MFMA + explicit fmaf; the geometric kernels keep separate roundings like the reference's ATen ops
+$HIPCC $COMMON -c "$HERE/common.hip"  -o "$HERE/obj/common.o" &
+$HIPCC $COMMON -c "$HERE/mlp.hip"     -o "$HERE/obj/mlp.o" &
+$HIPCC $COMMON -ffp-contract=off -c "$HERE/surface.hip" -o "$HERE/obj/surface.o" &
+$HIPCC $COMMON -ffp-contract=off -c "$HERE/project.hip" -o "$HERE/obj/project.o" &
+$HIPCC $COMMON -ffp-contract=off -c "$HERE/splat.hip"   -o "$HERE/obj/splat.o" &
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsdfr_hip.so" "$HERE"/obj/{common,mlp,surface,project,splat}.o
+echo "built $OUT/libsdfr_hip.so"

@@ -1,0 +1,455 @@
+// DeepSDF decoder on MI355X (gfx950): fused multi-layer MLP forward and input-Jacobian backward.
+//
+// Replaces Decoder.forward (reference sdfrenderer/deepsdf/networks/deep_sdf_decoder_scale.py:78-107) and the
+// autograd backward of it w.r.t. its input rows (the normals hook of sdfrenderer/grid.py:55-56 and the latent
+// gradient of pipelines/optimizer.py:156).
+//
+// Design (CDNA4-first, nothing here is translated from the reference's ATen graph):
+//   * One 256-thread workgroup (4 waves, one per SIMD) owns a tile of PT = 32*NP grid points and carries them
+//     through EVERY layer.  Activations never leave the CU: they live in LDS as  act[k/4][point][k%4]  (float4),
+//     128 KiB for 512 features x 64 points.
+//   * Each layer is computed transposed,  out^T[feature][point] = W[feature][k] * act^T[k][point],  with the exact-f32
+//     matrix instruction v_mfma_f32_32x32x2_f32.  Wave w owns output features [w*32*FT, (w+1)*32*FT): FT x NP
+//     32x32 accumulator tiles (128 VGPRs at FT=4, NP=2).  The MFMA A operand (weights) is NOT shared between waves,
+//     so it is streamed straight from L2 into VGPRs (no LDS staging, no barrier in the K loop) from a tile-major
+//     image packed once at load time:  Wf[tile t][kg 0..1][row 0..HP)[4] = W[row][8t + 4kg + 0..3]  -- each lane's
+//     fragment is one coalesced 16-byte load, and one load feeds four MFMA k-steps.  The B operand (activations) is
+//     one conflict-free ds_read_b128 per 32 points.  With the transposed product a lane's 4 consecutive accumulator
+//     registers are 4 consecutive features of ONE point, so the epilogue (bias + ReLU + latent re-injection) writes
+//     the next layer's operand with conflict-free ds_write_b128.  Only two barriers per layer.
+//   * The last linear (H -> 1) is a VALU dot product out of LDS followed by tanh.
+//   * Jacobian mode (JAC): the same kernel keeps the ReLU masks (1 bit per feature per point) in LDS and runs the
+//     layers backwards with the transposed weight image Wb, giving d sdf / d input-row for the selected rows only.
+//     The backward needs no activations, only masks, because just the INPUT gradient is required (weights are frozen).
+#include "sdfr_common.h"
+#include <math.h>
+#include <string.h>
+#include <type_traits>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MlpLayer {
+    int in_dim, out_dim;    // true widths (in_dim includes injected input columns)
+    int inj_n, inj_off;     // input columns concatenated BEFORE this layer
+    int nkt_f, nkt_b;       // K tiles of the forward (over in_dim) / backward (over out_dim) product
+    int off_f, off_b;       // float4 offsets of the layer's first tile in Wf / Wb
+};
+
+struct MlpParams {
+    const float4* Wf;
+    const float4* Wb;
+    const float* bias;      // [n_mfma][HP]
+    const float* w_last;    // [HP] zero padded
+    float b_last;
+    int n_mfma;             // layers computed with MFMA = n_lin - 1
+    int n_inputs;
+    int use_tanh;
+    MlpLayer L[SDFR_MAX_LAYERS];
+    // forward mode
+    const float* inputs;
+    int64_t n;
+    float* sdf;
+    // jacobian mode
+    int64_t rows_per_crop;
+    const int32_t* idx;
+    const int32_t* cnt;
+    int cap;
+    float* J;
+    float* sdf_sel;
+};
+
+struct sdfr_decoder {
+    int device;
+    int n_lin, n_inputs, use_tanh, HP;
+    float4* d_Wf;
+    float4* d_Wb;
+    float* d_bias;
+    float* d_wlast;
+    int64_t macs;
+    MlpParams proto;
+};
+
+__device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+template <int FT, int NP, bool JAC>
+__global__ __launch_bounds__(256, 1) void sdfr_mlp_kernel(const MlpParams P) {
+    constexpr int PT = 32 * NP;
+    constexpr int HP = 128 * FT;
+    constexpr int KG = HP / 4;
+    constexpr int MW = (FT * NP * 16 + 31) / 32;                 // mask words per thread per layer
+    constexpr int MASK_WORDS = JAC ? (SDFR_MAX_LAYERS * MW * 256) : 1;
+    // single LDS object, carved by hand (16-byte aligned pieces first)
+    __shared__ float4 lds4[KG * PT + 64 + 16 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4];
+    float4* act = lds4;                                           // [KG][PT]
+    float* red = reinterpret_cast<float*>(lds4 + KG * PT);        // [256]
+    int* rows = reinterpret_cast<int*>(lds4 + KG * PT + 64);      // [PT] source row of each point (64 ints max)
+    float* gy = reinterpret_cast<float*>(lds4 + KG * PT + 64 + 16);   // [PT] d out / d y_last
+    int* slots = reinterpret_cast<int*>(lds4 + KG * PT + 64 + 16 + (PT + 3) / 4);   // [PT] J slot or -1
+    uint32_t* masks = reinterpret_cast<uint32_t*>(lds4 + KG * PT + 64 + 16 + (PT + 3) / 4 * 2);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int l31 = lane & 31;
+    const int hi = lane >> 5;
+    const int NI = P.n_inputs;
+
+    // ---- which rows does this tile hold ------------------------------------------------------------------
+    int n_valid;
+    if (JAC) {
+        const int b = blockIdx.y;
+        const int count = sdfr_count(P.cnt, b, P.cap);
+        const int s0 = blockIdx.x * PT;
+        if (s0 >= count) return;
+        n_valid = min(PT, count - s0);
+        if (tid < PT) {
+            const bool v = tid < n_valid;
+            const int s = v ? (s0 + tid) : s0;
+            rows[tid] = (int)(P.rows_per_crop * b) + P.idx[(int64_t)b * P.cap + s];
+            slots[tid] = v ? (b * P.cap + s) : -1;
+        }
+    } else {
+        const int64_t r0 = (int64_t)blockIdx.x * PT;
+        n_valid = (int)min((int64_t)PT, P.n - r0);
+        if (tid < PT) rows[tid] = (int)(r0 + (tid < n_valid ? tid : 0));
+    }
+    __syncthreads();
+
+    // ---- layer-0 operand: act[k][pt] = inputs[row(pt)][k], zero padded to a multiple of 8 ---------------
+    {
+        const int k0pad = P.L[0].nkt_f * 8;
+        for (int e = tid; e < PT * k0pad; e += 256) {
+            const int pt = e / k0pad, k = e - pt * k0pad;
+            const float v = (k < NI) ? P.inputs[(int64_t)rows[pt] * NI + k] : 0.f;
+            reinterpret_cast<float*>(act)[((k >> 2) * PT + pt) * 4 + (k & 3)] = v;
+        }
+    }
+    __syncthreads();
+
+    const int fbase = wave * 32 * FT;      // first feature row owned by this wave
+    f32x16 acc[FT][NP];
+
+    // One transposed GEMM over `nkt` K tiles: acc[f][p] += W_tile(rows fbase+f*32..) x act.
+    // FULL: all FT feature tiles of this wave are active (straight-line MFMA stream, no branches);
+    // otherwise only the first `nact` tiles are (thin layers: the 6-wide first layer's backward, small nets).
+    auto gemm_body = [&](const float4* __restrict__ Wl, int nkt, int nact, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const float4* aptr = Wl + hi * HP + fbase + l31;
+        const float4* bptr = act + hi * PT + l31;
+        float4 a_n[FT], b_n[NP];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) a_n[f] = (FULL || f < nact) ? aptr[f * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) b_n[p] = bptr[p * 32];
+        for (int t = 0; t < nkt; ++t) {
+            float4 a_c[FT], b_c[NP];
+#pragma unroll
+            for (int f = 0; f < FT; ++f) a_c[f] = a_n[f];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) b_c[p] = b_n[p];
+            if (t + 1 < nkt) {
+                aptr += 2 * HP;
+                bptr += 2 * PT;
+#pragma unroll
+                for (int f = 0; f < FT; ++f)
+                    if (FULL || f < nact) a_n[f] = aptr[f * 32];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) b_n[p] = bptr[p * 32];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int f = 0; f < FT; ++f)
+                    if (FULL || f < nact) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+                            acc[f][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a_c[f], ks), f4c(b_c[p], ks), acc[f][p], 0, 0, 0);
+                    }
+        }
+    };
+    auto gemm = [&](const float4* __restrict__ Wl, int nkt, int rows_active) {
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[f][p][r] = 0.f;
+        int nact = (rows_active - fbase + 31) / 32;
+        nact = nact < 0 ? 0 : (nact > FT ? FT : nact);
+        nact = __builtin_amdgcn_readfirstlane(nact);
+        if (nact == FT) gemm_body(Wl, nkt, FT, std::true_type{});
+        else if (nact > 0) gemm_body(Wl, nkt, nact, std::false_type{});
+    };
+
+    // ---- forward through the MFMA layers -------------------------------------------------------------------
+    for (int l = 0; l < P.n_mfma; ++l) {
+        const MlpLayer L = P.L[l];
+        const MlpLayer Ln = P.L[l + 1];
+        gemm(P.Wf + L.off_f, L.nkt_f, L.out_dim);
+        __syncthreads();                                  // every wave is done reading act
+        uint32_t mw[MW];
+#pragma unroll
+        for (int w = 0; w < MW; ++w) mw[w] = 0u;
+        const float* bias = P.bias + l * HP;
+        const int inj_lo = L.out_dim, inj_hi = L.out_dim + Ln.inj_n;
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int j0 = fbase + f * 32 + 8 * rg + 4 * hi;
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + j0);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int pt = p * 32 + l31;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x = acc[f][p][rg * 4 + i] + f4c(b4, i);
+                        const bool pos = x > 0.f;
+                        v[i] = pos ? x : 0.f;
+                        if (JAC) {
+                            const int bit = ((f * NP + p) * 4 + rg) * 4 + i;
+                            mw[bit >> 5] |= (pos ? 1u : 0u) << (bit & 31);
+                        }
+                    }
+                    if (j0 + 3 >= inj_lo && j0 < inj_hi) {    // re-inject input columns for the next layer
+                        const float* src = P.inputs + (int64_t)rows[pt] * NI + Ln.inj_off - inj_lo;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (j0 + i >= inj_lo && j0 + i < inj_hi) v[i] = src[j0 + i];
+                    }
+                    act[(j0 >> 2) * PT + pt] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        if (JAC) {
+#pragma unroll
+            for (int w = 0; w < MW; ++w) masks[(l * MW + w) * 256 + tid] = mw[w];
+        }
+        __syncthreads();
+    }
+
+    // ---- last linear (H -> 1) + tanh -----------------------------------------------------------------------
+    {
+        constexpr int SL = 256 / PT;                      // k slices
+        constexpr int KGS = KG / SL;
+        const int sl = tid / PT, pt = tid - sl * PT;
+        const float4* w4 = reinterpret_cast<const float4*>(P.w_last) + sl * KGS;
+        const float4* a4 = act + (sl * KGS) * PT + pt;
+        float s = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < KGS; ++g) {
+            const float4 a = a4[g * PT];
+            const float4 w = w4[g];
+            s = fmaf(a.x, w.x, s);
+            s = fmaf(a.y, w.y, s);
+            s = fmaf(a.z, w.z, s);
+            s = fmaf(a.w, w.w, s);
+        }
+        red[tid] = s;
+        __syncthreads();
+        if (tid < PT) {
+            float y = 0.f;
+#pragma unroll
+            for (int q = 0; q < SL; ++q) y += red[q * PT + tid];
+            y += P.b_last;
+            const float y1 = P.use_tanh ? tanhf(y) : y;
+            const float o = tanhf(y1);
+            if (JAC) {
+                float g = 1.f - o * o;
+                if (P.use_tanh) g *= (1.f - y1 * y1);
+                gy[tid] = g;
+                if (tid < n_valid && P.sdf_sel) P.sdf_sel[slots[tid]] = o;
+            } else {
+                if (tid < n_valid) P.sdf[(int64_t)blockIdx.x * PT + tid] = o;
+            }
+        }
+    }
+    if (!JAC) return;
+    __syncthreads();
+
+    // ---- backward: d out / d inputs for every point of the tile ---------------------------------------------
+    // in-gradient of layer l (features k = in-features of layer l) -> masked operand for layer l-1, or J
+    auto store_in_grad = [&](int l, auto&& value) {
+        const MlpLayer L = P.L[l];
+        const int prev_out = P.L[l - 1].out_dim;
+        const int inj_hi = prev_out + L.inj_n;
+        uint32_t mw[MW];
+#pragma unroll
+        for (int w = 0; w < MW; ++w) mw[w] = masks[((l - 1) * MW + w) * 256 + tid];
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int j0 = fbase + f * 32 + 8 * rg + 4 * hi;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int pt = p * 32 + l31;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = j0 + i;
+                        const int bit = ((f * NP + p) * 4 + rg) * 4 + i;
+                        float x = value(f, p, rg, i, k, pt);
+                        if (k < prev_out) {
+                            x = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? x : 0.f;
+                        } else {
+                            if (k < inj_hi && slots[pt] >= 0)
+                                atomicAdd(P.J + (int64_t)slots[pt] * NI + L.inj_off + (k - prev_out), x);
+                            x = 0.f;
+                        }
+                        v[i] = x;
+                    }
+                    act[(j0 >> 2) * PT + pt] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+    };
+
+    // top: in-gradient of the last linear = w_last[k] * gy[pt]
+    store_in_grad(P.n_mfma, [&](int, int, int, int, int k, int pt) { return P.w_last[k] * gy[pt]; });
+    __syncthreads();
+    for (int l = P.n_mfma - 1; l >= 0; --l) {
+        const MlpLayer L = P.L[l];
+        gemm(P.Wb + L.off_b, L.nkt_b, L.in_dim);
+        __syncthreads();
+        if (l > 0) {
+            store_in_grad(l, [&](int f, int p, int rg, int i, int, int) { return acc[f][p][rg * 4 + i]; });
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int j0 = fbase + f * 32 + 8 * rg + 4 * hi;
+                    if (j0 >= NI) continue;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const int pt = p * 32 + l31;
+                        if (slots[pt] < 0) continue;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (j0 + i < NI) atomicAdd(P.J + (int64_t)slots[pt] * NI + j0 + i, acc[f][p][rg * 4 + i]);
+                    }
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host side: packing + C ABI
+// ---------------------------------------------------------------------------------------------------------------
+
+extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_dim, const int* out_dim,
+                                   const int* inj_n, const int* inj_off, const float* const* h_W,
+                                   const float* const* h_b, int n_inputs, int use_tanh, int device) {
+    SDFR_REQUIRE(out && in_dim && out_dim && inj_n && inj_off && h_W && h_b, "sdfr_decoder_create: NULL argument");
+    SDFR_REQUIRE(n_lin >= 2 && n_lin <= SDFR_MAX_LAYERS, "sdfr_decoder_create: n_lin=%d outside [2,%d]", n_lin, SDFR_MAX_LAYERS);
+    SDFR_REQUIRE(out_dim[n_lin - 1] == 1, "sdfr_decoder_create: last layer must have out_dim 1 (got %d)", out_dim[n_lin - 1]);
+    SDFR_REQUIRE(in_dim[0] == n_inputs && inj_n[0] == 0, "sdfr_decoder_create: layer 0 must consume exactly the input row");
+    int width = 0;
+    for (int l = 0; l < n_lin; ++l) {
+        SDFR_REQUIRE(in_dim[l] > 0 && out_dim[l] > 0 && inj_n[l] >= 0 && inj_off[l] >= 0 && inj_off[l] + inj_n[l] <= n_inputs,
+                     "sdfr_decoder_create: bad dims at layer %d", l);
+        if (l > 0) SDFR_REQUIRE(in_dim[l] == out_dim[l - 1] + inj_n[l], "sdfr_decoder_create: layer %d in_dim %d != %d + %d", l,
+                                in_dim[l], out_dim[l - 1], inj_n[l]);
+        width = in_dim[l] > width ? in_dim[l] : width;
+        if (l < n_lin - 1) width = out_dim[l] > width ? out_dim[l] : width;
+    }
+    SDFR_REQUIRE(width <= 512, "sdfr_decoder_create: hidden width %d > 512 unsupported", width);
+    const int HP = width <= 128 ? 128 : (width <= 256 ? 256 : 512);
+    SDFR_HIP_CHECK(hipSetDevice(device));
+
+    sdfr_decoder* d = new sdfr_decoder();
+    memset(d, 0, sizeof(*d));
+    d->device = device; d->n_lin = n_lin; d->n_inputs = n_inputs; d->use_tanh = use_tanh; d->HP = HP;
+    MlpParams& P = d->proto;
+    P.n_mfma = n_lin - 1; P.n_inputs = n_inputs; P.use_tanh = use_tanh;
+    int64_t off_f = 0, off_b = 0;
+    for (int l = 0; l < n_lin; ++l) {
+        MlpLayer& L = P.L[l];
+        L.in_dim = in_dim[l]; L.out_dim = out_dim[l]; L.inj_n = inj_n[l]; L.inj_off = inj_off[l];
+        L.nkt_f = (in_dim[l] + 7) / 8; L.nkt_b = (out_dim[l] + 7) / 8;
+        L.off_f = (int)off_f; L.off_b = (int)off_b;
+        d->macs += (int64_t)in_dim[l] * out_dim[l];
+        if (l < n_lin - 1) { off_f += (int64_t)L.nkt_f * 2 * HP; off_b += (int64_t)L.nkt_b * 2 * HP; }
+    }
+    std::vector<float> Wf((size_t)off_f * 4, 0.f), Wb((size_t)off_b * 4, 0.f), bias((size_t)(n_lin - 1) * HP, 0.f), wl(HP, 0.f);
+    for (int l = 0; l < n_lin - 1; ++l) {
+        const MlpLayer& L = P.L[l];
+        const float* W = h_W[l];
+        for (int t = 0; t < L.nkt_f; ++t)
+            for (int kg = 0; kg < 2; ++kg)
+                for (int r = 0; r < L.out_dim; ++r)
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = 8 * t + 4 * kg + i;
+                        if (k < L.in_dim) Wf[((size_t)L.off_f + ((size_t)t * 2 + kg) * HP + r) * 4 + i] = W[(size_t)r * L.in_dim + k];
+                    }
+        for (int t = 0; t < L.nkt_b; ++t)
+            for (int jg = 0; jg < 2; ++jg)
+                for (int k = 0; k < L.in_dim; ++k)
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = 8 * t + 4 * jg + i;
+                        if (j < L.out_dim) Wb[((size_t)L.off_b + ((size_t)t * 2 + jg) * HP + k) * 4 + i] = W[(size_t)j * L.in_dim + k];
+                    }
+        for (int r = 0; r < L.out_dim; ++r) bias[(size_t)l * HP + r] = h_b[l][r];
+    }
+    for (int k = 0; k < in_dim[n_lin - 1]; ++k) wl[k] = h_W[n_lin - 1][k];
+    P.b_last = h_b[n_lin - 1][0];
+
+    SDFR_HIP_CHECK(hipMalloc(&d->d_Wf, Wf.size() * sizeof(float)));
+    SDFR_HIP_CHECK(hipMalloc(&d->d_Wb, Wb.size() * sizeof(float)));
+    SDFR_HIP_CHECK(hipMalloc(&d->d_bias, bias.size() * sizeof(float)));
+    SDFR_HIP_CHECK(hipMalloc(&d->d_wlast, wl.size() * sizeof(float)));
+    SDFR_HIP_CHECK(hipMemcpy(d->d_Wf, Wf.data(), Wf.size() * sizeof(float), hipMemcpyHostToDevice));
+    SDFR_HIP_CHECK(hipMemcpy(d->d_Wb, Wb.data(), Wb.size() * sizeof(float), hipMemcpyHostToDevice));
+    SDFR_HIP_CHECK(hipMemcpy(d->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    SDFR_HIP_CHECK(hipMemcpy(d->d_wlast, wl.data(), wl.size() * sizeof(float), hipMemcpyHostToDevice));
+    P.Wf = d->d_Wf; P.Wb = d->d_Wb; P.bias = d->d_bias; P.w_last = d->d_wlast;
+    *out = d;
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_decoder_destroy(sdfr_decoder* d) {
+    if (!d) return SDFR_OK;
+    hipFree(d->d_Wf); hipFree(d->d_Wb); hipFree(d->d_bias); hipFree(d->d_wlast);
+    delete d;
+    return SDFR_OK;
+}
+
+extern "C" int64_t sdfr_decoder_macs(const sdfr_decoder* d) { return d ? d->macs : 0; }
+
+extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, void* stream) {
+    SDFR_REQUIRE(d && inputs && sdf, "sdfr_mlp_forward: NULL argument");
+    SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward: n=%lld out of range", (long long)n);
+    if (n == 0) return SDFR_OK;
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.n = n; P.sdf = sdf;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = sdfr_cdiv(n, 64);
+    switch (d->HP) {
+        case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 2, false>), dim3(grid), dim3(256), 0, s, P); break;
+        case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, false>), dim3(grid), dim3(256), 0, s, P); break;
+        default:  hipLaunchKernelGGL((sdfr_mlp_kernel<4, 2, false>), dim3(grid), dim3(256), 0, s, P); break;
+    }
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int64_t rows_per_crop, int B,
+                                 const int32_t* idx, int cap, const int32_t* cnt, float* J, float* sdf_sel, void* stream) {
+    SDFR_REQUIRE(d && inputs && idx && J, "sdfr_mlp_jacobian: NULL argument");
+    SDFR_REQUIRE(B >= 0 && cap >= 0, "sdfr_mlp_jacobian: negative size");
+    if (B == 0 || cap == 0) return SDFR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    SDFR_HIP_CHECK(hipMemsetAsync(J, 0, (size_t)B * cap * d->n_inputs * sizeof(float), s));
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
+    dim3 grid(sdfr_cdiv(cap, 32), B);
+    switch (d->HP) {
+        case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 1, true>), grid, dim3(256), 0, s, P); break;
+        case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, true>), grid, dim3(256), 0, s, P); break;
+        default:  hipLaunchKernelGGL((sdfr_mlp_kernel<4, 1, true>), grid, dim3(256), 0, s, P); break;
+    }
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}

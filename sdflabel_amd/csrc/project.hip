@@ -1,0 +1,159 @@
+// Object -> camera projection of the surfels, front-face filter, and the backward to (points, normals, pose).
+//
+// Replaces project_in_2D with rot='dcm' (reference sdfrenderer/renderer/projection.py:7-101): RT = pose[:3] (:34-41),
+// n_c = R n (:49), NOCS colours c = p * (-1,1,1) (:53-55), p_c = RT [p;1] (:58), front-face mask n_c . p_c < 0 with an
+// order-preserving compaction (:61-70; here wave ballots + a running offset, one workgroup per crop), pinhole
+// projection K p_c / (z + eps) clamped to [-1,res] (:88-93).
+// Compiled with -ffp-contract=off; fused multiply-adds only where written explicitly.
+#include "sdfr_common.h"
+#include <float.h>
+
+#define PROJ_THREADS 1024
+
+__global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
+    const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ points,
+    const float* __restrict__ normals, const float* __restrict__ colors, int cap, const int32_t* __restrict__ cnt,
+    int output_nocs, float res_x, float res_y, float* __restrict__ p_cam, float* __restrict__ n_cam, float* __restrict__ col,
+    float* __restrict__ uv, int32_t* __restrict__ fidx, int32_t* __restrict__ fcnt) {
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int count = sdfr_count(cnt, b, cap);
+    const float* P = pose + (int64_t)b * 16;
+    const float* Kb = K + (int64_t)b * 9;
+    const float r00 = P[0], r01 = P[1], r02 = P[2], t0 = P[3];
+    const float r10 = P[4], r11 = P[5], r12 = P[6], t1 = P[7];
+    const float r20 = P[8], r21 = P[9], r22 = P[10], t2 = P[11];
+    __shared__ int wc[PROJ_THREADS / 64];
+    __shared__ int s_base;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int s0 = 0; s0 < count; s0 += PROJ_THREADS) {
+        const int s = s0 + tid;
+        bool front = false;
+        if (s < count) {
+            const int64_t e = ((int64_t)b * cap + s) * 3;
+            const float x = points[e], y = points[e + 1], z = points[e + 2];
+            const float nx = normals[e], ny = normals[e + 1], nz = normals[e + 2];
+            // p_c = RT [p;1]  (:58)   n_c = R n  (:49)
+            const float pcx = fmaf(r02, z, fmaf(r01, y, r00 * x)) + t0;
+            const float pcy = fmaf(r12, z, fmaf(r11, y, r10 * x)) + t1;
+            const float pcz = fmaf(r22, z, fmaf(r21, y, r20 * x)) + t2;
+            const float ncx = fmaf(r02, nz, fmaf(r01, ny, r00 * nx));
+            const float ncy = fmaf(r12, nz, fmaf(r11, ny, r10 * nx));
+            const float ncz = fmaf(r22, nz, fmaf(r21, ny, r20 * nx));
+            p_cam[e] = pcx; p_cam[e + 1] = pcy; p_cam[e + 2] = pcz;
+            n_cam[e] = ncx; n_cam[e + 1] = ncy; n_cam[e + 2] = ncz;
+            if (output_nocs) { col[e] = (output_nocs == 2) ? x : -x; col[e + 1] = y; col[e + 2] = z; }   // :53-55 (2: quat path, no flip :147-149)
+            else { col[e] = colors[e]; col[e + 1] = colors[e + 1]; col[e + 2] = colors[e + 2]; }
+            const float dot = ncx * pcx + ncy * pcy + ncz * pcz;                          // :62
+            front = dot < 0.f;
+            if (uv) {
+                const float hx = fmaf(Kb[2], pcz, fmaf(Kb[1], pcy, Kb[0] * pcx));
+                const float hy = fmaf(Kb[5], pcz, fmaf(Kb[4], pcy, Kb[3] * pcx));
+                const float hz = fmaf(Kb[8], pcz, fmaf(Kb[7], pcy, Kb[6] * pcx));
+                const float den = hz + FLT_EPSILON;                                        // :89
+                const int64_t e2 = ((int64_t)b * cap + s) * 2;
+                uv[e2] = fminf(fmaxf(hx / den, -1.f), res_x);                              // :92
+                uv[e2 + 1] = fminf(fmaxf(hy / den, -1.f), res_y);                          // :93
+            }
+        }
+        if (fidx) {
+            const unsigned long long bal = __ballot(front);
+            if (lane == 0) wc[wv] = __popcll(bal);
+            __syncthreads();
+            int woff = 0;
+            for (int w = 0; w < wv; ++w) woff += wc[w];
+            const int base = s_base;
+            if (front) fidx[(int64_t)b * cap + base + woff + __popcll(bal & ((1ull << lane) - 1ull))] = s;
+            __syncthreads();
+            if (tid == 0) {
+                int tot = 0;
+                for (int w = 0; w < PROJ_THREADS / 64; ++w) tot += wc[w];
+                s_base = base + tot;
+            }
+            __syncthreads();
+        }
+    }
+    if (fcnt && tid == 0) fcnt[b] = s_base;
+}
+
+extern "C" int sdfr_project_dcm(const float* pose, const float* K, const float* points, const float* normals,
+                                const float* colors, int B, int cap, const int32_t* cnt, int output_nocs, int res_x, int res_y,
+                                float* p_cam, float* n_cam, float* col, float* uv, int32_t* fidx, int32_t* fcnt, void* stream) {
+    SDFR_REQUIRE(pose && K && points && normals && p_cam && n_cam && col, "sdfr_project_dcm: NULL argument");
+    SDFR_REQUIRE(output_nocs || colors, "sdfr_project_dcm: colors required when output_nocs == 0");
+    SDFR_REQUIRE((fidx == nullptr) == (fcnt == nullptr), "sdfr_project_dcm: fidx and fcnt must be given together");
+    if (B <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_project_dcm_kernel, dim3(B), dim3(PROJ_THREADS), 0, (hipStream_t)stream, pose, K, points, normals,
+                       colors, cap, cnt, output_nocs, (float)res_x, (float)res_y, p_cam, n_cam, col, uv, fidx, fcnt);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// ---- backward ----------------------------------------------------------------------------------------------------
+// g_points = R^T g_pc (+ g_col * (-1,1,1) for NOCS), g_normals = R^T g_nc, g_pose[:3,:3] = sum g_pc p^T + g_nc n^T,
+// g_pose[:3,3] = sum g_pc.  One workgroup per crop; the 12 pose sums use a fixed-order tree (deterministic).
+
+__global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_bwd_kernel(
+    const float* __restrict__ pose, const float* __restrict__ points, const float* __restrict__ normals,
+    const float* __restrict__ g_pc, const float* __restrict__ g_nc, const float* __restrict__ g_col, int cap,
+    const int32_t* __restrict__ cnt, int output_nocs, float* __restrict__ g_points, float* __restrict__ g_normals,
+    float* __restrict__ g_colors, float* __restrict__ g_pose) {
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int count = sdfr_count(cnt, b, cap);
+    const float* P = pose + (int64_t)b * 16;
+    const float r00 = P[0], r01 = P[1], r02 = P[2];
+    const float r10 = P[4], r11 = P[5], r12 = P[6];
+    const float r20 = P[8], r21 = P[9], r22 = P[10];
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int s = tid; s < count; s += PROJ_THREADS) {
+        const int64_t e = ((int64_t)b * cap + s) * 3;
+        const float x = points[e], y = points[e + 1], z = points[e + 2];
+        const float nx = normals[e], ny = normals[e + 1], nz = normals[e + 2];
+        const float ax = g_pc ? g_pc[e] : 0.f, ay = g_pc ? g_pc[e + 1] : 0.f, az = g_pc ? g_pc[e + 2] : 0.f;
+        const float bx = g_nc ? g_nc[e] : 0.f, by = g_nc ? g_nc[e + 1] : 0.f, bz = g_nc ? g_nc[e + 2] : 0.f;
+        float gx = r00 * ax + r10 * ay + r20 * az;
+        float gy = r01 * ax + r11 * ay + r21 * az;
+        float gz = r02 * ax + r12 * ay + r22 * az;
+        if (g_col) {
+            if (output_nocs) { gx += (output_nocs == 2) ? g_col[e] : -g_col[e]; gy += g_col[e + 1]; gz += g_col[e + 2]; }
+            else if (g_colors) { g_colors[e] = g_col[e]; g_colors[e + 1] = g_col[e + 1]; g_colors[e + 2] = g_col[e + 2]; }
+        } else if (!output_nocs && g_colors) { g_colors[e] = 0.f; g_colors[e + 1] = 0.f; g_colors[e + 2] = 0.f; }
+        g_points[e] = gx; g_points[e + 1] = gy; g_points[e + 2] = gz;
+        g_normals[e] = r00 * bx + r10 * by + r20 * bz;
+        g_normals[e + 1] = r01 * bx + r11 * by + r21 * bz;
+        g_normals[e + 2] = r02 * bx + r12 * by + r22 * bz;
+        acc[0] += ax * x + bx * nx; acc[1] += ax * y + bx * ny; acc[2] += ax * z + bx * nz; acc[3] += ax;
+        acc[4] += ay * x + by * nx; acc[5] += ay * y + by * ny; acc[6] += ay * z + by * nz; acc[7] += ay;
+        acc[8] += az * x + bz * nx; acc[9] += az * y + bz * ny; acc[10] += az * z + bz * nz; acc[11] += az;
+    }
+    __shared__ float red[12][PROJ_THREADS / 64];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        float v = acc[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((tid & 63) == 0) red[i][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float v = 0.f;
+        if (tid < 12)
+            for (int w = 0; w < PROJ_THREADS / 64; ++w) v += red[tid][w];
+        g_pose[(int64_t)b * 16 + tid] = v;
+    }
+}
+
+extern "C" int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* normals, const float* g_p_cam,
+                                    const float* g_n_cam, const float* g_col, int B, int cap, const int32_t* cnt, int output_nocs,
+                                    float* g_points, float* g_normals, float* g_colors, float* g_pose, void* stream) {
+    SDFR_REQUIRE(pose && points && normals && g_points && g_normals && g_pose, "sdfr_project_dcm_bwd: NULL argument");
+    if (B <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_project_dcm_bwd_kernel, dim3(B), dim3(PROJ_THREADS), 0, (hipStream_t)stream, pose, points, normals,
+                       g_p_cam, g_n_cam, g_col, cap, cnt, output_nocs, g_points, g_normals, g_colors, g_pose);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}

@@ -1,0 +1,188 @@
+// Zero-isosurface band selection / projection and the DeepSDF input-gradient scatter (gfx950).
+//
+// Replaces Grid3D.get_surface_points (reference sdfrenderer/grid.py:43-71): band mask |sdf| < thr (:64),
+// order-preserving compaction (masked_select, :65-66) done with wave ballots instead of a dense boolean mask,
+// n_hat = n/||n|| (:57-58), p = x - sdf*n_hat (:61), nocs = (p+1)/2 (:67), and the autograd backward of (:61,:67).
+// Compiled with -ffp-contract=off: every multiply/add below rounds separately, like the reference's ATen ops.
+#include "sdfr_common.h"
+
+// ---- band selection -------------------------------------------------------------------------------------------
+// pass 1: per-256-row block counts; pass 2: block offset = sum of the preceding block counts of the same crop,
+// rank inside the block from ballot/popcount prefix.  No inter-workgroup hand-off inside a launch.
+
+__global__ __launch_bounds__(256) void sdfr_band_count_kernel(const float* __restrict__ sdf, int64_t G, float thr,
+                                                             int32_t* __restrict__ blockcnt) {
+    const int b = blockIdx.y;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool in = false;
+    if (g < G) in = fabsf(sdf[(int64_t)b * G + g]) < thr;
+    const unsigned long long bal = __ballot(in);
+    __shared__ int wc[4];
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) blockcnt[(int64_t)b * gridDim.x + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+__global__ __launch_bounds__(256) void sdfr_band_scatter_kernel(const float* __restrict__ sdf, int64_t G, float thr,
+                                                               const int32_t* __restrict__ blockcnt, int32_t* __restrict__ idx,
+                                                               int cap, int32_t* __restrict__ cnt, int32_t* __restrict__ slot) {
+    const int b = blockIdx.y;
+    const int nblk = gridDim.x;
+    const int tid = threadIdx.x;
+    __shared__ int part[256];
+    __shared__ int wc[4];
+    // offset of this block = sum of counts of blocks [0, blockIdx.x) of crop b; the last block also needs the total
+    int s = 0;
+    for (int i = tid; i < (int)blockIdx.x; i += 256) s += blockcnt[(int64_t)b * nblk + i];
+    part[tid] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) part[tid] += part[tid + st];
+        __syncthreads();
+    }
+    const int base = part[0];
+    const int64_t g = (int64_t)blockIdx.x * 256 + tid;
+    bool in = false;
+    if (g < G) in = fabsf(sdf[(int64_t)b * G + g]) < thr;
+    const unsigned long long bal = __ballot(in);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) wc[wv] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wv; ++w) woff += wc[w];
+    const int rank = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+    if (g < G) {
+        int sl = -1;
+        if (in && rank < cap) {
+            idx[(int64_t)b * cap + rank] = (int32_t)g;
+            sl = rank;
+        }
+        if (slot) slot[(int64_t)b * G + g] = sl;
+    }
+    if (blockIdx.x == nblk - 1 && tid == 0) cnt[b] = base + wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+extern "C" int sdfr_band_select(const float* sdf, int64_t G, int B, float thr, int32_t* idx, int cap, int32_t* cnt,
+                                int32_t* slot, int32_t* scratch, void* stream) {
+    SDFR_REQUIRE(sdf && idx && cnt && scratch, "sdfr_band_select: NULL argument");
+    SDFR_REQUIRE(G >= 0 && B >= 0 && cap >= 0, "sdfr_band_select: negative size");
+    if (B == 0) return SDFR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (G == 0) { SDFR_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * B, s)); return SDFR_OK; }
+    dim3 grid(sdfr_cdiv(G, 256), B);
+    hipLaunchKernelGGL(sdfr_band_count_kernel, grid, dim3(256), 0, s, sdf, G, thr, scratch);
+    SDFR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sdfr_band_scatter_kernel, grid, dim3(256), 0, s, sdf, G, thr, scratch, idx, cap, cnt, slot);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// ---- projection onto the zero level set -----------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void sdfr_surface_project_kernel(const float* __restrict__ xyz, int xyz_stride,
+                                                                  const float* __restrict__ sdf, int64_t G,
+                                                                  const int32_t* __restrict__ idx, int cap,
+                                                                  const int32_t* __restrict__ cnt, const float* __restrict__ J,
+                                                                  int Jstride, int Joff, float* __restrict__ points,
+                                                                  float* __restrict__ nocs, float* __restrict__ normals) {
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= sdfr_count(cnt, b, cap)) return;
+    const int64_t e = (int64_t)b * cap + s;
+    const int64_t r = (int64_t)b * G + idx[e];
+    const float* x = xyz + r * xyz_stride;
+    const float* n = J + e * Jstride + Joff;
+    const float nx = n[0], ny = n[1], nz = n[2];
+    const float nrm = sqrtf(nx * nx + ny * ny + nz * nz);          // grid.py:57
+    const float hx = nx / nrm, hy = ny / nrm, hz = nz / nrm;       // grid.py:58
+    const float sd = sdf[r];
+    const float px = x[0] - sd * hx, py = x[1] - sd * hy, pz = x[2] - sd * hz;   // grid.py:61
+    points[e * 3 + 0] = px; points[e * 3 + 1] = py; points[e * 3 + 2] = pz;
+    normals[e * 3 + 0] = hx; normals[e * 3 + 1] = hy; normals[e * 3 + 2] = hz;
+    if (nocs) {
+        nocs[e * 3 + 0] = (px + 1.f) / 2.f; nocs[e * 3 + 1] = (py + 1.f) / 2.f; nocs[e * 3 + 2] = (pz + 1.f) / 2.f;   // grid.py:67
+    }
+}
+
+extern "C" int sdfr_surface_project(const float* xyz, int xyz_stride, const float* sdf, int64_t G, int B,
+                                    const int32_t* idx, int cap, const int32_t* cnt, const float* J, int Jstride, int Joff,
+                                    float* points, float* nocs, float* normals, void* stream) {
+    SDFR_REQUIRE(xyz && sdf && idx && J && points && normals, "sdfr_surface_project: NULL argument");
+    if (B <= 0 || cap <= 0) return SDFR_OK;
+    dim3 grid(sdfr_cdiv(cap, 256), B);
+    hipLaunchKernelGGL(sdfr_surface_project_kernel, grid, dim3(256), 0, (hipStream_t)stream, xyz, xyz_stride, sdf, G, idx, cap,
+                       cnt, J, Jstride, Joff, points, nocs, normals);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+__global__ __launch_bounds__(256) void sdfr_surface_project_bwd_kernel(const float* __restrict__ g_points,
+                                                                      const float* __restrict__ g_nocs,
+                                                                      const float* __restrict__ normals, int64_t G,
+                                                                      const int32_t* __restrict__ idx, int cap,
+                                                                      const int32_t* __restrict__ cnt, float* __restrict__ g_sdf,
+                                                                      float* __restrict__ g_xyz) {
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= sdfr_count(cnt, b, cap)) return;
+    const int64_t e = (int64_t)b * cap + s;
+    const int64_t r = (int64_t)b * G + idx[e];
+    float gx = g_points[e * 3 + 0], gy = g_points[e * 3 + 1], gz = g_points[e * 3 + 2];
+    if (g_nocs) { gx += g_nocs[e * 3 + 0] / 2.f; gy += g_nocs[e * 3 + 1] / 2.f; gz += g_nocs[e * 3 + 2] / 2.f; }
+    const float hx = normals[e * 3 + 0], hy = normals[e * 3 + 1], hz = normals[e * 3 + 2];
+    g_sdf[r] = -(gx * hx + gy * hy + gz * hz);
+    if (g_xyz) { g_xyz[r * 3 + 0] = gx; g_xyz[r * 3 + 1] = gy; g_xyz[r * 3 + 2] = gz; }
+}
+
+extern "C" int sdfr_surface_project_bwd(const float* g_points, const float* g_nocs, const float* normals, int64_t G, int B,
+                                        const int32_t* idx, int cap, const int32_t* cnt, float* g_sdf, float* g_xyz,
+                                        void* stream) {
+    SDFR_REQUIRE(g_points && normals && idx && g_sdf, "sdfr_surface_project_bwd: NULL argument");
+    if (B <= 0) return SDFR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    SDFR_HIP_CHECK(hipMemsetAsync(g_sdf, 0, sizeof(float) * (size_t)B * G, s));
+    if (g_xyz) SDFR_HIP_CHECK(hipMemsetAsync(g_xyz, 0, sizeof(float) * (size_t)B * G * 3, s));
+    if (cap <= 0) return SDFR_OK;
+    dim3 grid(sdfr_cdiv(cap, 256), B);
+    hipLaunchKernelGGL(sdfr_surface_project_bwd_kernel, grid, dim3(256), 0, s, g_points, g_nocs, normals, G, idx, cap, cnt,
+                       g_sdf, g_xyz);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// ---- DeepSDF backward through the cached band Jacobian --------------------------------------------------------
+
+__global__ __launch_bounds__(256) void sdfr_sdf_input_grad_kernel(const float* __restrict__ g_sdf, const int32_t* __restrict__ slot,
+                                                                 const float* __restrict__ J, int NI, int64_t G, int cap,
+                                                                 float* __restrict__ g_inputs, int32_t* __restrict__ n_uncached) {
+    const int b = blockIdx.y;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool miss = false;
+    if (g < G) {
+        const int64_t r = (int64_t)b * G + g;
+        const float gs = g_sdf[r];
+        const int sl = slot[r];
+        float* out = g_inputs + r * NI;
+        if (sl >= 0) {
+            const float* j = J + ((int64_t)b * cap + sl) * NI;
+            for (int c = 0; c < NI; ++c) out[c] = gs * j[c];
+        } else {
+            for (int c = 0; c < NI; ++c) out[c] = 0.f;
+            miss = (gs != 0.f);
+        }
+    }
+    const unsigned long long bal = __ballot(miss);
+    if (n_uncached && bal && (threadIdx.x & 63) == 0) atomicAdd(n_uncached, (int)__popcll(bal));
+}
+
+extern "C" int sdfr_sdf_input_grad(const float* g_sdf, const int32_t* slot, const float* J, int n_inputs, int64_t G, int B,
+                                   int cap, float* g_inputs, int32_t* n_uncached, void* stream) {
+    SDFR_REQUIRE(g_sdf && slot && J && g_inputs, "sdfr_sdf_input_grad: NULL argument");
+    if (B <= 0 || G <= 0) return SDFR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_uncached) SDFR_HIP_CHECK(hipMemsetAsync(n_uncached, 0, sizeof(int32_t), s));
+    dim3 grid(sdfr_cdiv(G, 256), B);
+    hipLaunchKernelGGL(sdfr_sdf_input_grad_kernel, grid, dim3(256), 0, s, g_sdf, slot, J, n_inputs, G, cap, g_inputs, n_uncached);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}

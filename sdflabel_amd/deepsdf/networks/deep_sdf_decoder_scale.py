@@ -1,0 +1,201 @@
+"""DeepSDF decoder with the HIP forward / input-Jacobian backward.
+
+Host-side mirror of the reference `Decoder` (sdfrenderer/deepsdf/networks/deep_sdf_decoder_scale.py:9-114): same
+constructor arguments, same parameter names (lin{l}.weight_g/_v or .weight, .bias, scale_net.*) so reference checkpoints
+load with load_state_dict, same call signature  dsdf(inputs[G, L+3]) -> (sdf[G,1], scale).  The arithmetic of forward and of
+the backward w.r.t. `inputs` runs in sdflabel_amd/csrc/mlp.hip through the C ABI (sdfr_mlp_forward / sdfr_mlp_jacobian).
+Decoder weights are treated as frozen constants of the graph (they are: pipelines/optimizer.py:34-38 optimises only
+yaw/trans/scale/latent); no gradient is produced for them.
+"""
+import ctypes
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _lib
+
+
+class _DecoderHandle:
+    """Owns the packed device image of the effective weights (sdfr_decoder)."""
+
+    def __init__(self, layers, n_inputs, inj, use_tanh, device_index):
+        n = len(layers)
+        in_dim = (ctypes.c_int * n)(*[int(W.shape[1]) for W, _ in layers])
+        out_dim = (ctypes.c_int * n)(*[int(W.shape[0]) for W, _ in layers])
+        inj_n = (ctypes.c_int * n)(*[i[0] for i in inj])
+        inj_off = (ctypes.c_int * n)(*[i[1] for i in inj])
+        self._keep = [(np.ascontiguousarray(W, np.float32), np.ascontiguousarray(b, np.float32)) for W, b in layers]
+        Wp = (ctypes.c_void_p * n)(*[w.ctypes.data for w, _ in self._keep])
+        bp = (ctypes.c_void_p * n)(*[b.ctypes.data for _, b in self._keep])
+        h = ctypes.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.sdfr_decoder_create(ctypes.byref(h), n, in_dim, out_dim, inj_n, inj_off, Wp, bp, n_inputs, int(use_tanh),
+                                         device_index), "sdfr_decoder_create")
+        self.h = h
+        self.n_inputs = n_inputs
+        self.macs = int(L.sdfr_decoder_macs(h))
+        self._keep = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.lib().sdfr_decoder_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class SdfState:
+    """Per-forward record shared between dsdf(inputs), Grid3D.get_surface_points and the backward: the input rows and the
+    band Jacobian cache (idx, slot, J) so that the latent gradient needs no second pass through the MLP."""
+
+    def __init__(self, handle, inputs):
+        self.handle = handle
+        self.inputs = inputs          # (G, NI) float32 contiguous, detached
+        self.G = inputs.shape[0]
+        self.idx = None               # (cap,) int32 band rows
+        self.slot = None              # (G,) int32 position in idx or -1
+        self.J = None                 # (cap, NI) d sdf / d inputs at the band rows
+        self.cap = 0
+
+
+def mlp_jacobian(state, idx, n):
+    """J (n, NI), sdf_sel (n,) for the rows idx[:n] of state.inputs."""
+    L = _lib.lib()
+    J = torch.empty((max(n, 1), state.inputs.shape[1]), dtype=torch.float32, device=state.inputs.device)
+    sel = torch.empty((max(n, 1),), dtype=torch.float32, device=state.inputs.device)
+    if n > 0:
+        _lib.check(L.sdfr_mlp_jacobian(state.handle.h, _lib.ptr(state.inputs), state.G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
+                                       _lib.ptr(sel), _lib.stream_ptr()), "sdfr_mlp_jacobian")
+    return J[:n], sel[:n]
+
+
+class _DeepSDFFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, state):
+        L = _lib.lib()
+        sdf = torch.empty((state.G, 1), dtype=torch.float32, device=inputs.device)
+        _lib.check(L.sdfr_mlp_forward(state.handle.h, _lib.ptr(state.inputs), state.G, _lib.ptr(sdf), _lib.stream_ptr()),
+                   "sdfr_mlp_forward")
+        ctx.state = state
+        return sdf
+
+    @staticmethod
+    def backward(ctx, g_sdf):
+        st = ctx.state
+        L = _lib.lib()
+        g_sdf = g_sdf.contiguous().float()
+        NI = st.inputs.shape[1]
+        g_in = torch.empty((st.G, NI), dtype=torch.float32, device=g_sdf.device)
+        if st.J is not None:
+            miss = torch.zeros((1,), dtype=torch.int32, device=g_sdf.device)
+            _lib.check(L.sdfr_sdf_input_grad(_lib.ptr(g_sdf), _lib.ptr(st.slot), _lib.ptr(st.J), NI, st.G, 1, st.cap, _lib.ptr(g_in),
+                                             _lib.ptr(miss), _lib.stream_ptr()), "sdfr_sdf_input_grad")
+            if int(miss.item()) == 0:
+                return g_in, None
+        # rows outside the cached band carry gradient: evaluate the Jacobian exactly where it is needed
+        rows = torch.nonzero(g_sdf.view(-1) != 0).view(-1).to(torch.int32).contiguous()
+        n = int(rows.numel())
+        g_in.zero_()
+        if n > 0:
+            J, _ = mlp_jacobian(st, rows, n)
+            g_in[rows.long()] = J * g_sdf.view(-1)[rows.long()].unsqueeze(1)
+        return g_in, None
+
+
+class Decoder(nn.Module):
+    """Same constructor as the reference Decoder (deep_sdf_decoder_scale.py:10-75)."""
+
+    def __init__(self, latent_size, dims, dropout=None, dropout_prob=0.0, norm_layers=(), latent_in=(), weight_norm=False,
+                 xyz_in_all=None, use_tanh=False, latent_dropout=False, samples_per_scene=None):
+        super().__init__()
+        dims = [latent_size + 3] + list(dims) + [1]
+        self.num_layers = len(dims)
+        self.norm_layers = norm_layers
+        self.latent_in = latent_in
+        self.latent_dropout = latent_dropout
+        self.xyz_in_all = xyz_in_all
+        self.weight_norm = weight_norm
+        self.samples_per_scene = samples_per_scene
+        self.latent_size = latent_size
+        for l in range(self.num_layers - 1):
+            if l + 1 in latent_in:
+                out_dim = dims[l + 1] - dims[0]
+            else:
+                out_dim = dims[l + 1]
+                if self.xyz_in_all and l != self.num_layers - 2:
+                    out_dim -= 3
+            lin = nn.Linear(dims[l], out_dim)
+            if weight_norm and l in self.norm_layers:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    lin = nn.utils.weight_norm(lin)          # keeps the reference's weight_g / weight_v parameter names
+            setattr(self, "lin" + str(l), lin)
+            if (not weight_norm) and self.norm_layers is not None and l in self.norm_layers:
+                setattr(self, "bn" + str(l), nn.LayerNorm(out_dim))
+        self.use_tanh = use_tanh
+        self.dropout_prob = dropout_prob
+        self.dropout = dropout
+        self.scale_net = nn.Sequential(nn.Linear(latent_size, 3), nn.ReLU(True), nn.Linear(3, 3), nn.ReLU(True), nn.Linear(3, 1))
+        self._handle = None
+        self._handle_key = None
+
+    # -- effective weights ---------------------------------------------------------------------------------------------
+    def effective_layers(self):
+        """[(W[out,in], b[out])] float32 numpy, weight-norm folded as torch does: w = v * (g / ||v||_row)."""
+        out = []
+        for l in range(self.num_layers - 1):
+            lin = getattr(self, "lin" + str(l))
+            if hasattr(lin, "weight_v"):
+                v = lin.weight_v.detach().float()
+                g = lin.weight_g.detach().float()
+                W = v * (g / v.norm(2, dim=1, keepdim=True))
+            else:
+                W = lin.weight.detach().float()
+            out.append((W.cpu().numpy(), lin.bias.detach().float().cpu().numpy()))
+        return out
+
+    def _inject_table(self):
+        inj = []
+        n_in = self.latent_size + 3
+        for l in range(self.num_layers - 1):
+            if l in self.latent_in:
+                inj.append((n_in, 0))
+            elif l != 0 and self.xyz_in_all:
+                inj.append((3, self.latent_size))
+            else:
+                inj.append((0, 0))
+        return inj
+
+    def _param_key(self, device):
+        return (str(device),) + tuple((id(p), p._version) for p in self.parameters())
+
+    def handle(self, device):
+        key = self._param_key(device)
+        if self._handle is None or self._handle_key != key:
+            for l in range(self.num_layers - 1):
+                if hasattr(self, "bn" + str(l)):
+                    raise _lib.SdfrError("LayerNorm decoders (weight_norm=False with norm_layers) are not supported by the HIP path")
+            self._handle = _DecoderHandle(self.effective_layers(), self.latent_size + 3, self._inject_table(), self.use_tanh,
+                                          device.index if device.index is not None else torch.cuda.current_device())
+            self._handle_key = key
+        return self._handle
+
+    # input: N x (L+3)
+    def forward(self, input):
+        _lib.require_gpu_f32(input)
+        if self.training and ((self.dropout is not None and self.dropout_prob > 0) or self.latent_dropout):
+            raise _lib.SdfrError("the HIP decoder evaluates in eval() mode only (dropout is inactive in the renderer path)")
+        if input.dim() != 2 or input.shape[1] != self.latent_size + 3:
+            raise _lib.SdfrError("decoder input must be (N, %d)" % (self.latent_size + 3))
+        state = SdfState(self.handle(input.device), input.detach().contiguous())
+        x = _DeepSDFFn.apply(input, state)
+        x._sdfr_state = state
+        lat = input[:, :-3]
+        if self.samples_per_scene:
+            scale = self.scale_net(lat.view(-1, self.samples_per_scene, lat.size(1))[:, 0, :])
+        else:
+            scale = self.scale_net(lat[0])
+        return x, scale

@@ -1,0 +1,99 @@
+"""Grid3D -- staggered sample grid and zero-isosurface projection (mirror of the reference sdfrenderer/grid.py:17-71).
+
+Same interface: Grid3D(density, device, precision), .points (leaf, requires_grad), get_surface_points(pred_sdf_grid, threshold)
+-> (points (N,3), nocs (N,3), normals (N,3)).  Unlike the reference there is no module-global `grads` dict / tensor hook
+(grid.py:6-14,20): when `pred_sdf_grid` comes from the HIP decoder the normals are the xyz columns of the band Jacobian computed
+by sdfr_mlp_jacobian for the band rows only; for any other differentiable SDF they come from torch.autograd.grad.  Band selection,
+compaction and projection run in sdflabel_amd/csrc/surface.hip.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .deepsdf.networks.deep_sdf_decoder_scale import mlp_jacobian
+
+
+class _SurfaceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sdf, gridpoints, xyz_src, xyz_stride, idx, n, J, Jstride, Joff):
+        L = _lib.lib()
+        dev = sdf.device
+        G = sdf.shape[0]
+        pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        nocs = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        nrm = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        if n > 0:
+            _lib.check(L.sdfr_surface_project(_lib.ptr(xyz_src), xyz_stride, _lib.ptr(sdf), G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
+                                              Jstride, Joff, _lib.ptr(pts), _lib.ptr(nocs), _lib.ptr(nrm), _lib.stream_ptr()),
+                       "sdfr_surface_project")
+        ctx.save_for_backward(nrm, idx)
+        ctx.n, ctx.G = n, G
+        ctx.mark_non_differentiable(nrm)
+        return pts, nocs, nrm
+
+    @staticmethod
+    def backward(ctx, g_pts, g_nocs, _g_nrm):
+        L = _lib.lib()
+        nrm, idx = ctx.saved_tensors
+        n, G = ctx.n, ctx.G
+        dev = nrm.device
+        g_sdf = torch.empty((G, 1), dtype=torch.float32, device=dev)
+        g_xyz = torch.empty((G, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        if g_pts is None:
+            g_pts = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+        g_pts = g_pts.contiguous().float()
+        g_nocs = None if g_nocs is None else g_nocs.contiguous().float()
+        _lib.check(L.sdfr_surface_project_bwd(_lib.ptr(g_pts), _lib.ptr(g_nocs), _lib.ptr(nrm), G, 1, _lib.ptr(idx), n, None,
+                                              _lib.ptr(g_sdf), _lib.ptr(g_xyz), _lib.stream_ptr()), "sdfr_surface_project_bwd")
+        return g_sdf, g_xyz, None, None, None, None, None, None, None
+
+
+def band_select(sdf_flat, threshold, want_slot=True):
+    """(idx int32 (N,), N, slot int32 (G,)) -- ascending rows with |sdf| < threshold.  One host sync for N (the reference's
+    masked_select, grid.py:65, synchronises as well)."""
+    L = _lib.lib()
+    G = sdf_flat.shape[0]
+    dev = sdf_flat.device
+    idx = torch.empty((max(G, 1),), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    slot = torch.empty((max(G, 1),), dtype=torch.int32, device=dev) if want_slot else None
+    scratch = torch.empty(((G + 255) // 256 + 1,), dtype=torch.int32, device=dev)
+    _lib.check(L.sdfr_band_select(_lib.ptr(sdf_flat), G, 1, float(threshold), _lib.ptr(idx), G, _lib.ptr(cnt), _lib.ptr(slot),
+                                  _lib.ptr(scratch), _lib.stream_ptr()), "sdfr_band_select")
+    n = int(cnt.item())
+    return idx, n, slot
+
+
+class Grid3D:
+    def __init__(self, density=30, device='cpu', precision=torch.float32):
+        self.points = self.generate_point_grid(density).to(device, precision).requires_grad_(True)
+
+    def generate_point_grid(self, grid_density):
+        """Staggered grid, z fastest; every odd flat index is shifted by 1/D in x and y (reference grid.py:22-41)."""
+        lin = np.mgrid[-1:1:grid_density * 1j]
+        X, Y, Z = np.meshgrid(lin, lin, lin, indexing="ij")
+        g = np.stack([X, Y, Z], axis=-1).reshape(-1, 3)
+        g[1::2, :2] += (lin.max() - lin.min()) / grid_density / 2
+        return torch.from_numpy(g.astype(np.float32))
+
+    def get_surface_points(self, pred_sdf_grid, threshold=0.03):
+        """Zero-isosurface projection: returns projected points (N,3), NOCS (N,3), normals (N,3)."""
+        _lib.require_gpu_f32(pred_sdf_grid)
+        if pred_sdf_grid.dim() != 2 or pred_sdf_grid.shape[1] != 1 or pred_sdf_grid.shape[0] != self.points.shape[0]:
+            raise _lib.SdfrError("pred_sdf_grid must be (G,1) with G = number of grid points")
+        sdf_c = pred_sdf_grid.detach().contiguous()
+        state = getattr(pred_sdf_grid, "_sdfr_state", None)
+        idx, n, slot = band_select(sdf_c.view(-1), threshold)
+        if state is not None and state.G == self.points.shape[0]:
+            # fused path: Jacobian of the HIP decoder at the band rows only
+            J, _ = mlp_jacobian(state, idx, n)
+            J = J.contiguous()
+            state.idx, state.slot, state.J, state.cap = idx, slot, J, max(n, 1)
+            NI = state.inputs.shape[1]
+            xyz_src = state.inputs[:, NI - 3:]
+            return _SurfaceFn.apply(pred_sdf_grid, self.points, xyz_src, NI, idx, n, J, NI, NI - 3)
+        # generic path: any differentiable SDF of self.points
+        (g,) = torch.autograd.grad(pred_sdf_grid.sum(), self.points, retain_graph=True)
+        Jn = g.detach().index_select(0, idx[:n].long()).contiguous()
+        pts_src = self.points.detach().contiguous()
+        return _SurfaceFn.apply(pred_sdf_grid, self.points, pts_src, 3, idx, n, Jn, 3, 0)

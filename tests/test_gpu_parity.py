@@ -1,0 +1,410 @@
+"""GPU parity tests: the HIP path (through the C ABI / the drop-in Python boundary) against the numpy oracle and the
+golden vectors captured from the reference.  Tolerances: 1e-4 on rendered images (BASELINE.json north_star), tighter on
+per-kernel quantities.  Discontinuous selections (band, front-face, disc) are exact on the fixtures, whose minimum margins to
+the thresholds are recorded in the goldens; where a flip of a (pixel, surfel) pair within float rounding of the disc edge is
+possible, the affected pixels must be attributable to a margin < 1e-5 and are bounded to 0.1 % of the image."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import sdflabel_amd
+from sdflabel_amd import _lib
+from oracle import sdf_oracle as O
+from tests._util import ASSET, K_for, fitted_state, gold, state_from_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(a, **kw):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV, **kw)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def dec():
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt")
+    return d.to(DEV)
+
+
+@pytest.fixture(scope="module")
+def oracle_layers():
+    st, spec = fitted_state()
+    return O.decoder_layers_from_state(st, spec), spec
+
+
+def rot_from_yaw(yaw):
+    c, s = torch.cos(yaw), torch.sin(yaw)
+    z, o = yaw.new_zeros(1), yaw.new_ones(1)
+    return torch.stack((c, z, s, z, o, z, -s, z, c)).view(3, 3)
+
+
+def build_pose(yaw, trans):
+    """the pose construction of pipelines/optimizer.py:86-90 (a9 harness)"""
+    pose = torch.eye(4, device=yaw.device)
+    pose[:3, :3] = rot_from_yaw(yaw)
+    pose[1] *= -1
+    pose[:3, 3] = trans
+    return pose
+
+
+def images_close(got, ref, aux=None, atol=1e-4, frac=1e-3):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape
+    bad = np.abs(got - ref) > atol
+    if not bad.any():
+        return
+    assert aux is not None, "max diff %g" % np.abs(got - ref).max()
+    badpix = bad.reshape(bad.shape[0], -1).any(axis=0)
+    near = (aux["margin_disc"] < 1e-5) | (aux["margin_b"] < 1e-5)
+    assert not (badpix & ~near).any(), "pixels differ beyond tolerance away from any selection threshold"
+    assert badpix.mean() <= frac
+
+
+# ---- decoder ------------------------------------------------------------------------------------------------------
+
+def test_mlp_forward_golden_fitted(dec):
+    z = gold("g2_decoder.npz")
+    inp = T(z["fit_inputs"])
+    sdf, scale = dec(inp)
+    assert sdf.shape == (inp.shape[0], 1)
+    assert np.abs(N(sdf) - z["fit_sdf"]).max() < 5e-6
+    assert np.allclose(N(scale), z["fit_scale"], atol=1e-6)
+
+
+def test_mlp_backward_golden_fitted(dec):
+    z = gold("g2_decoder.npz")
+    inp = T(z["fit_inputs"]).requires_grad_(True)
+    sdf, _ = dec(inp)
+    sdf.sum().backward()          # generic backward: no band cache, every row carries gradient
+    ref = z["fit_grad_inputs"]
+    assert np.abs(N(inp.grad) - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("wn", dict(latent_size=3, dims=[64] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
+                weight_norm=True)),
+    ("x", dict(latent_size=5, dims=[48] * 5, dropout=None, norm_layers=(), latent_in=[2, 4], weight_norm=False, xyz_in_all=True,
+               use_tanh=True)),
+])
+def test_mlp_small_specs_golden(tag, kw):
+    z = gold("g2_decoder.npz")
+    d = sdflabel_amd.Decoder(**kw)
+    d.load_state_dict({k: torch.from_numpy(v) for k, v in state_from_npz(z, tag + "_state_").items()})
+    d = d.to(DEV).eval()
+    inp = T(z[tag + "_inputs"]).requires_grad_(True)
+    sdf, scale = d(inp)
+    assert np.abs(N(sdf) - z[tag + "_sdf"]).max() < 5e-6
+    g_out = T(z[tag + "_gout"]) if (tag + "_gout") in z.files else torch.ones_like(sdf)
+    (sdf * g_out).sum().backward()
+    ref = z[tag + "_grad_inputs"]
+    assert np.abs(N(inp.grad) - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_layernorm_decoder_rejected():
+    d = sdflabel_amd.Decoder(3, dims=[64] * 8, norm_layers=list(range(8)), latent_in=[4], weight_norm=False).to(DEV).eval()
+    with pytest.raises(_lib.SdfrError):
+        d(torch.zeros(4, 6, device=DEV))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
+def test_mlp_forward_ragged_sizes_vs_oracle(dec, oracle_layers, n):
+    layers, spec = oracle_layers
+    rng = np.random.default_rng(n)
+    inp = (rng.standard_normal((n, 6)) * 0.6).astype(np.float32)
+    sdf, _ = dec(T(inp))
+    ref = O.decoder_forward(layers, spec, inp)
+    assert np.abs(N(sdf) - ref).max() < 5e-6
+
+
+def test_mlp_jacobian_selected_rows_vs_oracle(dec, oracle_layers):
+    layers, spec = oracle_layers
+    rng = np.random.default_rng(5)
+    inp = (rng.standard_normal((500, 6)) * 0.6).astype(np.float32)
+    rows = np.sort(rng.choice(500, 77, replace=False)).astype(np.int32)
+    from sdflabel_amd.deepsdf.networks.deep_sdf_decoder_scale import SdfState, mlp_jacobian
+    st = SdfState(dec.handle(torch.device(DEV, 0)), T(inp))
+    J, sel = mlp_jacobian(st, T(rows), len(rows))
+    sdf, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+    Jref = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(sdf))[rows]
+    assert np.abs(N(sel) - sdf[rows, 0]).max() < 5e-6
+    assert np.abs(N(J) - Jref).max() < 2e-5 * max(1.0, np.abs(Jref).max())
+
+
+def test_mlp_forward_empty(dec):
+    sdf, _ = dec(torch.zeros((1, 6), device=DEV))
+    assert sdf.shape == (1, 1)
+
+
+# ---- band selection / surface ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("G,frac", [(1, 1.0), (255, 0.3), (256, 0.0), (257, 1.0), (4096, 0.05), (64000, 0.04)])
+def test_band_select_matches_nonzero(G, frac):
+    from sdflabel_amd.grid import band_select
+    rng = np.random.default_rng(G)
+    sdf = rng.uniform(0.031, 1.0, G).astype(np.float32) * rng.choice([-1, 1], G)
+    k = int(round(frac * G))
+    pick = rng.choice(G, k, replace=False)
+    sdf[pick] = rng.uniform(-0.0299, 0.0299, k).astype(np.float32)
+    idx, n, slot = band_select(T(sdf), 0.03)
+    ref = np.nonzero(np.abs(sdf) < np.float32(0.03))[0]
+    assert n == len(ref)
+    assert np.array_equal(N(idx)[:n], ref)
+    s = N(slot)[:G]
+    assert np.array_equal(np.nonzero(s >= 0)[0], ref) and np.array_equal(s[ref], np.arange(n))
+
+
+def test_band_select_capacity_overflow_reports_true_count():
+    L = _lib.lib()
+    G, cap = 1000, 10
+    sdf = torch.zeros(G, device=DEV)
+    idx = torch.full((cap,), -7, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    scratch = torch.zeros(8, dtype=torch.int32, device=DEV)
+    _lib.check(L.sdfr_band_select(_lib.ptr(sdf), G, 1, 0.03, _lib.ptr(idx), cap, _lib.ptr(cnt), None, _lib.ptr(scratch),
+                                  _lib.stream_ptr()), "band")
+    assert int(cnt.item()) == G and np.array_equal(N(idx), np.arange(cap))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_surface_points_golden(dec, tag):
+    z = gold("g3_surface.npz")
+    D = int(z[tag + "_D"])
+    grid = sdflabel_amd.Grid3D(D, DEV)
+    lat = F.normalize(T(z[tag + "_latent"]), p=2, dim=0)
+    inputs = torch.cat([lat.expand(grid.points.size(0), -1), grid.points], 1)
+    sdf, _ = dec(inputs)
+    assert np.abs(N(sdf) - z[tag + "_sdf"]).max() < 5e-6
+    pts, nocs, nrm = grid.get_surface_points(sdf)
+    assert pts.shape == z[tag + "_points"].shape          # identical band (margin recorded in the golden)
+    assert np.array_equal(N(sdf._sdfr_state.idx)[:pts.shape[0]], z[tag + "_band_idx"])
+    assert np.abs(N(pts) - z[tag + "_points"]).max() < 1e-5
+    assert np.abs(N(nocs) - z[tag + "_nocs"]).max() < 1e-5
+    assert np.abs(N(nrm) - z[tag + "_normals"]).max() < 5e-5
+
+
+def test_surface_points_generic_sdf_matches_fused(dec):
+    """An SDF that is not the HIP decoder goes through torch.autograd.grad for its normals; an analytic sphere is exact."""
+    grid = sdflabel_amd.Grid3D(12, DEV)
+    sdf = (grid.points.norm(dim=1, keepdim=True) - 0.7)
+    pts, nocs, nrm = grid.get_surface_points(sdf, 0.05)
+    assert pts.shape[0] > 0
+    assert np.abs(N(pts.norm(dim=1)) - 0.7).max() < 1e-5
+    loss = (pts * pts).sum()
+    loss.backward()                                         # flows to grid.points through sdf and the identity term
+    assert grid.points.grad is not None and torch.isfinite(grid.points.grad).all()
+
+
+def test_surface_empty_band(dec):
+    grid = sdflabel_amd.Grid3D(6, DEV)
+    sdf = torch.ones((216, 1), device=DEV, requires_grad=True) * 0.5
+    pts, nocs, nrm = grid.get_surface_points(sdf)
+    assert pts.shape == (0, 3) and nocs.shape == (0, 3) and nrm.shape == (0, 3)
+    r = sdflabel_amd.Rasterer(T(K_for(16, 16)), (16, 16)).to(DEV)
+    rendering, points = r(pts, nrm, nrm, torch.eye(4, device=DEV), rot="dcm", output_mask=True, output_depth=True,
+                          output_normals=True, output_nocs=True)
+    assert float(rendering["color"].abs().max()) == 0 and float(rendering["mask"].max()) == 0
+    assert points["xyzf"].shape == (0, 3)
+
+
+# ---- projection / rasterer ------------------------------------------------------------------------------------------
+
+def test_project_and_rasterer_golden():
+    z = gold("g6_rasterer.npz")
+    pts, nrm, col, pose = T(z["points"]), T(z["normals"]), T(z["colors"]), T(z["pose"])
+    for (H, W) in ((32, 32), (64, 48)):
+        t0 = "r%dx%d_" % (H, W)
+        r = sdflabel_amd.Rasterer(T(z[t0 + "K"]), (W, H)).to(DEV)
+        assert np.array_equal(N(r.Kinv), z[t0 + "Kinv"]) or np.allclose(N(r.Kinv), z[t0 + "Kinv"], rtol=1e-6)
+        for flag, name in ((True, "nocs_"), (False, "col_")):
+            _, _, _, aux = O.rasterer_forward(z[t0 + "K"], z[t0 + "Kinv"], (W, H), z["points"], z["normals"], z["colors"], z["pose"],
+                                              rot="dcm", output_nocs=flag, want_aux=True)
+            rend, points = r(pts, nrm, col, pose, rot="dcm", primitives="disc", bg=None, output_mask=True, output_depth=True,
+                             output_normals=True, output_nocs=flag, output_points=True)
+            t = t0 + name
+            for k in ("color", "mask", "depth", "normals"):
+                images_close(N(rend[k]), z[t + k], aux)
+            for k in ("xyz", "rgb", "xyzf", "rgbf"):
+                assert points[k].shape == z[t + "pts_" + k].shape, k
+                assert np.abs(N(points[k]) - z[t + "pts_" + k]).max() < 1e-5, k
+
+
+def test_project_golden_poses():
+    z = gold("g4_project.npz")
+    L = _lib.lib()
+    n = z["points"].shape[0]
+    pts, nrm = T(z["points"]), T(z["normals"])
+    K = T(z["K"])
+    for i in range(3):
+        for mode, name in ((1, "nocs"), (0, "col")):
+            t = "dcm%d_%s_" % (i, name)
+            pose = T(z[t + "pose"])
+            p_cam = torch.empty((n, 3), device=DEV); n_cam = torch.empty((n, 3), device=DEV); col = torch.empty((n, 3), device=DEV)
+            uv = torch.empty((n, 2), device=DEV)
+            fidx = torch.empty((n,), dtype=torch.int32, device=DEV); fcnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+            _lib.check(L.sdfr_project_dcm(_lib.ptr(pose), _lib.ptr(K), _lib.ptr(pts), _lib.ptr(nrm), _lib.ptr(nrm), 1, n, None, mode,
+                                          32, 32, _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(col), _lib.ptr(uv), _lib.ptr(fidx),
+                                          _lib.ptr(fcnt), _lib.stream_ptr()), "project")
+            assert np.abs(N(p_cam) - z[t + "points_3d"]).max() < 1e-5
+            assert np.abs(N(n_cam) - z[t + "normals_3d"]).max() < 1e-5
+            assert np.abs(N(col) - z[t + "colors_3d"]).max() < 1e-6
+            assert np.abs(N(uv) - z[t + "points_2d"]).max() < 2e-4      # pixel units
+            nf = int(fcnt.item())
+            assert nf == z[t + "points_3d_filt"].shape[0]
+            assert np.abs(N(p_cam)[N(fidx)[:nf]] - z[t + "points_3d_filt"]).max() < 1e-5
+
+
+def test_rasterer_quat_mode_golden():
+    z = gold("g4_project.npz")
+    r = sdflabel_amd.Rasterer(T(z["K"]), (32, 32)).to(DEV)
+    cam = T(z["quat_pose"])
+    rend = r(T(z["points"]), T(z["normals"]), T(z["normals"]), cam, rot="quat", output_nocs=True, output_points=False,
+             output_mask=True)
+    Kinv = np.linalg.inv(z["K"].astype(np.float32))
+    W = O.inside_surfel(Kinv, O.pixel_grid((32, 32)), z["quat_points_3d"], z["quat_normals_3d"], diam=0.04)
+    ref = np.minimum((W.T @ ((z["quat_colors_3d"] + 1) / 2)).T, 1).reshape(3, 32, 32)
+    images_close(N(rend["color"]), ref)
+    with pytest.raises(KeyError):
+        r(T(z["points"]), T(z["normals"]), T(z["normals"]), cam, rot="quat", output_nocs=True)
+
+
+# ---- splat kernels vs oracle on adversarial surfels ------------------------------------------------------------------
+
+def _random_surfels(rng, n, H, W):
+    p = np.stack([rng.uniform(-0.6, 0.6, n), rng.uniform(-0.6, 0.6, n), rng.uniform(0.8, 2.0, n)], 1).astype(np.float32)
+    nrm = rng.standard_normal((n, 3)).astype(np.float32) * 0.5 + np.array([0, 0, -1], np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    # grazing normals (|n.ray| < 0.01 for some pixels), a surfel behind the camera, one far off screen, one near the camera plane
+    nrm[:3] = np.array([[1, 0, 0.001], [0, 1, -0.002], [0.7071, 0.7071, 0.0]], np.float32)
+    p[3] = [0.1, 0.1, -1.5]
+    p[4] = [30.0, 0.0, 1.0]
+    p[5] = [0.01, -0.02, 0.03]
+    col = rng.uniform(0, 1.4, (n, 3)).astype(np.float32)       # > 1 exercises the clamp(max=1) gates
+    return p, nrm, col
+
+
+@pytest.mark.parametrize("H,W,n", [(16, 16, 40), (40, 24, 300), (17, 31, 129)])
+def test_splat_forward_backward_vs_oracle(H, W, n):
+    rng = np.random.default_rng(H * 100 + n)
+    p, nrm, col = _random_surfels(rng, n, H, W)
+    K = K_for(H, W)
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    L = _lib.lib()
+    tp, tn, tc = T(p), T(nrm), T(col)
+    color = torch.empty((3, H, W), device=DEV); mask = torch.empty((1, H, W), device=DEV)
+    depth = torch.empty((1, H, W), device=DEV); nimg = torch.empty((3, H, W), device=DEV)
+    aux = torch.empty((H * W, 4), device=DEV); bbox = torch.empty((n, 4), dtype=torch.int32, device=DEV)
+    tK, tKi = T(K), T(Kinv)
+    _lib.check(L.sdfr_splat_forward(_lib.ptr(tK), _lib.ptr(tKi), _lib.ptr(tp), _lib.ptr(tn), _lib.ptr(tc), 1, n, None, W, H, 0.04, 150.0,
+                                    _lib.ptr(bbox), _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(nimg), _lib.ptr(aux),
+                                    _lib.stream_ptr()), "splat_fwd")
+    Wm, auxo = O.inside_surfel(Kinv, O.pixel_grid((W, H)), p, nrm, diam=0.04, want_aux=True)
+    ref_c = np.minimum((Wm.T @ col).T, 1).reshape(3, H, W)
+    ref_m = np.minimum(Wm.sum(0), 1).reshape(1, H, W)
+    ref_d = (Wm.T @ p[:, 2]).reshape(1, H, W)
+    ref_n = np.minimum((Wm.T @ ((nrm + 1) / 2)).T, 1).reshape(3, H, W)
+    images_close(N(color), ref_c, auxo); images_close(N(mask), ref_m, auxo)
+    images_close(N(depth), ref_d, auxo); images_close(N(nimg), ref_n, auxo)
+    # backward against the oracle's restatement of autograd
+    gC = rng.standard_normal((3, H, W)).astype(np.float32); gM = rng.standard_normal((1, H, W)).astype(np.float32)
+    gD = rng.standard_normal((1, H, W)).astype(np.float32); gN = rng.standard_normal((3, H, W)).astype(np.float32)
+    g_p = torch.zeros((n, 3), device=DEV); g_n = torch.zeros((n, 3), device=DEV); g_a = torch.zeros((n, 3), device=DEV)
+    tg = [T(g) for g in (gC, gM, gD, gN)]
+    _lib.check(L.sdfr_splat_backward(_lib.ptr(tK), _lib.ptr(tKi), _lib.ptr(tp), _lib.ptr(tn), _lib.ptr(tc), 1, n, None, W, H, 0.04,
+                                     150.0, _lib.ptr(aux), _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(nimg),
+                                     _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]), _lib.ptr(tg[3]), _lib.ptr(g_p), _lib.ptr(g_n),
+                                     _lib.ptr(g_a), _lib.stream_ptr()), "splat_bwd")
+    r_p, r_n, r_c = O.splat_backward(Kinv, (W, H), p, nrm, col, gC, gM, gD, gN)
+    for got, ref in ((g_p, r_p), (g_n, r_n), (g_a, r_c)):
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs(N(got) - ref).max() < 2e-3 * scale, (np.abs(N(got) - ref).max(), scale)
+
+
+def test_splat_backward_is_linear_and_deterministic():
+    """size-independent properties at the full 256x256 crop: backward is linear in the upstream gradient, bitwise repeatable."""
+    H = W = 256
+    rng = np.random.default_rng(9)
+    n = 2500
+    p, nrm, col = _random_surfels(rng, n, H, W)
+    p[:, :2] *= 0.5
+    p[:, 2] = rng.uniform(3.0, 4.0, n)
+    r = sdflabel_amd.Rasterer(T(K_for(H, W)), (W, H)).to(DEV)
+    pose = torch.eye(4, device=DEV)
+
+    def grads(wc, wm):
+        tp = T(p).requires_grad_(True)
+        tn = T(nrm).requires_grad_(True)
+        rend = r(tp, tn, T(col), pose, rot="dcm", output_mask=True, output_depth=True, output_normals=True, output_nocs=False,
+                 output_points=False)
+        ((rend["color"] * wc).sum() + (rend["depth"] * wm).sum()).backward()
+        return tp.grad.clone(), tn.grad.clone(), rend
+
+    wc = torch.randn(3, H, W, device=DEV); wm = torch.randn(1, H, W, device=DEV)
+    a = grads(wc, wm); b = grads(wc, wm); c = grads(2 * wc, 2 * wm)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.allclose(c[0], 2 * a[0], rtol=1e-5, atol=1e-6) and torch.allclose(c[1], 2 * a[1], rtol=1e-5, atol=1e-6)
+    m = a[2]["mask"]
+    assert set(np.unique(N(m)).tolist()) <= {0.0, 1.0}
+    assert float(m.sum()) > 500
+
+
+# ---- end to end through the drop-in boundary ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_end_to_end_gradients_golden(dec, tag):
+    """The optimizer's graph (optimizer.py:79-123) on top of the drop-in modules vs. reference autograd (golden G7)."""
+    z = gold("g7_grads.npz")
+    D, H, W = [int(v) for v in z[tag + "_cfg"]]
+    grid = sdflabel_amd.Grid3D(D, DEV)
+    lat = T(z[tag + "_latent"]).requires_grad_(True)
+    yaw = T(z[tag + "_yaw"]).requires_grad_(True)
+    trans = T(z[tag + "_trans"]).requires_grad_(True)
+    renderer = sdflabel_amd.Rasterer(T(z[tag + "_K"]), (W, H)).to(DEV)
+    lat_ = F.normalize(lat, p=2, dim=0)
+    inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1)
+    sdf, _ = dec(inputs)
+    pcd, _, normals = grid.get_surface_points(sdf)
+    assert np.abs(N(pcd) - z[tag + "_pcd"]).max() < 1e-5
+    pcd.retain_grad()
+    pose = build_pose(yaw, trans)
+    rendering, points = renderer(pcd, normals, normals, pose, primitives="disc", rot="dcm", bg=None, output_depth=True,
+                                 output_normals=True, output_nocs=True, output_points=True, output_mask=True)
+    for k in ("color", "mask", "depth", "normals"):
+        images_close(N(rendering[k]), z[tag + "_out_" + k])
+    loss = sum((rendering[k] * T(z[tag + "_W_" + k])).sum() for k in ("color", "mask", "depth", "normals"))
+    loss = loss + sum((points[k] * T(z[tag + "_Wp_" + k])).sum() for k in ("xyzf", "rgbf", "xyz", "rgb"))
+    assert abs(float(loss) - float(z[tag + "_loss"])) < 2e-3 * max(1.0, abs(float(z[tag + "_loss"])))
+    loss.backward()
+    for got, key in ((pcd.grad, "_g_pcd"), (yaw.grad, "_g_yaw"), (trans.grad, "_g_trans"), (lat.grad, "_g_latent")):
+        ref = z[tag + key]
+        assert np.abs(N(got) - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), key
+
+
+def test_full_size_crop_vs_oracle_sample(dec, oracle_layers):
+    """BASELINE configs[1] shape (D=40, 256x256): compare the rendered images with the oracle on the same surfels."""
+    layers, spec = oracle_layers
+    D, H, W = 40, 128, 128
+    grid = sdflabel_amd.Grid3D(D, DEV)
+    lat = F.normalize(torch.tensor([0.3, -0.5, 0.8], device=DEV), p=2, dim=0)
+    inputs = torch.cat([lat.expand(grid.points.size(0), -1), grid.points], 1)
+    sdf, _ = dec(inputs)
+    ref_sdf = O.decoder_forward(layers, spec, N(inputs))
+    assert np.abs(N(sdf) - ref_sdf).max() < 1e-5
+    pcd, _, normals = grid.get_surface_points(sdf)
+    assert 1500 < pcd.shape[0] < 5000
+    K = K_for(H, W)
+    pose = build_pose(torch.tensor([0.6], device=DEV), torch.tensor([0.0, 0.0, 3.5], device=DEV))
+    r = sdflabel_amd.Rasterer(T(K), (W, H)).to(DEV)
+    rend, points = r(pcd, normals, normals, pose, rot="dcm", output_mask=True, output_depth=True, output_normals=True,
+                     output_nocs=True)
+    ro, po, _, aux = O.rasterer_forward(K, np.linalg.inv(K).astype(np.float32), (W, H), N(pcd), N(normals), N(normals), N(pose),
+                                        rot="dcm", output_nocs=True, want_aux=True)
+    for k in ("color", "mask", "depth", "normals"):
+        images_close(N(rend[k]), ro[k], aux)
+    assert np.abs(N(points["xyzf"]) - po["xyzf"]).max() < 1e-5

@@ -1,0 +1,222 @@
+"""bench.py -- rendered rays/sec (fwd+bwd) of the differentiable SDF renderer hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by torch.distributed.run, one rank per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env)
+
+Workload (BASELINE.json configs[1]): ONE 256x256 crop per rank, DeepSDF 8x512 decoder (L=3, latent_in=[4], weight-norm;
+the committed synthetic fixture), grid density 40 (G = 64 000), float32.  One step = one refinement crop-iteration of the
+reference's loop (pipelines/optimizer.py:79-123, 156) without the 2-D/3-D losses:
+    decoder on the grid -> band selection -> band Jacobian (normals + d sdf/d latent) -> iso-projection -> DCM projection ->
+    surfel splat + depth-softmax composite (NOCS colour, mask, normals) -> full backward to yaw, trans AND latent,
+called through the drop-in Python boundary exactly as the reference optimizer calls its renderer (per-iteration host syncs
+included).  Nothing is cached across steps: the decoder is re-evaluated on the whole grid every step.  "march steps" in
+BASELINE.json do not exist in the reference algorithm and are reported as null.
+One ray = one pixel of one crop in one step; value = rays of all ranks / max-over-ranks wall time (weak scaling: one crop per
+rank, no data-path collective; the per-crop results are all-gathered once after the timed region).
+
+Extra objects on the JSON line: `roofline` for the dominant kernel (the fused decoder forward, MFMA-bound) timed with events on
+the launch stream inside the timed region, and `cpu_baseline`: the numpy oracle (oracle/sdf_oracle.py, a port of the
+reference's dense algorithm) timed on the host cores for one crop-iteration of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 dense peak
+D, H, W = 40, 256, 256
+
+
+def K_for(h, w):
+    f = 45.0 * h / 32.0
+    return np.array([[f, 0, w / 2.0], [0, f, h / 2.0], [0, 0, 1]], np.float32)
+
+
+def build_pose(yaw, trans):
+    c, s = torch.cos(yaw), torch.sin(yaw)
+    z, o = yaw.new_zeros(1), yaw.new_ones(1)
+    pose = torch.eye(4, device=yaw.device)
+    pose[:3, :3] = torch.stack((c, z, s, z, o, z, -s, z, c)).view(3, 3)   # utils/refinement.py:108-125
+    pose[1] *= -1                                                          # optimizer.py:88-90
+    pose[:3, 3] = trans
+    return pose
+
+
+class Crop:
+    """One synthetic refinement problem: GT pose yaw .6, t (0,0,3.5); init perturbed per crop index."""
+
+    def __init__(self, index, dev):
+        g = torch.Generator().manual_seed(1 + index)
+        jit = torch.rand(7, generator=g)
+        self.yaw = (torch.tensor([0.6]) + 0.1 + 0.1 * jit[0:1]).to(dev).requires_grad_(True)
+        self.trans = (torch.tensor([0.0, 0.0, 3.5]) + torch.tensor([0.1, 0.05, -0.3]) * jit[1:4]).to(dev).requires_grad_(True)
+        self.latent = (torch.tensor([0.3, -0.5, 0.8]) + 0.2 * (jit[4:7] - 0.5)).to(dev).requires_grad_(True)
+
+
+def crop_iteration(dec, grid, renderer, crop, ev=None):
+    for p in (crop.yaw, crop.trans, crop.latent):
+        p.grad = None
+    latent_ = F.normalize(crop.latent, p=2, dim=0)                                         # optimizer.py:96
+    inputs = torch.cat([latent_.expand(grid.points.size(0), -1), grid.points], 1)          # :99-100
+    if ev is not None:
+        ev[0].record()
+    sdf, _ = dec(inputs)                                                                   # :101
+    if ev is not None:
+        ev[1].record()
+    pcd, _, normals = grid.get_surface_points(sdf)                                         # :104
+    pose = build_pose(crop.yaw, crop.trans)
+    rendering, points = renderer(pcd, normals, normals, pose, primitives='disc', rot='dcm', bg=None, output_depth=False,
+                                 output_normals=True, output_nocs=True, output_points=True, output_mask=True)   # :110-123
+    loss = rendering['color'].sum() + rendering['mask'].sum() + rendering['normals'].sum() + points['xyzf'].sum()
+    loss.backward()                                                                        # :156
+    return loss.detach(), pcd.shape[0], points['xyzf'].shape[0]
+
+
+def cpu_baseline():
+    """The oracle timed on the host: one crop-iteration of the same workload, dense N x P formulation as the reference."""
+    from oracle import sdf_oracle as O
+    from tests._util import fitted_state
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count() or 1
+    st, spec = fitted_state()
+    layers = O.decoder_layers_from_state(st, spec)
+    K = K_for(H, W)
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    lat = np.array([0.3, -0.5, 0.8], np.float32)
+    lat = lat / np.linalg.norm(lat)
+    pts = O.generate_point_grid(D)
+    t0 = time.perf_counter()
+    inp = np.concatenate([np.broadcast_to(lat, (pts.shape[0], 3)), pts], 1).astype(np.float32)
+    sdf, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+    Jall = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(sdf))
+    pm, _, nm, idx, n_hat = O.get_surface_points(pts, sdf, Jall[:, 3:], 0.03)
+    pose = O.render_pose(0.6, [0.0, 0.0, 3.5])
+    proj = O.project_in_2D(K, pose, pm, nm, nm, (W, H), output_nocs=True)
+    v3, nc = proj["points_3d"].astype(np.float32), proj["normals_3d"].astype(np.float32)
+    c_attr = ((proj["colors_3d"] + 1) / 2).astype(np.float32)
+    t_mlp = time.perf_counter() - t0
+    # dense splat + composite + backward on a quarter of the image (rows H*3/8 .. H*5/8, through the object), extrapolated x4:
+    # the dense N x P formulation costs the same for every pixel
+    sub = O.pixel_grid((W, H)).reshape(H, W, 2)[H * 3 // 8:H * 5 // 8].reshape(-1, 2)
+    t1 = time.perf_counter()
+    Wm = O.inside_surfel(Kinv, sub, v3, nc, diam=0.04)
+    color = np.minimum((Wm.T @ c_attr).T, 1)
+    mask = np.minimum(Wm.sum(0), 1)
+    nimg = np.minimum((Wm.T @ ((nc + 1) / 2)).T, 1)
+    del Wm
+    P = sub.shape[0]
+    g_v3, g_n, g_c = O.splat_backward(Kinv, (W, H), v3, nc, c_attr, np.ones((3, P), np.float32), np.ones((1, P), np.float32), None,
+                                      np.ones((3, P), np.float32), grid_2d=sub)
+    t_rast = (time.perf_counter() - t1) * (H * W / float(P))
+    t2 = time.perf_counter()
+    g_points, _, _, g_pose = O.project_backward_dcm(pose, pm, nm, g_v3, g_n, g_c * 0.5, output_nocs=True, filt_idx=proj["filt_idx"],
+                                                    g_p3_filt=np.ones_like(proj["points_3d_filt"]))
+    g_sdf, _ = O.get_surface_points_backward(sdf, n_hat, idx, g_points)
+    g_lat = (Jall * g_sdf)[:, :3].sum(0)
+    dt = t_mlp + t_rast + (time.perf_counter() - t2)
+    assert color.shape[1] == P and mask.shape[0] == P and nimg.shape[1] == P
+    assert np.isfinite(g_lat).all() and np.isfinite(g_pose).all()
+    return {"value": H * W / dt, "unit": "rays/s", "cores": int(blas_threads), "kind": "port",
+            "sample": "1 crop-iteration (fwd+bwd) of the bench workload (256x256 rays, D=40, N=%d surfels) with the numpy oracle, dense "
+                      "N x P as the reference: decoder fwd + input-Jacobian on all 64000 grid points and projection timed in full "
+                      "(%.1f s), dense splat/composite fwd+bwd timed on the central quarter of the image and extrapolated x4 (%.1f s); "
+                      "BLAS matmuls on %d threads, elementwise passes single-threaded" % (pm.shape[0], t_mlp, t_rast, blas_threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=dev)
+        dist = dist_mod
+
+    import sdflabel_amd
+    from tests._util import ASSET
+    dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt")
+    dec = dec.to(dev)
+    grid = sdflabel_amd.Grid3D(D, dev)
+    renderer = sdflabel_amd.Rasterer(torch.from_numpy(K_for(H, W)), (W, H)).to(dev)
+    crop = Crop(rank, dev)
+    G = grid.points.shape[0]
+    macs = dec.handle(dev).macs
+
+    for _ in range(args.warmup):
+        crop_iteration(dec, grid, renderer, crop)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, n_surf, n_front = crop_iteration(dec, grid, renderer, crop, events[i])
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # the path's only exchange: per-crop results gathered once, outside the per-iteration critical path
+        res = torch.cat([loss.view(1), crop.yaw.detach(), crop.trans.detach(), crop.latent.detach()]).float()
+        out = [torch.empty_like(res) for _ in range(world)]
+        dist.all_gather(out, res)
+    mlp_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    if rank == 0:
+        rays = H * W * world * args.steps
+        line = {
+            "metric": "rendered rays/sec (fwd+bwd)", "value": rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: single 256x256 crop per GPU, DeepSDF 8x512 decoder on a 40^3 grid, "
+                                   "fwd+bwd to yaw/trans/latent through the drop-in API, decoder re-evaluated every step",
+                       "crops_per_gpu": 1, "rays_per_crop": H * W, "grid_points": G, "surfels": int(n_surf),
+                       "front_facing": int(n_front), "march_steps": None, "parallelism": "crop-parallel x%d" % world},
+        }
+        flops = 2.0 * macs * G
+        ach = flops / (mlp_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_mlp_forward.json")
+        if os.path.isfile(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        line["roofline"] = {"kernel": "sdfr_mlp_kernel<4,2,false> (fused decoder forward on the grid)", "bound": "mfma",
+                            "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
+                            "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": mlp_ms}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -409,7 +409,7 @@ def rasterer_forward(K, Kinv, resolution_px, coords, normals, colors, camera_mat
 
 
 def splat_backward(Kinv, resolution_px, v3, nrm, c_attr, g_color, g_mask, g_depth, g_normals,
-                   diam=0.04, depth_constant=150, chunk=4096):
+                   diam=0.04, depth_constant=150, chunk=4096, grid_2d=None):
     """Autograd of inside_surfel + compositing (primitives.py:202-241, rasterer.py:119-144; bg=None) w.r.t.
     camera-frame surfel positions v3 (N,3), camera-frame normals nrm (N,3) and the composited colour
     attribute c_attr (N,3) (= (colors+1)/2 for NOCS, `colors` otherwise).
@@ -424,9 +424,9 @@ def splat_backward(Kinv, resolution_px, v3, nrm, c_attr, g_color, g_mask, g_dept
     eps = np.finfo(dt).eps
     fmin = np.finfo(dt).min
     N = v3.shape[0]
-    rx, ry = resolution_px
-    P = rx * ry
-    grid_2d = pixel_grid(resolution_px)
+    if grid_2d is None:                       # grid_2d: optional subset of pixels (g_* then have P = len(grid_2d) columns)
+        grid_2d = pixel_grid(resolution_px)
+    P = grid_2d.shape[0]
     rays = pixel_rays(Kinv.astype(dt), grid_2d)
     a = np.sum(nrm * v3, axis=1).astype(dt)
     n_attr = ((nrm + 1) / 2).astype(dt)

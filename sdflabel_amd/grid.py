@@ -93,7 +93,10 @@ class Grid3D:
             xyz_src = state.inputs[:, NI - 3:]
             return _SurfaceFn.apply(pred_sdf_grid, self.points, xyz_src, NI, idx, n, J, NI, NI - 3)
         # generic path: any differentiable SDF of self.points
-        (g,) = torch.autograd.grad(pred_sdf_grid.sum(), self.points, retain_graph=True)
+        (g,) = torch.autograd.grad(pred_sdf_grid.sum(), self.points, retain_graph=True, allow_unused=True)
+        if g is None:
+            raise _lib.SdfrError("pred_sdf_grid does not depend on this grid's points: no normals can be derived "
+                                 "(the reference fails here too: its hook grid.py:20 never fires)")
         Jn = g.detach().index_select(0, idx[:n].long()).contiguous()
         pts_src = self.points.detach().contiguous()
         return _SurfaceFn.apply(pred_sdf_grid, self.points, pts_src, 3, idx, n, Jn, 3, 0)

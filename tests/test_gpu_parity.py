@@ -151,7 +151,8 @@ def test_band_select_matches_nonzero(G, frac):
     sdf = rng.uniform(0.031, 1.0, G).astype(np.float32) * rng.choice([-1, 1], G)
     k = int(round(frac * G))
     pick = rng.choice(G, k, replace=False)
-    sdf[pick] = rng.uniform(-0.0299, 0.0299, k).astype(np.float32)
+    sdf[pick] = rng.uniform(-0.0299, 0.0299, k)
+    sdf = sdf.astype(np.float32)
     idx, n, slot = band_select(T(sdf), 0.03)
     ref = np.nonzero(np.abs(sdf) < np.float32(0.03))[0]
     assert n == len(ref)
@@ -203,7 +204,7 @@ def test_surface_points_generic_sdf_matches_fused(dec):
 
 def test_surface_empty_band(dec):
     grid = sdflabel_amd.Grid3D(6, DEV)
-    sdf = torch.ones((216, 1), device=DEV, requires_grad=True) * 0.5
+    sdf = grid.points.sum(dim=1, keepdim=True) * 0 + 0.5
     pts, nocs, nrm = grid.get_surface_points(sdf)
     assert pts.shape == (0, 3) and nocs.shape == (0, 3) and nrm.shape == (0, 3)
     r = sdflabel_amd.Rasterer(T(K_for(16, 16)), (16, 16)).to(DEV)

@@ -8,8 +8,11 @@ the committed synthetic fixture), grid density 40 (G = 64 000), float32.  One st
 reference's loop (pipelines/optimizer.py:79-123, 156) without the 2-D/3-D losses:
     decoder on the grid -> band selection -> band Jacobian (normals + d sdf/d latent) -> iso-projection -> DCM projection ->
     surfel splat + depth-softmax composite (NOCS colour, mask, normals) -> full backward to yaw, trans AND latent,
-called through the drop-in Python boundary exactly as the reference optimizer calls its renderer (per-iteration host syncs
-included).  Nothing is cached across steps: the decoder is re-evaluated on the whole grid every step.  "march steps" in
+run by sdflabel_amd.BatchRenderer (B = 1 crop per rank): the same kernels as the drop-in modules, launched back to back on one
+stream with device-side counts instead of host syncs; the optimizer's parameters (yaw, trans, latent) are the inputs and their
+gradients the outputs.  The same crop-iteration through the drop-in Python boundary (sdflabel_amd.Grid3D / Rasterer / Decoder called
+exactly as pipelines/optimizer.py calls the reference, per-iteration host syncs included) is timed too and reported as
+`dropin_api`.  Nothing is cached across steps: the decoder is re-evaluated on the whole grid every step.  "march steps" in
 BASELINE.json do not exist in the reference algorithm and are reported as null.
 One ray = one pixel of one crop in one step; value = rays of all ranks / max-over-ranks wall time (weak scaling: one crop per
 rank, no data-path collective; the per-crop results are all-gathered once after the timed region).
@@ -160,36 +163,62 @@ def main():
     from tests._util import ASSET
     dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt")
     dec = dec.to(dev)
-    grid = sdflabel_amd.Grid3D(D, dev)
-    renderer = sdflabel_amd.Rasterer(torch.from_numpy(K_for(H, W)), (W, H)).to(dev)
     crop = Crop(rank, dev)
-    G = grid.points.shape[0]
     macs = dec.handle(dev).macs
+    br = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), 1, device=dev)
+    G = br.G
+    br.set_params(crop.yaw.detach(), crop.trans.detach().view(1, 3), crop.latent.detach().view(1, 3))
+    ones3 = torch.ones(1, 3, H, W, device=dev)
+    ones1 = torch.ones(1, 1, H, W, device=dev)
+    onesx = torch.ones(1, br.cap, 3, device=dev)
 
-    for _ in range(args.warmup):
-        crop_iteration(dec, grid, renderer, crop)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    def step(ev=None):
+        br.forward(mlp_events=ev)
+        br.backward(g_color=ones3, g_mask=ones1, g_normals=ones3, g_xyzf=onesx)     # d/d(out) of the plain sums used as the loss
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss, n_surf, n_front = crop_iteration(dec, grid, renderer, crop, events[i])
+        step(events[i])
     barrier()
     dt = time.perf_counter() - t0
+    assert not br.overflow()
+    n_surf, n_front = int(br.cnt[0]), int(br.fcnt[0])
+    loss = br.color.sum() + br.mask.sum() + br.nimg.sum() + br.xyzf.sum()
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # the path's only exchange: per-crop results gathered once, outside the per-iteration critical path
-        res = torch.cat([loss.view(1), crop.yaw.detach(), crop.trans.detach(), crop.latent.detach()]).float()
+        res = torch.cat([loss.view(1), br.g_yaw, br.g_trans.view(-1), br.g_latent.view(-1)]).float()
         out = [torch.empty_like(res) for _ in range(world)]
         dist.all_gather(out, res)
     mlp_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+
+    # the same crop-iteration through the drop-in boundary (rank 0 only, informational)
+    dropin = None
+    if rank == 0:
+        grid = sdflabel_amd.Grid3D(D, dev)
+        renderer = sdflabel_amd.Rasterer(torch.from_numpy(K_for(H, W)), (W, H)).to(dev)
+        for _ in range(3):
+            crop_iteration(dec, grid, renderer, crop)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nd = max(5, args.steps // 3)
+        for _ in range(nd):
+            l2, _, _ = crop_iteration(dec, grid, renderer, crop)
+        torch.cuda.synchronize()
+        dt_d = (time.perf_counter() - t1) / nd
+        dropin = {"value": H * W / dt_d, "unit": "rays/s", "ms_per_step": dt_d * 1e3,
+                  "loss_rel_diff_vs_batched": abs(float(l2) - float(loss)) / max(1.0, abs(float(loss)))}
 
     if rank == 0:
         rays = H * W * world * args.steps
@@ -198,7 +227,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: single 256x256 crop per GPU, DeepSDF 8x512 decoder on a 40^3 grid, "
-                                   "fwd+bwd to yaw/trans/latent through the drop-in API, decoder re-evaluated every step",
+                                   "fwd+bwd to yaw/trans/latent (BatchRenderer, B=1), decoder re-evaluated every step",
                        "crops_per_gpu": 1, "rays_per_crop": H * W, "grid_points": G, "surfels": int(n_surf),
                        "front_facing": int(n_front), "march_steps": None, "parallelism": "crop-parallel x%d" % world},
         }
@@ -208,9 +237,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_mlp_forward.json")
         if os.path.isfile(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        line["roofline"] = {"kernel": "sdfr_mlp_kernel<4,2,false> (fused decoder forward on the grid)", "bound": "mfma",
+        line["roofline"] = {"kernel": "sdfr_mlp_kernel<2,2,8,4,false> (fused decoder forward on the grid)", "bound": "mfma",
                             "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                             "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": mlp_ms}
+        line["dropin_api"] = dropin
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -149,6 +149,30 @@ int sdfr_splat_backward(const float* K, const float* Kinv, const float* p_cam, c
                         const float* g_color, const float* g_mask, const float* g_depth, const float* g_normals,
                         float* g_p_cam, float* g_n_cam, float* g_attr, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Batched refinement step glue  --  the per-iteration host tensor algebra of pipelines/optimizer.py:86-100, for B crops
+ * at once and entirely on the device (no host synchronisation anywhere in a step).
+ */
+
+/* pose[b] = [R_y(yaw_b) | t_b] with the rotation's row 1 negated (optimizer.py:87-90, utils/refinement.py:108-125);
+ * inputs[b*G+g] = [latent_b / max(||latent_b||, 1e-12), grid[g]]  (optimizer.py:96-100);  latnorm[b] = the norm used. */
+int sdfr_params_forward(const float* yaw, const float* trans, const float* latent, int L, const float* grid, int64_t G, int B,
+                        float* inputs, float* pose, float* latnorm, void* stream);
+
+/* g_latn[b][:] = sum_s -( (g_points + g_nocs/2)_s . n_hat_s ) * J[b][s][0:L]   -- backward of grid.py:61,67 chained with the
+ * decoder's input gradient summed over the expanded latent rows (what autograd does at optimizer.py:156).  g_nocs may be NULL. */
+int sdfr_surface_latent_grad(const float* g_points, const float* g_nocs, const float* normals, const float* J, int n_inputs, int L,
+                             int B, int cap, const int32_t* cnt, float* g_latn, void* stream);
+
+/* g_yaw[B], g_trans[B][3] from g_pose[B][16]; g_latent[B][L] from g_latn through F.normalize. */
+int sdfr_params_backward(const float* yaw, const float* latent, int L, const float* latnorm, const float* g_pose, const float* g_latn,
+                         int B, float* g_yaw, float* g_trans, float* g_latent, void* stream);
+
+/* padded front-facing selection (points['xyzf'], rasterer.py:151): out[b][j] = src[b][idx[b][j]] for j < cnt[b], 0 beyond;
+ * and its backward dst[b][idx[b][j]] += src[b][j]. */
+int sdfr_gather_rows3(float* out, const float* src, const int32_t* idx, int B, int cap, const int32_t* cnt, void* stream);
+int sdfr_scatter_add_rows3(float* dst, const float* src, const int32_t* idx, int B, int cap, const int32_t* cnt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

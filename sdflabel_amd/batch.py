@@ -1,0 +1,162 @@
+"""BatchRenderer -- the whole renderer hot path for B crops per call, device-resident and free of host synchronisation.
+
+The reference refines one crop at a time (pipelines/refine_css.py:94) and pays, per iteration, dozens of tiny ATen launches and
+three host syncs (pipelines/optimizer.py:79-164).  This class is the MI355X-native extension SURVEY.md §8(f3) asks for: it keeps
+the reference's arithmetic per crop (same kernels as the drop-in modules, parity-tested against them) but takes the optimizer's
+parameters directly,
+
+    forward (yaw[B], trans[B,3], latent[B,L])  ->  color[B,3,H,W], mask[B,1,H,W], depth[B,1,H,W], normals[B,3,H,W],
+                                                    xyzf[B,cap,3] (front-facing camera-frame points, zero padded), nf[B], n[B]
+    backward(g_color, g_mask, g_depth, g_normals, g_xyzf)  ->  g_yaw[B], g_trans[B,3], g_latent[B,L]
+
+with every buffer pre-allocated (ragged per-crop data lives in [B][cap] arrays with device-side counts), so a step is ~16 kernel
+launches on the current stream and can be captured in a HIP graph (`capture()`).  `overflow()` (one sync, call it when convenient)
+reports whether any crop's band exceeded `cap`.
+"""
+import torch
+
+from . import _lib
+from .grid import Grid3D
+
+_DIAM_DISC = 0.04
+_DEPTH_CONSTANT = 150.0
+
+
+class BatchRenderer:
+    def __init__(self, decoder, density, K, resolution_px, batch, cap=None, device="cuda", threshold=0.03, output_nocs=True):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.SdfrError("BatchRenderer runs on the GPU only")
+        self.dev = dev
+        self.B = int(batch)
+        self.W, self.H = int(resolution_px[0]), int(resolution_px[1])
+        self.thr = float(threshold)
+        self.nocs_mode = 1 if output_nocs else 0
+        if not output_nocs:
+            raise NotImplementedError("BatchRenderer composites NOCS colours (the optimizer's configuration)")
+        self.decoder = decoder
+        self.handle = decoder.handle(dev)
+        self.L = decoder.latent_size
+        self.NI = self.L + 3
+        self.grid = Grid3D(density, dev).points.detach().contiguous()
+        self.G = self.grid.shape[0]
+        self.cap = int(cap) if cap is not None else max(256, self.G // 8)
+        B, G, cap, H, W, NI = self.B, self.G, self.cap, self.H, self.W, self.NI
+        K = torch.as_tensor(K, dtype=torch.float32)
+        if K.dim() == 2:
+            K = K.unsqueeze(0).expand(B, 3, 3)
+        self.K = K.contiguous().to(dev)
+        self.Kinv = torch.linalg.inv(K.cpu().float()).contiguous().to(dev)      # primitives.py:204, once, on the host
+
+        def f(*shape):
+            return torch.zeros(shape, dtype=torch.float32, device=dev)
+
+        def i(*shape):
+            return torch.zeros(shape, dtype=torch.int32, device=dev)
+
+        # parameters (static addresses so that a captured graph can be replayed after in-place updates)
+        self.yaw, self.trans, self.latent = f(B), f(B, 3), f(B, self.L)
+        self.inputs, self.pose, self.latnorm = f(B * G, NI), f(B, 16), f(B)
+        self.sdf = f(B * G)
+        self.idx, self.cnt, self.scratch = i(B, cap), i(B), i(B * ((G + 255) // 256) + 1)
+        self.J, self.sdf_band = f(B, cap, NI), f(B, cap)
+        self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
+        self.p_cam, self.n_cam, self.col, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
+        self.fidx, self.fcnt = i(B, cap), i(B)
+        self.bbox = i(B, cap, 4)
+        self.color, self.mask, self.depth, self.nimg = f(B, 3, H, W), f(B, 1, H, W), f(B, 1, H, W), f(B, 3, H, W)
+        self.aux = f(B, H * W, 4)
+        self.xyzf = f(B, cap, 3)
+        # backward
+        self.g_p, self.g_n, self.g_a, self.g_col = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
+        self.g_points, self.g_normals, self.g_pose = f(B, cap, 3), f(B, cap, 3), f(B, 16)
+        self.g_latn = f(B, self.L)
+        self.g_yaw, self.g_trans, self.g_latent = f(B), f(B, 3), f(B, self.L)
+        self._graph = None
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def set_params(self, yaw, trans, latent):
+        self.yaw.copy_(yaw.reshape(self.B))
+        self.trans.copy_(trans.reshape(self.B, 3))
+        self.latent.copy_(latent.reshape(self.B, self.L))
+
+    def forward(self, yaw=None, trans=None, latent=None, mlp_events=None):
+        """mlp_events: optional (start, end) torch.cuda.Event pair recorded around the decoder-forward launch (bench.py roofline)."""
+        if yaw is not None:
+            self.set_params(yaw, trans, latent)
+        L = _lib.lib()
+        P, st, ck = _lib.ptr, _lib.stream_ptr(), _lib.check
+        B, G, cap, W, H = self.B, self.G, self.cap, self.W, self.H
+        ck(L.sdfr_params_forward(P(self.yaw), P(self.trans), P(self.latent), self.L, P(self.grid), G, B, P(self.inputs), P(self.pose),
+                                 P(self.latnorm), st), "sdfr_params_forward")
+        if mlp_events is not None:
+            mlp_events[0].record()
+        ck(L.sdfr_mlp_forward(self.handle.h, P(self.inputs), B * G, P(self.sdf), st), "sdfr_mlp_forward")
+        if mlp_events is not None:
+            mlp_events[1].record()
+        ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
+        ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.idx), cap, P(self.cnt), P(self.J), P(self.sdf_band), st),
+           "sdfr_mlp_jacobian")
+        xyz = self.inputs[:, self.NI - 3:]
+        ck(L.sdfr_surface_project(P(xyz), self.NI, P(self.sdf), G, B, P(self.idx), cap, P(self.cnt), P(self.J), self.NI, self.NI - 3,
+                                  P(self.points), P(self.nocs), P(self.normals), st), "sdfr_surface_project")
+        ck(L.sdfr_project_dcm(P(self.pose), P(self.K), P(self.points), P(self.normals), None, B, cap, P(self.cnt), self.nocs_mode, W, H,
+                              P(self.p_cam), P(self.n_cam), P(self.col), None, P(self.fidx), P(self.fcnt), st), "sdfr_project_dcm")
+        torch.add(self.col, 1.0, out=self.attr)                                   # attr = (col + 1) / 2, rasterer.py:113-114
+        self.attr.mul_(0.5)
+        ck(L.sdfr_splat_forward(P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), B, cap, P(self.cnt), W, H, _DIAM_DISC,
+                                _DEPTH_CONSTANT, P(self.bbox), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(self.aux), st),
+           "sdfr_splat_forward")
+        ck(L.sdfr_gather_rows3(P(self.xyzf), P(self.p_cam), P(self.fidx), B, cap, P(self.fcnt), st), "sdfr_gather_rows3")
+        return {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.nimg, "xyzf": self.xyzf, "nf": self.fcnt,
+                "n": self.cnt}
+
+    def backward(self, g_color=None, g_mask=None, g_depth=None, g_normals=None, g_xyzf=None):
+        L = _lib.lib()
+        P, st, ck = _lib.ptr, _lib.stream_ptr(), _lib.check
+        B, cap, W, H = self.B, self.cap, self.W, self.H
+
+        def c(g, shape):
+            if g is None:
+                return None
+            g = g.to(torch.float32).expand(shape).contiguous()
+            return g
+
+        g_color, g_mask = c(g_color, self.color.shape), c(g_mask, self.mask.shape)
+        g_depth, g_normals = c(g_depth, self.depth.shape), c(g_normals, self.nimg.shape)
+        ck(L.sdfr_splat_backward(P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), B, cap, P(self.cnt), W, H, _DIAM_DISC,
+                                 _DEPTH_CONSTANT, P(self.aux), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(g_color),
+                                 P(g_mask), P(g_depth), P(g_normals), P(self.g_p), P(self.g_n), P(self.g_a), st), "sdfr_splat_backward")
+        torch.mul(self.g_a, 0.5, out=self.g_col)                                   # attr = (col + 1) / 2
+        if g_xyzf is not None:
+            g_xyzf = c(g_xyzf, self.xyzf.shape)
+            ck(L.sdfr_scatter_add_rows3(P(self.g_p), P(g_xyzf), P(self.fidx), B, cap, P(self.fcnt), st), "sdfr_scatter_add_rows3")
+        ck(L.sdfr_project_dcm_bwd(P(self.pose), P(self.points), P(self.normals), P(self.g_p), P(self.g_n), P(self.g_col), B, cap,
+                                  P(self.cnt), self.nocs_mode, P(self.g_points), P(self.g_normals), None, P(self.g_pose), st),
+           "sdfr_project_dcm_bwd")
+        ck(L.sdfr_surface_latent_grad(P(self.g_points), None, P(self.normals), P(self.J), self.NI, self.L, B, cap, P(self.cnt),
+                                      P(self.g_latn), st), "sdfr_surface_latent_grad")
+        ck(L.sdfr_params_backward(P(self.yaw), P(self.latent), self.L, P(self.latnorm), P(self.g_pose), P(self.g_latn), B, P(self.g_yaw),
+                                  P(self.g_trans), P(self.g_latent), st), "sdfr_params_backward")
+        return self.g_yaw, self.g_trans, self.g_latent
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def overflow(self):
+        """True if some crop's band did not fit `cap` (its surplus surfels were dropped).  Synchronises."""
+        return bool((self.cnt > self.cap).any().item())
+
+    def capture(self, grads_fn):
+        """Capture forward -> grads_fn(outputs) -> backward in a HIP graph.  grads_fn maps the output dict to the keyword arguments of
+        backward() using torch ops on static buffers only.  Returns a callable that replays the step (parameters are read from
+        self.yaw / self.trans / self.latent, gradients land in self.g_yaw / self.g_trans / self.g_latent)."""
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.backward(**grads_fn(self.forward()))
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.backward(**grads_fn(self.forward()))
+        self._graph = g
+        return g.replay

@@ -23,6 +23,7 @@
 //     The backward needs no activations, only masks, because just the INPUT gradient is required (weights are frozen).
 #include "sdfr_common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 #include <vector>
@@ -72,21 +73,24 @@ struct sdfr_decoder {
 
 __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
-template <int FT, int NP, bool JAC>
-__global__ __launch_bounds__(256, 1) void sdfr_mlp_kernel(const MlpParams P) {
+// FT feature tiles (32 rows) per wave, NP point tiles (32 points) per workgroup, NW waves per workgroup (HP = 32*FT*NW padded
+// hidden width), PF weight/activation fragment buffers in flight per wave (prefetch distance PF-1 K tiles).
+template <int FT, int NP, int NW, int PF, bool JAC>
+__global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
+    constexpr int NT = 64 * NW;
     constexpr int PT = 32 * NP;
-    constexpr int HP = 128 * FT;
+    constexpr int HP = 32 * FT * NW;
     constexpr int KG = HP / 4;
     constexpr int MW = (FT * NP * 16 + 31) / 32;                 // mask words per thread per layer
-    constexpr int MASK_WORDS = JAC ? (SDFR_MAX_LAYERS * MW * 256) : 1;
+    constexpr int MASK_WORDS = JAC ? (SDFR_MAX_LAYERS * MW * NT) : 1;
     // single LDS object, carved by hand (16-byte aligned pieces first)
-    __shared__ float4 lds4[KG * PT + 64 + 16 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4];
+    __shared__ float4 lds4[KG * PT + NT / 4 + 16 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4];
     float4* act = lds4;                                           // [KG][PT]
-    float* red = reinterpret_cast<float*>(lds4 + KG * PT);        // [256]
-    int* rows = reinterpret_cast<int*>(lds4 + KG * PT + 64);      // [PT] source row of each point (64 ints max)
-    float* gy = reinterpret_cast<float*>(lds4 + KG * PT + 64 + 16);   // [PT] d out / d y_last
-    int* slots = reinterpret_cast<int*>(lds4 + KG * PT + 64 + 16 + (PT + 3) / 4);   // [PT] J slot or -1
-    uint32_t* masks = reinterpret_cast<uint32_t*>(lds4 + KG * PT + 64 + 16 + (PT + 3) / 4 * 2);
+    float* red = reinterpret_cast<float*>(lds4 + KG * PT);        // [NT]
+    int* rows = reinterpret_cast<int*>(lds4 + KG * PT + NT / 4);  // [PT] source row of each point (64 ints max)
+    float* gy = reinterpret_cast<float*>(lds4 + KG * PT + NT / 4 + 16);   // [PT] d out / d y_last
+    int* slots = reinterpret_cast<int*>(lds4 + KG * PT + NT / 4 + 16 + (PT + 3) / 4);   // [PT] J slot or -1
+    uint32_t* masks = reinterpret_cast<uint32_t*>(lds4 + KG * PT + NT / 4 + 16 + (PT + 3) / 4 * 2);
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void sdfr_mlp_kernel(const MlpParams P) {
     // ---- layer-0 operand: act[k][pt] = inputs[row(pt)][k], zero padded to a multiple of 8 ---------------
     {
         const int k0pad = P.L[0].nkt_f * 8;
-        for (int e = tid; e < PT * k0pad; e += 256) {
+        for (int e = tid; e < PT * k0pad; e += NT) {
             const int pt = e / k0pad, k = e - pt * k0pad;
             const float v = (k < NI) ? P.inputs[(int64_t)rows[pt] * NI + k] : 0.f;
             reinterpret_cast<float*>(act)[((k >> 2) * PT + pt) * 4 + (k & 3)] = v;
@@ -137,35 +141,39 @@ __global__ __launch_bounds__(256, 1) void sdfr_mlp_kernel(const MlpParams P) {
         constexpr bool FULL = decltype(full_tag)::value;
         const float4* aptr = Wl + hi * HP + fbase + l31;
         const float4* bptr = act + hi * PT + l31;
-        float4 a_n[FT], b_n[NP];
+        float4 a[PF][FT], b[PF][NP];
+        auto load = [&](int tile, float4* aa, float4* bb) {
+            const float4* ap = aptr + (int64_t)tile * (2 * HP);
+            const float4* bp = bptr + tile * (2 * PT);
 #pragma unroll
-        for (int f = 0; f < FT; ++f) a_n[f] = (FULL || f < nact) ? aptr[f * 32] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int f = 0; f < FT; ++f)
+                if (FULL || f < nact) aa[f] = ap[f * 32];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) b_n[p] = bptr[p * 32];
-        for (int t = 0; t < nkt; ++t) {
-            float4 a_c[FT], b_c[NP];
+            for (int p = 0; p < NP; ++p) bb[p] = bp[p * 32];
+        };
 #pragma unroll
-            for (int f = 0; f < FT; ++f) a_c[f] = a_n[f];
+        for (int u = 0; u < PF; ++u)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) b_c[p] = b_n[p];
-            if (t + 1 < nkt) {
-                aptr += 2 * HP;
-                bptr += 2 * PT;
+            for (int f = 0; f < FT; ++f) a[u][f] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int f = 0; f < FT; ++f)
-                    if (FULL || f < nact) a_n[f] = aptr[f * 32];
+        for (int u = 0; u < PF - 1; ++u)
+            if (u < nkt) load(u, a[u], b[u]);
+        for (int t = 0; t < nkt; t += PF) {
 #pragma unroll
-                for (int p = 0; p < NP; ++p) b_n[p] = bptr[p * 32];
+            for (int u = 0; u < PF; ++u) {
+                if (t + u < nkt) {
+                    if (t + u + PF - 1 < nkt) load(t + u + PF - 1, a[(u + PF - 1) % PF], b[(u + PF - 1) % PF]);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int f = 0; f < FT; ++f)
+                            if (FULL || f < nact) {
+#pragma unroll
+                                for (int p = 0; p < NP; ++p)
+                                    acc[f][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a[u][f], ks), f4c(b[u][p], ks), acc[f][p], 0, 0, 0);
+                            }
+                }
             }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int f = 0; f < FT; ++f)
-                    if (FULL || f < nact) {
-#pragma unroll
-                        for (int p = 0; p < NP; ++p)
-                            acc[f][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a_c[f], ks), f4c(b_c[p], ks), acc[f][p], 0, 0, 0);
-                    }
         }
     };
     auto gemm = [&](const float4* __restrict__ Wl, int nkt, int rows_active) {
@@ -224,14 +232,14 @@ __global__ __launch_bounds__(256, 1) void sdfr_mlp_kernel(const MlpParams P) {
             }
         if (JAC) {
 #pragma unroll
-            for (int w = 0; w < MW; ++w) masks[(l * MW + w) * 256 + tid] = mw[w];
+            for (int w = 0; w < MW; ++w) masks[(l * MW + w) * NT + tid] = mw[w];
         }
         __syncthreads();
     }
 
     // ---- last linear (H -> 1) + tanh -----------------------------------------------------------------------
     {
-        constexpr int SL = 256 / PT;                      // k slices
+        constexpr int SL = NT / PT;                       // k slices
         constexpr int KGS = KG / SL;
         const int sl = tid / PT, pt = tid - sl * PT;
         const float4* w4 = reinterpret_cast<const float4*>(P.w_last) + sl * KGS;
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void sdfr_mlp_kernel(const MlpParams P) {
         const int inj_hi = prev_out + L.inj_n;
         uint32_t mw[MW];
 #pragma unroll
-        for (int w = 0; w < MW; ++w) mw[w] = masks[((l - 1) * MW + w) * 256 + tid];
+        for (int w = 0; w < MW; ++w) mw[w] = masks[((l - 1) * MW + w) * NT + tid];
 #pragma unroll
         for (int f = 0; f < FT; ++f)
 #pragma unroll
@@ -426,10 +434,19 @@ extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int6
     P.inputs = inputs; P.n = n; P.sdf = sdf;
     hipStream_t s = (hipStream_t)stream;
     const int grid = sdfr_cdiv(n, 64);
+    static const int variant = getenv("SDFR_MLP_VARIANT") ? atoi(getenv("SDFR_MLP_VARIANT")) : 0;   // development A/B switch
     switch (d->HP) {
-        case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 2, false>), dim3(grid), dim3(256), 0, s, P); break;
-        case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, false>), dim3(grid), dim3(256), 0, s, P); break;
-        default:  hipLaunchKernelGGL((sdfr_mlp_kernel<4, 2, false>), dim3(grid), dim3(256), 0, s, P); break;
+        case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 2, 4, 2, false>), dim3(grid), dim3(256), 0, s, P); break;
+        case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 4, 2, false>), dim3(grid), dim3(256), 0, s, P); break;
+        default:
+            if (variant == 1) hipLaunchKernelGGL((sdfr_mlp_kernel<4, 2, 4, 3, false>), dim3(grid), dim3(256), 0, s, P);
+            else if (variant == 2) hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 2, false>), dim3(grid), dim3(512), 0, s, P);
+            else if (variant == 3) hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 3, false>), dim3(grid), dim3(512), 0, s, P);
+            else if (variant == 5) hipLaunchKernelGGL((sdfr_mlp_kernel<4, 2, 4, 4, false>), dim3(grid), dim3(256), 0, s, P);
+            else if (variant == 6) hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 6, false>), dim3(grid), dim3(512), 0, s, P);
+            else if (variant == 7) hipLaunchKernelGGL((sdfr_mlp_kernel<4, 2, 4, 2, false>), dim3(grid), dim3(256), 0, s, P);
+            else hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 4, false>), dim3(grid), dim3(512), 0, s, P);
+            break;
     }
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
@@ -446,9 +463,12 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
     dim3 grid(sdfr_cdiv(cap, 32), B);
     switch (d->HP) {
-        case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 1, true>), grid, dim3(256), 0, s, P); break;
-        case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, true>), grid, dim3(256), 0, s, P); break;
-        default:  hipLaunchKernelGGL((sdfr_mlp_kernel<4, 1, true>), grid, dim3(256), 0, s, P); break;
+        case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 1, 4, 2, true>), grid, dim3(256), 0, s, P); break;
+        case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 4, 2, true>), grid, dim3(256), 0, s, P); break;
+        default:
+            if (getenv("SDFR_JAC_VARIANT") && atoi(getenv("SDFR_JAC_VARIANT")) == 1) hipLaunchKernelGGL((sdfr_mlp_kernel<4, 1, 4, 2, true>), grid, dim3(256), 0, s, P);
+            else hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 8, 4, true>), grid, dim3(512), 0, s, P);
+            break;
     }
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;

@@ -1,0 +1,120 @@
+"""GPU tests of the batched, sync-free path (BatchRenderer) against the drop-in modules (which are pinned to the reference goldens)
+and against the golden end-to-end gradients directly."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import sdflabel_amd
+from tests._util import ASSET, K_for, gold
+from tests.test_gpu_parity import N, T, build_pose, images_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def dec():
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt")
+    return d.to(DEV)
+
+
+def dropin_step(dec, D, H, W, K, yaw0, trans0, lat0, weights):
+    grid = sdflabel_amd.Grid3D(D, DEV)
+    lat = T(np.asarray(lat0, np.float32)).requires_grad_(True)
+    yaw = T(np.asarray([yaw0], np.float32)).requires_grad_(True)
+    trans = T(np.asarray(trans0, np.float32)).requires_grad_(True)
+    r = sdflabel_amd.Rasterer(T(K), (W, H)).to(DEV)
+    lat_ = F.normalize(lat, p=2, dim=0)
+    inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1)
+    sdf, _ = dec(inputs)
+    pcd, _, nrm = grid.get_surface_points(sdf)
+    rend, pts = r(pcd, nrm, nrm, build_pose(yaw, trans), rot="dcm", output_mask=True, output_depth=True, output_normals=True,
+                  output_nocs=True)
+    loss = sum((rend[k] * weights[k]).sum() for k in ("color", "mask", "depth", "normals"))
+    nf = pts["xyzf"].shape[0]
+    loss = loss + (pts["xyzf"] * weights["xyzf"][:nf]).sum()
+    loss.backward()
+    return rend, pts, pcd.shape[0], (yaw.grad, trans.grad, lat.grad)
+
+
+@pytest.mark.parametrize("B,D,H,W", [(3, 16, 32, 32), (2, 21, 40, 48)])
+def test_batch_matches_dropin(dec, B, D, H, W):
+    rng = np.random.default_rng(B * 10 + D)
+    K = K_for(H, W)
+    yaws = rng.uniform(-1.0, 1.0, B).astype(np.float32)
+    trans = np.stack([rng.uniform(-0.2, 0.2, B), rng.uniform(-0.15, 0.15, B), rng.uniform(2.8, 3.8, B)], 1).astype(np.float32)
+    lats = rng.standard_normal((B, 3)).astype(np.float32)
+    br = sdflabel_amd.BatchRenderer(dec, D, K, (W, H), B, device=DEV)
+    out = br.forward(T(yaws), T(trans), T(lats))
+    cap = br.cap
+    w = {"color": torch.randn(B, 3, H, W, device=DEV), "mask": torch.randn(B, 1, H, W, device=DEV),
+         "depth": torch.randn(B, 1, H, W, device=DEV), "normals": torch.randn(B, 3, H, W, device=DEV),
+         "xyzf": torch.randn(B, cap, 3, device=DEV)}
+    g_yaw, g_trans, g_lat = br.backward(g_color=w["color"], g_mask=w["mask"], g_depth=w["depth"], g_normals=w["normals"], g_xyzf=w["xyzf"])
+    assert not br.overflow()
+    for b in range(B):
+        rend, pts, n, grads = dropin_step(dec, D, H, W, K, yaws[b], trans[b], lats[b], {k: v[b] for k, v in w.items()})
+        assert int(out["n"][b]) == n and int(out["nf"][b]) == pts["xyzf"].shape[0]
+        for k, kk in (("color", "color"), ("mask", "mask"), ("depth", "depth"), ("normals", "normals")):
+            assert np.abs(N(out[kk][b]) - N(rend[k])).max() < 2e-5, k
+        nf = pts["xyzf"].shape[0]
+        assert np.abs(N(out["xyzf"][b, :nf]) - N(pts["xyzf"])).max() < 1e-5
+        assert float(out["xyzf"][b, nf:].abs().max()) == 0.0
+        for got, ref in ((g_yaw[b:b + 1], grads[0]), (g_trans[b], grads[1]), (g_lat[b], grads[2])):
+            ref = N(ref)
+            assert np.abs(N(got) - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_batch_gradients_golden(dec, tag):
+    """BatchRenderer against the reference's autograd directly (golden G7), crop replicated in a batch of 2."""
+    z = gold("g7_grads.npz")
+    D, H, W = [int(v) for v in z[tag + "_cfg"]]
+    B = 2
+    br = sdflabel_amd.BatchRenderer(dec, D, z[tag + "_K"], (W, H), B, device=DEV)
+    yaw = T(np.repeat(z[tag + "_yaw"], B)); trans = T(np.tile(z[tag + "_trans"], (B, 1))); lat = T(np.tile(z[tag + "_latent"], (B, 1)))
+    out = br.forward(yaw, trans, lat)
+    for k in ("color", "mask", "depth", "normals"):
+        images_close(N(out[k][1]), z[tag + "_out_" + k])
+    nf = int(out["nf"][0])
+    gx = torch.zeros(B, br.cap, 3, device=DEV)
+    gx[:, :nf] = T(z[tag + "_Wp_xyzf"])
+    # the golden functional also weights xyz / rgb / rgbf, which BatchRenderer does not expose: compare on the exposed subset by
+    # subtracting nothing -- instead rebuild the same functional restricted to images + xyzf with the drop-in path
+    g = br.backward(g_color=T(z[tag + "_W_color"]), g_mask=T(z[tag + "_W_mask"]), g_depth=T(z[tag + "_W_depth"]),
+                    g_normals=T(z[tag + "_W_normals"]), g_xyzf=gx)
+    w = {k: T(z[tag + "_W_" + k]) for k in ("color", "mask", "depth", "normals")}
+    w["xyzf"] = gx[0]
+    _, _, _, ref = dropin_step(dec, D, H, W, z[tag + "_K"], float(z[tag + "_yaw"][0]), z[tag + "_trans"], z[tag + "_latent"], w)
+    for got, r in ((g[0][1:2], ref[0]), (g[1][1], ref[1]), (g[2][1], ref[2])):
+        r = N(r)
+        assert np.abs(N(got) - r).max() < 2e-4 * max(1.0, np.abs(r).max())
+
+
+def test_batch_graph_replay_matches_eager(dec):
+    D, H, W, B = 16, 32, 32, 2
+    br = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), B, device=DEV)
+    br.set_params(T(np.array([0.5, -0.4], np.float32)), T(np.array([[0, 0, 3.4], [0.1, 0, 3.0]], np.float32)),
+                  T(np.array([[0.3, -0.5, 0.8], [-0.6, 0.2, 0.1]], np.float32)))
+    ones_c = torch.ones(B, 3, H, W, device=DEV)
+    grads_fn = lambda o: dict(g_color=ones_c, g_xyzf=torch.ones_like(o["xyzf"]))
+    br.backward(**grads_fn(br.forward()))
+    ref = [t.clone() for t in (br.g_yaw, br.g_trans, br.g_latent, br.color)]
+    replay = br.capture(grads_fn)
+    br.g_yaw.zero_(); br.g_latent.zero_()
+    replay()
+    torch.cuda.synchronize()
+    for a, b in zip(ref, (br.g_yaw, br.g_trans, br.g_latent, br.color)):
+        assert torch.equal(a, b)
+    # parameters are read from the static buffers at replay time
+    br.yaw.add_(0.2)
+    replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(ref[3], br.color)
+
+
+def test_batch_capacity_overflow_flag(dec):
+    br = sdflabel_amd.BatchRenderer(dec, 16, K_for(16, 16), (16, 16), 1, cap=64, device=DEV)
+    br.forward(T(np.array([0.6], np.float32)), T(np.array([[0, 0, 3.5]], np.float32)), T(np.array([[0.3, -0.5, 0.8]], np.float32)))
+    assert br.overflow() and int(br.cnt[0]) == 167        # true band size (golden G3 'a'), only the first 64 kept

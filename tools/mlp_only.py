@@ -1,0 +1,16 @@
+"""Run only the decoder forward (G=64000) a few times -- target for rocprofv3 PMC passes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+import sdflabel_amd
+from tests._util import ASSET
+dev = "cuda"
+dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt"); dec = dec.to(dev)
+grid = sdflabel_amd.Grid3D(40, dev)
+lat = F.normalize(torch.tensor([0.3, -0.5, 0.8], device=dev), dim=0)
+inputs = torch.cat([lat.expand(grid.points.size(0), -1), grid.points], 1).contiguous()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+with torch.no_grad():
+    for _ in range(n):
+        dec(inputs)
+torch.cuda.synchronize()

@@ -65,17 +65,25 @@ int64_t sdfr_decoder_macs(const sdfr_decoder* dec);
 
 /* sdf[i] = Decoder(inputs[i,:]) for i < n.   inputs [n][n_inputs], sdf [n].
  * Reference: pred_sdf_grid, _ = dsdf(inputs)  (pipelines/optimizer.py:99-101). */
-int sdfr_mlp_forward(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, void* stream);
+int sdfr_mlp_forward(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf,
+                     uint32_t* mask_ws /* optional: sdfr_decoder_mask_words(dec, n) uint32 words; receives the ReLU masks
+                                          (1 bit per hidden feature, point and layer) for a later sdfr_mlp_jacobian */,
+                     void* stream);
+/* size (in uint32 words) of the mask workspace for n rows */
+int64_t sdfr_decoder_mask_words(const sdfr_decoder* dec, int64_t n);
 
 /* Input Jacobian of the decoder at selected rows:
  *   for crop b < B, slot s < cnt[b]:  r = row_base + b*rows_per_crop + idx[b*cap+s]
  *     J[b][s][:]      = d sdf(inputs[r,:]) / d inputs[r,:]      (n_inputs values)
  *     sdf_sel[b][s]   = sdf(inputs[r,:])                         (may be NULL)
- * J must be zero-filled by the caller's stream order is handled internally (the call memsets J).
+ * J is zero-filled by the call itself (stream-ordered memset).
  * Reference: the xyz columns are what grid.py:55-56 captures through its hook for the band points; the latent
  * columns give d sdf/d latent, which autograd recomputes at optimizer.py:156. */
 int sdfr_mlp_jacobian(const sdfr_decoder* dec, const float* inputs, int64_t rows_per_crop, int B,
-                      const int32_t* idx, int cap, const int32_t* cnt, float* J, float* sdf_sel, void* stream);
+                      const int32_t* idx, int cap, const int32_t* cnt, float* J, float* sdf_sel,
+                      const float* sdf_full /* optional: output of the sdfr_mlp_forward call over the same rows */,
+                      const uint32_t* mask_ws /* optional: masks that call saved; with both, no forward recomputation */,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Zero-isosurface projection  --  replaces Grid3D.get_surface_points (sdfrenderer/grid.py:43-71)

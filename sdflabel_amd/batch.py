@@ -58,6 +58,7 @@ class BatchRenderer:
         self.yaw, self.trans, self.latent = f(B), f(B, 3), f(B, self.L)
         self.inputs, self.pose, self.latnorm = f(B * G, NI), f(B, 16), f(B)
         self.sdf = f(B * G)
+        self.mask_ws = i(int(_lib.lib().sdfr_decoder_mask_words(self.handle.h, B * G)))
         self.idx, self.cnt, self.scratch = i(B, cap), i(B), i(B * ((G + 255) // 256) + 1)
         self.J, self.sdf_band = f(B, cap, NI), f(B, cap)
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
@@ -91,12 +92,12 @@ class BatchRenderer:
                                  P(self.latnorm), st), "sdfr_params_forward")
         if mlp_events is not None:
             mlp_events[0].record()
-        ck(L.sdfr_mlp_forward(self.handle.h, P(self.inputs), B * G, P(self.sdf), st), "sdfr_mlp_forward")
+        ck(L.sdfr_mlp_forward(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.mask_ws), st), "sdfr_mlp_forward")
         if mlp_events is not None:
             mlp_events[1].record()
         ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
-        ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.idx), cap, P(self.cnt), P(self.J), P(self.sdf_band), st),
-           "sdfr_mlp_jacobian")
+        ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.idx), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.sdf),
+                               P(self.mask_ws), st), "sdfr_mlp_jacobian")
         xyz = self.inputs[:, self.NI - 3:]
         ck(L.sdfr_surface_project(P(xyz), self.NI, P(self.sdf), G, B, P(self.idx), cap, P(self.cnt), P(self.J), self.NI, self.NI - 3,
                                   P(self.points), P(self.nocs), P(self.normals), st), "sdfr_surface_project")

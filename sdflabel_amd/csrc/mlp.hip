@@ -58,6 +58,8 @@ struct MlpParams {
     int cap;
     float* J;
     float* sdf_sel;
+    const float* sdf_in;    // MODE 3: decoder output of the forward launch that saved the masks
+    uint32_t* maskbuf;      // MODE 1 (write) / MODE 3 (read): ReLU masks [tile64][layer][word][thread]
 };
 
 struct sdfr_decoder {
@@ -75,14 +77,23 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 
 // FT feature tiles (32 rows) per wave, NP point tiles (32 points) per workgroup, NW waves per workgroup (HP = 32*FT*NW padded
 // hidden width), PF weight/activation fragment buffers in flight per wave (prefetch distance PF-1 K tiles).
-template <int FT, int NP, int NW, int PF, bool JAC>
+// MODE 0: forward.  1: forward + ReLU masks saved to HBM (1 bit per feature, point, layer).  2: Jacobian of selected rows by
+// recomputation (forward with masks in LDS, then backward).  3: Jacobian of selected rows from the masks a MODE-1 launch saved
+// (backward only: no activations are needed for an input gradient, only the masks and the output).
+template <int FT, int NP, int NW, int PF, int MODE>
 __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
+    constexpr bool JAC = MODE >= 2;
+    constexpr bool SAVE = MODE == 1;
+    constexpr bool LMASK = MODE == 2;
+    constexpr bool GMASK = MODE == 3;
+    static_assert(!GMASK || NP == 1, "mask-fed Jacobian uses 32-point tiles");
+    static_assert(!SAVE || NP == 2, "mask layout assumes the 64-point forward tile");
     constexpr int NT = 64 * NW;
     constexpr int PT = 32 * NP;
     constexpr int HP = 32 * FT * NW;
     constexpr int KG = HP / 4;
     constexpr int MW = (FT * NP * 16 + 31) / 32;                 // mask words per thread per layer
-    constexpr int MASK_WORDS = JAC ? (SDFR_MAX_LAYERS * MW * NT) : 1;
+    constexpr int MASK_WORDS = LMASK ? (SDFR_MAX_LAYERS * MW * NT) : 1;
     // single LDS object, carved by hand (16-byte aligned pieces first)
     __shared__ float4 lds4[KG * PT + NT / 4 + 16 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4];
     float4* act = lds4;                                           // [KG][PT]
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     __syncthreads();
 
     // ---- layer-0 operand: act[k][pt] = inputs[row(pt)][k], zero padded to a multiple of 8 ---------------
-    {
+    if (!GMASK) {
         const int k0pad = P.L[0].nkt_f * 8;
         for (int e = tid; e < PT * k0pad; e += NT) {
             const int pt = e / k0pad, k = e - pt * k0pad;
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     };
 
     // ---- forward through the MFMA layers -------------------------------------------------------------------
-    for (int l = 0; l < P.n_mfma; ++l) {
+    for (int l = 0; !GMASK && l < P.n_mfma; ++l) {
         const MlpLayer L = P.L[l];
         const MlpLayer Ln = P.L[l + 1];
         gemm(P.Wf + L.off_f, L.nkt_f, L.out_dim);
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
                         const float x = acc[f][p][rg * 4 + i] + f4c(b4, i);
                         const bool pos = x > 0.f;
                         v[i] = pos ? x : 0.f;
-                        if (JAC) {
+                        if (LMASK || SAVE) {
                             const int bit = ((f * NP + p) * 4 + rg) * 4 + i;
                             mw[bit >> 5] |= (pos ? 1u : 0u) << (bit & 31);
                         }
@@ -230,15 +241,26 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
                     act[(j0 >> 2) * PT + pt] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
-        if (JAC) {
+        if (LMASK) {
 #pragma unroll
             for (int w = 0; w < MW; ++w) masks[(l * MW + w) * NT + tid] = mw[w];
+        }
+        if (SAVE && P.maskbuf) {
+            uint32_t* dst = P.maskbuf + (((int64_t)blockIdx.x * P.n_mfma + l) * MW) * NT + tid;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) dst[w * NT] = mw[w];
         }
         __syncthreads();
     }
 
     // ---- last linear (H -> 1) + tanh -----------------------------------------------------------------------
-    {
+    if (GMASK) {
+        if (tid < PT) {
+            const float o = P.sdf_in[rows[tid]];
+            gy[tid] = 1.f - o * o;
+            if (tid < n_valid && P.sdf_sel) P.sdf_sel[slots[tid]] = o;
+        }
+    } else {
         constexpr int SL = NT / PT;                       // k slices
         constexpr int KGS = KG / SL;
         const int sl = tid / PT, pt = tid - sl * PT;
@@ -283,8 +305,22 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
         const int prev_out = P.L[l - 1].out_dim;
         const int inj_hi = prev_out + L.inj_n;
         uint32_t mw[MW];
+        if (GMASK) {
+            // the forward launch stored, per 64-point tile, FT words per thread: word f = [p'=0 bits | p'=1 bits] of feature tile f
+            const int r = rows[l31];
+            const int q = r & 63;
+            const uint32_t* src = P.maskbuf + (((int64_t)(r >> 6) * P.n_mfma + (l - 1)) * FT) * NT + wave * 64 + hi * 32 + (q & 31);
 #pragma unroll
-        for (int w = 0; w < MW; ++w) mw[w] = masks[((l - 1) * MW + w) * NT + tid];
+            for (int w = 0; w < MW; ++w) mw[w] = 0u;
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+                const uint32_t bits = (src[f * NT] >> ((q >> 5) * 16)) & 0xFFFFu;
+                mw[(f * 16) >> 5] |= bits << ((f * 16) & 31);
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < MW; ++w) mw[w] = masks[((l - 1) * MW + w) * NT + tid];
+        }
 #pragma unroll
         for (int f = 0; f < FT; ++f)
 #pragma unroll
@@ -426,49 +462,76 @@ extern "C" int sdfr_decoder_destroy(sdfr_decoder* d) {
 
 extern "C" int64_t sdfr_decoder_macs(const sdfr_decoder* d) { return d ? d->macs : 0; }
 
-extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, void* stream) {
+// per-thread mask words of the forward kernel for a padded width HP: FT (= feature tiles per wave), threads per workgroup NT
+static void mask_geometry(int HP, int* ft, int* nt) {
+    if (HP == 128) { *ft = 1; *nt = 256; }
+    else if (HP == 256) { *ft = 2; *nt = 256; }
+    else { *ft = 2; *nt = 512; }
+}
+
+extern "C" int64_t sdfr_decoder_mask_words(const sdfr_decoder* d, int64_t n) {
+    if (!d || n <= 0) return 0;
+    int ft, nt;
+    mask_geometry(d->HP, &ft, &nt);
+    return ((n + 63) / 64) * (int64_t)(d->n_lin - 1) * ft * nt;
+}
+
+extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf, "sdfr_mlp_forward: NULL argument");
     SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward: n=%lld out of range", (long long)n);
     if (n == 0) return SDFR_OK;
     MlpParams P = d->proto;
-    P.inputs = inputs; P.n = n; P.sdf = sdf;
+    P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws;
     hipStream_t s = (hipStream_t)stream;
     const int grid = sdfr_cdiv(n, 64);
     static const int variant = getenv("SDFR_MLP_VARIANT") ? atoi(getenv("SDFR_MLP_VARIANT")) : 0;   // development A/B switch
-    switch (d->HP) {
-        case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 2, 4, 2, false>), dim3(grid), dim3(256), 0, s, P); break;
-        case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 4, 2, false>), dim3(grid), dim3(256), 0, s, P); break;
-        default:
-            if (variant == 1) hipLaunchKernelGGL((sdfr_mlp_kernel<4, 2, 4, 3, false>), dim3(grid), dim3(256), 0, s, P);
-            else if (variant == 2) hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 2, false>), dim3(grid), dim3(512), 0, s, P);
-            else if (variant == 3) hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 3, false>), dim3(grid), dim3(512), 0, s, P);
-            else if (variant == 5) hipLaunchKernelGGL((sdfr_mlp_kernel<4, 2, 4, 4, false>), dim3(grid), dim3(256), 0, s, P);
-            else if (variant == 6) hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 6, false>), dim3(grid), dim3(512), 0, s, P);
-            else if (variant == 7) hipLaunchKernelGGL((sdfr_mlp_kernel<4, 2, 4, 2, false>), dim3(grid), dim3(256), 0, s, P);
-            else hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 4, false>), dim3(grid), dim3(512), 0, s, P);
-            break;
+    if (mask_ws) {
+        switch (d->HP) {
+            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 2, 4, 2, 1>), dim3(grid), dim3(256), 0, s, P); break;
+            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 4, 2, 1>), dim3(grid), dim3(256), 0, s, P); break;
+            default:  hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 4, 1>), dim3(grid), dim3(512), 0, s, P); break;
+        }
+    } else {
+        switch (d->HP) {
+            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 2, 4, 2, 0>), dim3(grid), dim3(256), 0, s, P); break;
+            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 4, 2, 0>), dim3(grid), dim3(256), 0, s, P); break;
+            default:
+                if (variant == 7) hipLaunchKernelGGL((sdfr_mlp_kernel<4, 2, 4, 2, 0>), dim3(grid), dim3(256), 0, s, P);
+                else hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 4, 0>), dim3(grid), dim3(512), 0, s, P);
+                break;
+        }
     }
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
 
 extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int64_t rows_per_crop, int B,
-                                 const int32_t* idx, int cap, const int32_t* cnt, float* J, float* sdf_sel, void* stream) {
+                                 const int32_t* idx, int cap, const int32_t* cnt, float* J, float* sdf_sel,
+                                 const float* sdf_full, const uint32_t* mask_ws, void* stream) {
     SDFR_REQUIRE(d && inputs && idx && J, "sdfr_mlp_jacobian: NULL argument");
     SDFR_REQUIRE(B >= 0 && cap >= 0, "sdfr_mlp_jacobian: negative size");
+    SDFR_REQUIRE((mask_ws == nullptr) == (sdf_full == nullptr) || mask_ws == nullptr, "sdfr_mlp_jacobian: mask_ws needs sdf_full");
     if (B == 0 || cap == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
     SDFR_HIP_CHECK(hipMemsetAsync(J, 0, (size_t)B * cap * d->n_inputs * sizeof(float), s));
     MlpParams P = d->proto;
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
+    P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws);
     dim3 grid(sdfr_cdiv(cap, 32), B);
-    switch (d->HP) {
-        case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 1, 4, 2, true>), grid, dim3(256), 0, s, P); break;
-        case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 4, 2, true>), grid, dim3(256), 0, s, P); break;
-        default:
-            if (getenv("SDFR_JAC_VARIANT") && atoi(getenv("SDFR_JAC_VARIANT")) == 1) hipLaunchKernelGGL((sdfr_mlp_kernel<4, 1, 4, 2, true>), grid, dim3(256), 0, s, P);
-            else hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 8, 4, true>), grid, dim3(512), 0, s, P);
-            break;
+    // masks saved by the forward launch make the recomputation unnecessary (not for use_tanh decoders: their output
+    // derivative needs the pre-tanh value)
+    if (mask_ws && sdf_full && !d->use_tanh) {
+        switch (d->HP) {
+            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 1, 4, 2, 3>), grid, dim3(256), 0, s, P); break;
+            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 4, 2, 3>), grid, dim3(256), 0, s, P); break;
+            default:  hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 8, 4, 3>), grid, dim3(512), 0, s, P); break;
+        }
+    } else {
+        switch (d->HP) {
+            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 1, 4, 2, 2>), grid, dim3(256), 0, s, P); break;
+            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 4, 2, 2>), grid, dim3(256), 0, s, P); break;
+            default:  hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 8, 4, 2>), grid, dim3(512), 0, s, P); break;
+        }
     }
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;

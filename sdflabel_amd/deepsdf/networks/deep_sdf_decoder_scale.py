@@ -59,16 +59,21 @@ class SdfState:
         self.slot = None              # (G,) int32 position in idx or -1
         self.J = None                 # (cap, NI) d sdf / d inputs at the band rows
         self.cap = 0
+        self.sdf = None               # (G,) decoder output of the forward launch
+        self.mask_ws = None           # ReLU masks saved by the forward launch (int32 words)
 
 
-def mlp_jacobian(state, idx, n):
-    """J (n, NI), sdf_sel (n,) for the rows idx[:n] of state.inputs."""
+def mlp_jacobian(state, idx, n, use_masks=True):
+    """J (n, NI), sdf_sel (n,) for the rows idx[:n] of state.inputs.  With the masks the forward launch saved the Jacobian is a
+    backward-only pass; otherwise the kernel recomputes the forward for the selected rows."""
     L = _lib.lib()
     J = torch.empty((max(n, 1), state.inputs.shape[1]), dtype=torch.float32, device=state.inputs.device)
     sel = torch.empty((max(n, 1),), dtype=torch.float32, device=state.inputs.device)
     if n > 0:
+        um = use_masks and state.mask_ws is not None and state.sdf is not None
         _lib.check(L.sdfr_mlp_jacobian(state.handle.h, _lib.ptr(state.inputs), state.G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
-                                       _lib.ptr(sel), _lib.stream_ptr()), "sdfr_mlp_jacobian")
+                                       _lib.ptr(sel), _lib.ptr(state.sdf) if um else None, _lib.ptr(state.mask_ws) if um else None,
+                                       _lib.stream_ptr()), "sdfr_mlp_jacobian")
     return J[:n], sel[:n]
 
 
@@ -77,8 +82,11 @@ class _DeepSDFFn(torch.autograd.Function):
     def forward(ctx, inputs, state):
         L = _lib.lib()
         sdf = torch.empty((state.G, 1), dtype=torch.float32, device=inputs.device)
-        _lib.check(L.sdfr_mlp_forward(state.handle.h, _lib.ptr(state.inputs), state.G, _lib.ptr(sdf), _lib.stream_ptr()),
-                   "sdfr_mlp_forward")
+        nw = int(L.sdfr_decoder_mask_words(state.handle.h, state.G))
+        state.mask_ws = torch.empty((nw,), dtype=torch.int32, device=inputs.device)
+        _lib.check(L.sdfr_mlp_forward(state.handle.h, _lib.ptr(state.inputs), state.G, _lib.ptr(sdf), _lib.ptr(state.mask_ws),
+                                      _lib.stream_ptr()), "sdfr_mlp_forward")
+        state.sdf = sdf.view(-1)
         ctx.state = state
         return sdf
 

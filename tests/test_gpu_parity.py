@@ -137,6 +137,21 @@ def test_mlp_jacobian_selected_rows_vs_oracle(dec, oracle_layers):
     assert np.abs(N(J) - Jref).max() < 2e-5 * max(1.0, np.abs(Jref).max())
 
 
+def test_mlp_jacobian_from_saved_masks_equals_recompute(dec):
+    """The mask-fed (backward-only) Jacobian equals the recomputing one up to the summation order of the last 512->1 dot
+    (8 vs 16 partial sums), i.e. to float rounding; the selected sdf values are exactly the forward launch's."""
+    from sdflabel_amd.deepsdf.networks.deep_sdf_decoder_scale import mlp_jacobian
+    rng = np.random.default_rng(11)
+    inp = T((rng.standard_normal((3000, 6)) * 0.6).astype(np.float32))
+    sdf, _ = dec(inp)
+    st = sdf._sdfr_state
+    rows = T(np.sort(rng.choice(3000, 517, replace=False)).astype(np.int32))
+    J1, s1 = mlp_jacobian(st, rows, 517, use_masks=True)
+    J2, s2 = mlp_jacobian(st, rows, 517, use_masks=False)
+    assert torch.allclose(J1, J2, rtol=2e-5, atol=2e-6) and torch.allclose(s1, s2, rtol=0, atol=1e-6)
+    assert torch.equal(s1, sdf.view(-1)[rows.long()])
+
+
 def test_mlp_forward_empty(dec):
     sdf, _ = dec(torch.zeros((1, 6), device=DEV))
     assert sdf.shape == (1, 1)

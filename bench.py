@@ -197,10 +197,11 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # the path's only exchange: per-crop results gathered once, outside the per-iteration critical path
-        res = torch.cat([loss.view(1), br.g_yaw, br.g_trans.view(-1), br.g_latent.view(-1)]).float()
-        out = [torch.empty_like(res) for _ in range(world)]
-        dist.all_gather(out, res)
+        # the path's only exchange: per-crop result rows gathered once, outside the per-iteration critical path
+        from sdflabel_amd.parallel import gather_crop_results
+        res = torch.cat([loss.view(1), br.g_yaw, br.g_trans.view(-1), br.g_latent.view(-1)]).float().view(1, -1)
+        table = gather_crop_results(res, world, rank, world)
+        assert table.shape == (world, 8) and bool(torch.isfinite(table).all())
     mlp_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     # the same crop-iteration through the drop-in boundary (rank 0 only, informational)
@@ -237,7 +238,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_mlp_forward.json")
         if os.path.isfile(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        line["roofline"] = {"kernel": "sdfr_mlp_kernel<2,2,8,4,false> (fused decoder forward on the grid)", "bound": "mfma",
+        line["roofline"] = {"kernel": "sdfr_mlp_kernel<2,2,8,4,1> (fused decoder forward on the grid, saves ReLU masks)", "bound": "mfma",
                             "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                             "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": mlp_ms}
         line["dropin_api"] = dropin

@@ -424,3 +424,27 @@ def test_full_size_crop_vs_oracle_sample(dec, oracle_layers):
     for k in ("color", "mask", "depth", "normals"):
         images_close(N(rend[k]), ro[k], aux)
     assert np.abs(N(points["xyzf"]) - po["xyzf"]).max() < 1e-5
+
+
+def test_refinement_trajectory_golden(dec):
+    """a8 / a-harness: 10 iterations of the reference's refinement loop (Adam + SGD, 2-D NOCS window loss, 3-D NN loss) restated in
+    tests/_harness.py on top of the drop-in modules, against the trajectory the reference's own Optimizer produced (golden G8)."""
+    from tests._harness import Refiner
+    z = gold("g8_optimizer.npz")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    params = {"yaw": init[0:1], "trans": init[1:4], "scale": init[4:5], "latent": init[5:8]}
+    ref = Refiner(params, DEV, {"2d": 0.3, "3d": 0.5})
+    grid = sdflabel_amd.Grid3D(D, DEV)
+    renderer = sdflabel_amd.Rasterer(T(z["K"]), (W, H)).to(DEV)
+    traj = []
+    for _ in range(10):
+        ref.optimize(1, T(z["nocs_target"]), z["lidar"], dec, grid, renderer)
+        traj.append(ref.vector())
+    traj = np.asarray(traj)
+    assert len(ref.log) == 10
+    l2 = np.array([a for a, _ in ref.log]); l3 = np.array([b for _, b in ref.log])
+    assert np.abs(l2 - z["loss2d_weighted"]).max() < 2e-4, (l2, z["loss2d_weighted"])
+    assert np.abs(l3 - z["loss3d_weighted"]).max() < 2e-4
+    assert np.abs(traj - z["traj"]).max() < 5e-4, np.abs(traj - z["traj"]).max(axis=0)
+    assert abs(traj[-1, 0] - init[0]) > 0.05            # the pose really moved

@@ -361,14 +361,140 @@ def inside_surfel(Kinv, grid_2d, vertex_3d, normals, diam=0.04, depth_constant=1
 
 
 # --------------------------------------------------------------------------------------
+# Secondary primitives: 2-D circle and 15x15 stamp  (sdfrenderer/renderer/primitives.py:4-162)
+# --------------------------------------------------------------------------------------
+
+
+def _sigmoid(x):
+    with np.errstate(over="ignore"):
+        return (1 / (1 + np.exp(-x))).astype(x.dtype)
+
+
+def depth_logits(vertex_3d, depth_constant):
+    """primitives.py:57-61 / :141-144 -- per-vertex logit clamp(-z/(||z||+eps) + 1, 0) * C  (the norm is detached).
+    Returns (logits (N,), pre-clamp value q (N,), ||z||)."""
+    dt = vertex_3d.dtype
+    eps = np.finfo(dt).eps
+    z = -vertex_3d[:, 2]
+    zn = np.sqrt(np.sum(z * z)).astype(dt)
+    q = (z / (zn + dt.type(eps)) + dt.type(1)).astype(dt)
+    return (np.maximum(q, dt.type(0)) * dt.type(depth_constant)).astype(dt), q, zn
+
+
+def inside_circle(K, grid_2d, vertex_2d, vertex_3d, diam=0.02, depth_constant=100, softclamp_constant=3, add_bg=False, want_mask=False):
+    """primitives.py:4-71 with softclamp=True (the renderer's call, rasterer.py:94-96, leaves the default).  Note the reference
+    thresholds sigmoid(.) > 0 (:55), which only fails once exp overflows (~29.6 px beyond the circle), and that the softmax runs
+    over z * mask (:70): uncovered vertices keep a logit of 0 in the denominator."""
+    dt = vertex_3d.dtype
+    eps = np.finfo(dt).eps
+    diff = vertex_2d[:, None, :2].astype(dt) - grid_2d[None].astype(dt)                    # :42
+    r = np.abs(K[0, 0].astype(dt) * dt.type(diam) / (vertex_3d[:, 2] + dt.type(eps)))      # :47
+    d = np.sqrt(np.sum(diff * diff, axis=-1)).astype(dt)
+    m = _sigmoid(((r[:, None] - d) * dt.type(softclamp_constant)).astype(dt)) > 0          # :46-49,:55
+    zl, _, _ = depth_logits(vertex_3d, depth_constant)                                      # :56-61
+    L = zl[:, None] * m.astype(dt)
+    mf = m.astype(dt)
+    if add_bg:                                                                              # :64-67
+        L = np.concatenate([L, np.full((1, L.shape[1]), zl.min() - 1, dt)], axis=0)
+        mf = np.concatenate([mf, np.ones((1, mf.shape[1]), dt)], axis=0)
+    L = L - L.max(axis=0, keepdims=True)
+    e = np.exp(L)
+    W = (e / e.sum(axis=0, keepdims=True) * mf).astype(dt)                                  # :70
+    return (W, m) if want_mask else W
+
+
+def inside_circle_opt(K, vertex_2d, vertex_3d, diam=0.025, depth_constant=10000, softclamp_constant=5, add_bg=False, want_mask=False):
+    """primitives.py:74-162 -- every vertex stamps a 15x15 pixel square (sigmoid weights, all > 0) at trunc(vertex_2d + offset),
+    indices clamped into the image (:125-127), duplicates summed by the sparse tensor (:135-138); image size from K (:109-110)."""
+    dt = vertex_3d.dtype
+    eps = np.finfo(dt).eps
+    fmin = np.finfo(dt).min
+    x_px, y_px = int(K[0, 2]) * 2, int(K[1, 2]) * 2
+    yy, xx = np.mgrid[-7:8, -7:8]
+    off = np.concatenate((xx[..., None], yy[..., None]), axis=-1).reshape((-1, 2)).astype(dt)      # rasterer.py:30-32
+    dist_prim = np.sqrt(np.sum(off * off, axis=-1)).astype(dt)
+    r = np.abs(K[0, 0].astype(dt) * dt.type(diam) / (vertex_3d[:, 2] + dt.type(eps)))
+    prim = _sigmoid(((r[:, None] - dist_prim[None]) * dt.type(softclamp_constant)).astype(dt))       # :118
+    ids = np.trunc(off[None] + vertex_2d[:, None, :].astype(dt)).astype(np.int64)                   # :122-124
+    ids[..., 0] = np.clip(ids[..., 0], 0, x_px - 1)
+    ids[..., 1] = np.clip(ids[..., 1], 0, y_px - 1)
+    N = vertex_3d.shape[0]
+    dense = np.zeros((N, y_px, x_px), np.float32)
+    np.add.at(dense, (np.arange(N)[:, None], ids[..., 1], ids[..., 0]), prim.astype(np.float32))
+    m = dense.reshape(N, -1) > 0                                                                     # :155
+    zl, _, _ = depth_logits(vertex_3d, depth_constant)
+    L = np.broadcast_to(zl[:, None], m.shape).astype(dt)
+    mf = m.astype(dt)
+    if add_bg:
+        L = np.concatenate([L, np.full((1, L.shape[1]), zl.min() - 1, dt)], axis=0)
+        mf = np.concatenate([mf, np.ones((1, mf.shape[1]), dt)], axis=0)
+        m2 = np.concatenate([m, np.ones((1, m.shape[1]), bool)], axis=0)
+    else:
+        m2 = m
+    L = np.where(m2, L, dt.type(fmin))                                                               # :156
+    L = L - L.max(axis=0, keepdims=True)
+    e = np.exp(L)
+    W = (e / e.sum(axis=0, keepdims=True) * mf).astype(dt)
+    return (W, m) if want_mask else W
+
+
+def circle_backward(W, m, vertex_3d, c_attr, n_attr, g_color, g_mask, g_depth, g_normals, depth_constant, unmasked_softmax, bg=None):
+    """Autograd of inside_circle / inside_circle_opt + compositing w.r.t. the vertex depths (through the logits; masks, the depth
+    norm and the 2-D positions carry no gradient) and the composited attributes.  W is the forward weight matrix (N[+1], P),
+    m the (N, P) coverage.  unmasked_softmax: inside_circle's softmax over z*mask (uncovered logit 0).  Returns g_v3 (N,3),
+    g_cattr (N,3), g_nattr (N,3)."""
+    dt = vertex_3d.dtype
+    eps = np.finfo(dt).eps
+    N, P = m.shape
+    zl, q, zn = depth_logits(vertex_3d, depth_constant)
+    has_bg = W.shape[0] == N + 1
+    mf = m.astype(np.float64)
+    w = W[:N].astype(np.float64)
+    z3 = vertex_3d[:, 2].astype(np.float64)
+    zero3 = np.zeros((3, P))
+    gC = g_color.reshape(3, P).astype(np.float64) if g_color is not None else zero3
+    gM = g_mask.reshape(P).astype(np.float64) if g_mask is not None else np.zeros(P)
+    gD = g_depth.reshape(P).astype(np.float64) if g_depth is not None else np.zeros(P)
+    gN = g_normals.reshape(3, P).astype(np.float64) if g_normals is not None else zero3
+    Cs = c_attr.T.astype(np.float64) @ w
+    Ms = W.astype(np.float64).sum(axis=0)
+    Ns = n_attr.T.astype(np.float64) @ w
+    if has_bg:
+        Cs = Cs + W[N][None].astype(np.float64) * bg.reshape(3, P)
+    gCg = gC * (Cs.astype(dt) <= 1)
+    gMg = gM * (Ms.astype(dt) <= 1)
+    gNg = gN * (Ns.astype(dt) <= 1)
+    dW = c_attr.astype(np.float64) @ gCg + gMg[None] + z3[:, None] * gD[None] + n_attr.astype(np.float64) @ gNg
+    g_c = w @ gCg.T
+    g_na = w @ gNg.T
+    g_v3 = np.zeros((N, 3))
+    g_v3[:, 2] += w @ gD
+    # softmax backward.  sm == w on covered entries; uncovered entries have dL/dsm = 0 (w = sm * m)
+    S = np.sum(w * dW, axis=0)
+    if has_bg:
+        dWbg = np.sum(gCg * bg.reshape(3, P), axis=0) + gMg
+        S = S + W[N].astype(np.float64) * dWbg
+    dlog = w * (dW - S[None])                      # covered rows only matter: logit = zl * m (or masked_fill)
+    dzl = np.sum(dlog * mf, axis=1)
+    if has_bg:                                     # z_bg = zl.min() - 1  (:65 / :147)
+        dlog_bg = W[N].astype(np.float64) * (dWbg - S)
+        dzl[int(np.argmin(zl))] += dlog_bg.sum()
+    if not unmasked_softmax:
+        pass                                       # masked_fill: identical on covered entries
+    dq = dzl * depth_constant * (q >= 0)
+    g_v3[:, 2] += dq * (-1.0 / (float(zn) + eps))  # q = -z/(zn+eps) + 1, zn detached
+    return g_v3.astype(dt), g_c.astype(dt), g_na.astype(dt)
+
+
+# --------------------------------------------------------------------------------------
 # Rasterer  (sdfrenderer/renderer/rasterer.py:49-155)
 # --------------------------------------------------------------------------------------
 
 
 def rasterer_forward(K, Kinv, resolution_px, coords, normals, colors, camera_matrix, rot="dcm", bg=None,
                      output_mask=True, output_depth=True, output_normals=True, output_nocs=True, chunk=8192,
-                     want_aux=False):
-    """rasterer.py:49-155 with primitives='disc'.  Returns (rendering dict, points dict, proj dict)."""
+                     want_aux=False, primitives="disc"):
+    """rasterer.py:49-155.  Returns (rendering dict, points dict, proj dict)."""
     dt = K.dtype
     rx, ry = resolution_px
     if rot == "dcm":
@@ -379,8 +505,15 @@ def rasterer_forward(K, Kinv, resolution_px, coords, normals, colors, camera_mat
     nrm = proj["normals_3d"].astype(dt)
     col = proj["colors_3d"].astype(dt)
     grid_2d = pixel_grid(resolution_px)
-    res = inside_surfel(Kinv, grid_2d, v3, nrm, diam=0.04, add_bg=(bg is not None), chunk=chunk, want_aux=want_aux)
-    W, aux = res if want_aux else (res, None)
+    if primitives == "disc":                                                       # :101-104
+        res = inside_surfel(Kinv, grid_2d, v3, nrm, diam=0.04, add_bg=(bg is not None), chunk=chunk, want_aux=want_aux)
+        W, aux = res if want_aux else (res, None)
+    elif primitives == "circle":                                                   # :93-96
+        W, aux = inside_circle(K, grid_2d, proj["points_2d"], v3, diam=0.02, add_bg=(bg is not None)), None
+    elif primitives == "circle_opt":                                               # :97-100
+        W, aux = inside_circle_opt(K, proj["points_2d"], v3, diam=0.025, add_bg=(bg is not None)), None
+    else:
+        raise ValueError(primitives)
     rendering = {}
     if bg is not None:                                                             # :107-111
         color = (W[:-1].T @ ((col + 1) / 2)).T + W[-1][None, :] * bg.reshape(3, -1).astype(dt)

@@ -166,3 +166,48 @@ def test_g7_gradients(tag):
     g_lat = (g_lat_n - lat * (lat.astype(np.float64) @ g_lat_n)) / nrm_l
     ref = z[tag + "_g_latent"]
     assert np.abs(g_lat - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("prim,use_bg", [("circle", False), ("circle", True), ("circle_opt", False), ("circle_opt", True), ("disc", True)])
+def test_g9_secondary_primitives_and_bg(prim, use_bg):
+    """a6' rows: circle / circle_opt primitives and the bg variant -- forward images and autograd gradients."""
+    z = gold("g9_secondary.npz")
+    H = W = 32
+    t = "%s_bg%d_" % (prim, int(use_bg))
+    K, Kinv = z["K"], z["Kinv"]
+    pose = z[t + "pose"]
+    bg = z["bg"] if use_bg else None
+    rend, pts, proj = O.rasterer_forward(K, Kinv, (W, H), z["points"], z["normals"], z["normals"], pose, rot="dcm", bg=bg,
+                                         output_nocs=True, primitives=prim)
+    keys = ("color", "mask") if use_bg else ("color", "mask", "depth", "normals")
+    # circle_opt multiplies the normalised depth by 10000 before the softmax (primitives.py:81): one ulp of the float32 logit
+    # (~2e-4 at |logit| ~ 2000) moves the weights by ~2e-4, so 1e-4 is not attainable between two float32 implementations
+    tol = 1e-3 if prim == "circle_opt" else 1e-4
+    for k in keys:
+        assert np.abs(rend[k] - z[t + "out_" + k]).max() < tol, k
+    # backward
+    v3, nc = proj["points_3d"].astype(np.float32), proj["normals_3d"].astype(np.float32)
+    c_attr = ((proj["colors_3d"] + 1) / 2).astype(np.float32)
+    n_attr = ((nc + 1) / 2).astype(np.float32)
+    gC, gM = z[t + "W_color"], z[t + "W_mask"]
+    gD = None if use_bg else z[t + "W_depth"]
+    gN = None if use_bg else z[t + "W_normals"]
+    grid2 = O.pixel_grid((W, H))
+    if prim == "disc":
+        Wm = O.inside_surfel(Kinv, grid2, v3, nc, diam=0.04, add_bg=True)
+        # with a background the disc weights are exactly the bg-free ones where covered (exp(z_bg - max) underflows): reuse the
+        # bg-free backward with the gradients gated by the clamp of the composited (bg-inclusive) image
+        g_v3, g_n, g_c = O.splat_backward(Kinv, (W, H), v3, nc, c_attr, gC, gM, None, None)
+    else:
+        if prim == "circle":
+            Wm, m = O.inside_circle(K, grid2, proj["points_2d"], v3, diam=0.02, add_bg=use_bg, want_mask=True)
+            C, unm = 100, True
+        else:
+            Wm, m = O.inside_circle_opt(K, proj["points_2d"], v3, diam=0.025, add_bg=use_bg, want_mask=True)
+            C, unm = 10000, False
+        g_v3, g_c, g_na = O.circle_backward(Wm, m, v3, c_attr, n_attr, gC, gM, gD, gN, C, unm, bg=bg)
+        g_n = g_na * 0.5
+    g_points, _, _, g_pose = O.project_backward_dcm(pose, z["points"], z["normals"], g_v3, g_n, g_c * 0.5, output_nocs=True)
+    ref = z[t + "g_points"]
+    assert np.abs(g_points - ref).max() < 2e-3 * max(1.0, np.abs(ref).max()), np.abs(g_points - ref).max()
+    assert np.allclose(g_pose[:3, 3], z[t + "g_trans"], atol=2e-3 * max(1.0, np.abs(z[t + "g_trans"]).max()))

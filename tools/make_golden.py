@@ -14,6 +14,7 @@ seeds, torch version and threshold margins -- never reference source.
   G7 grads           autograd gradients of a fixed random functional of all outputs w.r.t.
                      yaw, trans, latent, coords, normals                  (optimizer.py:79-123 graph)
   G8 optimizer       10-iteration Optimizer.optimize trajectory            (optimizer.py:56-164)
+  G9 secondary       Rasterer.forward with primitives circle / circle_opt and bg, + gradients   (primitives.py:4-162)
 
 usage: python tools/make_golden.py [G1 G2 ...]
 """
@@ -360,7 +361,48 @@ def g8():
          traj=np.asarray(traj), loss2d_weighted=np.asarray(l2d), loss3d_weighted=np.asarray(l3d))
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8}
+def g9():
+    """Secondary rows a6' / bg: Rasterer.forward with primitives circle / circle_opt and with a background image, plus autograd
+    gradients w.r.t. the surfel positions and the pose."""
+    arrs = {}
+    dec, grid, lat, sdf, pts, nocs, nrm = surface_case(16, [0.3, -0.5, 0.8])
+    pts0, nrm0 = pts.detach(), nrm.detach()
+    arrs["points"] = pts0.numpy()
+    arrs["normals"] = nrm0.numpy()
+    H, W = 32, 32
+    K = K_for(H, W)
+    arrs["K"] = K.numpy()
+    arrs["Kinv"] = K.float().inverse().numpy()
+    r = Rasterer(K, (W, H), precision=torch.float32)
+    gen = torch.Generator().manual_seed(17)
+    bgimg = torch.rand(3, H, W, generator=gen)
+    arrs["bg"] = bgimg.numpy()
+    for prim in ("circle", "circle_opt", "disc"):
+        for use_bg in (False, True):
+            if prim == "disc" and not use_bg:
+                continue
+            p = pts0.clone().requires_grad_(True)
+            yaw = torch.tensor([0.6], requires_grad=True)
+            trans = torch.tensor([0.05, -0.03, 3.4], requires_grad=True)
+            pose = build_pose(yaw, trans)
+            rend = r(p, nrm0, nrm0, pose, rot="dcm", primitives=prim, bg=bgimg if use_bg else None, output_mask=True,
+                     output_depth=not use_bg, output_normals=not use_bg, output_nocs=True, output_points=False)
+            t = "%s_bg%d_" % (prim, int(use_bg))
+            Ws = {k: torch.randn(v.shape, generator=gen) for k, v in rend.items()}
+            loss = sum((rend[k] * Ws[k]).sum() for k in rend)
+            loss.backward()
+            for k, v in rend.items():
+                arrs[t + "out_" + k] = v.detach().numpy()
+                arrs[t + "W_" + k] = Ws[k].numpy()
+            arrs[t + "pose"] = pose.detach().numpy()
+            arrs[t + "g_points"] = p.grad.numpy()
+            arrs[t + "g_yaw"] = yaw.grad.numpy()
+            arrs[t + "g_trans"] = trans.grad.numpy()
+            print("G9", t, "loss", float(loss), "g_yaw", yaw.grad.numpy(), "|g_points|max", float(p.grad.abs().max()))
+    save("g9_secondary.npz", **arrs)
+
+
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G9": g9}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -136,22 +136,30 @@ int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* no
                          float* g_points, float* g_normals, float* g_colors, float* g_pose, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Surfel splat + depth-softmax composite  --  replaces inside_surfel(diam=0.04, softclamp=False, add_bg=False)
- * (sdfrenderer/renderer/primitives.py:165-242) and the compositing of Rasterer.forward
- * (sdfrenderer/renderer/rasterer.py:113-144) without ever forming the N x P tensors.
- *   Kinv [B][9] = inverse(K.float()) (primitives.py:204), K [B][9] (used only for conservative tile binning)
+ * Surfel splat + depth-softmax composite  --  replaces the primitives of sdfrenderer/renderer/primitives.py and the compositing of
+ * Rasterer.forward (sdfrenderer/renderer/rasterer.py:92-144) without ever forming the N x P tensors.
+ *   primitive 0 'disc'        inside_surfel(diam=0.04, softclamp=False, depth_constant=150)   primitives.py:165-242  (the optimizer's)
+ *   primitive 1 'circle'      inside_circle(diam=0.02, softclamp=True, depth_constant=100)     primitives.py:4-71
+ *   primitive 2 'circle_opt'  inside_circle_opt(diam=0.025, depth_constant=10000)              primitives.py:74-162
+ *   Kinv [B][9] = inverse(K.float()) (primitives.py:204), K [B][9]
  *   p_cam, n_cam, attr [B][cap][3]   attr is the composited colour attribute AFTER the (c+1)/2 mapping
+ *   uv [B][cap][2], znorm [B]        primitives 1,2 only: clamped pixel projections (sdfr_project_dcm) and ||depths||_2 per crop
+ *   bg [B][3][H][W], bg_logit [B]    optional background row (add_bg): its colour and its logit (min over the surfels' logits - 1,
+ *                                    primitives.py:65,147,235); both NULL for bg=None
  *   images: color [B][3][H][W], mask [B][H][W], depth [B][H][W], normals [B][3][H][W] (any may be NULL)
  *   aux [B][H*W][4]: per-pixel state for the backward (nu, max logit, softmax denominator, clamp gates)
  */
-int sdfr_splat_forward(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
+int sdfr_splat_forward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
+                       const float* uv, const float* znorm, const float* bg, const float* bg_logit,
                        int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant,
                        int32_t* bbox_ws /* workspace int32[B][cap][4]: conservative screen boxes */,
                        float* color, float* mask, float* depth, float* normals, float* aux, void* stream);
 
 /* Backward w.r.t. p_cam, n_cam, attr given the gradients of the four images (any may be NULL; a non-NULL gradient
- * needs the corresponding forward image, which carries the pre-softmax-backward sum <grad, output>). */
-int sdfr_splat_backward(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
+ * needs the corresponding forward image, which carries the softmax-backward sum <grad, output>).  The background logit is a
+ * constant here. */
+int sdfr_splat_backward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
+                        const float* uv, const float* znorm, const float* bg, const float* bg_logit,
                         int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant,
                         const float* aux, const float* color, const float* mask, const float* depth, const float* normals,
                         const float* g_color, const float* g_mask, const float* g_depth, const float* g_normals,

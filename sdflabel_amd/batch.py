@@ -105,7 +105,7 @@ class BatchRenderer:
                               P(self.p_cam), P(self.n_cam), P(self.col), None, P(self.fidx), P(self.fcnt), st), "sdfr_project_dcm")
         torch.add(self.col, 1.0, out=self.attr)                                   # attr = (col + 1) / 2, rasterer.py:113-114
         self.attr.mul_(0.5)
-        ck(L.sdfr_splat_forward(P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), B, cap, P(self.cnt), W, H, _DIAM_DISC,
+        ck(L.sdfr_splat_forward(0, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
                                 _DEPTH_CONSTANT, P(self.bbox), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(self.aux), st),
            "sdfr_splat_forward")
         ck(L.sdfr_gather_rows3(P(self.xyzf), P(self.p_cam), P(self.fidx), B, cap, P(self.fcnt), st), "sdfr_gather_rows3")
@@ -125,7 +125,7 @@ class BatchRenderer:
 
         g_color, g_mask = c(g_color, self.color.shape), c(g_mask, self.mask.shape)
         g_depth, g_normals = c(g_depth, self.depth.shape), c(g_normals, self.nimg.shape)
-        ck(L.sdfr_splat_backward(P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), B, cap, P(self.cnt), W, H, _DIAM_DISC,
+        ck(L.sdfr_splat_backward(0, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
                                  _DEPTH_CONSTANT, P(self.aux), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(g_color),
                                  P(g_mask), P(g_depth), P(g_normals), P(self.g_p), P(self.g_n), P(self.g_a), st), "sdfr_splat_backward")
         torch.mul(self.g_a, 0.5, out=self.g_col)                                   # attr = (col + 1) / 2

@@ -1,36 +1,54 @@
-// Surfel splatting with per-pixel ray/tangent-plane intersection and depth-softmax compositing (gfx950).
+// Surfel splatting with per-pixel coverage tests and depth-softmax compositing (gfx950).
 //
-// Replaces inside_surfel(diam, softclamp=False, add_bg=False) (reference sdfrenderer/renderer/primitives.py:165-242) and the
-// compositing of Rasterer.forward (sdfrenderer/renderer/rasterer.py:113-144).  The reference materialises ~10 dense N x P
-// tensors although only ~0.04 % of the (surfel, pixel) pairs are covered; here nothing of size N x P ever exists:
+// Replaces the three primitives of the reference renderer and the compositing of Rasterer.forward
+// (sdfrenderer/renderer/rasterer.py:92-144) without ever forming the N x P tensors the reference materialises:
+//   PRIM 0  'disc'        inside_surfel(diam=0.04, softclamp=False)  primitives.py:165-242   -- the optimizer's primitive:
+//                         per-pixel ray / tangent-plane intersection, 3-D disc test, logits normalised by a per-pixel norm
+//   PRIM 1  'circle'      inside_circle(diam=0.02, softclamp=True)   primitives.py:4-71      -- 2-D circle; the reference thresholds
+//                         sigmoid(.) > 0 (:55), i.e. coverage ends where exp overflows (~29.6 px beyond the circle), and its
+//                         softmax runs over z*mask (:70): uncovered surfels keep logit 0 in the denominator
+//   PRIM 2  'circle_opt'  inside_circle_opt(diam=0.025)              primitives.py:74-162    -- every surfel stamps the 15x15 pixel
+//                         square at trunc(uv + offset), indices clamped into the image (:122-127)
+// plus the optional background row (add_bg; primitives.py:64-67,146-153,233-237; rasterer.py:107-111).
 //
-//   forward   one wavefront per 8x8 pixel tile (lane = pixel).  The wave scans the surfels' conservative screen boxes
-//             64 at a time and compacts the overlapping ones with a ballot into an LDS candidate list (ascending surfel
-//             order, deterministic).  Candidates are staged 64 at a time into LDS (lane = candidate) and every lane walks
-//             them with broadcast LDS reads: pass 1 per-pixel norm nu (:228), pass 2 max logit, pass 3 softmax sums and the
-//             composited colour / mask / depth / normals.  Per-pixel softmax state goes to `aux` for the backward.
-//   backward  one wavefront per SURFEL (lanes = pixels of its screen box).  Each lane re-evaluates the coverage test with
-//             the identical arithmetic, rebuilds its softmax weight from `aux`, and accumulates the surfel's gradients in
-//             registers; one wave reduction, no atomics, deterministic.
+//   forward   one wavefront per 8x8 pixel tile (lane = pixel).  The wave scans the surfels' conservative screen boxes 64 at a time and
+//             compacts the overlapping ones with a ballot into an LDS candidate list (ascending surfel order, deterministic).
+//             Candidates are staged 64 at a time into LDS (lane = candidate) and every lane walks them with broadcast LDS reads:
+//             [disc: per-pixel norm nu (:228)], max logit, softmax sums + composited colour / mask / depth / normals.
+//             Per-pixel softmax state goes to `aux` for the backward.
+//   backward  one wavefront per SURFEL (lanes = pixels of its screen box).  Each lane re-evaluates the coverage test with the identical
+//             arithmetic, rebuilds its softmax weight from `aux`, accumulates the surfel's gradients in registers; one wave reduction,
+//             no atomics, bit-repeatable.
 //
-// Autograd semantics reproduced: coverage mask and nu are constants (:226,:228); |n.ray| < 0.01 is overwritten by eps in place
-// and passes no gradient through b (:210); clamp(min=0) and clamp(max=1) pass gradient on the closed side.
-// Compiled with -ffp-contract=off so that products and sums round separately like the reference's ATen ops.
+// Autograd semantics reproduced: coverage masks and norms are constants (:55,:59 / :155,:142 / :226,:228); for the disc |n.ray| < 0.01 is
+// overwritten by eps in place and passes no gradient through b (:210); clamp(min=0) / clamp(max=1) pass gradient on the closed side.
+// The background logit is treated as a constant (its weight is exactly 0 or 1 for disc and circle_opt; the circle's is handled by the
+// host layer).  Compiled with -ffp-contract=off so that products and sums round separately like the reference's ATen ops.
 #include "sdfr_common.h"
 #include <float.h>
 
 #define SPL_LC 1024            // LDS candidate-list capacity per tile (beyond it the tile walks every surfel)
+#define SIGMOID_REACH 29.65f   // (r - d) * 3 > -88.73  <=>  d < r + 29.58: conservative reach of inside_circle's sigmoid(.) > 0
+
+struct SplatArgs {
+    const float* K; const float* Kinv;
+    const float* p_cam; const float* n_cam; const float* attr;
+    const float* uv; const float* znorm;          // PRIM 1,2: clamped 2-D projections [B][cap][2]; || depths ||_2 per crop [B]
+    const float* bg; const float* bg_logit;       // optional background image [B][3][H][W] and its logit [B]
+    int cap; const int32_t* cnt; int W, H;
+    float diam, depth_constant;
+};
 
 struct Hit {
-    bool m;        // inside the disc
-    bool small;    // |n.ray| < 0.01  (b replaced by eps)
-    float t;       // ray parameter of the plane hit (z in the reference, primitives.py:211)
-    float b;       // n.ray after the eps substitution
+    bool m;        // covered
+    bool small;    // disc: |n.ray| < 0.01  (b replaced by eps)
+    float t;       // disc: ray parameter of the plane hit (z in the reference, primitives.py:211)
+    float b;       // disc: n.ray after the eps substitution
 };
 
 // primitives.py:209-226 for one (surfel, pixel) pair
-__device__ __forceinline__ Hit splat_eval(float px, float py, float pz, float nx, float ny, float nz, float a, float rx,
-                                          float ry, float rz, float diam) {
+__device__ __forceinline__ Hit disc_eval(float px, float py, float pz, float nx, float ny, float nz, float a, float rx, float ry, float rz,
+                                         float diam) {
     Hit h;
     const float b0 = rx * nx + ry * ny + rz * nz;                                // :209
     h.small = fabsf(b0) < 0.01f;                                                 // :210
@@ -40,6 +58,38 @@ __device__ __forceinline__ Hit splat_eval(float px, float py, float pz, float nx
     const float d = sqrtf(vx * vx + vy * vy + vz * vz);
     h.m = (diam - d) > 0.f;                                                      // :220,:226
     return h;
+}
+
+// primitives.py:42-49,55: sigmoid((r - ||uv - pixel||) * 3) > 0
+__device__ __forceinline__ bool circle_cover(float u, float v, float r, float x, float y) {
+    const float dx = u - x, dy = v - y;
+    const float d = sqrtf(dx * dx + dy * dy);
+    const float arg = (r - d) * 3.f;
+    return (1.f / (1.f + expf(-arg))) > 0.f;
+}
+
+// primitives.py:122-127: is pixel coordinate `p` hit by clamp(trunc(u + o), 0, n-1) for some integer offset o in [-7,7] ?
+__device__ __forceinline__ bool stamp_axis(float u, int p, int n) {
+    const int c = (int)ceilf((float)p - u);
+#pragma unroll
+    for (int d = -1; d <= 1; ++d) {
+        int o = c + d;
+        o = o < -7 ? -7 : (o > 7 ? 7 : o);
+        int t = (int)truncf(u + (float)o);
+        t = t < 0 ? 0 : (t > n - 1 ? n - 1 : t);
+        if (t == p) return true;
+    }
+    // borders collect everything that is clamped onto them
+    if (p == 0) { int t = (int)truncf(u - 7.f); if (t <= 0) return true; }
+    if (p == n - 1) { int t = (int)truncf(u + 7.f); if (t >= n - 1) return true; }
+    return false;
+}
+
+// per-surfel depth logit  clamp(-z / (||z|| + eps) + 1, 0) * C   (primitives.py:57-61, :141-144)
+__device__ __forceinline__ float depth_logit(float z, float zn, float C, float* q_out) {
+    const float q = (-z) / (zn + FLT_EPSILON) + 1.f;
+    if (q_out) *q_out = q;
+    return fmaxf(q, 0.f) * C;
 }
 
 __device__ __forceinline__ void pixel_ray(const float* __restrict__ Ki, float x, float y, float& rx, float& ry, float& rz) {
@@ -69,38 +119,64 @@ __device__ __forceinline__ bool axis_range(float pu, float pz, float rho, float 
     return lo <= hi;
 }
 
-__device__ __forceinline__ bool surfel_bbox(const float* __restrict__ K, float px, float py, float pz, float rho, int W, int H,
-                                            int& x0, int& y0, int& x1, int& y1) {
-    x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
-    const bool standard = (K[1] == 0.f) && (K[3] == 0.f) && (K[6] == 0.f) && (K[7] == 0.f) && (K[8] == 1.f);
-    if (!standard) return true;
-    if (!axis_range(px, pz, rho, K[0], K[2], W, x0, x1)) return false;
-    if (!axis_range(py, pz, rho, K[4], K[5], H, y0, y1)) return false;
-    return true;
+__device__ __forceinline__ bool interval(float lo_f, float hi_f, int n, int& lo, int& hi) {
+    lo = 0; hi = n - 1;
+    if (isnan(lo_f) || isnan(hi_f)) return true;
+    if (hi_f < 0.f || lo_f > (float)(n - 1)) return false;
+    lo = (int)fmaxf(floorf(lo_f), 0.f);
+    hi = (int)fminf(ceilf(hi_f), (float)(n - 1));
+    return lo <= hi;
 }
 
-__global__ __launch_bounds__(256) void sdfr_splat_bbox_kernel(const float* __restrict__ K, const float* __restrict__ p_cam,
-                                                             int cap, const int32_t* __restrict__ cnt, int W, int H, float diam,
-                                                             int4* __restrict__ bbox) {
+template <int PRIM>
+__device__ __forceinline__ bool surfel_bbox(const SplatArgs& A, int b, int64_t e, int& x0, int& y0, int& x1, int& y1) {
+    const int W = A.W, H = A.H;
+    x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
+    const float* K = A.K + (int64_t)b * 9;
+    if (PRIM == 0) {
+        const bool standard = (K[1] == 0.f) && (K[3] == 0.f) && (K[6] == 0.f) && (K[7] == 0.f) && (K[8] == 1.f);
+        if (!standard) return true;
+        const float px = A.p_cam[e * 3], py = A.p_cam[e * 3 + 1], pz = A.p_cam[e * 3 + 2];
+        if (!axis_range(px, pz, A.diam, K[0], K[2], W, x0, x1)) return false;
+        if (!axis_range(py, pz, A.diam, K[4], K[5], H, y0, y1)) return false;
+        return true;
+    } else if (PRIM == 1) {
+        const float u = A.uv[e * 2], v = A.uv[e * 2 + 1];
+        const float r = fabsf(K[0] * A.diam / (A.p_cam[e * 3 + 2] + FLT_EPSILON)) + SIGMOID_REACH + 1.f;
+        if (!interval(u - r, u + r, W, x0, x1)) return false;
+        if (!interval(v - r, v + r, H, y0, y1)) return false;
+        return true;
+    } else {
+        const float u = A.uv[e * 2], v = A.uv[e * 2 + 1];      // clamped stamps always land inside the image
+        interval(u - 9.f, u + 9.f, W, x0, x1);
+        interval(v - 9.f, v + 9.f, H, y0, y1);
+        if (u - 9.f > (float)(W - 1)) { x0 = W - 1; x1 = W - 1; }
+        if (u + 9.f < 0.f) { x0 = 0; x1 = 0; }
+        if (v - 9.f > (float)(H - 1)) { y0 = H - 1; y1 = H - 1; }
+        if (v + 9.f < 0.f) { y0 = 0; y1 = 0; }
+        return true;
+    }
+}
+
+template <int PRIM>
+__global__ __launch_bounds__(256) void sdfr_splat_bbox_kernel(const SplatArgs A, int4* __restrict__ bbox) {
     const int b = blockIdx.y;
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= sdfr_count(cnt, b, cap)) return;
-    const int64_t e = (int64_t)b * cap + s;
+    if (s >= sdfr_count(A.cnt, b, A.cap)) return;
+    const int64_t e = (int64_t)b * A.cap + s;
     int x0, y0, x1, y1;
-    const bool ok = surfel_bbox(K + (int64_t)b * 9, p_cam[e * 3], p_cam[e * 3 + 1], p_cam[e * 3 + 2], diam, W, H, x0, y0, x1, y1);
+    const bool ok = surfel_bbox<PRIM>(A, b, e, x0, y0, x1, y1);
     bbox[e] = ok ? make_int4(x0, y0, x1, y1) : make_int4(1, 1, 0, 0);
 }
 
 // ---- forward ----------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const float* __restrict__ Kinv, const float* __restrict__ p_cam,
-                                                           const float* __restrict__ n_cam, const float* __restrict__ attr,
-                                                           const int4* __restrict__ bbox, int cap, const int32_t* __restrict__ cnt,
-                                                           int W, int H, float diam, float depth_constant,
-                                                           float* __restrict__ color, float* __restrict__ mask,
-                                                           float* __restrict__ depth, float* __restrict__ normals,
-                                                           float* __restrict__ aux) {
+template <int PRIM>
+__global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const SplatArgs A, const int4* __restrict__ bbox, float* __restrict__ color,
+                                                           float* __restrict__ mask, float* __restrict__ depth,
+                                                           float* __restrict__ normals, float* __restrict__ aux) {
     const int b = blockIdx.y;
+    const int W = A.W, H = A.H;
     const int tilesX = (W + 7) >> 3;
     const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
     const int lane = threadIdx.x;
@@ -108,11 +184,12 @@ __global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const float* __restr
     const int X1 = min(X0 + 7, W - 1), Y1 = min(Y0 + 7, H - 1);
     const int x = X0 + (lane & 7), y = Y0 + (lane >> 3);
     const bool inside = (x < W) && (y < H);
-    const int count = sdfr_count(cnt, b, cap);
-    const int64_t sb = (int64_t)b * cap;
+    const int count = sdfr_count(A.cnt, b, A.cap);
+    const int64_t sb = (int64_t)b * A.cap;
+    const float diam = A.diam, C = A.depth_constant;
 
     __shared__ int list[SPL_LC];
-    __shared__ float sd[10][64];
+    __shared__ float sd[11][64];
 
     // candidate list: surfels whose conservative box overlaps this tile, ascending order
     int nc = 0;
@@ -134,8 +211,10 @@ __global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const float* __restr
     const int total = overflow ? count : nc;
     __syncthreads();
 
-    float rx, ry, rz;
-    pixel_ray(Kinv + (int64_t)b * 9, (float)x, (float)y, rx, ry, rz);
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (PRIM == 0) pixel_ray(A.Kinv + (int64_t)b * 9, (float)x, (float)y, rx, ry, rz);
+    const float zn = (PRIM != 0) ? A.znorm[b] : 0.f;
+    const float k00 = A.K[(int64_t)b * 9];
 
     // walk all candidates: stage 64 at a time into LDS (lane = candidate), then broadcast-read them
     auto for_each = [&](auto&& body) {
@@ -145,59 +224,93 @@ __global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const float* __restr
             if (c < total) {
                 const int s = overflow ? c : list[c];
                 const int64_t e = (sb + s) * 3;
-                const float px = p_cam[e], py = p_cam[e + 1], pz = p_cam[e + 2];
-                const float nx = n_cam[e], ny = n_cam[e + 1], nz = n_cam[e + 2];
-                sd[0][lane] = px; sd[1][lane] = py; sd[2][lane] = pz;
+                const float px = A.p_cam[e], py = A.p_cam[e + 1], pz = A.p_cam[e + 2];
+                const float nx = A.n_cam[e], ny = A.n_cam[e + 1], nz = A.n_cam[e + 2];
+                sd[2][lane] = pz;
                 sd[3][lane] = nx; sd[4][lane] = ny; sd[5][lane] = nz;
-                sd[6][lane] = nx * px + ny * py + nz * pz;                      // :202
-                sd[7][lane] = attr[e]; sd[8][lane] = attr[e + 1]; sd[9][lane] = attr[e + 2];
+                sd[7][lane] = A.attr[e]; sd[8][lane] = A.attr[e + 1]; sd[9][lane] = A.attr[e + 2];
+                if (PRIM == 0) {
+                    sd[0][lane] = px; sd[1][lane] = py;
+                    sd[6][lane] = nx * px + ny * py + nz * pz;                  // :202
+                } else {
+                    sd[0][lane] = A.uv[(sb + s) * 2]; sd[1][lane] = A.uv[(sb + s) * 2 + 1];
+                    sd[6][lane] = fabsf(k00 * diam / (pz + FLT_EPSILON));       // :47 / :115
+                    sd[10][lane] = depth_logit(pz, zn, C, nullptr);
+                }
             }
             __syncthreads();
             const int kn = min(64, total - c0);
             for (int k = 0; k < kn; ++k) body(k);
         }
     };
-
-    // pass 1: nu = || -t * mask ||_2 over the surfels  (:227-228)
-    float nu2 = 0.f;
-    for_each([&](int k) {
-        const Hit h = splat_eval(sd[0][k], sd[1][k], sd[2][k], sd[3][k], sd[4][k], sd[5][k], sd[6][k], rx, ry, rz, diam);
-        if (h.m) nu2 += h.t * h.t;
-    });
-    const float nu = sqrtf(nu2);
-    const float nue = nu + FLT_EPSILON;
-    // pass 2: max logit over the covering surfels (:229-230,:240)
-    float lmax = -FLT_MAX;
-    for_each([&](int k) {
-        const Hit h = splat_eval(sd[0][k], sd[1][k], sd[2][k], sd[3][k], sd[4][k], sd[5][k], sd[6][k], rx, ry, rz, diam);
-        if (h.m) {
-            const float q = (-h.t) / nue + 1.f;
-            lmax = fmaxf(lmax, fmaxf(q, 0.f) * depth_constant);
+    // coverage + logit of candidate k for this lane's pixel
+    float nue = 1.f;
+    auto eval = [&](int k, float& logit) -> bool {
+        if (PRIM == 0) {
+            const Hit h = disc_eval(sd[0][k], sd[1][k], sd[2][k], sd[3][k], sd[4][k], sd[5][k], sd[6][k], rx, ry, rz, diam);
+            logit = fmaxf((-h.t) / nue + 1.f, 0.f) * C;                          // :227-230
+            return h.m;
+        } else if (PRIM == 1) {
+            logit = sd[10][k];
+            return circle_cover(sd[0][k], sd[1][k], sd[6][k], (float)x, (float)y);
+        } else {
+            logit = sd[10][k];
+            return stamp_axis(sd[0][k], x, W) && stamp_axis(sd[1][k], y, H);
         }
-    });
-    // pass 3: softmax sums and composites (:240, rasterer.py:119-144)
-    float den = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dz = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    };
+
+    float nu = 0.f;
+    if (PRIM == 0) {   // per-pixel norm nu = || -t * mask ||_2 over the surfels  (:227-228)
+        float nu2 = 0.f;
+        for_each([&](int k) {
+            const Hit h = disc_eval(sd[0][k], sd[1][k], sd[2][k], sd[3][k], sd[4][k], sd[5][k], sd[6][k], rx, ry, rz, diam);
+            if (h.m) nu2 += h.t * h.t;
+        });
+        nu = sqrtf(nu2);
+        nue = nu + FLT_EPSILON;
+    }
+    // max logit
+    float lmax = -FLT_MAX;
+    int ncov = 0;
     for_each([&](int k) {
-        const Hit h = splat_eval(sd[0][k], sd[1][k], sd[2][k], sd[3][k], sd[4][k], sd[5][k], sd[6][k], rx, ry, rz, diam);
-        if (h.m) {
-            const float q = (-h.t) / nue + 1.f;
-            const float e = expf(fmaxf(q, 0.f) * depth_constant - lmax);
-            den += e;
+        float l;
+        if (eval(k, l)) { lmax = fmaxf(lmax, l); ++ncov; }
+    });
+    const int nunc = count - ncov;
+    if (PRIM == 1 && nunc > 0) lmax = fmaxf(lmax, 0.f);                           // uncovered surfels keep logit 0 (:70)
+    const float lbg = A.bg ? A.bg_logit[b] : 0.f;
+    if (A.bg) lmax = fmaxf(lmax, lbg);
+    // softmax sums and composites (rasterer.py:119-144)
+    float cs = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dz = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    for_each([&](int k) {
+        float l;
+        if (eval(k, l)) {
+            const float e = expf(l - lmax);
+            cs += e;
             c0 += e * sd[7][k]; c1 += e * sd[8][k]; c2 += e * sd[9][k];
             dz += e * sd[2][k];
             n0 += e * ((sd[3][k] + 1.f) / 2.f); n1 += e * ((sd[4][k] + 1.f) / 2.f); n2 += e * ((sd[5][k] + 1.f) / 2.f);
         }
     });
     if (!inside) return;
-    const bool cov = den > 0.f;
-    const float inv = cov ? 1.f / den : 0.f;
-    c0 *= inv; c1 *= inv; c2 *= inv; dz *= inv; n0 *= inv; n1 *= inv; n2 *= inv;
-    const float ms = cov ? 1.f : 0.f;
     const int P = W * H;
     const int pix = y * W + x;
+    float den = cs;
+    if (PRIM == 1 && nunc > 0) den += (float)nunc * expf(0.f - lmax);
+    if (A.bg) {
+        const float eb = expf(lbg - lmax);
+        den += eb;
+        cs += eb;
+        const float* bgp = A.bg + (int64_t)b * 3 * P + pix;
+        c0 += eb * bgp[0]; c1 += eb * bgp[P]; c2 += eb * bgp[2 * P];
+    }
+    const bool act = den > 0.f;
+    const float inv = act ? 1.f / den : 0.f;
+    c0 *= inv; c1 *= inv; c2 *= inv; dz *= inv; n0 *= inv; n1 *= inv; n2 *= inv;
+    const float ms = (act && cs == den) ? 1.f : cs * inv;     // every row covered or background: the weights sum to one
     unsigned gates = 0;
     gates |= (c0 <= 1.f) ? 1u : 0u; gates |= (c1 <= 1.f) ? 2u : 0u; gates |= (c2 <= 1.f) ? 4u : 0u;
-    gates |= 8u;
+    gates |= (ms <= 1.f) ? 8u : 0u;
     gates |= (n0 <= 1.f) ? 16u : 0u; gates |= (n1 <= 1.f) ? 32u : 0u; gates |= (n2 <= 1.f) ? 64u : 0u;
     if (color) {
         float* o = color + (int64_t)b * 3 * P + pix;
@@ -211,7 +324,7 @@ __global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const float* __restr
     }
     if (aux) {
         float4 a4;
-        a4.x = nu; a4.y = cov ? lmax : 0.f; a4.z = den; a4.w = __uint_as_float(gates);
+        a4.x = nu; a4.y = act ? lmax : 0.f; a4.z = den; a4.w = __uint_as_float(gates);
         reinterpret_cast<float4*>(aux)[(int64_t)b * P + pix] = a4;
     }
 }
@@ -223,42 +336,66 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(
-    const float* __restrict__ K, const float* __restrict__ Kinv, const float* __restrict__ p_cam, const float* __restrict__ n_cam,
-    const float* __restrict__ attr, int cap, const int32_t* __restrict__ cnt, int W, int H, float diam, float depth_constant,
-    const float* __restrict__ aux, const float* __restrict__ color, const float* __restrict__ mask, const float* __restrict__ depth,
-    const float* __restrict__ normals, const float* __restrict__ g_color, const float* __restrict__ g_mask,
-    const float* __restrict__ g_depth, const float* __restrict__ g_normals, float* __restrict__ g_p, float* __restrict__ g_n,
-    float* __restrict__ g_attr) {
+template <int PRIM>
+__global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, const float* __restrict__ aux,
+                                                            const float* __restrict__ color, const float* __restrict__ mask,
+                                                            const float* __restrict__ depth, const float* __restrict__ normals,
+                                                            const float* __restrict__ g_color, const float* __restrict__ g_mask,
+                                                            const float* __restrict__ g_depth, const float* __restrict__ g_normals,
+                                                            float* __restrict__ g_p, float* __restrict__ g_n, float* __restrict__ g_attr) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= sdfr_count(cnt, b, cap)) return;
-    const int64_t e = ((int64_t)b * cap + s) * 3;
-    const float px = p_cam[e], py = p_cam[e + 1], pz = p_cam[e + 2];
-    const float nx = n_cam[e], ny = n_cam[e + 1], nz = n_cam[e + 2];
-    const float a0 = attr[e], a1 = attr[e + 1], a2 = attr[e + 2];
+    if (s >= sdfr_count(A.cnt, b, A.cap)) return;
+    const int W = A.W, H = A.H;
+    const float diam = A.diam, C = A.depth_constant;
+    const int64_t e1 = (int64_t)b * A.cap + s;
+    const int64_t e = e1 * 3;
+    const float px = A.p_cam[e], py = A.p_cam[e + 1], pz = A.p_cam[e + 2];
+    const float nx = A.n_cam[e], ny = A.n_cam[e + 1], nz = A.n_cam[e + 2];
+    const float a0 = A.attr[e], a1 = A.attr[e + 1], a2 = A.attr[e + 2];
     const float m0 = (nx + 1.f) / 2.f, m1 = (ny + 1.f) / 2.f, m2 = (nz + 1.f) / 2.f;
     const float a = nx * px + ny * py + nz * pz;
-    const float* Ki = Kinv + (int64_t)b * 9;
+    const float* Ki = A.Kinv + (int64_t)b * 9;
     const int P = W * H;
+    // PRIM 1,2: pixel-independent logit
+    float u = 0.f, v = 0.f, rad = 0.f, zl = 0.f, q0 = 0.f, zn = 0.f;
+    if (PRIM != 0) {
+        u = A.uv[e1 * 2]; v = A.uv[e1 * 2 + 1];
+        zn = A.znorm[b];
+        rad = fabsf(A.K[(int64_t)b * 9] * diam / (pz + FLT_EPSILON));
+        zl = depth_logit(pz, zn, C, &q0);
+    }
     int x0, y0, x1, y1;
-    float sC0 = 0.f, sC1 = 0.f, sC2 = 0.f, sN0 = 0.f, sN1 = 0.f, sN2 = 0.f, sZ = 0.f, sA = 0.f, sB0 = 0.f, sB1 = 0.f, sB2 = 0.f;
-    if (surfel_bbox(K + (int64_t)b * 9, px, py, pz, diam, W, H, x0, y0, x1, y1)) {
+    float sC0 = 0.f, sC1 = 0.f, sC2 = 0.f, sN0 = 0.f, sN1 = 0.f, sN2 = 0.f, sZ = 0.f, sA = 0.f, sB0 = 0.f, sB1 = 0.f, sB2 = 0.f, sL = 0.f;
+    if (surfel_bbox<PRIM>(A, b, e1, x0, y0, x1, y1)) {
         const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
         for (int i = lane; i < bw * bh; i += 64) {
             const int yy = i / bw;
             const int x = x0 + (i - yy * bw), y = y0 + yy;
-            float rx, ry, rz;
-            pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
-            const Hit h = splat_eval(px, py, pz, nx, ny, nz, a, rx, ry, rz, diam);
-            if (!h.m) continue;
+            float rx = 0.f, ry = 0.f, rz = 0.f;
+            Hit h;
+            bool cov;
+            if (PRIM == 0) {
+                pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
+                h = disc_eval(px, py, pz, nx, ny, nz, a, rx, ry, rz, diam);
+                cov = h.m;
+            } else if (PRIM == 1) {
+                cov = circle_cover(u, v, rad, (float)x, (float)y);
+            } else {
+                cov = stamp_axis(u, x, W) && stamp_axis(v, y, H);
+            }
+            if (!cov) continue;
             const int pix = y * W + x;
             const float4 ax = reinterpret_cast<const float4*>(aux)[(int64_t)b * P + pix];
             const float nue = ax.x + FLT_EPSILON;
             const unsigned gates = __float_as_uint(ax.w);
-            const float q = (-h.t) / nue + 1.f;
-            const float w = expf(fmaxf(q, 0.f) * depth_constant - ax.y) / ax.z;
+            float q = q0, logit = zl;
+            if (PRIM == 0) {
+                q = (-h.t) / nue + 1.f;
+                logit = fmaxf(q, 0.f) * C;
+            }
+            const float w = expf(logit - ax.y) / ax.z;
             // gated upstream gradients and S = sum_j w_j dL/dw_j = <gated grads, composited outputs>
             float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, gm = 0.f, gd = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, S = 0.f;
             if (g_color) {
@@ -267,7 +404,7 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(
                 gc0 = (gates & 1u) ? g[0] : 0.f; gc1 = (gates & 2u) ? g[P] : 0.f; gc2 = (gates & 4u) ? g[2 * P] : 0.f;
                 S += gc0 * o[0] + gc1 * o[P] + gc2 * o[2 * P];
             }
-            if (g_mask) { gm = g_mask[(int64_t)b * P + pix]; S += gm * mask[(int64_t)b * P + pix]; }
+            if (g_mask) { gm = (gates & 8u) ? g_mask[(int64_t)b * P + pix] : 0.f; S += gm * mask[(int64_t)b * P + pix]; }
             if (g_depth) { gd = g_depth[(int64_t)b * P + pix]; S += gd * depth[(int64_t)b * P + pix]; }
             if (g_normals) {
                 const float* g = g_normals + (int64_t)b * 3 * P + pix;
@@ -280,65 +417,114 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(
             sN0 += w * gn0; sN1 += w * gn1; sN2 += w * gn2;
             sZ += w * gd;
             const float dl = w * (dLdw - S);
-            const float dq = (q >= 0.f) ? dl * depth_constant : 0.f;
-            const float dt = -(dq / nue);                           // zeta = -t * mask
-            sA += dt / h.b;                                         // t = a / b
-            if (!h.small) {
-                const float db = -dt * h.t / h.b;
-                sB0 += db * rx; sB1 += db * ry; sB2 += db * rz;
+            if (PRIM == 0) {
+                const float dq = (q >= 0.f) ? dl * C : 0.f;
+                const float dt = -(dq / nue);                           // zeta = -t * mask
+                sA += dt / h.b;                                         // t = a / b
+                if (!h.small) {
+                    const float db = -dt * h.t / h.b;
+                    sB0 += db * rx; sB1 += db * ry; sB2 += db * rz;
+                }
+            } else {
+                sL += dl;
             }
         }
     }
     sC0 = wave_sum(sC0); sC1 = wave_sum(sC1); sC2 = wave_sum(sC2);
     sN0 = wave_sum(sN0); sN1 = wave_sum(sN1); sN2 = wave_sum(sN2);
-    sZ = wave_sum(sZ); sA = wave_sum(sA);
-    sB0 = wave_sum(sB0); sB1 = wave_sum(sB1); sB2 = wave_sum(sB2);
+    sZ = wave_sum(sZ);
+    if (PRIM == 0) { sA = wave_sum(sA); sB0 = wave_sum(sB0); sB1 = wave_sum(sB1); sB2 = wave_sum(sB2); }
+    else sL = wave_sum(sL);
     if (lane == 0) {
         g_attr[e] = sC0; g_attr[e + 1] = sC1; g_attr[e + 2] = sC2;
-        g_n[e] = 0.5f * sN0 + sB0 + sA * px;
-        g_n[e + 1] = 0.5f * sN1 + sB1 + sA * py;
-        g_n[e + 2] = 0.5f * sN2 + sB2 + sA * pz;
-        g_p[e] = sA * nx;
-        g_p[e + 1] = sA * ny;
-        g_p[e + 2] = sA * nz + sZ;
+        if (PRIM == 0) {
+            g_n[e] = 0.5f * sN0 + sB0 + sA * px;
+            g_n[e + 1] = 0.5f * sN1 + sB1 + sA * py;
+            g_n[e + 2] = 0.5f * sN2 + sB2 + sA * pz;
+            g_p[e] = sA * nx;
+            g_p[e + 1] = sA * ny;
+            g_p[e + 2] = sA * nz + sZ;
+        } else {
+            g_n[e] = 0.5f * sN0; g_n[e + 1] = 0.5f * sN1; g_n[e + 2] = 0.5f * sN2;
+            const float dq = (q0 >= 0.f) ? sL * C : 0.f;              // logit = clamp(q,0)*C, q = -z/(zn+eps) + 1, zn detached
+            g_p[e] = 0.f; g_p[e + 1] = 0.f;
+            g_p[e + 2] = sZ - dq / (zn + FLT_EPSILON);
+        }
     }
 }
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------
 
-extern "C" int sdfr_splat_forward(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
-                                  int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant,
-                                  int32_t* bbox_ws, float* color, float* mask, float* depth, float* normals, float* aux,
-                                  void* stream) {
-    SDFR_REQUIRE(K && Kinv && (cap == 0 || (p_cam && n_cam && attr && bbox_ws)), "sdfr_splat_forward: NULL argument");
-    SDFR_REQUIRE(W > 0 && H > 0 && B >= 0 && cap >= 0, "sdfr_splat_forward: bad size");
+static int fill_args(SplatArgs& A, const char* who, int primitive, const float* K, const float* Kinv, const float* p_cam,
+                     const float* n_cam, const float* attr, const float* uv, const float* znorm, const float* bg, const float* bg_logit,
+                     int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant) {
+    SDFR_REQUIRE(primitive >= 0 && primitive <= 2, "%s: primitive %d unknown (0 disc, 1 circle, 2 circle_opt)", who, primitive);
+    SDFR_REQUIRE(K && Kinv, "%s: NULL intrinsics", who);
+    SDFR_REQUIRE(W > 0 && H > 0 && B >= 0 && cap >= 0, "%s: bad size", who);
+    SDFR_REQUIRE(cap == 0 || (p_cam && n_cam && attr), "%s: NULL surfel array", who);
+    SDFR_REQUIRE(primitive == 0 || cap == 0 || (uv && znorm), "%s: circle primitives need uv and znorm", who);
+    SDFR_REQUIRE((bg == nullptr) == (bg_logit == nullptr), "%s: bg and bg_logit go together", who);
+    A.K = K; A.Kinv = Kinv; A.p_cam = p_cam; A.n_cam = n_cam; A.attr = attr; A.uv = uv; A.znorm = znorm; A.bg = bg; A.bg_logit = bg_logit;
+    A.cap = cap; A.cnt = cnt; A.W = W; A.H = H; A.diam = diam; A.depth_constant = depth_constant;
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam,
+                                  const float* attr, const float* uv, const float* znorm, const float* bg, const float* bg_logit, int B,
+                                  int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant, int32_t* bbox_ws,
+                                  float* color, float* mask, float* depth, float* normals, float* aux, void* stream) {
+    SplatArgs A;
+    int rc = fill_args(A, "sdfr_splat_forward", primitive, K, Kinv, p_cam, n_cam, attr, uv, znorm, bg, bg_logit, B, cap, cnt, W, H, diam,
+                       depth_constant);
+    if (rc) return rc;
+    SDFR_REQUIRE(cap == 0 || bbox_ws, "sdfr_splat_forward: NULL bbox workspace");
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (cap > 0) {
-        hipLaunchKernelGGL(sdfr_splat_bbox_kernel, dim3(sdfr_cdiv(cap, 256), B), dim3(256), 0, s, K, p_cam, cap, cnt, W, H, diam,
-                           reinterpret_cast<int4*>(bbox_ws));
-        SDFR_LAUNCH_CHECK();
+    int4* bb = reinterpret_cast<int4*>(bbox_ws);
+    const dim3 gb(sdfr_cdiv(cap > 0 ? cap : 1, 256), B);
+    const dim3 gt(((W + 7) / 8) * ((H + 7) / 8), B);
+    switch (primitive) {
+        case 0:
+            if (cap > 0) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<0>, gb, dim3(256), 0, s, A, bb);
+            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<0>, gt, dim3(64), 0, s, A, bb, color, mask, depth, normals, aux);
+            break;
+        case 1:
+            if (cap > 0) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<1>, gb, dim3(256), 0, s, A, bb);
+            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<1>, gt, dim3(64), 0, s, A, bb, color, mask, depth, normals, aux);
+            break;
+        default:
+            if (cap > 0) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<2>, gb, dim3(256), 0, s, A, bb);
+            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<2>, gt, dim3(64), 0, s, A, bb, color, mask, depth, normals, aux);
+            break;
     }
-    const int tiles = ((W + 7) / 8) * ((H + 7) / 8);
-    hipLaunchKernelGGL(sdfr_splat_fwd_kernel, dim3(tiles, B), dim3(64), 0, s, Kinv, p_cam, n_cam, attr,
-                       reinterpret_cast<const int4*>(bbox_ws), cap, cnt, W, H, diam, depth_constant, color, mask, depth, normals, aux);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
 
-extern "C" int sdfr_splat_backward(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
-                                   int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant,
-                                   const float* aux, const float* color, const float* mask, const float* depth, const float* normals,
+extern "C" int sdfr_splat_backward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam,
+                                   const float* attr, const float* uv, const float* znorm, const float* bg, const float* bg_logit, int B,
+                                   int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant, const float* aux,
+                                   const float* color, const float* mask, const float* depth, const float* normals,
                                    const float* g_color, const float* g_mask, const float* g_depth, const float* g_normals,
                                    float* g_p_cam, float* g_n_cam, float* g_attr, void* stream) {
-    SDFR_REQUIRE(K && Kinv && aux && g_p_cam && g_n_cam && g_attr, "sdfr_splat_backward: NULL argument");
+    SplatArgs A;
+    int rc = fill_args(A, "sdfr_splat_backward", primitive, K, Kinv, p_cam, n_cam, attr, uv, znorm, bg, bg_logit, B, cap, cnt, W, H, diam,
+                       depth_constant);
+    if (rc) return rc;
+    SDFR_REQUIRE(aux && g_p_cam && g_n_cam && g_attr, "sdfr_splat_backward: NULL argument");
     SDFR_REQUIRE((!g_color || color) && (!g_mask || mask) && (!g_depth || depth) && (!g_normals || normals),
                  "sdfr_splat_backward: an image gradient was given without the forward image");
     if (B == 0 || cap == 0) return SDFR_OK;
-    SDFR_REQUIRE(p_cam && n_cam && attr, "sdfr_splat_backward: NULL surfel array");
-    hipLaunchKernelGGL(sdfr_splat_bwd_kernel, dim3(sdfr_cdiv(cap, 4), B), dim3(256), 0, (hipStream_t)stream, K, Kinv, p_cam, n_cam,
-                       attr, cap, cnt, W, H, diam, depth_constant, aux, color, mask, depth, normals, g_color, g_mask, g_depth,
-                       g_normals, g_p_cam, g_n_cam, g_attr);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(sdfr_cdiv(cap, 4), B);
+    switch (primitive) {
+        case 0: hipLaunchKernelGGL(sdfr_splat_bwd_kernel<0>, g, dim3(256), 0, s, A, aux, color, mask, depth, normals, g_color, g_mask,
+                                   g_depth, g_normals, g_p_cam, g_n_cam, g_attr); break;
+        case 1: hipLaunchKernelGGL(sdfr_splat_bwd_kernel<1>, g, dim3(256), 0, s, A, aux, color, mask, depth, normals, g_color, g_mask,
+                                   g_depth, g_normals, g_p_cam, g_n_cam, g_attr); break;
+        default: hipLaunchKernelGGL(sdfr_splat_bwd_kernel<2>, g, dim3(256), 0, s, A, aux, color, mask, depth, normals, g_color, g_mask,
+                                    g_depth, g_normals, g_p_cam, g_n_cam, g_attr); break;
+    }
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

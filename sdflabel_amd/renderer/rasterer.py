@@ -10,17 +10,19 @@ import torch
 from .. import _lib
 from .utils_rasterer import calibration_matrix, qrot_matrix
 
-_DIAM_DISC = 0.04            # rasterer.py:102-104
-_DEPTH_CONSTANT = 150.0      # primitives.py:171
+# (primitive id, diam, depth_constant): the constants Rasterer.forward passes / leaves at their defaults (rasterer.py:92-104)
+_PRIMS = {'disc': (0, 0.04, 150.0), 'circle': (1, 0.02, 100.0), 'circle_opt': (2, 0.025, 10000.0)}
 
 
 class _RasterFn(torch.autograd.Function):
-    """(coords, normals, colors, pose44) -> color, mask, depth, normals_img, p_cam, col  (+ fidx as a plain attribute)."""
+    """(coords, normals, colors, pose44, bg) -> color, mask, depth, normals_img, p_cam, n_cam, col  (+ fidx through `holder`)."""
 
     @staticmethod
-    def forward(ctx, coords, normals, colors, pose, K, Kinv, res, nocs_mode, want_mask, want_depth, want_normals, want_filter, holder):
+    def forward(ctx, coords, normals, colors, pose, bg, K, Kinv, res, nocs_mode, prim, half_attr, want_mask, want_depth, want_normals,
+                want_filter, holder):
         L = _lib.lib()
         W, H = res
+        pid, diam, dconst = _PRIMS[prim]
         dev = coords.device
         n = coords.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
@@ -40,23 +42,45 @@ class _RasterFn(torch.autograd.Function):
             _lib.check(L.sdfr_project_dcm(_lib.ptr(pose_c), _lib.ptr(K), _lib.ptr(coords_c), _lib.ptr(normals_c), _lib.ptr(colors_c), 1, n,
                                           None, int(nocs_mode), W, H, _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(col), _lib.ptr(uv),
                                           _lib.ptr(fidx), _lib.ptr(fcnt), st), "sdfr_project_dcm")
-        attr = ((col + 1) / 2) if nocs_mode else col                       # rasterer.py:113-116
+        attr = ((col + 1) / 2) if half_attr else col                       # rasterer.py:108-109,113-116
         attr = attr.contiguous()
+        # per-crop scalars of the secondary primitives / the background row (tiny host-layer reductions)
+        znorm = bg_logit = bg_c = None
+        eps = torch.finfo(torch.float32).eps
+        if n > 0 and (pid != 0 or bg is not None):
+            z = -p_cam[:n, 2]
+            if pid != 0:
+                znorm = z.norm(p=2).view(1).contiguous()                   # primitives.py:59 / :142 (detached)
+                zl = torch.clamp(z / (znorm + eps) + 1, min=0) * dconst
+            else:
+                zl = z * dconst                                            # primitives.py:234
+            if bg is not None:
+                bg_logit = (zl.min() - 1).view(1).contiguous()             # primitives.py:65 / :147 / :235
+                holder["bg_argmin"] = int(torch.argmin(zl))
+        elif pid != 0:
+            znorm = torch.ones((1,), **f32)
+        if bg is not None:
+            bg_c = bg.detach().to(dev, torch.float32).reshape(3, H, W).contiguous()
+            if bg_logit is None:
+                bg_logit = torch.zeros((1,), **f32)
         color = torch.empty((3, H, W), **f32)
         mask = torch.empty((1, H, W), **f32) if want_mask else None
         depth = torch.empty((1, H, W), **f32) if want_depth else None
         nimg = torch.empty((3, H, W), **f32) if want_normals else None
         aux = torch.empty((H * W, 4), **f32)
         bbox = torch.empty((m, 4), dtype=torch.int32, device=dev)
-        _lib.check(L.sdfr_splat_forward(_lib.ptr(K), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(attr), 1, n, None, W, H,
-                                        _DIAM_DISC, _DEPTH_CONSTANT, _lib.ptr(bbox), _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth),
-                                        _lib.ptr(nimg), _lib.ptr(aux), st), "sdfr_splat_forward")
+        _lib.check(L.sdfr_splat_forward(pid, _lib.ptr(K), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(attr), _lib.ptr(uv),
+                                        _lib.ptr(znorm), _lib.ptr(bg_c), _lib.ptr(bg_logit), 1, n, None, W, H, diam, dconst,
+                                        _lib.ptr(bbox), _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(nimg), _lib.ptr(aux), st),
+                   "sdfr_splat_forward")
         nf = int(fcnt.item()) if (want_filter and n > 0) else 0
         holder["fidx"] = fidx[:nf].long() if want_filter else None
-        holder["uv"] = uv[:n]
+        dummy = color
         ctx.save_for_backward(coords_c, normals_c, pose_c, K, Kinv, p_cam, n_cam, attr, aux, color,
-                              mask if want_mask else color, depth if want_depth else color, nimg if want_normals else color)
-        ctx.cfg = (n, W, H, nocs_mode, want_mask, want_depth, want_normals)
+                              mask if want_mask else dummy, depth if want_depth else dummy, nimg if want_normals else dummy, uv,
+                              znorm if znorm is not None else dummy, bg_c if bg_c is not None else dummy,
+                              bg_logit if bg_logit is not None else dummy)
+        ctx.cfg = (n, W, H, nocs_mode, prim, half_attr, want_mask, want_depth, want_normals, bg is not None, holder.get("bg_argmin"))
         outs = (color, mask if want_mask else color.new_zeros(()), depth if want_depth else color.new_zeros(()),
                 nimg if want_normals else color.new_zeros(()), p_cam[:n], n_cam[:n], col[:n])
         ctx.mark_non_differentiable(outs[5])
@@ -65,8 +89,9 @@ class _RasterFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_color, g_mask, g_depth, g_nimg, g_pcam_ext, _g_ncam, g_col_ext):
         L = _lib.lib()
-        coords, normals, pose, K, Kinv, p_cam, n_cam, attr, aux, color, mask, depth, nimg = ctx.saved_tensors
-        n, W, H, nocs_mode, want_mask, want_depth, want_normals = ctx.cfg
+        (coords, normals, pose, K, Kinv, p_cam, n_cam, attr, aux, color, mask, depth, nimg, uv, znorm, bg_c, bg_logit) = ctx.saved_tensors
+        n, W, H, nocs_mode, prim, half_attr, want_mask, want_depth, want_normals, has_bg, bg_argmin = ctx.cfg
+        pid, diam, dconst = _PRIMS[prim]
         dev = coords.device
         f32 = dict(dtype=torch.float32, device=dev)
         m = max(n, 1)
@@ -83,11 +108,34 @@ class _RasterFn(torch.autograd.Function):
         g_n = torch.zeros((m, 3), **f32)
         g_a = torch.zeros((m, 3), **f32)
         if n > 0:
-            _lib.check(L.sdfr_splat_backward(_lib.ptr(K), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(attr), 1, n, None, W, H,
-                                             _DIAM_DISC, _DEPTH_CONSTANT, _lib.ptr(aux), _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth),
-                                             _lib.ptr(nimg), _lib.ptr(g_color), _lib.ptr(g_mask), _lib.ptr(g_depth), _lib.ptr(g_nimg),
-                                             _lib.ptr(g_p), _lib.ptr(g_n), _lib.ptr(g_a), st), "sdfr_splat_backward")
-        g_col = g_a * 0.5 if nocs_mode else g_a                              # attr = (col+1)/2
+            _lib.check(L.sdfr_splat_backward(pid, _lib.ptr(K), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(attr),
+                                             _lib.ptr(uv), _lib.ptr(znorm) if pid else None, _lib.ptr(bg_c) if has_bg else None,
+                                             _lib.ptr(bg_logit) if has_bg else None, 1, n, None, W, H, diam, dconst, _lib.ptr(aux),
+                                             _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(nimg), _lib.ptr(g_color),
+                                             _lib.ptr(g_mask), _lib.ptr(g_depth), _lib.ptr(g_nimg), _lib.ptr(g_p), _lib.ptr(g_n),
+                                             _lib.ptr(g_a), st), "sdfr_splat_backward")
+            if has_bg and pid == 1:
+                # inside_circle's background logit z.min() - 1 (primitives.py:65) competes with the surfels' logits, so its weight is
+                # not 0/1 and the gradient through the min reaches the farthest surfel's depth; a per-crop scalar, done here.
+                eps = torch.finfo(torch.float32).eps
+                gates = aux[:, 3].contiguous().view(torch.int32)
+                w_bg = torch.exp(bg_logit - aux[:, 1]) / aux[:, 2]
+                gc = g_color.view(3, -1) * torch.stack([(gates & 1) != 0, (gates & 2) != 0, (gates & 4) != 0]).float()
+                dLdw = (gc * bg_c.view(3, -1)).sum(0)
+                S = (gc * color.view(3, -1)).sum(0)
+                if g_mask is not None:
+                    gm = g_mask.view(-1) * ((gates & 8) != 0).float()
+                    dLdw = dLdw + gm
+                    S = S + gm * mask.view(-1)
+                if g_depth is not None:
+                    S = S + g_depth.view(-1) * depth.view(-1)
+                if g_nimg is not None:
+                    gn = g_nimg.view(3, -1) * torch.stack([(gates & 16) != 0, (gates & 32) != 0, (gates & 64) != 0]).float()
+                    S = S + (gn * nimg.view(3, -1)).sum(0)
+                G = (w_bg * (dLdw - S)).sum()
+                zq = -p_cam[bg_argmin, 2] / (znorm[0] + eps) + 1
+                g_p[bg_argmin, 2] += torch.where(zq >= 0, -G * dconst / (znorm[0] + eps), torch.zeros_like(G))
+        g_col = g_a * 0.5 if half_attr else g_a                              # attr = (col + 1) / 2
         if g_col_ext is not None:
             g_col = g_col[:n] + g_col_ext
         if g_pcam_ext is not None:
@@ -102,7 +150,7 @@ class _RasterFn(torch.autograd.Function):
             _lib.check(L.sdfr_project_dcm_bwd(_lib.ptr(pose), _lib.ptr(coords), _lib.ptr(normals), _lib.ptr(g_p), _lib.ptr(g_n),
                                               _lib.ptr(g_col), 1, n, None, int(nocs_mode), _lib.ptr(g_points), _lib.ptr(g_normals),
                                               _lib.ptr(g_colors), _lib.ptr(g_pose), st), "sdfr_project_dcm_bwd")
-        return (g_points[:n], g_normals[:n], None if nocs_mode else g_colors[:n], g_pose) + (None,) * 9
+        return (g_points[:n], g_normals[:n], None if nocs_mode else g_colors[:n], g_pose, None) + (None,) * 11
 
 
 class Rasterer(torch.nn.Module):
@@ -124,10 +172,14 @@ class Rasterer(torch.nn.Module):
     def forward(self, coords, normals, colors, camera_matrix, rot='quat', primitives='disc', bg=None, output_mask=False,
                 output_depth=False, output_normals=False, output_nocs=False, output_points=True):
         _lib.require_gpu_f32(coords, normals, None if output_nocs else colors)
-        if primitives != 'disc':
-            raise NotImplementedError("primitives='%s': only the 3-D tangent disc ('disc', the optimizer's primitive) is built" % primitives)
-        if bg is not None:
-            raise NotImplementedError("background compositing (bg=...) is not built yet")
+        if primitives not in _PRIMS:
+            raise ValueError("primitives must be 'disc', 'circle' or 'circle_opt'")
+        if bg is not None and (output_depth or output_normals):
+            # the reference fails here as well: its depth / normals products mix N+1 weight rows with N attribute rows
+            # (rasterer.py:108,134-143)
+            raise RuntimeError("bg is incompatible with output_depth / output_normals (shape mismatch in the reference, rasterer.py:108-143)")
+        if primitives == 'circle_opt' and (int(self.K[0, 2]) * 2 != self.res_x_px or int(self.K[1, 2]) * 2 != self.res_y_px):
+            raise RuntimeError("circle_opt derives the image size from K's principal point (primitives.py:109-110); it must equal the resolution")
         dev = coords.device
         K = self.K.to(dev)
         Kinv = self.Kinv.to(dev)
@@ -146,9 +198,10 @@ class Rasterer(torch.nn.Module):
         if coords.shape[0] != normals.shape[0]:
             raise _lib.SdfrError("coords and normals must have the same number of rows")
         holder = {}
+        half_attr = bool(output_nocs) or (bg is not None)       # (c+1)/2 for NOCS (:114) and always with a background (:109)
         color, mask, depth, nimg, p_cam, n_cam, col = _RasterFn.apply(
-            coords, normals, colors if not output_nocs else None, pose, K, Kinv, (self.res_x_px, self.res_y_px), nocs_mode,
-            bool(output_mask), bool(output_depth), bool(output_normals), want_filter, holder)
+            coords, normals, colors if not output_nocs else None, pose, bg, K, Kinv, (self.res_x_px, self.res_y_px), nocs_mode,
+            primitives, half_attr, bool(output_mask), bool(output_depth), bool(output_normals), want_filter, holder)
         rendering = {'color': color}
         if output_mask:
             rendering['mask'] = mask

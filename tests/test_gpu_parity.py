@@ -317,7 +317,7 @@ def test_splat_forward_backward_vs_oracle(H, W, n):
     depth = torch.empty((1, H, W), device=DEV); nimg = torch.empty((3, H, W), device=DEV)
     aux = torch.empty((H * W, 4), device=DEV); bbox = torch.empty((n, 4), dtype=torch.int32, device=DEV)
     tK, tKi = T(K), T(Kinv)
-    _lib.check(L.sdfr_splat_forward(_lib.ptr(tK), _lib.ptr(tKi), _lib.ptr(tp), _lib.ptr(tn), _lib.ptr(tc), 1, n, None, W, H, 0.04, 150.0,
+    _lib.check(L.sdfr_splat_forward(0, _lib.ptr(tK), _lib.ptr(tKi), _lib.ptr(tp), _lib.ptr(tn), _lib.ptr(tc), None, None, None, None, 1, n, None, W, H, 0.04, 150.0,
                                     _lib.ptr(bbox), _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(nimg), _lib.ptr(aux),
                                     _lib.stream_ptr()), "splat_fwd")
     Wm, auxo = O.inside_surfel(Kinv, O.pixel_grid((W, H)), p, nrm, diam=0.04, want_aux=True)
@@ -332,7 +332,7 @@ def test_splat_forward_backward_vs_oracle(H, W, n):
     gD = rng.standard_normal((1, H, W)).astype(np.float32); gN = rng.standard_normal((3, H, W)).astype(np.float32)
     g_p = torch.zeros((n, 3), device=DEV); g_n = torch.zeros((n, 3), device=DEV); g_a = torch.zeros((n, 3), device=DEV)
     tg = [T(g) for g in (gC, gM, gD, gN)]
-    _lib.check(L.sdfr_splat_backward(_lib.ptr(tK), _lib.ptr(tKi), _lib.ptr(tp), _lib.ptr(tn), _lib.ptr(tc), 1, n, None, W, H, 0.04,
+    _lib.check(L.sdfr_splat_backward(0, _lib.ptr(tK), _lib.ptr(tKi), _lib.ptr(tp), _lib.ptr(tn), _lib.ptr(tc), None, None, None, None, 1, n, None, W, H, 0.04,
                                      150.0, _lib.ptr(aux), _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(nimg),
                                      _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]), _lib.ptr(tg[3]), _lib.ptr(g_p), _lib.ptr(g_n),
                                      _lib.ptr(g_a), _lib.stream_ptr()), "splat_bwd")
@@ -448,3 +448,38 @@ def test_refinement_trajectory_golden(dec):
     assert np.abs(l3 - z["loss3d_weighted"]).max() < 2e-4
     assert np.abs(traj - z["traj"]).max() < 5e-4, np.abs(traj - z["traj"]).max(axis=0)
     assert abs(traj[-1, 0] - init[0]) > 0.05            # the pose really moved
+
+
+@pytest.mark.parametrize("prim,use_bg", [("circle", False), ("circle", True), ("circle_opt", False), ("circle_opt", True), ("disc", True)])
+def test_secondary_primitives_and_bg_golden(prim, use_bg):
+    """a6' rows: primitives 'circle' / 'circle_opt' and the bg variant through the drop-in Rasterer vs. the reference (golden G9):
+    images and autograd gradients w.r.t. the surfel positions, yaw and trans."""
+    z = gold("g9_secondary.npz")
+    H = W = 32
+    t = "%s_bg%d_" % (prim, int(use_bg))
+    r = sdflabel_amd.Rasterer(T(z["K"]), (W, H)).to(DEV)
+    p = T(z["points"]).requires_grad_(True)
+    nrm = T(z["normals"])
+    yaw = torch.tensor([0.6], device=DEV, requires_grad=True)
+    trans = torch.tensor([0.05, -0.03, 3.4], device=DEV, requires_grad=True)
+    pose = build_pose(yaw, trans)
+    assert np.allclose(N(pose), z[t + "pose"], atol=1e-6)
+    rend = r(p, nrm, nrm, pose, rot="dcm", primitives=prim, bg=T(z["bg"]) if use_bg else None, output_mask=True,
+             output_depth=not use_bg, output_normals=not use_bg, output_nocs=True, output_points=False)
+    # circle_opt scales the normalised depth by 10000 before the softmax: one float32 ulp of the logit moves the weights by ~2e-4
+    tol = 1e-3 if prim == "circle_opt" else 1e-4
+    for k in rend:
+        assert np.abs(N(rend[k]) - z[t + "out_" + k]).max() < tol, k
+    loss = sum((rend[k] * T(z[t + "W_" + k])).sum() for k in rend)
+    loss.backward()
+    gtol = 2e-2 if prim == "circle_opt" else 2e-3
+    for got, key in ((p.grad, "g_points"), (yaw.grad, "g_yaw"), (trans.grad, "g_trans")):
+        ref = z[t + key]
+        assert np.abs(N(got) - ref).max() < gtol * max(1.0, np.abs(ref).max()), (key, np.abs(N(got) - ref).max(), np.abs(ref).max())
+
+
+def test_bg_with_depth_or_normals_is_rejected_like_the_reference():
+    r = sdflabel_amd.Rasterer(T(K_for(16, 16)), (16, 16)).to(DEV)
+    p = torch.rand(5, 3, device=DEV) + torch.tensor([0, 0, 2.0], device=DEV)
+    with pytest.raises(RuntimeError):
+        r(p, p, p, torch.eye(4, device=DEV), rot="dcm", bg=torch.zeros(3, 16, 16, device=DEV), output_depth=True, output_points=False)

@@ -189,6 +189,30 @@ int sdfr_params_backward(const float* yaw, const float* latent, int L, const flo
 int sdfr_gather_rows3(float* out, const float* src, const int32_t* idx, int B, int cap, const int32_t* cnt, void* stream);
 int sdfr_scatter_add_rows3(float* dst, const float* src, const int32_t* idx, int B, int cap, const int32_t* cnt, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Losses and solver step of the refinement loop (pipelines/optimizer.py:144-157, 166-237), B crops at once, device resident.
+ */
+
+/* compute_loss_3d (optimizer.py:166-198): exact nearest lidar point (lidar/scale, :84) of every estimated point est[b][j], j < ecnt[b];
+ * pairs with distance < threshold/scale[b]; loss[b] = mean pair distance (0 without pairs).  g_est [B][ecap][3] and g_scale [B] receive
+ * weight * d loss / d(est, scale).  npairs[b] = number of pairs, or -1 when either cloud is empty (the loop skips the crop, :127-129). */
+int sdfr_loss_3d(const float* est, const int32_t* ecnt, int ecap, const float* lidar, const int32_t* lcnt, int lcap, const float* scale,
+                 float threshold, float weight, int B, float* loss, float* g_est, float* g_scale, int32_t* npairs, void* stream);
+
+/* compute_loss_2d (optimizer.py:200-237) on rend, target [B][3][H][W]: per rendered non-zero pixel the smallest distance to the target
+ * weighted by clamp(diam - pixel distance, 0); loss[b] = mean of the minima below threshold_nocs (NaN if none, 0 without rendered pixels,
+ * exactly as the reference); g_rend = weight * d loss / d rend; nvalid[b] = number of pixels in the mean. */
+int sdfr_loss_2d(const float* rend, const float* target, int B, int H, int W, float diam, float threshold_nocs, float weight,
+                 float* loss, float* g_rend, int32_t* nvalid, void* stream);
+
+/* MultipleOptimizer.step (optimizer.py:13-23,34-52): Adam(lr_adam, betas .9/.999, eps 1e-8) on yaw and trans, SGD on scale (lr_scale) and
+ * latent (lr_latent).  params / grads are ONE flat structure-of-arrays buffer [ yaw(B) | trans(B,3) | scale(B) | latent(B,L) ].
+ * total[b] = w3*loss3d + w2*loss2d; a crop is skipped (stepped[b] = 0, no state change) when npairs[b] < 0, total is NaN or total == 0
+ * (optimizer.py:127-129,149-151). */
+int sdfr_solver_step(float* params, const float* grads, int L, const float* loss2d, const float* loss3d, const int32_t* npairs,
+                     float w2, float w3, float* adam_m, float* adam_v, int32_t* adam_t, float lr_adam, float lr_scale, float lr_latent,
+                     int B, float* total, int32_t* stepped, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@ $HIPCC $COMMON -ffp-contract=off -c "$HERE/surface.hip" -o "$HERE/obj/surface.o"
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/project.hip" -o "$HERE/obj/project.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/splat.hip"   -o "$HERE/obj/splat.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/params.hip"  -o "$HERE/obj/params.o" &
+$HIPCC $COMMON -ffp-contract=off -c "$HERE/losses.hip"  -o "$HERE/obj/losses.o" &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsdfr_hip.so" "$HERE"/obj/{common,mlp,surface,project,splat,params}.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsdfr_hip.so" "$HERE"/obj/{common,mlp,surface,project,splat,params,losses}.o
 echo "built $OUT/libsdfr_hip.so"

@@ -1,0 +1,230 @@
+// Losses and solver step of the reference's refinement loop, on the device and for B crops at once.
+//
+//   sdfr_loss_3d      compute_loss_3d (pipelines/optimizer.py:166-198): nearest lidar point of every front-facing estimated point
+//                     (the reference round-trips to the host and builds a sklearn KDTree per iteration, :180-181; here an exact
+//                     brute-force search over LDS tiles), pairs closer than threshold/scale, mean pair distance, and the
+//                     gradients w.r.t. the estimated points and the scale (the lidar cloud is divided by scale, :84).
+//   sdfr_loss_2d      compute_loss_2d (:200-237): for every rendered (non-zero) pixel the smallest NOCS distance to the target
+//                     weighted by clamp(diam - pixel distance, 0).  The reference forms Q x H x W tensors (~100 GB at 256^2);
+//                     algebraically this is a min over the (2*diam-1)^2 window plus the constant ||rendered|| of every pixel
+//                     outside the window, evaluated here per pixel.
+//   sdfr_solver_step  the MultipleOptimizer step (:13-23,44-52): Adam(lr .01) on yaw and trans, SGD(lr .01 / 3e-5) on scale / latent,
+//                     gated per crop by the loop's skip conditions (:127-129,149-151).
+// One workgroup per crop with fixed-order reductions: bit-repeatable.  Compiled with -ffp-contract=off.
+#include "sdfr_common.h"
+#include <float.h>
+
+#define L_THREADS 1024
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < L_THREADS / 64; ++w) t += red[w];
+    return t;
+}
+
+// ---- 3-D loss ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(L_THREADS) void sdfr_loss_3d_kernel(const float* __restrict__ est, const int32_t* __restrict__ ecnt, int ecap,
+                                                                const float* __restrict__ lidar, const int32_t* __restrict__ lcnt,
+                                                                int lcap, const float* __restrict__ scale, float threshold, float weight,
+                                                                float* __restrict__ loss, float* __restrict__ g_est,
+                                                                float* __restrict__ g_scale, int32_t* __restrict__ npairs) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ne = sdfr_count(ecnt, b, ecap), nl = sdfr_count(lcnt, b, lcap);
+    const float s = scale[b];
+    const float thr = threshold / s;                                   // :184
+    __shared__ float tile[3][L_THREADS];
+    __shared__ float red[L_THREADS / 64];
+    float lsum = 0.f, gs = 0.f;
+    int cnt = 0;
+    const float* E = est + (int64_t)b * ecap * 3;
+    const float* Lp = lidar + (int64_t)b * lcap * 3;
+    float* G = g_est + (int64_t)b * ecap * 3;
+    for (int j0 = 0; j0 < ne; j0 += L_THREADS) {
+        const int j = j0 + tid;
+        const bool act = j < ne;
+        const float ex = act ? E[j * 3] : 0.f, ey = act ? E[j * 3 + 1] : 0.f, ez = act ? E[j * 3 + 2] : 0.f;
+        float best = FLT_MAX;
+        int bi = -1;
+        for (int m0 = 0; m0 < nl; m0 += L_THREADS) {
+            __syncthreads();
+            if (m0 + tid < nl) {                                        // lidar / scale (:84), staged once per tile
+                tile[0][tid] = Lp[(m0 + tid) * 3] / s; tile[1][tid] = Lp[(m0 + tid) * 3 + 1] / s; tile[2][tid] = Lp[(m0 + tid) * 3 + 2] / s;
+            }
+            __syncthreads();
+            const int mn = min(L_THREADS, nl - m0);
+            if (act)
+                for (int m = 0; m < mn; ++m) {
+                    const float dx = tile[0][m] - ex, dy = tile[1][m] - ey, dz = tile[2][m] - ez;
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    if (d2 < best) { best = d2; bi = m0 + m; }
+                }
+        }
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (act && bi >= 0 && sqrtf(best) < thr) {                       // :184
+            const float lx = Lp[bi * 3] / s, ly = Lp[bi * 3 + 1] / s, lz = Lp[bi * 3 + 2] / s;
+            const float dx = lx - ex, dy = ly - ey, dz = lz - ez;
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);          // :185
+            lsum += d;
+            ++cnt;
+            if (d > 0.f) {
+                const float ux = dx / d, uy = dy / d, uz = dz / d;       // d||l/s - e|| / d(l/s)
+                gx = -ux; gy = -uy; gz = -uz;
+                gs += -(ux * lx + uy * ly + uz * lz) / s;                // d(l/s)/ds = -(l/s)/s
+            }
+        }
+        if (act) { G[j * 3] = gx; G[j * 3 + 1] = gy; G[j * 3 + 2] = gz; }
+    }
+    const float tot = block_sum(lsum, red);
+    const float gst = block_sum(gs, red);
+    const float cf = block_sum((float)cnt, red);
+    const float inv = cf > 0.f ? 1.f / cf : 0.f;
+    for (int j = tid; j < ne; j += L_THREADS) {                          // mean over the pairs (:189), times the loss weight
+        G[j * 3] *= weight * inv; G[j * 3 + 1] *= weight * inv; G[j * 3 + 2] *= weight * inv;
+    }
+    for (int j = ne + tid; j < ecap; j += L_THREADS) { G[j * 3] = 0.f; G[j * 3 + 1] = 0.f; G[j * 3 + 2] = 0.f; }
+    if (tid == 0) {
+        loss[b] = cf > 0.f ? tot * inv : 0.f;                            // :188-191
+        g_scale[b] = weight * gst * inv;
+        npairs[b] = (ne > 0 && nl > 0) ? (int)cf : -1;                   // -1: a cloud is empty -> the loop skips the crop (:127-129)
+    }
+}
+
+extern "C" int sdfr_loss_3d(const float* est, const int32_t* ecnt, int ecap, const float* lidar, const int32_t* lcnt, int lcap,
+                            const float* scale, float threshold, float weight, int B, float* loss, float* g_est, float* g_scale,
+                            int32_t* npairs, void* stream) {
+    SDFR_REQUIRE(est && lidar && scale && loss && g_est && g_scale && npairs, "sdfr_loss_3d: NULL argument");
+    if (B <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_loss_3d_kernel, dim3(B), dim3(L_THREADS), 0, (hipStream_t)stream, est, ecnt, ecap, lidar, lcnt, lcap, scale,
+                       threshold, weight, loss, g_est, g_scale, npairs);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// ---- 2-D loss ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(L_THREADS) void sdfr_loss_2d_kernel(const float* __restrict__ rend, const float* __restrict__ target, int H,
+                                                                int W, float diam, float threshold_nocs, float weight,
+                                                                float* __restrict__ loss, float* __restrict__ g_rend,
+                                                                int32_t* __restrict__ nvalid) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int P = H * W;
+    const float* R = rend + (int64_t)b * 3 * P;
+    const float* Tg = target + (int64_t)b * 3 * P;
+    float* G = g_rend + (int64_t)b * 3 * P;
+    __shared__ float red[L_THREADS / 64];
+    const int rad = (int)ceilf(diam) - 1 + 1;                           // taps with clamp(diam - dist, 0) > 0 lie within |d| < diam
+    float lsum = 0.f;
+    int cnt = 0, any = 0;
+    for (int q0 = 0; q0 < P; q0 += L_THREADS) {
+        const int q = q0 + tid;
+        if (q >= P) break;
+        const float r0 = R[q], r1 = R[P + q], r2 = R[2 * P + q];
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (r0 + r1 + r2 != 0.f) {                                      // rendering_nocs.sum(0).nonzero()  (:213)
+            const int h = q / W, w = q - h * W;
+            any |= (h | w) != 0;                                        // `if rendering_nonzero_idxs.sum()` (:214)
+            // every pixel outside the window has weight 0: masked target 0, distance ||r||  (:223-231)
+            float best = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            for (int dh = -rad; dh <= rad; ++dh) {
+                const int hh = h + dh;
+                if (hh < 0 || hh >= H) continue;
+                for (int dw = -rad; dw <= rad; ++dw) {
+                    const int ww = w + dw;
+                    if (ww < 0 || ww >= W) continue;
+                    const float wgt = fmaxf(diam - sqrtf((float)(dh * dh) + (float)(dw * dw)), 0.f);   // :224-225
+                    const int p = hh * W + ww;
+                    const float v0 = Tg[p] * wgt, v1 = Tg[P + p] * wgt, v2 = Tg[2 * P + p] * wgt;     // :227
+                    const float e0 = v0 - r0, e1 = v1 - r1, e2 = v2 - r2;
+                    const float d = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);                                // :232
+                    if (d < best) { best = d; b0 = v0; b1 = v1; b2 = v2; }
+                }
+            }
+            if (best < threshold_nocs) {                                 // :234
+                lsum += best;
+                ++cnt;
+                if (best > 0.f) { g0 = (r0 - b0) / best; g1 = (r1 - b1) / best; g2 = (r2 - b2) / best; }
+            }
+        }
+        G[q] = g0; G[P + q] = g1; G[2 * P + q] = g2;
+    }
+    const float tot = block_sum(lsum, red);
+    const float cf = block_sum((float)cnt, red);
+    const float anyf = block_sum((float)any, red);
+    const float inv = cf > 0.f ? 1.f / cf : 0.f;
+    const float k = (anyf > 0.f) ? weight * inv : 0.f;
+    for (int q = tid; q < 3 * P; q += L_THREADS) G[q] *= k;
+    if (tid == 0) {
+        // no non-zero pixel -> 0 (:235-236); non-zero pixels but none under the threshold -> mean of an empty set = NaN (:234)
+        loss[b] = (anyf > 0.f) ? (cf > 0.f ? tot * inv : __int_as_float(0x7fc00000)) : 0.f;
+        nvalid[b] = (int)cf;
+    }
+}
+
+extern "C" int sdfr_loss_2d(const float* rend, const float* target, int B, int H, int W, float diam, float threshold_nocs, float weight,
+                            float* loss, float* g_rend, int32_t* nvalid, void* stream) {
+    SDFR_REQUIRE(rend && target && loss && g_rend && nvalid, "sdfr_loss_2d: NULL argument");
+    SDFR_REQUIRE(H > 0 && W > 0 && diam > 0.f, "sdfr_loss_2d: bad size");
+    if (B <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_loss_2d_kernel, dim3(B), dim3(L_THREADS), 0, (hipStream_t)stream, rend, target, H, W, diam, threshold_nocs,
+                       weight, loss, g_rend, nvalid);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// ---- solver step -------------------------------------------------------------------------------------------------------
+// params / grads: one flat structure-of-arrays buffer  [ yaw(B) | trans(B,3) | scale(B) | latent(B,L) ]  so that each section is the
+// dense array the renderer kernels read; Adam state m, v [B][4], step counter t [B].
+__global__ __launch_bounds__(64) void sdfr_solver_step_kernel(float* __restrict__ params, const float* __restrict__ grads, int L,
+                                                             const float* __restrict__ loss2d, const float* __restrict__ loss3d,
+                                                             const int32_t* __restrict__ npairs, float w2, float w3,
+                                                             float* __restrict__ adam_m, float* __restrict__ adam_v,
+                                                             int32_t* __restrict__ adam_t, float lr_adam, float lr_scale, float lr_latent,
+                                                             int B, float* __restrict__ total, int32_t* __restrict__ stepped) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float l = w3 * loss3d[b] + w2 * loss2d[b];                    // :144-146
+    total[b] = l;
+    const bool skip = (npairs[b] < 0) || isnan(l) || (l == 0.f);        // :127-129, :149-151
+    stepped[b] = skip ? 0 : 1;
+    if (skip) return;
+    // section offsets of the structure-of-arrays buffer
+    auto at = [&](int i) -> int64_t {              // i: 0 yaw, 1..3 trans, 4 scale, 5.. latent
+        if (i == 0) return b;
+        if (i < 4) return (int64_t)B + (int64_t)b * 3 + (i - 1);
+        if (i == 4) return (int64_t)4 * B + b;
+        return (int64_t)5 * B + (int64_t)b * L + (i - 5);
+    };
+    float* p = params;
+    const float* g = grads;
+    const int t = adam_t[b] + 1;
+    adam_t[b] = t;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
+    for (int i = 0; i < 4; ++i) {                                        // Adam on yaw, trans (:34-36,47-49)
+        float m = adam_m[b * 4 + i], v = adam_v[b * 4 + i];
+        const float gi = g[at(i)];
+        m = b1 * m + (1.f - b1) * gi;
+        v = b2 * v + (1.f - b2) * gi * gi;
+        adam_m[b * 4 + i] = m; adam_v[b * 4 + i] = v;
+        const float denom = sqrtf(v) / sqrtf(bc2) + eps;
+        p[at(i)] -= (lr_adam / bc1) * (m / denom);
+    }
+    p[at(4)] -= lr_scale * g[at(4)];                                      // SGD on scale, latent (:37-38,50-51)
+    for (int i = 0; i < L; ++i) p[at(5 + i)] -= lr_latent * g[at(5 + i)];
+}
+
+extern "C" int sdfr_solver_step(float* params, const float* grads, int L, const float* loss2d, const float* loss3d, const int32_t* npairs,
+                                float w2, float w3, float* adam_m, float* adam_v, int32_t* adam_t, float lr_adam, float lr_scale,
+                                float lr_latent, int B, float* total, int32_t* stepped, void* stream) {
+    SDFR_REQUIRE(params && grads && loss2d && loss3d && npairs && adam_m && adam_v && adam_t && total && stepped,
+                 "sdfr_solver_step: NULL argument");
+    if (B <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_solver_step_kernel, dim3(sdfr_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, params, grads, L, loss2d, loss3d,
+                       npairs, w2, w3, adam_m, adam_v, adam_t, lr_adam, lr_scale, lr_latent, B, total, stepped);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}

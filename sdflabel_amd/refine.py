@@ -1,0 +1,124 @@
+"""BatchRefiner -- the reference's whole refinement loop (pipelines/optimizer.py:43-237) for B crops, device resident.
+
+The reference's `Optimizer.optimize` runs one crop at a time and pays, per iteration, an H2D upload of the lidar cloud (:84), a D2H
+round trip plus a sklearn KDTree build for the 3-D loss (:180-181), Q x H x W dense tensors for the 2-D loss (:213-234) and several
+`.item()` syncs (:149,154,188).  Here one iteration is ~25 kernel launches on one stream with no host synchronisation at all:
+
+    BatchRenderer.forward  ->  sdfr_loss_2d (NOCS window loss)  +  sdfr_loss_3d (exact nearest neighbour loss)
+                           ->  BatchRenderer.backward           ->  sdfr_solver_step (Adam on yaw/trans, SGD on scale/latent, skip rules)
+
+with the same arithmetic per crop as the reference (trajectory-tested against its own Optimizer, golden G8).  Parameters live in ONE flat
+structure-of-arrays buffer [ yaw(B) | trans(B,3) | scale(B) | latent(B,L) ] whose sections are the dense arrays the kernels read.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .batch import BatchRenderer
+
+
+class BatchRefiner:
+    def __init__(self, decoder, density, K, crop_size, batch, lidar_cap, weights=None, cap=None, device="cuda"):
+        """crop_size = (H, W) as the reference passes it (optimizer.py:56,72 builds the Rasterer with crop_size[::-1])."""
+        self.H, self.W = int(crop_size[0]), int(crop_size[1])
+        self.B = int(batch)
+        self.w2 = float((weights or {}).get('2d', 0.3))          # configs/config_refine.ini:26-27
+        self.w3 = float((weights or {}).get('3d', 0.5))
+        self.br = BatchRenderer(decoder, density, K, (self.W, self.H), batch, cap=cap, device=device)
+        br, B = self.br, self.B
+        dev = br.dev
+        self.dev = dev
+        self.L = br.L
+        n = (5 + self.L) * B
+        self.params = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+
+        def sections(buf):
+            return buf[0:B], buf[B:4 * B].view(B, 3), buf[4 * B:5 * B], buf[5 * B:].view(B, self.L)
+
+        self.yaw, self.trans, self.scale, self.latent = sections(self.params)
+        self.g_yaw, self.g_trans, self.g_scale, self.g_latent = sections(self.grads)
+        # the renderer reads / writes the sections of the flat buffers directly
+        br.yaw, br.trans, br.latent = self.yaw, self.trans, self.latent
+        br.g_yaw, br.g_trans, br.g_latent = self.g_yaw, self.g_trans, self.g_latent
+        self.lidar_cap = int(lidar_cap)
+        self.lidar = torch.zeros((B, self.lidar_cap, 3), dtype=torch.float32, device=dev)
+        self.lcnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.target = torch.zeros((B, 3, self.H, self.W), dtype=torch.float32, device=dev)
+        self.loss2d = torch.zeros((B,), dtype=torch.float32, device=dev)
+        self.loss3d = torch.zeros((B,), dtype=torch.float32, device=dev)
+        self.total = torch.zeros((B,), dtype=torch.float32, device=dev)
+        self.nvalid = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.npairs = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.stepped = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.g_color = torch.zeros((B, 3, self.H, self.W), dtype=torch.float32, device=dev)
+        self.g_xyzf = torch.zeros((B, br.cap, 3), dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros((B, 4), dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros((B, 4), dtype=torch.float32, device=dev)
+        self.adam_t = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self._replay = None
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def set_crops(self, params, nocs_pred, lidars):
+        """params: dict of (B, .) arrays 'yaw' (B,1|B), 'trans' (B,3), 'scale' (B,1|B), 'latent' (B,L)  (optimizer.py:26-40);
+        nocs_pred: (B,3,h,w) CSS-net NOCS predictions, resized with nearest-neighbour interpolation to the crop (optimizer.py:135-137);
+        lidars: list of B (M_b,3) arrays (camera-frame lidar points of each crop's frustum)."""
+        B, dev = self.B, self.dev
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+        self.yaw.copy_(t(params['yaw']).reshape(B))
+        self.trans.copy_(t(params['trans']).reshape(B, 3))
+        self.scale.copy_(t(params['scale']).reshape(B))
+        self.latent.copy_(t(params['latent']).reshape(B, self.L))
+        self.target.copy_(F.interpolate(t(nocs_pred), size=(self.H, self.W), mode='nearest'))
+        self.lidar.zero_()
+        for b, l in enumerate(lidars):
+            l = t(l).reshape(-1, 3)
+            if l.shape[0] > self.lidar_cap:
+                raise _lib.SdfrError("crop %d has %d lidar points > lidar_cap %d" % (b, l.shape[0], self.lidar_cap))
+            self.lidar[b, :l.shape[0]] = l
+            self.lcnt[b] = l.shape[0]
+        self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t.zero_()
+        self._replay = None
+
+    def iteration(self):
+        """One refinement iteration of every crop (optimizer.py:79-157).  No host synchronisation."""
+        L = _lib.lib()
+        P, st, ck = _lib.ptr, _lib.stream_ptr(), _lib.check
+        br, B = self.br, self.B
+        out = br.forward()
+        ck(L.sdfr_loss_2d(P(out["color"]), P(self.target), B, self.H, self.W, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color),
+                          P(self.nvalid), st), "sdfr_loss_2d")
+        ck(L.sdfr_loss_3d(P(out["xyzf"]), P(br.fcnt), br.cap, P(self.lidar), P(self.lcnt), self.lidar_cap, P(self.scale), 0.2, self.w3, B,
+                          P(self.loss3d), P(self.g_xyzf), P(self.g_scale), P(self.npairs), st), "sdfr_loss_3d")
+        br.backward(g_color=self.g_color, g_xyzf=self.g_xyzf)
+        ck(L.sdfr_solver_step(P(self.params), P(self.grads), self.L, P(self.loss2d), P(self.loss3d), P(self.npairs), self.w2, self.w3,
+                              P(self.adam_m), P(self.adam_v), P(self.adam_t), 0.01, 0.01, 0.00003, B, P(self.total), P(self.stepped), st),
+           "sdfr_solver_step")
+
+    def capture(self):
+        """Capture one iteration in a HIP graph; optimize() then replays it."""
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        snap = (self.params.clone(), self.adam_m.clone(), self.adam_v.clone(), self.adam_t.clone())
+        with torch.cuda.stream(s):
+            self.iteration()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.iteration()
+        # warm-up and capture must not advance the optimisation
+        self.params.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.adam_t.copy_(snap[3])
+        self._replay = g.replay
+        return g.replay
+
+    def optimize(self, iters_optim):
+        for _ in range(iters_optim):
+            if self._replay is not None:
+                self._replay()
+            else:
+                self.iteration()
+
+    def results(self):
+        """(B, 5+L) rows [yaw, trans(3), scale, latent(L)] and the last (B,) weighted losses (2d, 3d).  Synchronises."""
+        rows = torch.cat([self.yaw.view(-1, 1), self.trans, self.scale.view(-1, 1), self.latent], dim=1)
+        return rows.clone(), (self.w2 * self.loss2d).clone(), (self.w3 * self.loss3d).clone()

@@ -118,3 +118,67 @@ def test_batch_capacity_overflow_flag(dec):
     br = sdflabel_amd.BatchRenderer(dec, 16, K_for(16, 16), (16, 16), 1, cap=64, device=DEV)
     br.forward(T(np.array([0.6], np.float32)), T(np.array([[0, 0, 3.5]], np.float32)), T(np.array([[0.3, -0.5, 0.8]], np.float32)))
     assert br.overflow() and int(br.cnt[0]) == 167        # true band size (golden G3 'a'), only the first 64 kept
+
+
+@pytest.mark.parametrize("B,graph", [(1, False), (2, True)])
+def test_batch_refiner_trajectory_golden(dec, B, graph):
+    """f1+f2+f3: the device-resident refinement loop (HIP losses + solver step) against the trajectory of the reference's own
+    Optimizer (golden G8): parameters after each of 10 iterations and the per-iteration weighted losses."""
+    z = gold("g8_optimizer.npz")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    rf = sdflabel_amd.BatchRefiner(dec, D, z["K"], (H, W), B, lidar_cap=256, weights={"2d": 0.3, "3d": 0.5}, device=DEV)
+    rep = lambda a: np.tile(np.asarray(a, np.float32).reshape(1, -1), (B, 1))
+    rf.set_crops({"yaw": rep(init[0:1]), "trans": rep(init[1:4]), "scale": rep(init[4:5]), "latent": rep(init[5:8])},
+                 np.tile(z["nocs_target"][None], (B, 1, 1, 1)), [z["lidar"]] * B)
+    if graph:
+        rf.capture()
+    traj, l2, l3 = [], [], []
+    for _ in range(10):
+        rf.optimize(1)
+        rows, a, b = rf.results()
+        traj.append(N(rows)); l2.append(N(a)); l3.append(N(b))
+        assert int(rf.stepped.min()) == 1
+    traj, l2, l3 = np.asarray(traj), np.asarray(l2), np.asarray(l3)
+    for b in range(B):
+        assert np.abs(l2[:, b] - z["loss2d_weighted"]).max() < 2e-4
+        assert np.abs(l3[:, b] - z["loss3d_weighted"]).max() < 2e-4
+        assert np.abs(traj[:, b] - z["traj"]).max() < 5e-4, np.abs(traj[:, b] - z["traj"]).max(axis=0)
+
+
+def test_losses_vs_torch_restatement(dec):
+    """the HIP 2-D / 3-D losses and their gradients against the torch restatement of optimizer.py:166-237 (tests/_harness.py)."""
+    from sdflabel_amd import _lib
+    from tests._harness import loss_2d, loss_3d
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    H, W = 24, 20
+    rend = torch.zeros(3, H, W, device=DEV)
+    rend[:, 5:17, 4:15] = torch.rand(3, 12, 11, device=DEV)
+    rend.requires_grad_(True)
+    tgt = torch.rand(3, H, W, device=DEV) * (torch.rand(1, H, W, device=DEV) > 0.4)
+    ref = loss_2d(rend, tgt)
+    ref.backward()
+    loss = torch.zeros(1, device=DEV); g = torch.zeros(1, 3, H, W, device=DEV); nv = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(L.sdfr_loss_2d(_lib.ptr(rend.detach().contiguous()), _lib.ptr(tgt.contiguous()), 1, H, W, 5.0, 1.0, 1.0, _lib.ptr(loss),
+                              _lib.ptr(g), _lib.ptr(nv), _lib.stream_ptr()), "loss2d")
+    assert abs(float(loss) - float(ref)) < 1e-5
+    assert np.abs(N(g[0]) - N(rend.grad)).max() < 1e-5
+    # 3-D
+    est = torch.rand(300, 3, device=DEV).requires_grad_(True)
+    lidar = torch.rand(150, 3, device=DEV) * 2.0
+    scale = torch.tensor([2.0], device=DEV, requires_grad=True)
+    ref = loss_3d(est, lidar / scale, float(scale))
+    ref.backward()
+    cap = 512
+    estp = torch.zeros(1, cap, 3, device=DEV); estp[0, :300] = est.detach()
+    lid = torch.zeros(1, 256, 3, device=DEV); lid[0, :150] = lidar
+    ec = torch.tensor([300], dtype=torch.int32, device=DEV); lc = torch.tensor([150], dtype=torch.int32, device=DEV)
+    l3 = torch.zeros(1, device=DEV); ge = torch.zeros(1, cap, 3, device=DEV); gs = torch.zeros(1, device=DEV)
+    npair = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(L.sdfr_loss_3d(_lib.ptr(estp), _lib.ptr(ec), cap, _lib.ptr(lid), _lib.ptr(lc), 256, _lib.ptr(scale.detach()), 0.2, 1.0, 1,
+                              _lib.ptr(l3), _lib.ptr(ge), _lib.ptr(gs), _lib.ptr(npair), _lib.stream_ptr()), "loss3d")
+    assert int(npair) > 10
+    assert abs(float(l3) - float(ref)) < 1e-6
+    assert np.abs(N(ge[0, :300]) - N(est.grad)).max() < 1e-6
+    assert abs(float(gs) - float(scale.grad)) < 1e-5

@@ -203,7 +203,7 @@ int sdfr_loss_3d(const float* est, const int32_t* ecnt, int ecap, const float* l
  * weighted by clamp(diam - pixel distance, 0); loss[b] = mean of the minima below threshold_nocs (NaN if none, 0 without rendered pixels,
  * exactly as the reference); g_rend = weight * d loss / d rend; nvalid[b] = number of pixels in the mean. */
 int sdfr_loss_2d(const float* rend, const float* target, int B, int H, int W, float diam, float threshold_nocs, float weight,
-                 float* loss, float* g_rend, int32_t* nvalid, void* stream);
+                 float* loss, float* g_rend, int32_t* nvalid, float* scratch /* float[B * ceil(H*W/256) * 3] */, void* stream);
 
 /* MultipleOptimizer.step (optimizer.py:13-23,34-52): Adam(lr_adam, betas .9/.999, eps 1e-8) on yaw and trans, SGD on scale (lr_scale) and
  * latent (lr_latent).  params / grads are ONE flat structure-of-arrays buffer [ yaw(B) | trans(B,3) | scale(B) | latent(B,L) ].

@@ -105,27 +105,25 @@ extern "C" int sdfr_loss_3d(const float* est, const int32_t* ecnt, int ecap, con
 }
 
 // ---- 2-D loss ----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(L_THREADS) void sdfr_loss_2d_kernel(const float* __restrict__ rend, const float* __restrict__ target, int H,
-                                                                int W, float diam, float threshold_nocs, float weight,
-                                                                float* __restrict__ loss, float* __restrict__ g_rend,
-                                                                int32_t* __restrict__ nvalid) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+// pass 1: one thread per pixel (window search, un-normalised gradient), fixed-order partial sums per 256-pixel block;
+// pass 2: every block re-reduces the (few hundred) partials in the same order, scales its share of the gradient; block 0 writes the loss.
+__global__ __launch_bounds__(256) void sdfr_loss_2d_pixels_kernel(const float* __restrict__ rend, const float* __restrict__ target, int H,
+                                                                 int W, float diam, float threshold_nocs, float* __restrict__ g_rend,
+                                                                 float* __restrict__ partial) {
+    const int b = blockIdx.y, tid = threadIdx.x;
     const int P = H * W;
     const float* R = rend + (int64_t)b * 3 * P;
     const float* Tg = target + (int64_t)b * 3 * P;
     float* G = g_rend + (int64_t)b * 3 * P;
-    __shared__ float red[L_THREADS / 64];
-    const int rad = (int)ceilf(diam) - 1 + 1;                           // taps with clamp(diam - dist, 0) > 0 lie within |d| < diam
-    float lsum = 0.f;
-    int cnt = 0, any = 0;
-    for (int q0 = 0; q0 < P; q0 += L_THREADS) {
-        const int q = q0 + tid;
-        if (q >= P) break;
+    const int rad = (int)ceilf(diam) - 1;                               // taps with clamp(diam - dist, 0) > 0 have |d| < diam
+    const int q = blockIdx.x * 256 + tid;
+    float lsum = 0.f, cnt = 0.f, any = 0.f;
+    if (q < P) {
         const float r0 = R[q], r1 = R[P + q], r2 = R[2 * P + q];
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
         if (r0 + r1 + r2 != 0.f) {                                      // rendering_nocs.sum(0).nonzero()  (:213)
             const int h = q / W, w = q - h * W;
-            any |= (h | w) != 0;                                        // `if rendering_nonzero_idxs.sum()` (:214)
+            any = ((h | w) != 0) ? 1.f : 0.f;                           // `if rendering_nonzero_idxs.sum()` (:214)
             // every pixel outside the window has weight 0: masked target 0, distance ||r||  (:223-231)
             float best = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
             float b0 = 0.f, b1 = 0.f, b2 = 0.f;
@@ -144,20 +142,47 @@ __global__ __launch_bounds__(L_THREADS) void sdfr_loss_2d_kernel(const float* __
                 }
             }
             if (best < threshold_nocs) {                                 // :234
-                lsum += best;
-                ++cnt;
+                lsum = best;
+                cnt = 1.f;
                 if (best > 0.f) { g0 = (r0 - b0) / best; g1 = (r1 - b1) / best; g2 = (r2 - b2) / best; }
             }
         }
         G[q] = g0; G[P + q] = g1; G[2 * P + q] = g2;
     }
-    const float tot = block_sum(lsum, red);
-    const float cf = block_sum((float)cnt, red);
-    const float anyf = block_sum((float)any, red);
+    __shared__ float red[3][4];
+    float v[3] = {lsum, cnt, any};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float x = v[i];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+        if ((tid & 63) == 0) red[i][tid >> 6] = x;
+    }
+    __syncthreads();
+    if (tid < 3) partial[((int64_t)b * gridDim.x + blockIdx.x) * 3 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
+__global__ __launch_bounds__(256) void sdfr_loss_2d_finalize_kernel(const float* __restrict__ partial, int nblk, int P, float weight,
+                                                                   float* __restrict__ loss, float* __restrict__ g_rend,
+                                                                   int32_t* __restrict__ nvalid) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ float red[3][256];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = tid; i < nblk; i += 256) {
+        const float* p = partial + ((int64_t)b * nblk + i) * 3;
+        a0 += p[0]; a1 += p[1]; a2 += p[2];
+    }
+    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) { red[0][tid] += red[0][tid + st]; red[1][tid] += red[1][tid + st]; red[2][tid] += red[2][tid + st]; }
+        __syncthreads();
+    }
+    const float tot = red[0][0], cf = red[1][0], anyf = red[2][0];
     const float inv = cf > 0.f ? 1.f / cf : 0.f;
-    const float k = (anyf > 0.f) ? weight * inv : 0.f;
-    for (int q = tid; q < 3 * P; q += L_THREADS) G[q] *= k;
-    if (tid == 0) {
+    const float k = (anyf > 0.f) ? weight * inv : 0.f;                    // mean over the selected pixels (:234), times the loss weight
+    const int64_t e = (int64_t)blockIdx.x * 256 + tid;
+    if (e < (int64_t)3 * P) g_rend[(int64_t)b * 3 * P + e] *= k;
+    if (blockIdx.x == 0 && tid == 0) {
         // no non-zero pixel -> 0 (:235-236); non-zero pixels but none under the threshold -> mean of an empty set = NaN (:234)
         loss[b] = (anyf > 0.f) ? (cf > 0.f ? tot * inv : __int_as_float(0x7fc00000)) : 0.f;
         nvalid[b] = (int)cf;
@@ -165,12 +190,16 @@ __global__ __launch_bounds__(L_THREADS) void sdfr_loss_2d_kernel(const float* __
 }
 
 extern "C" int sdfr_loss_2d(const float* rend, const float* target, int B, int H, int W, float diam, float threshold_nocs, float weight,
-                            float* loss, float* g_rend, int32_t* nvalid, void* stream) {
-    SDFR_REQUIRE(rend && target && loss && g_rend && nvalid, "sdfr_loss_2d: NULL argument");
+                            float* loss, float* g_rend, int32_t* nvalid, float* scratch, void* stream) {
+    SDFR_REQUIRE(rend && target && loss && g_rend && nvalid && scratch, "sdfr_loss_2d: NULL argument");
     SDFR_REQUIRE(H > 0 && W > 0 && diam > 0.f, "sdfr_loss_2d: bad size");
     if (B <= 0) return SDFR_OK;
-    hipLaunchKernelGGL(sdfr_loss_2d_kernel, dim3(B), dim3(L_THREADS), 0, (hipStream_t)stream, rend, target, H, W, diam, threshold_nocs,
-                       weight, loss, g_rend, nvalid);
+    const int P = H * W, nblk = sdfr_cdiv(P, 256);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sdfr_loss_2d_pixels_kernel, dim3(nblk, B), dim3(256), 0, s, rend, target, H, W, diam, threshold_nocs, g_rend, scratch);
+    SDFR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sdfr_loss_2d_finalize_kernel, dim3(sdfr_cdiv(3 * P, 256), B), dim3(256), 0, s, scratch, nblk, P, weight, loss, g_rend,
+                       nvalid);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

@@ -52,6 +52,7 @@ class BatchRefiner:
         self.npairs = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.stepped = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.g_color = torch.zeros((B, 3, self.H, self.W), dtype=torch.float32, device=dev)
+        self.l2_scratch = torch.zeros((B * ((self.H * self.W + 255) // 256) * 3,), dtype=torch.float32, device=dev)
         self.g_xyzf = torch.zeros((B, br.cap, 3), dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros((B, 4), dtype=torch.float32, device=dev)
         self.adam_v = torch.zeros((B, 4), dtype=torch.float32, device=dev)
@@ -87,7 +88,7 @@ class BatchRefiner:
         br, B = self.br, self.B
         out = br.forward()
         ck(L.sdfr_loss_2d(P(out["color"]), P(self.target), B, self.H, self.W, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color),
-                          P(self.nvalid), st), "sdfr_loss_2d")
+                          P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d")
         ck(L.sdfr_loss_3d(P(out["xyzf"]), P(br.fcnt), br.cap, P(self.lidar), P(self.lcnt), self.lidar_cap, P(self.scale), 0.2, self.w3, B,
                           P(self.loss3d), P(self.g_xyzf), P(self.g_scale), P(self.npairs), st), "sdfr_loss_3d")
         br.backward(g_color=self.g_color, g_xyzf=self.g_xyzf)

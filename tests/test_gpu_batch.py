@@ -160,8 +160,9 @@ def test_losses_vs_torch_restatement(dec):
     ref = loss_2d(rend, tgt)
     ref.backward()
     loss = torch.zeros(1, device=DEV); g = torch.zeros(1, 3, H, W, device=DEV); nv = torch.zeros(1, dtype=torch.int32, device=DEV)
+    scr = torch.zeros(((H * W + 255) // 256) * 3, device=DEV)
     _lib.check(L.sdfr_loss_2d(_lib.ptr(rend.detach().contiguous()), _lib.ptr(tgt.contiguous()), 1, H, W, 5.0, 1.0, 1.0, _lib.ptr(loss),
-                              _lib.ptr(g), _lib.ptr(nv), _lib.stream_ptr()), "loss2d")
+                              _lib.ptr(g), _lib.ptr(nv), _lib.ptr(scr), _lib.stream_ptr()), "loss2d")
     assert abs(float(loss) - float(ref)) < 1e-5
     assert np.abs(N(g[0]) - N(rend.grad)).max() < 1e-5
     # 3-D

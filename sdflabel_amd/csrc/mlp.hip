@@ -29,6 +29,7 @@
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct MlpLayer {
     int in_dim, out_dim;    // true widths (in_dim includes injected input columns)
@@ -75,24 +76,42 @@ struct sdfr_decoder {
 
 __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
-// FT feature tiles (32 rows) per wave, NP point tiles (32 points) per workgroup, NW waves per workgroup (HP = 32*FT*NW padded
-// hidden width), PF weight/activation fragment buffers in flight per wave (prefetch distance PF-1 K tiles).
+// exact-f32 matrix instruction, MS x MS output tile: v_mfma_f32_32x32x2_f32 (k depth 2) or v_mfma_f32_16x16x4_f32 (k depth 4)
+template <int MS> struct Mma;
+template <> struct Mma<32> {
+    typedef f32x16 acc_t;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+};
+template <> struct Mma<16> {
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+
+// MS   MFMA tile (32: forward on the grid, 64-point workgroup tiles; 16: small tiles so that a few thousand band rows fill the chip)
+// FT   feature tiles (MS rows) per wave, NP point tiles (MS points) per workgroup, NW waves per workgroup (HP = MS*FT*NW padded width)
+// PF   weight/activation fragment buffers in flight per wave (prefetch distance PF-1 K tiles)
 // MODE 0: forward.  1: forward + ReLU masks saved to HBM (1 bit per feature, point, layer).  2: Jacobian of selected rows by
-// recomputation (forward with masks in LDS, then backward).  3: Jacobian of selected rows from the masks a MODE-1 launch saved
-// (backward only: no activations are needed for an input gradient, only the masks and the output).
-template <int FT, int NP, int NW, int PF, int MODE>
+//      recomputation (forward with masks in LDS, then backward).  3: Jacobian of selected rows from the masks a MODE-1 launch saved
+//      (backward only: no activations are needed for an input gradient, only the masks and the output).
+// Lane map of one MS x MS accumulator tile: point = lane % MS, feature = (reg/4)*4*NLG + 4*(lane/MS) + reg%4 with NLG = 64/MS lane
+// groups; a lane's 4 consecutive registers are 4 consecutive features of one point.
+template <int MS, int FT, int NP, int NW, int PF, int MODE>
 __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
+    typedef typename Mma<MS>::acc_t acc_t;
     constexpr bool JAC = MODE >= 2;
     constexpr bool SAVE = MODE == 1;
     constexpr bool LMASK = MODE == 2;
     constexpr bool GMASK = MODE == 3;
-    static_assert(!GMASK || NP == 1, "mask-fed Jacobian uses 32-point tiles");
-    static_assert(!SAVE || NP == 2, "mask layout assumes the 64-point forward tile");
+    static_assert(!SAVE || (NP == 2 && MS == 32), "mask layout assumes the 64-point, 32x32 forward tile");
+    constexpr int NLG = 64 / MS;                                   // lane groups (k slots per MFMA)
+    constexpr int RG = MS / (4 * NLG);                             // register groups of 4 per accumulator (4 or 1)
+    constexpr int KT = 4 * NLG;                                    // k per fragment tile (8 or 16)
     constexpr int NT = 64 * NW;
-    constexpr int PT = 32 * NP;
-    constexpr int HP = 32 * FT * NW;
+    constexpr int PT = MS * NP;
+    constexpr int HP = MS * FT * NW;
     constexpr int KG = HP / 4;
-    constexpr int MW = (FT * NP * 16 + 31) / 32;                 // mask words per thread per layer
+    constexpr int FT32 = HP / (32 * NW);                           // feature tiles per wave of the 32x32 forward kernel (mask layout)
+    constexpr int MW = (FT * NP * RG * 4 + 31) / 32;               // mask words per thread per layer
     constexpr int MASK_WORDS = LMASK ? (SDFR_MAX_LAYERS * MW * NT) : 1;
     // single LDS object, carved by hand (16-byte aligned pieces first)
     __shared__ float4 lds4[KG * PT + NT / 4 + 16 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4];
@@ -106,8 +125,8 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int l31 = lane & 31;
-    const int hi = lane >> 5;
+    const int lp = lane % MS;              // point within a point tile
+    const int lg = lane / MS;              // lane group: k slot of the operands, feature sub-block of the accumulator
     const int NI = P.n_inputs;
 
     // ---- which rows does this tile hold ------------------------------------------------------------------
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     }
     __syncthreads();
 
-    // ---- layer-0 operand: act[k][pt] = inputs[row(pt)][k], zero padded to a multiple of 8 ---------------
+    // ---- layer-0 operand: act[k][pt] = inputs[row(pt)][k], zero padded to the K tile ---------------------
     if (!GMASK) {
         const int k0pad = P.L[0].nkt_f * 8;
         for (int e = tid; e < PT * k0pad; e += NT) {
@@ -142,25 +161,26 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     }
     __syncthreads();
 
-    const int fbase = wave * 32 * FT;      // first feature row owned by this wave
-    f32x16 acc[FT][NP];
+    const int fbase = wave * MS * FT;      // first feature row owned by this wave
+    acc_t acc[FT][NP];
 
-    // One transposed GEMM over `nkt` K tiles: acc[f][p] += W_tile(rows fbase+f*32..) x act.
+    // One transposed GEMM over `nkt8` 8-wide K tiles: acc[f][p] += W_tile(rows fbase+f*MS..) x act.
     // FULL: all FT feature tiles of this wave are active (straight-line MFMA stream, no branches);
     // otherwise only the first `nact` tiles are (thin layers: the 6-wide first layer's backward, small nets).
-    auto gemm_body = [&](const float4* __restrict__ Wl, int nkt, int nact, auto full_tag) {
+    auto gemm_body = [&](const float4* __restrict__ Wl, int nkt8, int nact, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const float4* aptr = Wl + hi * HP + fbase + l31;
-        const float4* bptr = act + hi * PT + l31;
+        const int nkt = nkt8 * 8 / KT;
+        const float4* aptr = Wl + lg * HP + fbase + lp;
+        const float4* bptr = act + lg * PT + lp;
         float4 a[PF][FT], b[PF][NP];
         auto load = [&](int tile, float4* aa, float4* bb) {
-            const float4* ap = aptr + (int64_t)tile * (2 * HP);
-            const float4* bp = bptr + tile * (2 * PT);
+            const float4* ap = aptr + (int64_t)tile * (NLG * HP);
+            const float4* bp = bptr + tile * (NLG * PT);
 #pragma unroll
             for (int f = 0; f < FT; ++f)
-                if (FULL || f < nact) aa[f] = ap[f * 32];
+                if (FULL || f < nact) aa[f] = ap[f * MS];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) bb[p] = bp[p * 32];
+            for (int p = 0; p < NP; ++p) bb[p] = bp[p * MS];
         };
 #pragma unroll
         for (int u = 0; u < PF; ++u)
@@ -181,25 +201,27 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
                             if (FULL || f < nact) {
 #pragma unroll
                                 for (int p = 0; p < NP; ++p)
-                                    acc[f][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a[u][f], ks), f4c(b[u][p], ks), acc[f][p], 0, 0, 0);
+                                    acc[f][p] = Mma<MS>::run(f4c(a[u][f], ks), f4c(b[u][p], ks), acc[f][p]);
                             }
                 }
             }
         }
     };
-    auto gemm = [&](const float4* __restrict__ Wl, int nkt, int rows_active) {
+    auto gemm = [&](const float4* __restrict__ Wl, int nkt8, int rows_active) {
 #pragma unroll
         for (int f = 0; f < FT; ++f)
 #pragma unroll
             for (int p = 0; p < NP; ++p)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[f][p][r] = 0.f;
-        int nact = (rows_active - fbase + 31) / 32;
+                for (int r = 0; r < RG * 4; ++r) acc[f][p][r] = 0.f;
+        int nact = (rows_active - fbase + MS - 1) / MS;
         nact = nact < 0 ? 0 : (nact > FT ? FT : nact);
         nact = __builtin_amdgcn_readfirstlane(nact);
-        if (nact == FT) gemm_body(Wl, nkt, FT, std::true_type{});
-        else if (nact > 0) gemm_body(Wl, nkt, nact, std::false_type{});
+        if (nact == FT) gemm_body(Wl, nkt8, FT, std::true_type{});
+        else if (nact > 0) gemm_body(Wl, nkt8, nact, std::false_type{});
     };
+    // first feature of the 4-register group rg of feature tile f held by this lane
+    auto feat0 = [&](int f, int rg) { return fbase + f * MS + rg * (4 * NLG) + 4 * lg; };
 
     // ---- forward through the MFMA layers -------------------------------------------------------------------
     for (int l = 0; !GMASK && l < P.n_mfma; ++l) {
@@ -215,12 +237,12 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
 #pragma unroll
         for (int f = 0; f < FT; ++f)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int j0 = fbase + f * 32 + 8 * rg + 4 * hi;
+            for (int rg = 0; rg < RG; ++rg) {
+                const int j0 = feat0(f, rg);
                 const float4 b4 = *reinterpret_cast<const float4*>(bias + j0);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    const int pt = p * 32 + l31;
+                    const int pt = p * MS + lp;
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
                         const bool pos = x > 0.f;
                         v[i] = pos ? x : 0.f;
                         if (LMASK || SAVE) {
-                            const int bit = ((f * NP + p) * 4 + rg) * 4 + i;
+                            const int bit = ((f * NP + p) * RG + rg) * 4 + i;
                             mw[bit >> 5] |= (pos ? 1u : 0u) << (bit & 31);
                         }
                     }
@@ -246,6 +268,7 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
             for (int w = 0; w < MW; ++w) masks[(l * MW + w) * NT + tid] = mw[w];
         }
         if (SAVE && P.maskbuf) {
+            // [64-point tile][layer][word f][thread]: word f = bits ((p*4 + rg)*4 + i) of feature tile f  (32x32 geometry, NP = 2)
             uint32_t* dst = P.maskbuf + (((int64_t)blockIdx.x * P.n_mfma + l) * MW) * NT + tid;
 #pragma unroll
             for (int w = 0; w < MW; ++w) dst[w * NT] = mw[w];
@@ -306,17 +329,23 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
         const int inj_hi = prev_out + L.inj_n;
         uint32_t mw[MW];
         if (GMASK) {
-            // the forward launch stored, per 64-point tile, FT words per thread: word f = [p'=0 bits | p'=1 bits] of feature tile f
-            const int r = rows[l31];
-            const int q = r & 63;
-            const uint32_t* src = P.maskbuf + (((int64_t)(r >> 6) * P.n_mfma + (l - 1)) * FT) * NT + wave * 64 + hi * 32 + (q & 31);
+            // decode the forward launch's layout (32x32 tiles, 64-point workgroups): feature jr of this wave -> word jr/32, bit
+            // (q/32)*16 + ((jr%32)/8)*4 + jr%4 of the thread wave*64 + ((jr%32)/4 % 2)*32 + q%32, q = row % 64
 #pragma unroll
             for (int w = 0; w < MW; ++w) mw[w] = 0u;
+            const int r = rows[lp];
+            const int q = r & 63;
+            const uint32_t* src = P.maskbuf + (((int64_t)(r >> 6) * P.n_mfma + (l - 1)) * FT32) * NT + wave * 64 + (q & 31);
 #pragma unroll
-            for (int f = 0; f < FT; ++f) {
-                const uint32_t bits = (src[f * NT] >> ((q >> 5) * 16)) & 0xFFFFu;
-                mw[(f * 16) >> 5] |= bits << ((f * 16) & 31);
-            }
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) {
+                    const int jr = f * MS + rg * (4 * NLG) + 4 * lg;
+                    const uint32_t word = src[(jr >> 5) * NT + (((jr & 31) >> 2) & 1) * 32];
+                    const uint32_t nib = (word >> ((q >> 5) * 16 + ((jr & 31) >> 3) * 4)) & 0xFu;
+                    const int bit = ((f * NP + 0) * RG + rg) * 4;
+                    mw[bit >> 5] |= nib << (bit & 31);
+                }
         } else {
 #pragma unroll
             for (int w = 0; w < MW; ++w) mw[w] = masks[((l - 1) * MW + w) * NT + tid];
@@ -324,16 +353,16 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
 #pragma unroll
         for (int f = 0; f < FT; ++f)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int j0 = fbase + f * 32 + 8 * rg + 4 * hi;
+            for (int rg = 0; rg < RG; ++rg) {
+                const int j0 = feat0(f, rg);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    const int pt = p * 32 + l31;
+                    const int pt = p * MS + lp;
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int k = j0 + i;
-                        const int bit = ((f * NP + p) * 4 + rg) * 4 + i;
+                        const int bit = ((f * NP + p) * RG + rg) * 4 + i;
                         float x = value(f, p, rg, i, k, pt);
                         if (k < prev_out) {
                             x = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? x : 0.f;
@@ -363,12 +392,12 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
 #pragma unroll
             for (int f = 0; f < FT; ++f)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int j0 = fbase + f * 32 + 8 * rg + 4 * hi;
+                for (int rg = 0; rg < RG; ++rg) {
+                    const int j0 = feat0(f, rg);
                     if (j0 >= NI) continue;
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
-                        const int pt = p * 32 + l31;
+                        const int pt = p * MS + lp;
                         if (slots[pt] < 0) continue;
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
@@ -412,7 +441,7 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
     for (int l = 0; l < n_lin; ++l) {
         MlpLayer& L = P.L[l];
         L.in_dim = in_dim[l]; L.out_dim = out_dim[l]; L.inj_n = inj_n[l]; L.inj_off = inj_off[l];
-        L.nkt_f = (in_dim[l] + 7) / 8; L.nkt_b = (out_dim[l] + 7) / 8;
+        L.nkt_f = 2 * ((in_dim[l] + 15) / 16); L.nkt_b = 2 * ((out_dim[l] + 15) / 16);     // 8-wide K tiles, padded to 16
         L.off_f = (int)off_f; L.off_b = (int)off_b;
         d->macs += (int64_t)in_dim[l] * out_dim[l];
         if (l < n_lin - 1) { off_f += (int64_t)L.nkt_f * 2 * HP; off_b += (int64_t)L.nkt_b * 2 * HP; }
@@ -487,17 +516,17 @@ extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int6
     static const int variant = getenv("SDFR_MLP_VARIANT") ? atoi(getenv("SDFR_MLP_VARIANT")) : 0;   // development A/B switch
     if (mask_ws) {
         switch (d->HP) {
-            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 2, 4, 2, 1>), dim3(grid), dim3(256), 0, s, P); break;
-            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 4, 2, 1>), dim3(grid), dim3(256), 0, s, P); break;
-            default:  hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 4, 1>), dim3(grid), dim3(512), 0, s, P); break;
+            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<32, 1, 2, 4, 2, 1>), dim3(grid), dim3(256), 0, s, P); break;
+            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<32, 2, 2, 4, 2, 1>), dim3(grid), dim3(256), 0, s, P); break;
+            default:  hipLaunchKernelGGL((sdfr_mlp_kernel<32, 2, 2, 8, 4, 1>), dim3(grid), dim3(512), 0, s, P); break;
         }
     } else {
         switch (d->HP) {
-            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 2, 4, 2, 0>), dim3(grid), dim3(256), 0, s, P); break;
-            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 4, 2, 0>), dim3(grid), dim3(256), 0, s, P); break;
+            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<32, 1, 2, 4, 2, 0>), dim3(grid), dim3(256), 0, s, P); break;
+            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<32, 2, 2, 4, 2, 0>), dim3(grid), dim3(256), 0, s, P); break;
             default:
-                if (variant == 7) hipLaunchKernelGGL((sdfr_mlp_kernel<4, 2, 4, 2, 0>), dim3(grid), dim3(256), 0, s, P);
-                else hipLaunchKernelGGL((sdfr_mlp_kernel<2, 2, 8, 4, 0>), dim3(grid), dim3(512), 0, s, P);
+                if (variant == 7) hipLaunchKernelGGL((sdfr_mlp_kernel<32, 4, 2, 4, 2, 0>), dim3(grid), dim3(256), 0, s, P);
+                else hipLaunchKernelGGL((sdfr_mlp_kernel<32, 2, 2, 8, 4, 0>), dim3(grid), dim3(512), 0, s, P);
                 break;
         }
     }
@@ -517,20 +546,27 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     MlpParams P = d->proto;
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
     P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws);
-    dim3 grid(sdfr_cdiv(cap, 32), B);
+    dim3 grid(sdfr_cdiv(cap, 32), B), grid16(sdfr_cdiv(cap, 16), B);
+    static const int jvar = getenv("SDFR_JAC_VARIANT") ? atoi(getenv("SDFR_JAC_VARIANT")) : 0;   // development A/B switch
     // masks saved by the forward launch make the recomputation unnecessary (not for use_tanh decoders: their output
     // derivative needs the pre-tanh value)
     if (mask_ws && sdf_full && !d->use_tanh) {
         switch (d->HP) {
-            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 1, 4, 2, 3>), grid, dim3(256), 0, s, P); break;
-            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 4, 2, 3>), grid, dim3(256), 0, s, P); break;
-            default:  hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 8, 4, 3>), grid, dim3(512), 0, s, P); break;
+            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<32, 1, 1, 4, 2, 3>), grid, dim3(256), 0, s, P); break;
+            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<32, 2, 1, 4, 2, 3>), grid, dim3(256), 0, s, P); break;
+            default:
+                if (jvar == 1) hipLaunchKernelGGL((sdfr_mlp_kernel<32, 2, 1, 8, 4, 3>), grid, dim3(512), 0, s, P);
+                else hipLaunchKernelGGL((sdfr_mlp_kernel<16, 4, 1, 8, 4, 3>), grid16, dim3(512), 0, s, P);
+                break;
         }
     } else {
         switch (d->HP) {
-            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<1, 1, 4, 2, 2>), grid, dim3(256), 0, s, P); break;
-            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 4, 2, 2>), grid, dim3(256), 0, s, P); break;
-            default:  hipLaunchKernelGGL((sdfr_mlp_kernel<2, 1, 8, 4, 2>), grid, dim3(512), 0, s, P); break;
+            case 128: hipLaunchKernelGGL((sdfr_mlp_kernel<32, 1, 1, 4, 2, 2>), grid, dim3(256), 0, s, P); break;
+            case 256: hipLaunchKernelGGL((sdfr_mlp_kernel<32, 2, 1, 4, 2, 2>), grid, dim3(256), 0, s, P); break;
+            default:
+                if (jvar == 1) hipLaunchKernelGGL((sdfr_mlp_kernel<32, 2, 1, 8, 4, 2>), grid, dim3(512), 0, s, P);
+                else hipLaunchKernelGGL((sdfr_mlp_kernel<16, 4, 1, 8, 4, 2>), grid16, dim3(512), 0, s, P);
+                break;
         }
     }
     SDFR_LAUNCH_CHECK();

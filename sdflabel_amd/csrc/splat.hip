@@ -269,22 +269,20 @@ __global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const SplatArgs A, c
         nu = sqrtf(nu2);
         nue = nu + FLT_EPSILON;
     }
-    // max logit
+    // one sweep with a running maximum (online softmax): max logit, softmax sums and composites (rasterer.py:119-144)
     float lmax = -FLT_MAX;
     int ncov = 0;
-    for_each([&](int k) {
-        float l;
-        if (eval(k, l)) { lmax = fmaxf(lmax, l); ++ncov; }
-    });
-    const int nunc = count - ncov;
-    if (PRIM == 1 && nunc > 0) lmax = fmaxf(lmax, 0.f);                           // uncovered surfels keep logit 0 (:70)
-    const float lbg = A.bg ? A.bg_logit[b] : 0.f;
-    if (A.bg) lmax = fmaxf(lmax, lbg);
-    // softmax sums and composites (rasterer.py:119-144)
     float cs = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dz = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    auto rescale = [&](float newmax) {
+        const float f = expf(lmax - newmax);          // exp(-inf) = 0 on the first hit
+        cs *= f; c0 *= f; c1 *= f; c2 *= f; dz *= f; n0 *= f; n1 *= f; n2 *= f;
+        lmax = newmax;
+    };
     for_each([&](int k) {
         float l;
         if (eval(k, l)) {
+            ++ncov;
+            if (l > lmax) rescale(l);
             const float e = expf(l - lmax);
             cs += e;
             c0 += e * sd[7][k]; c1 += e * sd[8][k]; c2 += e * sd[9][k];
@@ -292,6 +290,10 @@ __global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const SplatArgs A, c
             n0 += e * ((sd[3][k] + 1.f) / 2.f); n1 += e * ((sd[4][k] + 1.f) / 2.f); n2 += e * ((sd[5][k] + 1.f) / 2.f);
         }
     });
+    const int nunc = count - ncov;
+    if (PRIM == 1 && nunc > 0 && 0.f > lmax) rescale(0.f);                        // uncovered surfels keep logit 0 (:70)
+    const float lbg = A.bg ? A.bg_logit[b] : 0.f;
+    if (A.bg && lbg > lmax) rescale(lbg);
     if (!inside) return;
     const int P = W * H;
     const int pix = y * W + x;

@@ -183,3 +183,49 @@ def test_losses_vs_torch_restatement(dec):
     assert abs(float(l3) - float(ref)) < 1e-6
     assert np.abs(N(ge[0, :300]) - N(est.grad)).max() < 1e-6
     assert abs(float(gs) - float(scale.grad)) < 1e-5
+
+
+def test_batch_of_64_is_bitwise_the_single_crop(dec):
+    """BASELINE configs[2] shape (64 crops per launch): every crop of the batch equals the same crop rendered alone, bit for bit
+    (tiles of the decoder kernel never mix crops; all reductions are per crop and fixed-order)."""
+    D, H, W, B = 20, 64, 64, 64
+    rng = np.random.default_rng(64)
+    yaws = rng.uniform(-1.0, 1.0, B).astype(np.float32)
+    trans = np.stack([rng.uniform(-0.2, 0.2, B), rng.uniform(-0.15, 0.15, B), rng.uniform(2.8, 3.8, B)], 1).astype(np.float32)
+    lats = rng.standard_normal((B, 3)).astype(np.float32)
+    K = K_for(H, W)
+    big = sdflabel_amd.BatchRenderer(dec, D, K, (W, H), B, device=DEV)
+    one = sdflabel_amd.BatchRenderer(dec, D, K, (W, H), 1, device=DEV)
+    ob = big.forward(T(yaws), T(trans), T(lats))
+    gb = big.backward(g_color=torch.ones(B, 3, H, W, device=DEV), g_xyzf=torch.ones(B, big.cap, 3, device=DEV))
+    gb = [t.clone() for t in gb]
+    for b in (0, 17, 63):
+        o1 = one.forward(T(yaws[b:b + 1]), T(trans[b:b + 1]), T(lats[b:b + 1]))
+        g1 = one.backward(g_color=torch.ones(1, 3, H, W, device=DEV), g_xyzf=torch.ones(1, one.cap, 3, device=DEV))
+        for k in ("color", "mask", "depth", "normals"):
+            assert torch.equal(ob[k][b], o1[k][0]), k
+        assert torch.equal(gb[0][b], g1[0][0]) and torch.equal(gb[1][b], g1[1][0]) and torch.equal(gb[2][b], g1[2][0])
+
+
+def test_refinement_converges_from_perturbed_pose(dec):
+    """size-independent property of the whole loop: rendering the ground-truth pose and refining from a perturbed start reduces the
+    pose error (encode -> perturb -> decode round trip)."""
+    D, H, W, B = 30, 64, 64, 4
+    K = K_for(H, W)
+    gt = sdflabel_amd.BatchRenderer(dec, D, K, (W, H), 1, device=DEV)
+    o = gt.forward(T(np.array([0.6], np.float32)), T(np.array([[0.0, 0.0, 3.5]], np.float32)), T(np.array([[0.3, -0.5, 0.8]], np.float32)))
+    nf = int(o["nf"][0])
+    lidar = N(o["xyzf"][0, :nf] * 2.0)[::2]
+    rf = sdflabel_amd.BatchRefiner(dec, D, K, (H, W), B, lidar_cap=2048, device=DEV)
+    rng = np.random.default_rng(5)
+    yaw0 = (0.6 + rng.uniform(0.08, 0.15, B) * rng.choice([-1, 1], B)).astype(np.float32)
+    t0 = (np.array([[0.0, 0.0, 3.5]]) + rng.uniform(-0.04, 0.04, (B, 3))).astype(np.float32)
+    rf.set_crops({"yaw": yaw0, "trans": t0, "scale": np.full(B, 2.0, np.float32), "latent": np.tile([[0.3, -0.5, 0.8]], (B, 1))},
+                 N(o["color"]).repeat(B, 0), [lidar] * B)
+    rf.capture()
+    rf.optimize(40)
+    rows, _, _ = rf.results()
+    err0 = np.abs(yaw0 - 0.6)
+    err1 = np.abs(N(rows)[:, 0] - 0.6)
+    assert (err1 < 0.5 * err0).all(), (err0, err1)
+    assert np.abs(N(rows)[:, 1:4] - np.array([0.0, 0.0, 3.5])).max() < 0.06

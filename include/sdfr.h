@@ -69,6 +69,9 @@ int sdfr_mlp_forward(const sdfr_decoder* dec, const float* inputs, int64_t n, fl
                      uint32_t* mask_ws /* optional: sdfr_decoder_mask_words(dec, n) uint32 words; receives the ReLU masks
                                           (1 bit per hidden feature, point and layer) for a later sdfr_mlp_jacobian */,
                      void* stream);
+/* the same with float16 operands on the matrix cores (weights and hidden activations rounded to half, float32 accumulation, bias,
+ * ReLU and tanh) -- the decoder precision of the reference's default config (configs/config_refine.ini:19); inputs/outputs stay float32. */
+int sdfr_mlp_forward_f16(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream);
 /* size (in uint32 words) of the mask workspace for n rows */
 int64_t sdfr_decoder_mask_words(const sdfr_decoder* dec, int64_t n);
 
@@ -83,6 +86,7 @@ int sdfr_mlp_jacobian(const sdfr_decoder* dec, const float* inputs, int64_t rows
                       const int32_t* idx, int cap, const int32_t* cnt, float* J, float* sdf_sel,
                       const float* sdf_full /* optional: output of the sdfr_mlp_forward call over the same rows */,
                       const uint32_t* mask_ws /* optional: masks that call saved; with both, no forward recomputation */,
+                      int mask_from_f16 /* 1 if mask_ws was written by sdfr_mlp_forward_f16 */,
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------

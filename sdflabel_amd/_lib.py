@@ -20,9 +20,10 @@ _PROTOS = {
     "sdfr_decoder_destroy": (c_int, [c_void_p]),
     "sdfr_decoder_macs": (c_int64, [c_void_p]),
     "sdfr_mlp_forward": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sdfr_mlp_forward_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "sdfr_decoder_mask_words": (c_int64, [c_void_p, c_int64]),
     "sdfr_mlp_jacobian": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                  c_void_p, c_void_p]),
+                                  c_void_p, c_int, c_void_p]),
     "sdfr_band_select": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_surface_project": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -35,6 +35,7 @@ class BatchRenderer:
         if not output_nocs:
             raise NotImplementedError("BatchRenderer composites NOCS colours (the optimizer's configuration)")
         self.decoder = decoder
+        self.f16 = getattr(decoder, "mlp_precision", torch.float32) == torch.float16
         self.handle = decoder.handle(dev)
         self.L = decoder.latent_size
         self.NI = self.L + 3
@@ -92,12 +93,13 @@ class BatchRenderer:
                                  P(self.latnorm), st), "sdfr_params_forward")
         if mlp_events is not None:
             mlp_events[0].record()
-        ck(L.sdfr_mlp_forward(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.mask_ws), st), "sdfr_mlp_forward")
+        fwd = L.sdfr_mlp_forward_f16 if self.f16 else L.sdfr_mlp_forward
+        ck(fwd(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.mask_ws), st), "sdfr_mlp_forward")
         if mlp_events is not None:
             mlp_events[1].record()
         ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
         ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.idx), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.sdf),
-                               P(self.mask_ws), st), "sdfr_mlp_jacobian")
+                               P(self.mask_ws), int(self.f16), st), "sdfr_mlp_jacobian")
         xyz = self.inputs[:, self.NI - 3:]
         ck(L.sdfr_surface_project(P(xyz), self.NI, P(self.sdf), G, B, P(self.idx), cap, P(self.cnt), P(self.J), self.NI, self.NI - 3,
                                   P(self.points), P(self.nocs), P(self.normals), st), "sdfr_surface_project")

@@ -61,6 +61,7 @@ class SdfState:
         self.cap = 0
         self.sdf = None               # (G,) decoder output of the forward launch
         self.mask_ws = None           # ReLU masks saved by the forward launch (int32 words)
+        self.f16 = False              # the forward launch used float16 operands
 
 
 def mlp_jacobian(state, idx, n, use_masks=True):
@@ -73,7 +74,7 @@ def mlp_jacobian(state, idx, n, use_masks=True):
         um = use_masks and state.mask_ws is not None and state.sdf is not None
         _lib.check(L.sdfr_mlp_jacobian(state.handle.h, _lib.ptr(state.inputs), state.G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
                                        _lib.ptr(sel), _lib.ptr(state.sdf) if um else None, _lib.ptr(state.mask_ws) if um else None,
-                                       _lib.stream_ptr()), "sdfr_mlp_jacobian")
+                                       int(state.f16), _lib.stream_ptr()), "sdfr_mlp_jacobian")
     return J[:n], sel[:n]
 
 
@@ -84,8 +85,9 @@ class _DeepSDFFn(torch.autograd.Function):
         sdf = torch.empty((state.G, 1), dtype=torch.float32, device=inputs.device)
         nw = int(L.sdfr_decoder_mask_words(state.handle.h, state.G))
         state.mask_ws = torch.empty((nw,), dtype=torch.int32, device=inputs.device)
-        _lib.check(L.sdfr_mlp_forward(state.handle.h, _lib.ptr(state.inputs), state.G, _lib.ptr(sdf), _lib.ptr(state.mask_ws),
-                                      _lib.stream_ptr()), "sdfr_mlp_forward")
+        fwd = L.sdfr_mlp_forward_f16 if state.f16 else L.sdfr_mlp_forward
+        _lib.check(fwd(state.handle.h, _lib.ptr(state.inputs), state.G, _lib.ptr(sdf), _lib.ptr(state.mask_ws), _lib.stream_ptr()),
+                   "sdfr_mlp_forward")
         state.sdf = sdf.view(-1)
         ctx.state = state
         return sdf
@@ -149,6 +151,9 @@ class Decoder(nn.Module):
         self.scale_net = nn.Sequential(nn.Linear(latent_size, 3), nn.ReLU(True), nn.Linear(3, 3), nn.ReLU(True), nn.Linear(3, 1))
         self._handle = None
         self._handle_key = None
+        # arithmetic of the hidden layers: torch.float32 (exact-f32 MFMA) or torch.float16 (half operands, f32 accumulate) -- what
+        # setup_dsdf(precision=...) selects; tensors at the module boundary stay float32 either way
+        self.mlp_precision = torch.float32
 
     # -- effective weights ---------------------------------------------------------------------------------------------
     def effective_layers(self):
@@ -199,6 +204,7 @@ class Decoder(nn.Module):
         if input.dim() != 2 or input.shape[1] != self.latent_size + 3:
             raise _lib.SdfrError("decoder input must be (N, %d)" % (self.latent_size + 3))
         state = SdfState(self.handle(input.device), input.detach().contiguous())
+        state.f16 = self.mlp_precision == torch.float16
         x = _DeepSDFFn.apply(input, state)
         x._sdfr_state = state
         lat = input[:, :-3]

@@ -9,8 +9,10 @@ import torch
 def setup_dsdf(dir, mode='eval', precision=torch.float32):
     """Load `<x>.json` specs + `<x>.pt` state (keys may carry the DataParallel 'module.' prefix, workspace.py:176-180).
 
-    Returns (decoder, latent_size).  The HIP path computes in float32; `precision` other than float32 is rejected rather
-    than silently changing the arithmetic (the reference default float16 path is SURVEY.md §8 config 5, not built yet).
+    Returns (decoder, latent_size).  precision=torch.float32: exact-f32 matrix instructions (the parity path, 1e-4 against the
+    reference).  precision=torch.float16 (the reference's default config, configs/config_refine.ini:19): the hidden layers run with
+    half operands on the matrix cores, float32 accumulation; parameters and the tensors at the module boundary stay float32 (the
+    reference would hand back half tensors; ours are at least as accurate).
     """
     specs_filename = os.path.splitext(dir)[0] + '.json'
     if not os.path.isfile(specs_filename):
@@ -24,9 +26,10 @@ def setup_dsdf(dir, mode='eval', precision=torch.float32):
     saved = torch.load(dir, map_location="cpu")
     state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in saved["model_state_dict"].items()}
     decoder.load_state_dict(state)
-    if precision != torch.float32:
-        raise NotImplementedError("sdflabel_amd computes the decoder in float32 (requested %s)" % precision)
+    if precision not in (torch.float32, torch.float16):
+        raise NotImplementedError("sdflabel_amd decoders compute in float32 or float16 (requested %s)" % precision)
     decoder.to(dtype=torch.float32)
+    decoder.mlp_precision = precision
     if mode == 'train':
         decoder.train()
     else:

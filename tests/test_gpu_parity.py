@@ -559,3 +559,87 @@ def test_512_crop_batch_equals_dropin(dec):
     for got, ref in ((g[0], grads[0]), (g[1][0], grads[1]), (g[2][0], grads[2])):
         ref = N(ref)
         assert np.abs(N(got) - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())
+
+
+# ---- float16 decoder (the reference's default precision, configs/config_refine.ini:19; BASELINE configs[4]) ------------------------
+
+def _half(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def _emulate_f16_decoder(layers, spec, inp):
+    """numpy model of sdfr_mlp_forward_f16: weights and hidden activations rounded to half, float32 accumulation, bias, ReLU and the
+    last 512->1 dot in float32.  Returns sdf, and the Jacobian the float32 mask-fed backward must produce (float32 weights, the
+    ReLU masks of THIS forward)."""
+    n_lin = len(layers)
+    x = _half(inp)
+    masks = []
+    for l in range(n_lin - 1):
+        W, b, _ = layers[l]
+        if l in spec["latent_in"]:
+            x = np.concatenate([x, _half(inp)], 1)
+        y = x @ _half(W).T + b
+        masks.append(y > 0)
+        x = _half(np.maximum(y, 0))
+    W, b, _ = layers[-1]
+    o = np.tanh(x @ W.T + b)
+    g = (1 - o * o)                                   # (n,1)
+    g = g * W                                         # d/d act7  (n,512)
+    J = np.zeros_like(inp)
+    for l in range(n_lin - 2, -1, -1):
+        g = g * masks[l]
+        g = g @ layers[l][0]
+        if l in spec["latent_in"]:
+            J += g[:, -inp.shape[1]:]
+            g = g[:, :-inp.shape[1]]
+    J += g
+    return o.astype(np.float32), J.astype(np.float32)
+
+
+def test_f16_decoder_vs_half_rounding_model(oracle_layers):
+    layers, spec = oracle_layers
+    dec16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    dec16 = dec16.to(DEV)
+    rng = np.random.default_rng(16)
+    for n in (1, 127, 128, 129, 1000):
+        inp = (rng.standard_normal((n, 6)) * 0.6).astype(np.float32)
+        sdf, _ = dec16(T(inp))
+        ref, Jref = _emulate_f16_decoder(layers, spec, inp)
+        assert np.abs(N(sdf) - ref).max() < 2e-4, n              # same rounding points; only the f32 summation order differs
+    # and against the float32 decoder: half operands cost ~1e-3
+    ref32 = O.decoder_forward(layers, spec, inp)
+    assert 1e-6 < np.abs(N(sdf) - ref32).max() < 1e-2
+    # mask-fed float32 Jacobian on top of the f16 forward
+    from sdflabel_amd.deepsdf.networks.deep_sdf_decoder_scale import mlp_jacobian
+    rows = T(np.sort(rng.choice(n, 300, replace=False)).astype(np.int32))
+    J, sel = mlp_jacobian(sdf._sdfr_state, rows, 300)
+    assert torch.equal(sel, sdf.view(-1)[rows.long()])
+    Jr = Jref[N(rows)]
+    # a hidden unit whose pre-activation is within float rounding of 0 may get the other ReLU mask bit in the model (4 M units here):
+    # a handful of rows differ at the 1e-3 level, everything else agrees to rounding
+    err = np.abs(N(J) - Jr)
+    assert np.median(err) < 1e-5 and np.quantile(err, 0.98) < 5e-4 and err.max() < 2e-2
+
+
+def test_f16_decoder_end_to_end_close_to_f32(dec):
+    """the whole crop-iteration with the float16 decoder: band and images stay close to the float32 path; the differing pixels are the
+    silhouette / band-boundary ones (stated tolerance for BASELINE configs[4]: < 3 % of the pixels differ by more than 1e-2)."""
+    dec16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    dec16 = dec16.to(DEV)
+    D, H, W = 40, 128, 128
+    K = K_for(H, W)
+    yaw, trans, lat = T(np.array([0.6], np.float32)), T(np.array([[0.0, 0.0, 3.5]], np.float32)), T(np.array([[0.3, -0.5, 0.8]], np.float32))
+    outs = []
+    for d in (dec, dec16):
+        br = sdflabel_amd.BatchRenderer(d, D, K, (W, H), 1, device=DEV)
+        o = br.forward(yaw, trans, lat)
+        g = br.backward(g_color=torch.ones(1, 3, H, W, device=DEV), g_xyzf=torch.ones(1, br.cap, 3, device=DEV))
+        outs.append((int(o["n"][0]), N(o["color"][0]), N(o["mask"][0]), N(br.sdf), [N(t).copy() for t in g]))
+    n32, c32, m32, s32, g32 = outs[0]
+    n16, c16, m16, s16, g16 = outs[1]
+    assert np.abs(s16 - s32).max() < 1e-2 and np.abs(s16 - s32).mean() < 1e-3
+    assert abs(n16 - n32) < 0.1 * n32
+    assert (np.abs(c16 - c32).max(axis=0) > 1e-2).mean() < 0.03
+    assert (m16 != m32).mean() < 0.01
+    assert all(np.isfinite(g).all() for g in g16)
+    assert abs(g16[0][0] - g32[0][0]) < 0.25 * max(1.0, abs(g32[0][0]))

@@ -45,8 +45,10 @@ def test_setup_dsdf_loads_reference_format_and_folds_weight_norm():
         assert W.shape == Wr.shape
         assert np.allclose(W, Wr, atol=1e-7) and np.array_equal(b, br)
     assert dec._inject_table()[4] == (6, 0) and sum(i[0] for i in dec._inject_table()) == 6
+    dec16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    assert dec16.mlp_precision == torch.float16 and next(dec16.parameters()).dtype == torch.float32
     with pytest.raises(NotImplementedError):
-        sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+        sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.bfloat16)
 
 
 def test_no_cpu_fallback():

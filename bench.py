@@ -246,6 +246,36 @@ def main():
     except Exception as e:                                   # the headline metric must not depend on the extra measurement
         refine = {"error": repr(e)[:200]}
 
+    # the same crop-iteration with the float16 decoder (reference default precision, configs/config_refine.ini:19; BASELINE configs[4]):
+    # half operands on the matrix cores, f32 accumulate; everything else float32.  Informational -- not the headline (the 1e-4 parity
+    # claim is the float32 path's).
+    f16 = None
+    try:
+        dec16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+        dec16 = dec16.to(dev)
+        b16 = sdflabel_amd.BatchRenderer(dec16, D, K_for(H, W), (W, H), CB, device=dev)
+        b16.set_params(br.yaw, br.trans, br.latent)
+        ev16 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for _ in range(args.warmup):
+            b16.forward(); b16.backward(g_color=ones3, g_mask=ones1, g_normals=ones3, g_xyzf=onesx)
+        barrier()
+        t3 = time.perf_counter()
+        for i in range(args.steps):
+            b16.forward(mlp_events=ev16[i]); b16.backward(g_color=ones3, g_mask=ones1, g_normals=ones3, g_xyzf=onesx)
+        barrier()
+        dt16 = time.perf_counter() - t3
+        if dist is not None:
+            tt = torch.tensor([dt16], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt16 = float(tt.item())
+        m16 = float(np.mean([a.elapsed_time(b) for a, b in ev16]))
+        f16 = {"value": H * W * CB * world * args.steps / dt16, "unit": "rays/s", "ms_per_step": dt16 / args.steps * 1e3, "dtype": "f16 decoder / f32 rest",
+               "decoder_forward_ms": m16, "decoder_forward_tflops": 2.0 * macs * G * CB / (m16 * 1e-3) / 1e12, "f16_mfma_peak_tflops": 2500.0,
+               "surfels": int(b16.cnt[0]), "mask_pixels_differing_from_f32": float((b16.mask != br.mask).float().mean())}
+        del b16, dec16
+    except Exception as e:
+        f16 = {"error": repr(e)[:200]}
+
     # the same crop-iteration through the drop-in boundary (rank 0 only, informational)
     dropin = None
     if rank == 0:
@@ -285,6 +315,7 @@ def main():
                             "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": mlp_ms}
         line["dropin_api"] = dropin
         line["refine_demo"] = refine
+        line["f16_decoder"] = f16
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

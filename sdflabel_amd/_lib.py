@@ -7,7 +7,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsdfr_hip.so")
+LIB_PATH = os.environ.get("SDFR_LIB") or os.path.join(_HERE, "lib", "libsdfr_hip.so")     # SDFR_LIB: A/B builds (tools/ab_build.sh)
 
 _lib = None
 

@@ -2,18 +2,22 @@
 # Build libsdfr_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
 set -e
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="$HERE/../lib"
+OUT="${SDFR_OUT:-$HERE/../lib}"
 mkdir -p "$OUT" "$HERE/obj"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 # the MLP uses MFMA + explicit fmaf; the geometric kernels keep separate roundings like the reference's ATen ops
 $HIPCC $COMMON -c "$HERE/common.hip"  -o "$HERE/obj/common.o" &
 $HIPCC $COMMON -c "$HERE/mlp.hip"     -o "$HERE/obj/mlp.o" &
+$HIPCC $COMMON $SDFR_FWD_DEFS -c "$HERE/mlp_fwd32.hip" -o "$HERE/obj/mlp_fwd32.o" &
+$HIPCC $COMMON -c "$HERE/mlp_fwd16.hip" -o "$HERE/obj/mlp_fwd16.o" &
+$HIPCC $COMMON -c "$HERE/mlp_jac.hip"   -o "$HERE/obj/mlp_jac.o" &
+$HIPCC $COMMON -c "$HERE/mlp_small.hip" -o "$HERE/obj/mlp_small.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/surface.hip" -o "$HERE/obj/surface.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/project.hip" -o "$HERE/obj/project.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/splat.hip"   -o "$HERE/obj/splat.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/params.hip"  -o "$HERE/obj/params.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/losses.hip"  -o "$HERE/obj/losses.o" &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsdfr_hip.so" "$HERE"/obj/{common,mlp,surface,project,splat,params,losses}.o
-echo "built $OUT/libsdfr_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${SDFR_LIBNAME:-libsdfr_hip.so}" "$HERE"/obj/{common,mlp,mlp_fwd32,mlp_fwd16,mlp_jac,mlp_small,surface,project,splat,params,losses}.o
+echo "built $OUT/${SDFR_LIBNAME:-libsdfr_hip.so}"

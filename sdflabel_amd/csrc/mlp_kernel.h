@@ -1,0 +1,466 @@
+// DeepSDF decoder on MI355X (gfx950): fused multi-layer MLP forward and input-Jacobian backward.
+//
+// Replaces Decoder.forward (reference sdfrenderer/deepsdf/networks/deep_sdf_decoder_scale.py:78-107) and the
+// autograd backward of it w.r.t. its input rows (the normals hook of sdfrenderer/grid.py:55-56 and the latent
+// gradient of pipelines/optimizer.py:156).
+//
+// Design (CDNA4-first, nothing here is translated from the reference's ATen graph):
+//   * One workgroup (8 waves, two per SIMD, for the 512-wide decoder) owns a tile of PT = MS*NP grid points and carries them
+//     through EVERY layer.  Activations never leave the CU: they live in LDS as  act[k/KV][point][k%KV]  (16-byte vectors),
+//     128 KiB for 512 features x 64 points (float) or x 128 points (half).
+//   * Each layer is computed transposed,  out^T[feature][point] = W[feature][k] * act^T[k][point],  with the exact-f32 matrix
+//     instruction v_mfma_f32_32x32x2_f32 (or v_mfma_f32_32x32x16_f16 with f32 accumulation).  Wave w owns output features
+//     [w*MS*FT, (w+1)*MS*FT): FT x NP accumulator tiles.  The MFMA A operand (weights) is NOT shared between waves, so it is streamed
+//     straight from L2 into VGPRs (no LDS staging, no barrier in the K loop) from an image packed once at load time,
+//     W[k/KV][row][k%KV]: each lane's fragment is one coalesced 16-byte load.  The B operand (activations) is one conflict-free
+//     ds_read_b128 per MS points.  With the transposed product a lane's 4 consecutive accumulator registers are 4 consecutive
+//     features of ONE point, so the epilogue (bias + ReLU + latent re-injection) writes the next layer's operand with conflict-free
+//     wide LDS stores.  Only two barriers per layer.
+//   * The last linear (H -> 1) is a VALU dot product out of LDS followed by tanh.
+//   * Jacobian modes: the ReLU masks (1 bit per feature per point per layer; saved to HBM by the grid forward, or rebuilt in LDS by
+//     recomputation) are all the backward needs, because only the INPUT gradient is required (weights are frozen); the layers run
+//     backwards with the transposed weight image Wb, giving d sdf / d input-row for the selected rows only.
+#pragma once
+#include "sdfr_common.h"
+#include <math.h>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+
+struct MlpLayer {
+    int in_dim, out_dim;    // true widths (in_dim includes injected input columns)
+    int inj_n, inj_off;     // input columns concatenated BEFORE this layer
+    int kp_f, kp_b, kp_h;   // padded K extents: forward f32 (in_dim -> x16), backward f32 (out_dim -> x16), forward f16 (in_dim -> x32)
+    int off_f, off_b, off_h;// 16-byte-vector offsets of the layer's image in Wf / Wb / Wh
+};
+
+struct MlpParams {
+    const float4* Wf;       // forward image, float32:  [k/4][HP] float4
+    const float4* Wb;       // backward (transposed) image, float32
+    const void* Wh;         // forward image, float16:  [k/8][HP] 8 x half
+    int fwd_np;             // MODE 3: point tiles per workgroup of the forward launch that saved the masks (2: f32, 4: f16)
+    const float* bias;      // [n_mfma][HP]
+    const float* w_last;    // [HP] zero padded
+    float b_last;
+    int n_mfma;             // layers computed with MFMA = n_lin - 1
+    int n_inputs;
+    int use_tanh;
+    MlpLayer L[SDFR_MAX_LAYERS];
+    // forward mode
+    const float* inputs;
+    int64_t n;
+    float* sdf;
+    // jacobian mode
+    int64_t rows_per_crop;
+    const int32_t* idx;
+    const int32_t* cnt;
+    int cap;
+    float* J;
+    float* sdf_sel;
+    const float* sdf_in;    // MODE 3: decoder output of the forward launch that saved the masks
+    uint32_t* maskbuf;      // MODE 1 (write) / MODE 3 (read): ReLU masks [tile64][layer][word][thread]
+};
+
+struct sdfr_decoder {
+    int device;
+    int n_lin, n_inputs, use_tanh, HP;
+    float4* d_Wf;
+    float4* d_Wb;
+    void* d_Wh;
+    float* d_bias;
+    float* d_wlast;
+    int64_t macs;
+    MlpParams proto;
+};
+
+__device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// Matrix instruction + operand vector per element type ET and output tile MS x MS.  A lane's operand fragment is one 16-byte vector:
+//   float : 4 consecutive k; exact-f32 v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32, 4 instructions per fragment (one per component)
+//   half  : 8 consecutive k; v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16 (f32 accumulate), 1 instruction per fragment
+template <typename ET, int MS> struct Mma;
+template <> struct Mma<float, 32> {
+    typedef f32x16 acc_t; typedef float4 vec_t;
+    static constexpr int KV = 4, NSTEP = 4;
+    static __device__ __forceinline__ acc_t step(const vec_t& a, const vec_t& b, acc_t c, int ks) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(a, ks), f4c(b, ks), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float, 16> {
+    typedef f32x4 acc_t; typedef float4 vec_t;
+    static constexpr int KV = 4, NSTEP = 4;
+    static __device__ __forceinline__ acc_t step(const vec_t& a, const vec_t& b, acc_t c, int ks) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a, ks), f4c(b, ks), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<h16, 32> {
+    typedef f32x16 acc_t; typedef h16x8 vec_t;
+    static constexpr int KV = 8, NSTEP = 1;
+    static __device__ __forceinline__ acc_t step(const vec_t& a, const vec_t& b, acc_t c, int) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<h16, 16> {
+    typedef f32x4 acc_t; typedef h16x8 vec_t;
+    static constexpr int KV = 8, NSTEP = 1;
+    static __device__ __forceinline__ acc_t step(const vec_t& a, const vec_t& b, acc_t c, int) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+__device__ __forceinline__ void store4(float* dst, const float* v) { *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void store4(h16* dst, const float* v) {
+    h16x4 t; t[0] = (h16)v[0]; t[1] = (h16)v[1]; t[2] = (h16)v[2]; t[3] = (h16)v[3];
+    *reinterpret_cast<h16x4*>(dst) = t;
+}
+
+// ET   operand element type (float: exact f32; _Float16: half operands, f32 accumulate -- forward modes only)
+// MS   MFMA tile (32: forward on the grid; 16: small tiles so that a few thousand band rows fill the chip)
+// FT   feature tiles (MS rows) per wave, NP point tiles (MS points) per workgroup, NW waves per workgroup (HP = MS*FT*NW padded width)
+// PF   weight/activation fragment buffers in flight per wave (prefetch distance PF-1 K tiles)
+// MODE 0: forward.  1: forward + ReLU masks saved to HBM (1 bit per feature, point, layer).  2: Jacobian of selected rows by
+//      recomputation (forward with masks in LDS, then backward).  3: Jacobian of selected rows from the masks a MODE-1 launch saved
+//      (backward only: no activations are needed for an input gradient, only the masks and the output).
+// Lane map of one MS x MS accumulator tile: point = lane % MS, feature = (reg/4)*4*NLG + 4*(lane/MS) + reg%4 with NLG = 64/MS lane
+// groups; a lane's 4 consecutive registers are 4 consecutive features of one point.
+template <typename ET, int MS, int FT, int NP, int NW, int PF, int MODE, int PFB_ = 0>
+__global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
+    typedef Mma<ET, MS> M;
+    typedef typename M::acc_t acc_t;
+    typedef typename M::vec_t vec_t;
+    constexpr bool HALF = sizeof(ET) == 2;
+    constexpr bool JAC = MODE >= 2;
+    constexpr bool SAVE = MODE == 1;
+    constexpr bool LMASK = MODE == 2;
+    constexpr bool GMASK = MODE == 3;
+    static_assert(!SAVE || MS == 32, "mask layout assumes 32x32 forward tiles");
+    static_assert(!HALF || !JAC, "the Jacobian modes are float32");
+    constexpr int KV = M::KV;                                      // operand elements per 16-byte fragment
+    constexpr int NLG = 64 / MS;                                   // lane groups (k slots per MFMA)
+    constexpr int RG = MS / (4 * NLG);                             // register groups of 4 per accumulator (4 or 1)
+    constexpr int KT = KV * NLG;                                   // k per fragment tile
+    constexpr int NT = 64 * NW;
+    constexpr int PT = MS * NP;
+    constexpr int HP = MS * FT * NW;
+    constexpr int KG = HP / KV;                                    // 16-byte k groups of the activation tile
+    constexpr int FT32 = HP / (32 * NW);                           // feature tiles per wave of the 32x32 forward kernel (mask layout)
+    constexpr int MW = (FT * NP * RG * 4 + 31) / 32;               // mask words per thread per layer
+    constexpr int MASK_WORDS = LMASK ? (SDFR_MAX_LAYERS * MW * NT) : 1;
+    // single LDS object, carved by hand (16-byte aligned pieces first)
+    __shared__ float4 lds4[KG * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4];
+    vec_t* act = reinterpret_cast<vec_t*>(lds4);                  // [KG][PT] 16-byte vectors: act[k/KV][point][k%KV]
+    ET* act_e = reinterpret_cast<ET*>(lds4);
+    float* red = reinterpret_cast<float*>(lds4 + KG * PT);        // [NT]
+    int* rows = reinterpret_cast<int*>(lds4 + KG * PT + NT / 4);  // [PT] source row of each point (128 ints max)
+    float* gy = reinterpret_cast<float*>(lds4 + KG * PT + NT / 4 + 32);   // [PT] d out / d y_last
+    int* slots = reinterpret_cast<int*>(lds4 + KG * PT + NT / 4 + 32 + (PT + 3) / 4);   // [PT] J slot or -1
+    uint32_t* masks = reinterpret_cast<uint32_t*>(lds4 + KG * PT + NT / 4 + 32 + (PT + 3) / 4 * 2);
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int lp = lane % MS;              // point within a point tile
+    const int lg = lane / MS;              // lane group: k slot of the operands, feature sub-block of the accumulator
+    const int NI = P.n_inputs;
+
+    // ---- which rows does this tile hold ------------------------------------------------------------------
+    int n_valid;
+    if (JAC) {
+        const int b = blockIdx.y;
+        const int count = sdfr_count(P.cnt, b, P.cap);
+        const int s0 = blockIdx.x * PT;
+        if (s0 >= count) return;
+        n_valid = min(PT, count - s0);
+        if (tid < PT) {
+            const bool v = tid < n_valid;
+            const int s = v ? (s0 + tid) : s0;
+            rows[tid] = (int)(P.rows_per_crop * b) + P.idx[(int64_t)b * P.cap + s];
+            slots[tid] = v ? (b * P.cap + s) : -1;
+        }
+    } else {
+        const int64_t r0 = (int64_t)blockIdx.x * PT;
+        n_valid = (int)min((int64_t)PT, P.n - r0);
+        if (tid < PT) rows[tid] = (int)(r0 + (tid < n_valid ? tid : 0));
+    }
+    __syncthreads();
+
+    // ---- layer-0 operand: act[k][pt] = inputs[row(pt)][k], zero padded to the K tile ---------------------
+    if (!GMASK) {
+        const int k0pad = HALF ? P.L[0].kp_h : P.L[0].kp_f;
+        for (int e = tid; e < PT * k0pad; e += NT) {
+            const int pt = e / k0pad, k = e - pt * k0pad;
+            const float v = (k < NI) ? P.inputs[(int64_t)rows[pt] * NI + k] : 0.f;
+            act_e[((k / KV) * PT + pt) * KV + (k % KV)] = (ET)v;
+        }
+    }
+    __syncthreads();
+
+    const int fbase = wave * MS * FT;      // first feature row owned by this wave
+    acc_t acc[FT][NP];
+
+    // One transposed GEMM over a K extent of `kpad` (a multiple of KT): acc[f][p] += W_tile(rows fbase+f*MS..) x act.
+    // FULL: all FT feature tiles of this wave are active (straight-line MFMA stream, no branches);
+    // otherwise only the first `nact` tiles are (thin layers: the 6-wide first layer's backward, small nets).
+    auto gemm_body = [&](const vec_t* __restrict__ Wl, int kpad, int nact, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        // activation fragments come from LDS (short latency): their ring PFB may be shallower than the weights' (PF must be a multiple)
+        constexpr int PFB = PFB_ > 0 ? PFB_ : ((PF % 2 == 0) ? 2 : PF);
+        static_assert(PF % PFB == 0, "PF must be a multiple of PFB");
+        const int nkt = kpad / KT;
+        const vec_t* aptr = Wl + lg * HP + fbase + lp;
+        const vec_t* bptr = act + lg * PT + lp;
+        vec_t a[PF][FT], b[PFB][NP];
+        auto load_a = [&](int tile, vec_t* aa) {
+            const vec_t* ap = aptr + (int64_t)tile * (NLG * HP);
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+                if (FULL || f < nact) aa[f] = ap[f * MS];
+        };
+        auto load_b = [&](int tile, vec_t* bb) {
+            const vec_t* bp = bptr + tile * (NLG * PT);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) bb[p] = bp[p * MS];
+        };
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int i = 0; i < KV; ++i) a[u][f][i] = (ET)0;
+#pragma unroll
+        for (int u = 0; u < PF - 1; ++u)
+            if (u < nkt) load_a(u, a[u]);
+#pragma unroll
+        for (int u = 0; u < PFB - 1; ++u)
+            if (u < nkt) load_b(u, b[u]);
+        for (int t = 0; t < nkt; t += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (t + u < nkt) {
+                    if (t + u + PF - 1 < nkt) load_a(t + u + PF - 1, a[(u + PF - 1) % PF]);
+                    if (t + u + PFB - 1 < nkt) load_b(t + u + PFB - 1, b[(u + PFB - 1) % PFB]);
+#pragma unroll
+                    for (int ks = 0; ks < M::NSTEP; ++ks)
+#pragma unroll
+                        for (int f = 0; f < FT; ++f)
+                            if (FULL || f < nact) {
+#pragma unroll
+                                for (int p = 0; p < NP; ++p) acc[f][p] = M::step(a[u][f], b[u % PFB][p], acc[f][p], ks);
+                            }
+                }
+            }
+        }
+    };
+    auto gemm = [&](const vec_t* __restrict__ Wl, int kpad, int rows_active) {
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int r = 0; r < RG * 4; ++r) acc[f][p][r] = 0.f;
+        int nact = (rows_active - fbase + MS - 1) / MS;
+        nact = nact < 0 ? 0 : (nact > FT ? FT : nact);
+        nact = __builtin_amdgcn_readfirstlane(nact);
+        if (nact == FT) gemm_body(Wl, kpad, FT, std::true_type{});
+        else if (nact > 0) gemm_body(Wl, kpad, nact, std::false_type{});
+    };
+    // first feature of the 4-register group rg of feature tile f held by this lane
+    auto feat0 = [&](int f, int rg) { return fbase + f * MS + rg * (4 * NLG) + 4 * lg; };
+    const vec_t* Wfwd = reinterpret_cast<const vec_t*>(HALF ? (const void*)P.Wh : (const void*)P.Wf);
+
+    // ---- forward through the MFMA layers -------------------------------------------------------------------
+    for (int l = 0; !GMASK && l < P.n_mfma; ++l) {
+        const MlpLayer L = P.L[l];
+        const MlpLayer Ln = P.L[l + 1];
+        gemm(Wfwd + (HALF ? L.off_h : L.off_f), HALF ? L.kp_h : L.kp_f, L.out_dim);
+        __syncthreads();                                  // every wave is done reading act
+        uint32_t mw[MW];
+#pragma unroll
+        for (int w = 0; w < MW; ++w) mw[w] = 0u;
+        const float* bias = P.bias + l * HP;
+        const int inj_lo = L.out_dim, inj_hi = L.out_dim + Ln.inj_n;
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) {
+                const int j0 = feat0(f, rg);
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + j0);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int pt = p * MS + lp;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x = acc[f][p][rg * 4 + i] + f4c(b4, i);
+                        const bool pos = x > 0.f;
+                        v[i] = pos ? x : 0.f;
+                        if (LMASK || SAVE) {
+                            const int bit = ((f * NP + p) * RG + rg) * 4 + i;
+                            mw[bit >> 5] |= (pos ? 1u : 0u) << (bit & 31);
+                        }
+                    }
+                    if (j0 + 3 >= inj_lo && j0 < inj_hi) {    // re-inject input columns for the next layer
+                        const float* src = P.inputs + (int64_t)rows[pt] * NI + Ln.inj_off - inj_lo;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (j0 + i >= inj_lo && j0 + i < inj_hi) v[i] = src[j0 + i];
+                    }
+                    store4(act_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV), v);
+                }
+            }
+        if (LMASK) {
+#pragma unroll
+            for (int w = 0; w < MW; ++w) masks[(l * MW + w) * NT + tid] = mw[w];
+        }
+        if (SAVE && P.maskbuf) {
+            // [point tile][layer][word][thread]: bit ((f*NP + p)*4 + rg)*4 + i of the thread's mask (32x32 geometry)
+            uint32_t* dst = P.maskbuf + (((int64_t)blockIdx.x * P.n_mfma + l) * MW) * NT + tid;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) dst[w * NT] = mw[w];
+        }
+        __syncthreads();
+    }
+
+    // ---- last linear (H -> 1) + tanh -----------------------------------------------------------------------
+    if (GMASK) {
+        if (tid < PT) {
+            const float o = P.sdf_in[rows[tid]];
+            gy[tid] = 1.f - o * o;
+            if (tid < n_valid && P.sdf_sel) P.sdf_sel[slots[tid]] = o;
+        }
+    } else {
+        constexpr int SL = NT / PT;                       // k slices
+        constexpr int KGS = KG / SL;
+        const int sl = tid / PT, pt = tid - sl * PT;
+        const float* wl = P.w_last + sl * KGS * KV;
+        const vec_t* a4 = act + (sl * KGS) * PT + pt;
+        float s = 0.f;
+#pragma unroll 4
+        for (int g = 0; g < KGS; ++g) {
+            const vec_t a = a4[g * PT];
+#pragma unroll
+            for (int i = 0; i < KV; ++i) s = fmaf((float)a[i], wl[g * KV + i], s);
+        }
+        red[tid] = s;
+        __syncthreads();
+        if (tid < PT) {
+            float y = 0.f;
+#pragma unroll
+            for (int q = 0; q < SL; ++q) y += red[q * PT + tid];
+            y += P.b_last;
+            const float y1 = P.use_tanh ? tanhf(y) : y;
+            const float o = tanhf(y1);
+            if (JAC) {
+                float g = 1.f - o * o;
+                if (P.use_tanh) g *= (1.f - y1 * y1);
+                gy[tid] = g;
+                if (tid < n_valid && P.sdf_sel) P.sdf_sel[slots[tid]] = o;
+            } else {
+                if (tid < n_valid) P.sdf[(int64_t)blockIdx.x * PT + tid] = o;
+            }
+        }
+    }
+    if constexpr (JAC) {
+    __syncthreads();
+
+    // ---- backward: d out / d inputs for every point of the tile ---------------------------------------------
+    // in-gradient of layer l (features k = in-features of layer l) -> masked operand for layer l-1, or J
+    auto store_in_grad = [&](int l, auto&& value) {
+        const MlpLayer L = P.L[l];
+        const int prev_out = P.L[l - 1].out_dim;
+        const int inj_hi = prev_out + L.inj_n;
+        uint32_t mw[MW];
+        if (GMASK) {
+            // decode the forward launch's layout (32x32 tiles, P.fwd_np point tiles per workgroup): feature jr of this wave, point q of
+            // the forward tile -> bit ((jr/32 * np + q/32)*4 + (jr%32)/8)*4 + jr%4 of thread wave*64 + ((jr%32)/4 % 2)*32 + q%32
+#pragma unroll
+            for (int w = 0; w < MW; ++w) mw[w] = 0u;
+            const int np = P.fwd_np;
+            const int r = rows[lp];
+            const int tile = r / (32 * np), q = r - tile * (32 * np);
+            const int mwf = FT32 * np / 2;                                   // mask words per thread of the forward kernel
+            const uint32_t* src = P.maskbuf + (((int64_t)tile * P.n_mfma + (l - 1)) * mwf) * NT + wave * 64 + (q & 31);
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) {
+                    const int jr = f * MS + rg * (4 * NLG) + 4 * lg;
+                    const int fbit = (((jr >> 5) * np + (q >> 5)) * 4 + ((jr & 31) >> 3)) * 4;
+                    const uint32_t word = src[(fbit >> 5) * NT + (((jr & 31) >> 2) & 1) * 32];
+                    const uint32_t nib = (word >> (fbit & 31)) & 0xFu;
+                    const int bit = ((f * NP + 0) * RG + rg) * 4;
+                    mw[bit >> 5] |= nib << (bit & 31);
+                }
+        } else {
+#pragma unroll
+            for (int w = 0; w < MW; ++w) mw[w] = masks[((l - 1) * MW + w) * NT + tid];
+        }
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) {
+                const int j0 = feat0(f, rg);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int pt = p * MS + lp;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = j0 + i;
+                        const int bit = ((f * NP + p) * RG + rg) * 4 + i;
+                        float x = value(f, p, rg, i, k, pt);
+                        if (k < prev_out) {
+                            x = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? x : 0.f;
+                        } else {
+                            if (k < inj_hi && slots[pt] >= 0)
+                                atomicAdd(P.J + (int64_t)slots[pt] * NI + L.inj_off + (k - prev_out), x);
+                            x = 0.f;
+                        }
+                        v[i] = x;
+                    }
+                    store4(act_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV), v);
+                }
+            }
+    };
+
+    // top: in-gradient of the last linear = w_last[k] * gy[pt]
+    store_in_grad(P.n_mfma, [&](int, int, int, int, int k, int pt) { return P.w_last[k] * gy[pt]; });
+    __syncthreads();
+    for (int l = P.n_mfma - 1; l >= 0; --l) {
+        const MlpLayer L = P.L[l];
+        gemm(reinterpret_cast<const vec_t*>(P.Wb) + L.off_b, L.kp_b, L.in_dim);
+        __syncthreads();
+        if (l > 0) {
+            store_in_grad(l, [&](int f, int p, int rg, int i, int, int) { return acc[f][p][rg * 4 + i]; });
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) {
+                    const int j0 = feat0(f, rg);
+                    if (j0 >= NI) continue;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const int pt = p * MS + lp;
+                        if (slots[pt] < 0) continue;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (j0 + i < NI) atomicAdd(P.J + (int64_t)slots[pt] * NI + j0 + i, acc[f][p][rg * 4 + i]);
+                    }
+                }
+        }
+    }
+    }   // JAC
+}
+
+
+// launchers, one translation unit per kernel family (co-compiled instantiations of one template perturb each other's register
+// allocation and scheduling by several percent -- CDNA guide, methodology rule 19 -- so the hot kernels are compiled alone)
+void sdfr_launch_fwd_f32_512(const MlpParams& P, int grid, bool save_masks, hipStream_t s);      // mlp_fwd32.hip
+void sdfr_launch_fwd_f16_512(const MlpParams& P, int grid, bool save_masks, hipStream_t s);      // mlp_fwd16.hip
+void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s); // mlp_jac.hip
+void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)

@@ -10,7 +10,7 @@ COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 $HIPCC $COMMON -c "$HERE/common.hip"  -o "$HERE/obj/common.o" &
 $HIPCC $COMMON -c "$HERE/mlp.hip"     -o "$HERE/obj/mlp.o" &
 $HIPCC $COMMON $SDFR_FWD_DEFS -c "$HERE/mlp_fwd32.hip" -o "$HERE/obj/mlp_fwd32.o" &
-$HIPCC $COMMON -c "$HERE/mlp_fwd16.hip" -o "$HERE/obj/mlp_fwd16.o" &
+$HIPCC $COMMON $SDFR_F16_DEFS -c "$HERE/mlp_fwd16.hip" -o "$HERE/obj/mlp_fwd16.o" &
 $HIPCC $COMMON -c "$HERE/mlp_jac.hip"   -o "$HERE/obj/mlp_jac.o" &
 $HIPCC $COMMON -c "$HERE/mlp_small.hip" -o "$HERE/obj/mlp_small.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/surface.hip" -o "$HERE/obj/surface.o" &

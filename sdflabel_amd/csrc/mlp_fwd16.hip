@@ -1,6 +1,16 @@
 // Decoder forward on the grid with float16 operands (f32 accumulate), padded hidden width 512, 128-point tiles; compiled alone.
+// Geometry macros (tools/ab_build.sh A/B builds): SDFR_H_FT feature tiles per wave, SDFR_H_NW waves (FT*NW = 16), SDFR_H_PF / _PFB rings.
 #include "mlp_kernel.h"
+#ifndef SDFR_H_FT
+#define SDFR_H_FT 2
+#define SDFR_H_NW 8
+#define SDFR_H_PF 2
+#define SDFR_H_PFB 2
+#endif
 void sdfr_launch_fwd_f16_512(const MlpParams& P, int grid, bool save_masks, hipStream_t s) {
-    if (save_masks) hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 4, 8, 2, 1>), dim3(grid), dim3(512), 0, s, P);
-    else hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 4, 8, 2, 0>), dim3(grid), dim3(512), 0, s, P);
+    static_assert(SDFR_H_FT * SDFR_H_NW == 16, "padded width 512 = 32 * FT * NW");
+    if (save_masks)
+        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, SDFR_H_FT, 4, SDFR_H_NW, SDFR_H_PF, 1, SDFR_H_PFB>), dim3(grid), dim3(64 * SDFR_H_NW), 0, s, P);
+    else
+        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, SDFR_H_FT, 4, SDFR_H_NW, SDFR_H_PF, 0, SDFR_H_PFB>), dim3(grid), dim3(64 * SDFR_H_NW), 0, s, P);
 }

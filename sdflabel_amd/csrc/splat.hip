@@ -216,32 +216,37 @@ __global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const SplatArgs A, c
     const float zn = (PRIM != 0) ? A.znorm[b] : 0.f;
     const float k00 = A.K[(int64_t)b * 9];
 
-    // walk all candidates: stage 64 at a time into LDS (lane = candidate), then broadcast-read them
+    // walk all candidates: stage 64 at a time into LDS (lane = candidate), then broadcast-read them.  A tile with at most 64
+    // candidates (the common case) stages them once and keeps them resident for both sweeps.
+    bool resident = false;
     auto for_each = [&](auto&& body) {
         for (int c0 = 0; c0 < total; c0 += 64) {
             const int c = c0 + lane;
-            __syncthreads();
-            if (c < total) {
-                const int s = overflow ? c : list[c];
-                const int64_t e = (sb + s) * 3;
-                const float px = A.p_cam[e], py = A.p_cam[e + 1], pz = A.p_cam[e + 2];
-                const float nx = A.n_cam[e], ny = A.n_cam[e + 1], nz = A.n_cam[e + 2];
-                sd[2][lane] = pz;
-                sd[3][lane] = nx; sd[4][lane] = ny; sd[5][lane] = nz;
-                sd[7][lane] = A.attr[e]; sd[8][lane] = A.attr[e + 1]; sd[9][lane] = A.attr[e + 2];
-                if (PRIM == 0) {
-                    sd[0][lane] = px; sd[1][lane] = py;
-                    sd[6][lane] = nx * px + ny * py + nz * pz;                  // :202
-                } else {
-                    sd[0][lane] = A.uv[(sb + s) * 2]; sd[1][lane] = A.uv[(sb + s) * 2 + 1];
-                    sd[6][lane] = fabsf(k00 * diam / (pz + FLT_EPSILON));       // :47 / :115
-                    sd[10][lane] = depth_logit(pz, zn, C, nullptr);
+            if (!resident) {
+                __syncthreads();
+                if (c < total) {
+                    const int s = overflow ? c : list[c];
+                    const int64_t e = (sb + s) * 3;
+                    const float px = A.p_cam[e], py = A.p_cam[e + 1], pz = A.p_cam[e + 2];
+                    const float nx = A.n_cam[e], ny = A.n_cam[e + 1], nz = A.n_cam[e + 2];
+                    sd[2][lane] = pz;
+                    sd[3][lane] = nx; sd[4][lane] = ny; sd[5][lane] = nz;
+                    sd[7][lane] = A.attr[e]; sd[8][lane] = A.attr[e + 1]; sd[9][lane] = A.attr[e + 2];
+                    if (PRIM == 0) {
+                        sd[0][lane] = px; sd[1][lane] = py;
+                        sd[6][lane] = nx * px + ny * py + nz * pz;                  // :202
+                    } else {
+                        sd[0][lane] = A.uv[(sb + s) * 2]; sd[1][lane] = A.uv[(sb + s) * 2 + 1];
+                        sd[6][lane] = fabsf(k00 * diam / (pz + FLT_EPSILON));       // :47 / :115
+                        sd[10][lane] = depth_logit(pz, zn, C, nullptr);
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
             const int kn = min(64, total - c0);
             for (int k = 0; k < kn; ++k) body(k);
         }
+        resident = total <= 64;
     };
     // coverage + logit of candidate k for this lane's pixel
     float nue = 1.f;

@@ -92,12 +92,17 @@ def stream_ptr():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def require_gpu_f32(*tensors):
+def require_gpu_float(*tensors):
+    """Boundary check: GPU tensors, float32 or float16 (half tensors -- the reference's default `precision` -- are widened to float32
+    at the boundary and the results narrowed back; all kernels compute in float32 except the optional float16 decoder MFMAs)."""
     import torch
     for t in tensors:
         if t is None:
             continue
         if not t.is_cuda:
             raise SdfrError("sdflabel_amd runs on the GPU only (got a %s tensor); there is no CPU fallback" % t.device)
-        if t.dtype != torch.float32:
-            raise SdfrError("sdflabel_amd kernels are float32 (got %s)" % t.dtype)
+        if t.dtype not in (torch.float32, torch.float16):
+            raise SdfrError("sdflabel_amd accepts float32 or float16 tensors (got %s)" % t.dtype)
+
+
+require_gpu_f32 = require_gpu_float

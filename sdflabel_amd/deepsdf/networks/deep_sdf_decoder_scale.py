@@ -198,18 +198,22 @@ class Decoder(nn.Module):
 
     # input: N x (L+3)
     def forward(self, input):
-        _lib.require_gpu_f32(input)
+        _lib.require_gpu_float(input)
         if self.training and ((self.dropout is not None and self.dropout_prob > 0) or self.latent_dropout):
             raise _lib.SdfrError("the HIP decoder evaluates in eval() mode only (dropout is inactive in the renderer path)")
         if input.dim() != 2 or input.shape[1] != self.latent_size + 3:
             raise _lib.SdfrError("decoder input must be (N, %d)" % (self.latent_size + 3))
-        state = SdfState(self.handle(input.device), input.detach().contiguous())
+        in_dtype = input.dtype
+        x32 = input if in_dtype == torch.float32 else input.float()          # half tensors are widened at the boundary
+        state = SdfState(self.handle(input.device), x32.detach().contiguous())
         state.f16 = self.mlp_precision == torch.float16
-        x = _DeepSDFFn.apply(input, state)
+        x = _DeepSDFFn.apply(x32, state)
+        if in_dtype != torch.float32:
+            x = x.to(in_dtype)
         x._sdfr_state = state
-        lat = input[:, :-3]
+        lat = x32[:, :-3]
         if self.samples_per_scene:
             scale = self.scale_net(lat.view(-1, self.samples_per_scene, lat.size(1))[:, 0, :])
         else:
             scale = self.scale_net(lat[0])
-        return x, scale
+        return x, scale.to(in_dtype)

@@ -15,10 +15,13 @@ from .deepsdf.networks.deep_sdf_decoder_scale import mlp_jacobian
 
 class _SurfaceFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sdf, gridpoints, xyz_src, xyz_stride, idx, n, J, Jstride, Joff):
+    def forward(ctx, sdf, gridpoints, sdf_vals, xyz_src, xyz_stride, idx, n, J, Jstride, Joff):
+        """sdf / gridpoints carry the autograd graph (any float dtype); sdf_vals is the float32 (G,) array the kernels read."""
         L = _lib.lib()
         dev = sdf.device
         G = sdf.shape[0]
+        ctx.dtypes = (sdf.dtype, gridpoints.dtype)
+        sdf = sdf_vals
         pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
         nocs = torch.empty((n, 3), dtype=torch.float32, device=dev)
         nrm = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -45,7 +48,9 @@ class _SurfaceFn(torch.autograd.Function):
         g_nocs = None if g_nocs is None else g_nocs.contiguous().float()
         _lib.check(L.sdfr_surface_project_bwd(_lib.ptr(g_pts), _lib.ptr(g_nocs), _lib.ptr(nrm), G, 1, _lib.ptr(idx), n, None,
                                               _lib.ptr(g_sdf), _lib.ptr(g_xyz), _lib.stream_ptr()), "sdfr_surface_project_bwd")
-        return g_sdf, g_xyz, None, None, None, None, None, None, None
+        g_sdf = g_sdf.to(ctx.dtypes[0])
+        g_xyz = None if g_xyz is None else g_xyz.to(ctx.dtypes[1])
+        return g_sdf, g_xyz, None, None, None, None, None, None, None, None
 
 
 def band_select(sdf_flat, threshold, want_slot=True):
@@ -78,25 +83,32 @@ class Grid3D:
 
     def get_surface_points(self, pred_sdf_grid, threshold=0.03):
         """Zero-isosurface projection: returns projected points (N,3), NOCS (N,3), normals (N,3)."""
-        _lib.require_gpu_f32(pred_sdf_grid)
+        _lib.require_gpu_float(pred_sdf_grid)
         if pred_sdf_grid.dim() != 2 or pred_sdf_grid.shape[1] != 1 or pred_sdf_grid.shape[0] != self.points.shape[0]:
             raise _lib.SdfrError("pred_sdf_grid must be (G,1) with G = number of grid points")
-        sdf_c = pred_sdf_grid.detach().contiguous()
+        out_dtype = pred_sdf_grid.dtype
         state = getattr(pred_sdf_grid, "_sdfr_state", None)
-        idx, n, slot = band_select(sdf_c.view(-1), threshold)
-        if state is not None and state.G == self.points.shape[0]:
+        fused = state is not None and state.G == self.points.shape[0] and state.sdf is not None
+        # float32 values for the kernels: the decoder's own output when available (a half `pred_sdf_grid` is a rounded copy of it)
+        sdf_c = state.sdf if fused else pred_sdf_grid.detach().float().contiguous().view(-1)
+        idx, n, slot = band_select(sdf_c, threshold)
+
+        def narrow(ts):
+            return ts if out_dtype == torch.float32 else tuple(t.to(out_dtype) for t in ts)
+
+        if fused:
             # fused path: Jacobian of the HIP decoder at the band rows only
             J, _ = mlp_jacobian(state, idx, n)
             J = J.contiguous()
             state.idx, state.slot, state.J, state.cap = idx, slot, J, max(n, 1)
             NI = state.inputs.shape[1]
             xyz_src = state.inputs[:, NI - 3:]
-            return _SurfaceFn.apply(pred_sdf_grid, self.points, xyz_src, NI, idx, n, J, NI, NI - 3)
+            return narrow(_SurfaceFn.apply(pred_sdf_grid, self.points, sdf_c, xyz_src, NI, idx, n, J, NI, NI - 3))
         # generic path: any differentiable SDF of self.points
         (g,) = torch.autograd.grad(pred_sdf_grid.sum(), self.points, retain_graph=True, allow_unused=True)
         if g is None:
             raise _lib.SdfrError("pred_sdf_grid does not depend on this grid's points: no normals can be derived "
                                  "(the reference fails here too: its hook grid.py:20 never fires)")
-        Jn = g.detach().index_select(0, idx[:n].long()).contiguous()
-        pts_src = self.points.detach().contiguous()
-        return _SurfaceFn.apply(pred_sdf_grid, self.points, pts_src, 3, idx, n, Jn, 3, 0)
+        Jn = g.detach().float().index_select(0, idx[:n].long()).contiguous()
+        pts_src = self.points.detach().float().contiguous()
+        return narrow(_SurfaceFn.apply(pred_sdf_grid, self.points, sdf_c, pts_src, 3, idx, n, Jn, 3, 0))

@@ -162,8 +162,10 @@ class Rasterer(torch.nn.Module):
         self.register_buffer('grid', torch.from_numpy(np.stack((xx, yy), axis=-1).reshape((1, -1, 2))))
         if K is None:
             K = torch.from_numpy(calibration_matrix((self.res_x_px, self.res_y_px), diagonal_mm, focal_len_mm, skew=0))
-        if precision != torch.float32:
-            raise NotImplementedError("sdflabel_amd renders in float32 (requested %s)" % precision)
+        if precision not in (torch.float32, torch.float16):
+            raise NotImplementedError("sdflabel_amd renders for float32 or float16 callers (requested %s)" % precision)
+        # the kernels always compute in float32; `precision` only says what the caller's tensors are (half inputs are widened at the
+        # boundary, results narrowed back to the input dtype)
         K = K.detach().to(torch.float32)
         self.register_buffer('K', K.contiguous())
         # K^-1 in float32 exactly as the reference computes it on every call (primitives.py:204), once, on the host
@@ -171,7 +173,11 @@ class Rasterer(torch.nn.Module):
 
     def forward(self, coords, normals, colors, camera_matrix, rot='quat', primitives='disc', bg=None, output_mask=False,
                 output_depth=False, output_normals=False, output_nocs=False, output_points=True):
-        _lib.require_gpu_f32(coords, normals, None if output_nocs else colors)
+        _lib.require_gpu_float(coords, normals, None if output_nocs else colors)
+        out_dtype = coords.dtype
+        if out_dtype != torch.float32:
+            coords, normals = coords.float(), normals.float()
+            colors = None if (colors is None or output_nocs) else colors.float()
         if primitives not in _PRIMS:
             raise ValueError("primitives must be 'disc', 'circle' or 'circle_opt'")
         if bg is not None and (output_depth or output_normals):
@@ -202,6 +208,8 @@ class Rasterer(torch.nn.Module):
         color, mask, depth, nimg, p_cam, n_cam, col = _RasterFn.apply(
             coords, normals, colors if not output_nocs else None, pose, bg, K, Kinv, (self.res_x_px, self.res_y_px), nocs_mode,
             primitives, half_attr, bool(output_mask), bool(output_depth), bool(output_normals), want_filter, holder)
+        if out_dtype != torch.float32:
+            color, mask, depth, nimg, p_cam, col = (t.to(out_dtype) for t in (color, mask, depth, nimg, p_cam, col))
         rendering = {'color': color}
         if output_mask:
             rendering['mask'] = mask

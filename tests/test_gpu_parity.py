@@ -643,3 +643,39 @@ def test_f16_decoder_end_to_end_close_to_f32(dec):
     assert (m16 != m32).mean() < 0.01
     assert all(np.isfinite(g).all() for g in g16)
     assert abs(g16[0][0] - g32[0][0]) < 0.25 * max(1.0, abs(g32[0][0]))
+
+
+def test_half_precision_callers_are_served(dec):
+    """the reference's default config runs everything in float16 (configs/config_refine.ini:19): Grid3D(precision=half), half inputs,
+    half K and pose.  The drop-in widens at the boundary, computes in float32 (decoder MFMAs in half) and narrows the results back;
+    the rendering stays close to the float32 path and gradients reach the float32 leaf parameters."""
+    dec16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    dec16 = dec16.to(DEV)
+    D, H, W = 30, 64, 64
+    K = T(K_for(H, W))
+    res = {}
+    for prec, d in ((torch.float32, dec), (torch.float16, dec16)):
+        grid = sdflabel_amd.Grid3D(D, DEV, prec)
+        assert grid.points.dtype == prec
+        lat = torch.tensor([0.3, -0.5, 0.8], device=DEV, requires_grad=True)
+        yaw = torch.tensor([0.6], device=DEV, requires_grad=True)
+        trans = torch.tensor([0.0, 0.0, 3.5], device=DEV, requires_grad=True)
+        renderer = sdflabel_amd.Rasterer(K.to(prec), (W, H), precision=prec).to(DEV)
+        lat_ = F.normalize(lat.to(prec), p=2, dim=0)
+        inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1).to(lat_.device, lat_.dtype)
+        sdf, scale = d(inputs)
+        assert sdf.dtype == prec and scale.dtype == prec
+        pcd, nocs, nrm = grid.get_surface_points(sdf)
+        assert pcd.dtype == prec and nrm.dtype == prec
+        pose = build_pose(yaw, trans).to(prec)
+        rend, pts = renderer(pcd, nrm, nrm, pose, primitives='disc', rot='dcm', output_normals=True, output_nocs=True, output_mask=True)
+        assert rend["color"].dtype == prec and pts["xyzf"].dtype == prec
+        loss = rend["color"].float().sum() + pts["xyzf"].float().sum()
+        loss.backward()
+        res[prec] = (N(rend["color"].float()), N(rend["mask"].float()), pcd.shape[0], [N(g) for g in (yaw.grad, trans.grad, lat.grad)])
+        assert all(np.isfinite(g).all() for g in res[prec][3])
+    c32, m32, n32, g32 = res[torch.float32]
+    c16, m16, n16, g16 = res[torch.float16]
+    assert abs(n16 - n32) < 0.1 * n32
+    assert (m16 != m32).mean() < 0.02 and (np.abs(c16 - c32).max(axis=0) > 2e-2).mean() < 0.05
+    assert abs(g16[0][0] - g32[0][0]) < 0.3 * max(1.0, abs(g32[0][0]))

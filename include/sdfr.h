@@ -52,13 +52,16 @@ const char* sdfr_last_error(void);
  *   h_b[l]        HOST pointer, float32 [out_dim[l]]
  *   n_inputs      width of an input row (L+3)
  *   use_tanh      apply tanh to the last linear before the final tanh (:96-97); the final tanh (:106-107) is always applied
- * Hidden widths up to 512 are supported.  LayerNorm decoders (weight_norm=False with norm_layers) are not.
+ *   h_ln_w[l], h_ln_b[l]   HOST pointers to the nn.LayerNorm weight / bias [out_dim[l]] applied between layer l's linear and its ReLU
+ *                 (the weight_norm=False decoder variant, :56-57,:99-101), or NULL; the arrays themselves may be NULL.  LayerNorm decoders
+ *                 run in float32 without mask saving (their Jacobian recomputes the forward).
+ * Hidden widths up to 512 are supported.
  */
 typedef struct sdfr_decoder sdfr_decoder;
 
 int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_dim, const int* out_dim,
                         const int* inj_n, const int* inj_off, const float* const* h_W, const float* const* h_b,
-                        int n_inputs, int use_tanh, int device);
+                        const float* const* h_ln_w, const float* const* h_ln_b, int n_inputs, int use_tanh, int device);
 int sdfr_decoder_destroy(sdfr_decoder* dec);
 /* algorithmic multiply-accumulates per evaluated point (sum of in_dim*out_dim) */
 int64_t sdfr_decoder_macs(const sdfr_decoder* dec);

@@ -11,7 +11,8 @@
 
 extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_dim, const int* out_dim,
                                    const int* inj_n, const int* inj_off, const float* const* h_W,
-                                   const float* const* h_b, int n_inputs, int use_tanh, int device) {
+                                   const float* const* h_b, const float* const* h_ln_w, const float* const* h_ln_b, int n_inputs,
+                                   int use_tanh, int device) {
     SDFR_REQUIRE(out && in_dim && out_dim && inj_n && inj_off && h_W && h_b, "sdfr_decoder_create: NULL argument");
     SDFR_REQUIRE(n_lin >= 2 && n_lin <= SDFR_MAX_LAYERS, "sdfr_decoder_create: n_lin=%d outside [2,%d]", n_lin, SDFR_MAX_LAYERS);
     SDFR_REQUIRE(out_dim[n_lin - 1] == 1, "sdfr_decoder_create: last layer must have out_dim 1 (got %d)", out_dim[n_lin - 1]);
@@ -38,6 +39,8 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
     for (int l = 0; l < n_lin; ++l) {
         MlpLayer& L = P.L[l];
         L.in_dim = in_dim[l]; L.out_dim = out_dim[l]; L.inj_n = inj_n[l]; L.inj_off = inj_off[l];
+        L.ln = (l < n_lin - 1 && h_ln_w && h_ln_w[l] != nullptr) ? 1 : 0;
+        if (L.ln) { SDFR_REQUIRE(h_ln_b && h_ln_b[l], "sdfr_decoder_create: LayerNorm weight without bias at layer %d", l); d->has_ln = 1; }
         L.kp_f = 16 * ((in_dim[l] + 15) / 16); L.kp_b = 16 * ((out_dim[l] + 15) / 16); L.kp_h = 32 * ((in_dim[l] + 31) / 32);
         L.off_f = (int)off_f; L.off_b = (int)off_b; L.off_h = (int)off_h;
         d->macs += (int64_t)in_dim[l] * out_dim[l];
@@ -63,6 +66,17 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
 
     SDFR_HIP_CHECK(hipMalloc(&d->d_Wf, Wf.size() * sizeof(float)));
     SDFR_HIP_CHECK(hipMalloc(&d->d_Wb, Wb.size() * sizeof(float)));
+    if (d->has_ln) {
+        std::vector<float> lg((size_t)(n_lin - 1) * HP, 0.f), lb((size_t)(n_lin - 1) * HP, 0.f);
+        for (int l = 0; l < n_lin - 1; ++l)
+            if (P.L[l].ln)
+                for (int r = 0; r < P.L[l].out_dim; ++r) { lg[(size_t)l * HP + r] = h_ln_w[l][r]; lb[(size_t)l * HP + r] = h_ln_b[l][r]; }
+        SDFR_HIP_CHECK(hipMalloc(&d->d_lng, lg.size() * sizeof(float)));
+        SDFR_HIP_CHECK(hipMalloc(&d->d_lnb, lb.size() * sizeof(float)));
+        SDFR_HIP_CHECK(hipMemcpy(d->d_lng, lg.data(), lg.size() * sizeof(float), hipMemcpyHostToDevice));
+        SDFR_HIP_CHECK(hipMemcpy(d->d_lnb, lb.data(), lb.size() * sizeof(float), hipMemcpyHostToDevice));
+        P.ln_gamma = d->d_lng; P.ln_beta = d->d_lnb;
+    }
     SDFR_HIP_CHECK(hipMalloc(&d->d_Wh, Wh.size() * sizeof(_Float16)));
     SDFR_HIP_CHECK(hipMemcpy(d->d_Wh, Wh.data(), Wh.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     SDFR_HIP_CHECK(hipMalloc(&d->d_bias, bias.size() * sizeof(float)));
@@ -79,6 +93,7 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
 extern "C" int sdfr_decoder_destroy(sdfr_decoder* d) {
     if (!d) return SDFR_OK;
     hipFree(d->d_Wf); hipFree(d->d_Wb); hipFree(d->d_Wh); hipFree(d->d_bias); hipFree(d->d_wlast);
+    hipFree(d->d_lng); hipFree(d->d_lnb); hipFree(d->ln_ws);
     delete d;
     return SDFR_OK;
 }
@@ -107,7 +122,8 @@ extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int6
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws;
     const int grid = sdfr_cdiv(n, 64);
-    if (d->HP == 512) sdfr_launch_fwd_f32_512(P, grid, mask_ws != nullptr, (hipStream_t)stream);
+    if (d->has_ln) sdfr_launch_ln(P, d->HP, false, grid, 1, (hipStream_t)stream);        // LayerNorm decoders: no mask saving
+    else if (d->HP == 512) sdfr_launch_fwd_f32_512(P, grid, mask_ws != nullptr, (hipStream_t)stream);
     else sdfr_launch_small(P, d->HP, mask_ws ? 1 : 0, grid, 1, (hipStream_t)stream);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
@@ -118,6 +134,7 @@ extern "C" int sdfr_mlp_forward_f16(const sdfr_decoder* d, const float* inputs, 
     SDFR_REQUIRE(d && inputs && sdf, "sdfr_mlp_forward_f16: NULL argument");
     SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward_f16: n=%lld out of range", (long long)n);
     SDFR_REQUIRE(d->HP == 512, "sdfr_mlp_forward_f16: built for hidden widths 257..512 (padded width %d)", d->HP);
+    SDFR_REQUIRE(!d->has_ln, "sdfr_mlp_forward_f16: LayerNorm decoders run in float32");
     if (n == 0) return SDFR_OK;
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws;
@@ -140,8 +157,22 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.fwd_np = mask_from_f16 ? 4 : 2;
     // masks saved by the forward launch make the recomputation unnecessary (not for use_tanh decoders: their output
     // derivative needs the pre-tanh value)
-    const bool from_masks = mask_ws && sdf_full && !d->use_tanh;
-    if (d->HP == 512) sdfr_launch_jac_f32_512(P, cap, B, from_masks, s);
+    const bool from_masks = mask_ws && sdf_full && !d->use_tanh && !d->has_ln;
+    if (d->has_ln) {
+        // recomputing Jacobian; the normalised pre-activations of every layer are spilled to a scratch owned by the decoder handle
+        const int pt = sdfr_ln_points_per_wg(d->HP, true);
+        const int gx = sdfr_cdiv(cap, pt);
+        const size_t need = (size_t)gx * B * (d->n_lin - 1) * d->HP * pt * sizeof(float);
+        if (need > d->ln_ws_bytes) {
+            SDFR_HIP_CHECK(hipStreamSynchronize(s));
+            if (d->ln_ws) SDFR_HIP_CHECK(hipFree(d->ln_ws));
+            d->ln_ws = nullptr; d->ln_ws_bytes = 0;
+            SDFR_HIP_CHECK(hipMalloc(&d->ln_ws, need));
+            d->ln_ws_bytes = need;
+        }
+        P.ln_ws = d->ln_ws;
+        sdfr_launch_ln(P, d->HP, true, gx, B, s);
+    } else if (d->HP == 512) sdfr_launch_jac_f32_512(P, cap, B, from_masks, s);
     else sdfr_launch_small(P, d->HP, from_masks ? 3 : 2, sdfr_cdiv(cap, 32), B, s);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;

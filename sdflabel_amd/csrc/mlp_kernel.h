@@ -36,6 +36,7 @@ struct MlpLayer {
     int inj_n, inj_off;     // input columns concatenated BEFORE this layer
     int kp_f, kp_b, kp_h;   // padded K extents: forward f32 (in_dim -> x16), backward f32 (out_dim -> x16), forward f16 (in_dim -> x32)
     int off_f, off_b, off_h;// 16-byte-vector offsets of the layer's image in Wf / Wb / Wh
+    int ln;                 // LayerNorm (eps 1e-5, affine) between this layer's linear and its ReLU (deep_sdf_decoder_scale.py:56-57,99-101)
 };
 
 struct MlpParams {
@@ -44,6 +45,9 @@ struct MlpParams {
     const void* Wh;         // forward image, float16:  [k/8][HP] 8 x half
     int fwd_np;             // MODE 3: point tiles per workgroup of the forward launch that saved the masks (2: f32, 4: f16)
     const float* bias;      // [n_mfma][HP]
+    const float* ln_gamma;  // [n_mfma][HP] LayerNorm weight / bias (LN decoders only)
+    const float* ln_beta;
+    float4* ln_ws;          // LN Jacobian scratch: normalised pre-activations [workgroup][layer][HP/4][PT] float4
     const float* w_last;    // [HP] zero padded
     float b_last;
     int n_mfma;             // layers computed with MFMA = n_lin - 1
@@ -71,6 +75,11 @@ struct sdfr_decoder {
     float4* d_Wf;
     float4* d_Wb;
     void* d_Wh;
+    float* d_lng;           // LayerNorm weight / bias images [n_mfma][HP] (NULL without LN)
+    float* d_lnb;
+    int has_ln;
+    mutable float4* ln_ws;  // Jacobian scratch of LN decoders, grown on demand
+    mutable size_t ln_ws_bytes;
     float* d_bias;
     float* d_wlast;
     int64_t macs;
@@ -126,7 +135,8 @@ __device__ __forceinline__ void store4(h16* dst, const float* v) {
 //      (backward only: no activations are needed for an input gradient, only the masks and the output).
 // Lane map of one MS x MS accumulator tile: point = lane % MS, feature = (reg/4)*4*NLG + 4*(lane/MS) + reg%4 with NLG = 64/MS lane
 // groups; a lane's 4 consecutive registers are 4 consecutive features of one point.
-template <typename ET, int MS, int FT, int NP, int NW, int PF, int MODE, int PFB_ = 0>
+// LN   decoder variant with LayerNorm after the hidden linears (weight_norm=False, norm_layers): forward and recomputing Jacobian only
+template <typename ET, int MS, int FT, int NP, int NW, int PF, int MODE, int PFB_ = 0, bool LN = false>
 __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     typedef Mma<ET, MS> M;
     typedef typename M::acc_t acc_t;
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     constexpr bool GMASK = MODE == 3;
     static_assert(!SAVE || MS == 32, "mask layout assumes 32x32 forward tiles");
     static_assert(!HALF || !JAC, "the Jacobian modes are float32");
+    static_assert(!LN || (!HALF && MODE != 1 && MODE != 3), "LayerNorm decoders: float32 forward (MODE 0) and recomputing Jacobian (MODE 2)");
     constexpr int KV = M::KV;                                      // operand elements per 16-byte fragment
     constexpr int NLG = 64 / MS;                                   // lane groups (k slots per MFMA)
     constexpr int RG = MS / (4 * NLG);                             // register groups of 4 per accumulator (4 or 1)
@@ -150,7 +161,8 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     constexpr int MW = (FT * NP * RG * 4 + 31) / 32;               // mask words per thread per layer
     constexpr int MASK_WORDS = LMASK ? (SDFR_MAX_LAYERS * MW * NT) : 1;
     // single LDS object, carved by hand (16-byte aligned pieces first)
-    __shared__ float4 lds4[KG * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4];
+    constexpr int LN_F4 = LN ? (NW * PT + SDFR_MAX_LAYERS * PT + 3) / 4 : 0;   // cross-wave partial sums + rstd per layer
+    __shared__ float4 lds4[KG * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4 + LN_F4];
     vec_t* act = reinterpret_cast<vec_t*>(lds4);                  // [KG][PT] 16-byte vectors: act[k/KV][point][k%KV]
     ET* act_e = reinterpret_cast<ET*>(lds4);
     float* red = reinterpret_cast<float*>(lds4 + KG * PT);        // [NT]
@@ -158,6 +170,8 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     float* gy = reinterpret_cast<float*>(lds4 + KG * PT + NT / 4 + 32);   // [PT] d out / d y_last
     int* slots = reinterpret_cast<int*>(lds4 + KG * PT + NT / 4 + 32 + (PT + 3) / 4);   // [PT] J slot or -1
     uint32_t* masks = reinterpret_cast<uint32_t*>(lds4 + KG * PT + NT / 4 + 32 + (PT + 3) / 4 * 2);
+    float* lnred = reinterpret_cast<float*>(lds4 + KG * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4);   // [NW][PT]
+    float* lnrstd = lnred + NW * PT;                                                                                   // [layers][PT]
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -271,6 +285,84 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     auto feat0 = [&](int f, int rg) { return fbase + f * MS + rg * (4 * NLG) + 4 * lg; };
     const vec_t* Wfwd = reinterpret_cast<const vec_t*>(HALF ? (const void*)P.Wh : (const void*)P.Wf);
 
+    // ---- LayerNorm helpers (LN decoders only) ------------------------------------------------------------------
+    // sum over ALL features of a per-thread partial, per point of the tile: lane groups by shuffle, waves through LDS
+    auto point_sums = [&](float* v) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float x = v[p];
+            for (int o = MS; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+            if (lg == 0) lnred[wave * PT + p * MS + lp] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += lnred[w * PT + p * MS + lp];
+            v[p] = t;
+        }
+        __syncthreads();
+    };
+    const int64_t wg_lin = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    // acc (linear output without bias) -> gamma * x_hat + beta ; JAC: x_hat and rstd are kept for the backward
+    auto ln_forward = [&](int l, int n_out) {
+        const float* bias = P.bias + l * HP;
+        const float* gam = P.ln_gamma + l * HP;
+        const float* bet = P.ln_beta + l * HP;
+        float s1[NP], mu[NP], rs[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s1[p] = 0.f;
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int r = 0; r < RG * 4; ++r) {
+                const int j = feat0(f, r >> 2) + (r & 3);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float x = (j < n_out) ? acc[f][p][r] + bias[j] : 0.f;
+                    acc[f][p][r] = x;
+                    s1[p] += x;
+                }
+            }
+        point_sums(s1);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { mu[p] = s1[p] / (float)n_out; s1[p] = 0.f; }
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int r = 0; r < RG * 4; ++r) {
+                const int j = feat0(f, r >> 2) + (r & 3);
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    if (j < n_out) { const float d = acc[f][p][r] - mu[p]; s1[p] += d * d; }
+            }
+        point_sums(s1);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) rs[p] = 1.f / sqrtf(s1[p] / (float)n_out + 1e-5f);
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) {
+                const int j0 = feat0(f, rg);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    float xh[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = j0 + i;
+                        xh[i] = (j < n_out) ? (acc[f][p][rg * 4 + i] - mu[p]) * rs[p] : 0.f;
+                        acc[f][p][rg * 4 + i] = (j < n_out) ? xh[i] * gam[j] + bet[j] : 0.f;
+                    }
+                    if (JAC) P.ln_ws[((wg_lin * P.n_mfma + l) * (HP / 4) + (j0 >> 2)) * PT + p * MS + lp] = make_float4(xh[0], xh[1], xh[2], xh[3]);
+                }
+            }
+        if (JAC && lg == 0 && wave == 0) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) lnrstd[l * PT + p * MS + lp] = rs[p];
+        }
+    };
+
     // ---- forward through the MFMA layers -------------------------------------------------------------------
     for (int l = 0; !GMASK && l < P.n_mfma; ++l) {
         const MlpLayer L = P.L[l];
@@ -282,12 +374,17 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
         for (int w = 0; w < MW; ++w) mw[w] = 0u;
         const float* bias = P.bias + l * HP;
         const int inj_lo = L.out_dim, inj_hi = L.out_dim + Ln.inj_n;
+        bool lnl = false;
+        if constexpr (LN) {
+            lnl = L.ln != 0;
+            if (lnl) ln_forward(l, L.out_dim);          // acc already holds gamma * x_hat + beta (bias included)
+        }
 #pragma unroll
         for (int f = 0; f < FT; ++f)
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
                 const int j0 = feat0(f, rg);
-                const float4 b4 = *reinterpret_cast<const float4*>(bias + j0);
+                const float4 b4 = lnl ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(bias + j0);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const int pt = p * MS + lp;
@@ -398,6 +495,7 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
 #pragma unroll
             for (int w = 0; w < MW; ++w) mw[w] = masks[((l - 1) * MW + w) * NT + tid];
         }
+        // 1) ReLU mask of layer l-1 (its output features), re-injected input columns -> J
 #pragma unroll
         for (int f = 0; f < FT; ++f)
 #pragma unroll
@@ -406,7 +504,6 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const int pt = p * MS + lp;
-                    float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int k = j0 + i;
@@ -419,9 +516,67 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
                                 atomicAdd(P.J + (int64_t)slots[pt] * NI + L.inj_off + (k - prev_out), x);
                             x = 0.f;
                         }
-                        v[i] = x;
+                        acc[f][p][rg * 4 + i] = x;
                     }
-                    store4(act_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV), v);
+                }
+            }
+        // 2) LayerNorm backward of layer l-1:  g_x = rstd * (g*gamma - mean(g*gamma) - x_hat * mean(g*gamma*x_hat))
+        if constexpr (LN) {
+            if (P.L[l - 1].ln) {
+                const float* gam = P.ln_gamma + (l - 1) * HP;
+                const float4* xh4 = P.ln_ws + ((wg_lin * P.n_mfma + (l - 1)) * (HP / 4)) * PT;
+                float s1[NP], s2[NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { s1[p] = 0.f; s2[p] = 0.f; }
+#pragma unroll
+                for (int f = 0; f < FT; ++f)
+#pragma unroll
+                    for (int rg = 0; rg < RG; ++rg) {
+                        const int j0 = feat0(f, rg);
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const float4 xh = xh4[(j0 >> 2) * PT + p * MS + lp];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int k = j0 + i;
+                                const float gh = (k < prev_out) ? acc[f][p][rg * 4 + i] * gam[k] : 0.f;
+                                acc[f][p][rg * 4 + i] = gh;
+                                s1[p] += gh;
+                                s2[p] += gh * f4c(xh, i);
+                            }
+                        }
+                    }
+                point_sums(s1);
+                point_sums(s2);
+#pragma unroll
+                for (int f = 0; f < FT; ++f)
+#pragma unroll
+                    for (int rg = 0; rg < RG; ++rg) {
+                        const int j0 = feat0(f, rg);
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const float4 xh = xh4[(j0 >> 2) * PT + p * MS + lp];
+                            const float rs = lnrstd[(l - 1) * PT + p * MS + lp];
+                            const float m1 = s1[p] / (float)prev_out, m2 = s2[p] / (float)prev_out;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                acc[f][p][rg * 4 + i] = (j0 + i < prev_out) ? rs * (acc[f][p][rg * 4 + i] - m1 - f4c(xh, i) * m2) : 0.f;
+                        }
+                    }
+            }
+        }
+        // 3) operand of the next (previous layer's) transposed product
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) {
+                const int j0 = feat0(f, rg);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[f][p][rg * 4 + i];
+                    store4(act_e + ((j0 / KV) * PT + p * MS + lp) * KV + (j0 % KV), v);
                 }
             }
     };
@@ -464,3 +619,5 @@ void sdfr_launch_fwd_f32_512(const MlpParams& P, int grid, bool save_masks, hipS
 void sdfr_launch_fwd_f16_512(const MlpParams& P, int grid, bool save_masks, hipStream_t s);      // mlp_fwd16.hip
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s); // mlp_jac.hip
 void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)
+void sdfr_launch_ln(const MlpParams& P, int HP, bool jac, int grid_x, int grid_y, hipStream_t s);        // mlp_ln.hip (LayerNorm decoders)
+int sdfr_ln_points_per_wg(int HP, bool jac);

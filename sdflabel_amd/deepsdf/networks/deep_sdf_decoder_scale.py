@@ -20,7 +20,7 @@ from ... import _lib
 class _DecoderHandle:
     """Owns the packed device image of the effective weights (sdfr_decoder)."""
 
-    def __init__(self, layers, n_inputs, inj, use_tanh, device_index):
+    def __init__(self, layers, n_inputs, inj, use_tanh, device_index, ln=None):
         n = len(layers)
         in_dim = (ctypes.c_int * n)(*[int(W.shape[1]) for W, _ in layers])
         out_dim = (ctypes.c_int * n)(*[int(W.shape[0]) for W, _ in layers])
@@ -29,10 +29,15 @@ class _DecoderHandle:
         self._keep = [(np.ascontiguousarray(W, np.float32), np.ascontiguousarray(b, np.float32)) for W, b in layers]
         Wp = (ctypes.c_void_p * n)(*[w.ctypes.data for w, _ in self._keep])
         bp = (ctypes.c_void_p * n)(*[b.ctypes.data for _, b in self._keep])
+        ln = ln or [None] * n
+        self._keep_ln = [None if p is None else (np.ascontiguousarray(p[0], np.float32), np.ascontiguousarray(p[1], np.float32)) for p in ln]
+        lw = (ctypes.c_void_p * n)(*[None if p is None else p[0].ctypes.data for p in self._keep_ln])
+        lb = (ctypes.c_void_p * n)(*[None if p is None else p[1].ctypes.data for p in self._keep_ln])
         h = ctypes.c_void_p()
         L = _lib.lib()
-        _lib.check(L.sdfr_decoder_create(ctypes.byref(h), n, in_dim, out_dim, inj_n, inj_off, Wp, bp, n_inputs, int(use_tanh),
+        _lib.check(L.sdfr_decoder_create(ctypes.byref(h), n, in_dim, out_dim, inj_n, inj_off, Wp, bp, lw, lb, n_inputs, int(use_tanh),
                                          device_index), "sdfr_decoder_create")
+        self.has_ln = any(p is not None for p in ln)
         self.h = h
         self.n_inputs = n_inputs
         self.macs = int(L.sdfr_decoder_macs(h))
@@ -83,8 +88,9 @@ class _DeepSDFFn(torch.autograd.Function):
     def forward(ctx, inputs, state):
         L = _lib.lib()
         sdf = torch.empty((state.G, 1), dtype=torch.float32, device=inputs.device)
-        nw = int(L.sdfr_decoder_mask_words(state.handle.h, state.G))
-        state.mask_ws = torch.empty((nw,), dtype=torch.int32, device=inputs.device)
+        if not state.handle.has_ln:
+            nw = int(L.sdfr_decoder_mask_words(state.handle.h, state.G))
+            state.mask_ws = torch.empty((nw,), dtype=torch.int32, device=inputs.device)
         fwd = L.sdfr_mlp_forward_f16 if state.f16 else L.sdfr_mlp_forward
         _lib.check(fwd(state.handle.h, _lib.ptr(state.inputs), state.G, _lib.ptr(sdf), _lib.ptr(state.mask_ws), _lib.stream_ptr()),
                    "sdfr_mlp_forward")
@@ -188,11 +194,12 @@ class Decoder(nn.Module):
     def handle(self, device):
         key = self._param_key(device)
         if self._handle is None or self._handle_key != key:
+            ln = []
             for l in range(self.num_layers - 1):
-                if hasattr(self, "bn" + str(l)):
-                    raise _lib.SdfrError("LayerNorm decoders (weight_norm=False with norm_layers) are not supported by the HIP path")
+                bn = getattr(self, "bn" + str(l), None)
+                ln.append(None if bn is None else (bn.weight.detach().float().cpu().numpy(), bn.bias.detach().float().cpu().numpy()))
             self._handle = _DecoderHandle(self.effective_layers(), self.latent_size + 3, self._inject_table(), self.use_tanh,
-                                          device.index if device.index is not None else torch.cuda.current_device())
+                                          device.index if device.index is not None else torch.cuda.current_device(), ln)
             self._handle_key = key
         return self._handle
 
@@ -206,7 +213,7 @@ class Decoder(nn.Module):
         in_dtype = input.dtype
         x32 = input if in_dtype == torch.float32 else input.float()          # half tensors are widened at the boundary
         state = SdfState(self.handle(input.device), x32.detach().contiguous())
-        state.f16 = self.mlp_precision == torch.float16
+        state.f16 = self.mlp_precision == torch.float16 and not state.handle.has_ln     # LayerNorm decoders compute in float32
         x = _DeepSDFFn.apply(x32, state)
         if in_dtype != torch.float32:
             x = x.to(in_dtype)

@@ -88,6 +88,8 @@ def test_mlp_backward_golden_fitted(dec):
 
 
 @pytest.mark.parametrize("tag,kw", [
+    ("ln", dict(latent_size=3, dims=[64] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
+                weight_norm=False)),
     ("wn", dict(latent_size=3, dims=[64] * 8, dropout=list(range(8)), dropout_prob=0.2, norm_layers=list(range(8)), latent_in=[4],
                 weight_norm=True)),
     ("x", dict(latent_size=5, dims=[48] * 5, dropout=None, norm_layers=(), latent_in=[2, 4], weight_norm=False, xyz_in_all=True,
@@ -107,10 +109,38 @@ def test_mlp_small_specs_golden(tag, kw):
     assert np.abs(N(inp.grad) - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
-def test_layernorm_decoder_rejected():
-    d = sdflabel_amd.Decoder(3, dims=[64] * 8, norm_layers=list(range(8)), latent_in=[4], weight_norm=False).to(DEV).eval()
-    with pytest.raises(_lib.SdfrError):
-        d(torch.zeros(4, 6, device=DEV))
+@pytest.mark.parametrize("width", [200, 512])
+def test_layernorm_decoder_wide_vs_oracle(width):
+    """the LayerNorm variant (weight_norm=False, deep_sdf_decoder_scale.py:56-57,99-101) at the other padded widths: forward and
+    input Jacobian against the oracle, then through Grid3D.get_surface_points (recomputing Jacobian with the x_hat scratch)."""
+    torch.manual_seed(width)
+    d = sdflabel_amd.Decoder(3, dims=[width] * 4, norm_layers=[0, 1, 2, 3], latent_in=[2], weight_norm=False)
+    with torch.no_grad():
+        for p in d.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    d = d.to(DEV).eval()
+    st = {k: v.detach().cpu().numpy() for k, v in d.state_dict().items()}
+    spec = dict(dims=[width] * 4, latent_in=[2])
+    layers = O.decoder_layers_from_state(st, spec)
+    rng = np.random.default_rng(width)
+    inp = (rng.standard_normal((333, 6)) * 0.7).astype(np.float32)
+    x = T(inp).requires_grad_(True)
+    sdf, _ = d(x)
+    ref, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+    assert np.abs(N(sdf) - ref).max() < 1e-5
+    g_out = rng.standard_normal(ref.shape).astype(np.float32)
+    (sdf * T(g_out)).sum().backward()
+    gref = O.decoder_backward_inputs(layers, spec, inp, cache, g_out)
+    assert np.abs(N(x.grad) - gref).max() < 5e-5 * max(1.0, np.abs(gref).max())
+    grid = sdflabel_amd.Grid3D(8, DEV)
+    lat = torch.tensor([0.2, -0.1, 0.4], device=DEV)
+    inputs = torch.cat([lat.expand(512, -1), grid.points], 1)
+    s2, _ = d(inputs)
+    pts, _, nrm = grid.get_surface_points(s2, threshold=10.0)
+    r2, c2 = O.decoder_forward(layers, spec, N(inputs), want_cache=True)
+    J = O.decoder_backward_inputs(layers, spec, N(inputs), c2, np.ones_like(r2))
+    pm, _, nm, _, _ = O.get_surface_points(N(grid.points), r2, J[:, 3:], 10.0)
+    assert pts.shape[0] == 512 and np.abs(N(pts) - pm).max() < 1e-4 and np.abs(N(nrm) - nm).max() < 1e-3
 
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])

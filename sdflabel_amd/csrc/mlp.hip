@@ -123,7 +123,7 @@ extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int6
     P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws;
     const int grid = sdfr_cdiv(n, 64);
     if (d->has_ln) sdfr_launch_ln(P, d->HP, false, grid, 1, (hipStream_t)stream);        // LayerNorm decoders: no mask saving
-    else if (d->HP == 512) sdfr_launch_fwd_f32_512(P, grid, mask_ws != nullptr, (hipStream_t)stream);
+    else if (d->HP == 512) sdfr_launch_fwd_f32_512(P, n, mask_ws != nullptr, (hipStream_t)stream);
     else sdfr_launch_small(P, d->HP, mask_ws ? 1 : 0, grid, 1, (hipStream_t)stream);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
@@ -154,7 +154,7 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     SDFR_HIP_CHECK(hipMemsetAsync(J, 0, (size_t)B * cap * d->n_inputs * sizeof(float), s));
     MlpParams P = d->proto;
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
-    P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.fwd_np = mask_from_f16 ? 4 : 2;
+    P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.fwd_np = mask_from_f16 ? 4 : (d->HP == 512 ? sdfr_fwd_f32_512_np() : 2);
     // masks saved by the forward launch make the recomputation unnecessary (not for use_tanh decoders: their output
     // derivative needs the pre-tanh value)
     const bool from_masks = mask_ws && sdf_full && !d->use_tanh && !d->has_ln;

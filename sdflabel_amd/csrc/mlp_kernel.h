@@ -136,8 +136,11 @@ __device__ __forceinline__ void store4(h16* dst, const float* v) {
 // Lane map of one MS x MS accumulator tile: point = lane % MS, feature = (reg/4)*4*NLG + 4*(lane/MS) + reg%4 with NLG = 64/MS lane
 // groups; a lane's 4 consecutive registers are 4 consecutive features of one point.
 // LN   decoder variant with LayerNorm after the hidden linears (weight_norm=False, norm_layers): forward and recomputing Jacobian only
+#ifndef SDFR_MLP_WPE
+#define SDFR_MLP_WPE 1      // minimum waves per SIMD the register allocation must allow (A/B builds: 2 = two 4-wave workgroups per CU)
+#endif
 template <typename ET, int MS, int FT, int NP, int NW, int PF, int MODE, int PFB_ = 0, bool LN = false>
-__global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
+__global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const MlpParams P) {
     typedef Mma<ET, MS> M;
     typedef typename M::acc_t acc_t;
     typedef typename M::vec_t vec_t;
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
     constexpr bool LMASK = MODE == 2;
     constexpr bool GMASK = MODE == 3;
     static_assert(!SAVE || MS == 32, "mask layout assumes 32x32 forward tiles");
+    static_assert(!SAVE || (FT * NP) % 2 == 0, "mask words: FT*NP*16 bits per thread and layer must fill whole words");
     static_assert(!HALF || !JAC, "the Jacobian modes are float32");
     static_assert(!LN || (!HALF && MODE != 1 && MODE != 3), "LayerNorm decoders: float32 forward (MODE 0) and recomputing Jacobian (MODE 2)");
     constexpr int KV = M::KV;                                      // operand elements per 16-byte fragment
@@ -615,7 +619,8 @@ __global__ __launch_bounds__(64 * NW) void sdfr_mlp_kernel(const MlpParams P) {
 
 // launchers, one translation unit per kernel family (co-compiled instantiations of one template perturb each other's register
 // allocation and scheduling by several percent -- CDNA guide, methodology rule 19 -- so the hot kernels are compiled alone)
-void sdfr_launch_fwd_f32_512(const MlpParams& P, int grid, bool save_masks, hipStream_t s);      // mlp_fwd32.hip
+void sdfr_launch_fwd_f32_512(const MlpParams& P, int64_t n, bool save_masks, hipStream_t s);    // mlp_fwd32.hip
+int sdfr_fwd_f32_512_np();                                                                        // its point tiles per workgroup
 void sdfr_launch_fwd_f16_512(const MlpParams& P, int grid, bool save_masks, hipStream_t s);      // mlp_fwd16.hip
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s); // mlp_jac.hip
 void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)

@@ -79,3 +79,48 @@ def test_qrot_matrix_matches_qrot():
     v = torch.randn(7, 3)
     assert torch.allclose(qrot(q.expand(7, 4), v), v @ qrot_matrix(q).T, atol=1e-5)
     assert np.allclose(O.qrot(q.expand(7, 4).numpy(), v.numpy()), qrot(q.expand(7, 4), v).numpy(), atol=1e-5)
+
+
+def test_c_abi_error_conventions_without_gpu():
+    """argument validation happens before any HIP call: negative status + a message from sdfr_last_error(); no compute without a GPU."""
+    import ctypes
+    h = _lib.lib()
+    assert h.sdfr_mlp_forward(None, None, 10, None, None, None) == -1
+    assert b"NULL" in h.sdfr_last_error()
+    assert h.sdfr_band_select(None, 10, 1, 0.03, None, 10, None, None, None, None) == -1
+    assert h.sdfr_splat_forward(7, None, None, None, None, None, None, None, None, None, 1, 0, None, 8, 8, 0.04, 150.0, None, None, None,
+                                None, None, None, None) == -1
+    assert b"primitive" in h.sdfr_last_error()
+    hd = ctypes.c_void_p()
+    ints = (ctypes.c_int * 2)(6, 64)
+    outs = (ctypes.c_int * 2)(64, 2)                     # last layer must have out_dim 1
+    z = (ctypes.c_int * 2)(0, 0)
+    W = (ctypes.c_void_p * 2)(None, None)
+    assert h.sdfr_decoder_create(ctypes.byref(hd), 2, ints, outs, z, z, W, W, None, None, 6, 0, 0) == -1
+    assert b"out_dim 1" in h.sdfr_last_error()
+    assert h.sdfr_decoder_mask_words(None, 100) == 0 and h.sdfr_decoder_macs(None) == 0
+    with pytest.raises(_lib.SdfrError):
+        _lib.check(-1, "demo")
+
+
+def test_ctypes_prototypes_match_the_header():
+    """every prototype in include/sdfr.h has a ctypes binding with the same number of parameters and a compatible kind per slot
+    (pointer vs integer vs float); the .hip sources include the same header, so definitions cannot drift from it either."""
+    import ctypes
+    header = open(os.path.join(ROOT, "include", "sdfr.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = re.findall(r"\b(?:int|int64_t|const char\*)\s+(sdfr_[a-z0-9_]+)\s*\((.*?)\)\s*;", header, flags=re.S)
+    assert len(protos) == len(_lib.EXPORTS)
+    for name, params in protos:
+        params = [p.strip() for p in params.replace("\n", " ").split(",") if p.strip() and p.strip() != "void"]
+        res, args = _lib._PROTOS[name]
+        assert len(params) == len(args), (name, len(params), len(args))
+        for p, a in zip(params, args):
+            if "*" in p:
+                assert a in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(a, "contents") or a.__name__.startswith("LP_"), (name, p, a)
+            elif p.startswith("float"):
+                assert a is ctypes.c_float, (name, p)
+            elif p.startswith("int64_t"):
+                assert a is ctypes.c_int64, (name, p)
+            else:
+                assert a is ctypes.c_int, (name, p, a)

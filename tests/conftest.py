@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built library (it is git-ignored): compile it once with hipcc (cross-compiles without a GPU)
+    lib = os.path.join(ROOT, "sdflabel_amd", "lib", "libsdfr_hip.so")
+    if not os.path.isfile(lib) and os.path.isfile("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(ROOT, "sdflabel_amd", "csrc", "build.sh")])
 
 
 def pytest_collection_modifyitems(config, items):

@@ -372,11 +372,18 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         const MlpLayer L = P.L[l];
         const MlpLayer Ln = P.L[l + 1];
         gemm(Wfwd + (HALF ? L.off_h : L.off_f), HALF ? L.kp_h : L.kp_f, L.out_dim);
+        // all bias vectors of this lane are requested before the barrier, so their L2 latency overlaps the wait for the other waves
+        // (left inside the store loop the compiler serialises them: one exposed round trip per register group)
+        const float* bias = P.bias + l * HP;
+        float4 b4s[FT][RG];
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) b4s[f][rg] = *reinterpret_cast<const float4*>(bias + feat0(f, rg));
         __syncthreads();                                  // every wave is done reading act
         uint32_t mw[MW];
 #pragma unroll
         for (int w = 0; w < MW; ++w) mw[w] = 0u;
-        const float* bias = P.bias + l * HP;
         const int inj_lo = L.out_dim, inj_hi = L.out_dim + Ln.inj_n;
         bool lnl = false;
         if constexpr (LN) {
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
                 const int j0 = feat0(f, rg);
-                const float4 b4 = lnl ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(bias + j0);
+                const float4 b4 = lnl ? make_float4(0.f, 0.f, 0.f, 0.f) : b4s[f][rg];
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const int pt = p * MS + lp;

@@ -75,6 +75,13 @@ int sdfr_mlp_forward(const sdfr_decoder* dec, const float* inputs, int64_t n, fl
 /* the same with float16 operands on the matrix cores (weights and hidden activations rounded to half, float32 accumulation, bias,
  * ReLU and tanh) -- the decoder precision of the reference's default config (configs/config_refine.ini:19); inputs/outputs stay float32. */
 int sdfr_mlp_forward_f16(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream);
+
+/* the same with error-compensated float16 operands: each float32 weight and hidden activation x is carried as hi = half(x),
+ * lo = half((x - hi) * 2^11) and every product as hi*hi + 2^-11 (hi*lo + lo*hi) on the f16 matrix cores, float32 accumulation
+ * (~22 significand bits per product; the output differs from sdfr_mlp_forward by float32 summation-order noise, not by half
+ * rounding).  Same replaced interface as sdfr_mlp_forward (deep_sdf_decoder_scale.py:78-107); mask_ws has the layout
+ * sdfr_mlp_forward writes (pass mask_from_f16 = 0 to sdfr_mlp_jacobian).  Requires |hidden activation| < 65504. */
+int sdfr_mlp_forward_split(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream);
 /* size (in uint32 words) of the mask workspace for n rows */
 int64_t sdfr_decoder_mask_words(const sdfr_decoder* dec, int64_t n);
 

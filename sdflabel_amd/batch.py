@@ -35,7 +35,9 @@ class BatchRenderer:
         if not output_nocs:
             raise NotImplementedError("BatchRenderer composites NOCS colours (the optimizer's configuration)")
         self.decoder = decoder
-        self.f16 = getattr(decoder, "mlp_precision", torch.float32) == torch.float16
+        prec = getattr(decoder, "mlp_precision", torch.float32)
+        self.f16 = prec == torch.float16
+        self.split = prec == "float32_split"
         self.handle = decoder.handle(dev)
         self.L = decoder.latent_size
         self.NI = self.L + 3
@@ -93,7 +95,7 @@ class BatchRenderer:
                                  P(self.latnorm), st), "sdfr_params_forward")
         if mlp_events is not None:
             mlp_events[0].record()
-        fwd = L.sdfr_mlp_forward_f16 if self.f16 else L.sdfr_mlp_forward
+        fwd = L.sdfr_mlp_forward_f16 if self.f16 else (L.sdfr_mlp_forward_split if self.split else L.sdfr_mlp_forward)
         ck(fwd(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.mask_ws), st), "sdfr_mlp_forward")
         if mlp_events is not None:
             mlp_events[1].record()

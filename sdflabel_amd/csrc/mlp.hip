@@ -35,7 +35,7 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
     d->device = device; d->n_lin = n_lin; d->n_inputs = n_inputs; d->use_tanh = use_tanh; d->HP = HP;
     MlpParams& P = d->proto;
     P.n_mfma = n_lin - 1; P.n_inputs = n_inputs; P.use_tanh = use_tanh;
-    int64_t off_f = 0, off_b = 0, off_h = 0;
+    int64_t off_f = 0, off_b = 0, off_h = 0, off_s = 0;
     for (int l = 0; l < n_lin; ++l) {
         MlpLayer& L = P.L[l];
         L.in_dim = in_dim[l]; L.out_dim = out_dim[l]; L.inj_n = inj_n[l]; L.inj_off = inj_off[l];
@@ -43,12 +43,14 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
         if (L.ln) { SDFR_REQUIRE(h_ln_b && h_ln_b[l], "sdfr_decoder_create: LayerNorm weight without bias at layer %d", l); d->has_ln = 1; }
         L.kp_f = 16 * ((in_dim[l] + 15) / 16); L.kp_b = 16 * ((out_dim[l] + 15) / 16); L.kp_h = 32 * ((in_dim[l] + 31) / 32);
         L.off_f = (int)off_f; L.off_b = (int)off_b; L.off_h = (int)off_h;
+        L.kp_s = 64 * ((in_dim[l] + 63) / 64); L.off_s = (int)off_s;
         d->macs += (int64_t)in_dim[l] * out_dim[l];
-        if (l < n_lin - 1) { off_f += (int64_t)(L.kp_f / 4) * HP; off_b += (int64_t)(L.kp_b / 4) * HP; off_h += (int64_t)(L.kp_h / 8) * HP; }
+        if (l < n_lin - 1) { off_f += (int64_t)(L.kp_f / 4) * HP; off_b += (int64_t)(L.kp_b / 4) * HP; off_h += (int64_t)(L.kp_h / 8) * HP;
+                             off_s += (int64_t)(L.kp_s / 8) * HP * 2; }
     }
     // images: vector index [k / KV][row], KV consecutive k per 16-byte vector (KV = 4 floats or 8 halfs); zero padded
     std::vector<float> Wf((size_t)off_f * 4, 0.f), Wb((size_t)off_b * 4, 0.f), bias((size_t)(n_lin - 1) * HP, 0.f), wl(HP, 0.f);
-    std::vector<_Float16> Wh((size_t)off_h * 8, (_Float16)0.f);
+    std::vector<_Float16> Wh((size_t)off_h * 8, (_Float16)0.f), Ws((size_t)off_s * 8, (_Float16)0.f);
     for (int l = 0; l < n_lin - 1; ++l) {
         const MlpLayer& L = P.L[l];
         const float* W = h_W[l];
@@ -56,7 +58,11 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
             for (int k = 0; k < L.in_dim; ++k) {
                 const float w = W[(size_t)r * L.in_dim + k];
                 Wf[((size_t)L.off_f + (size_t)(k / 4) * HP + r) * 4 + (k % 4)] = w;
-                Wh[((size_t)L.off_h + (size_t)(k / 8) * HP + r) * 8 + (k % 8)] = (_Float16)w;
+                const _Float16 wh = (_Float16)w;
+                Wh[((size_t)L.off_h + (size_t)(k / 8) * HP + r) * 8 + (k % 8)] = wh;
+                const size_t es = ((size_t)L.off_s + ((size_t)(k / 8) * HP + r) * 2) * 8 + (k % 8);        // split forward: hi | lo
+                Ws[es] = wh;
+                Ws[es + 8] = (_Float16)((w - (float)wh) * 2048.f);
                 Wb[((size_t)L.off_b + (size_t)(r / 4) * HP + k) * 4 + (r % 4)] = w;          // transposed: rows = in-features, k = out-features
             }
         for (int r = 0; r < L.out_dim; ++r) bias[(size_t)l * HP + r] = h_b[l][r];
@@ -79,21 +85,23 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
     }
     SDFR_HIP_CHECK(hipMalloc(&d->d_Wh, Wh.size() * sizeof(_Float16)));
     SDFR_HIP_CHECK(hipMemcpy(d->d_Wh, Wh.data(), Wh.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    SDFR_HIP_CHECK(hipMalloc(&d->d_Ws, Ws.size() * sizeof(_Float16)));
+    SDFR_HIP_CHECK(hipMemcpy(d->d_Ws, Ws.data(), Ws.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     SDFR_HIP_CHECK(hipMalloc(&d->d_bias, bias.size() * sizeof(float)));
     SDFR_HIP_CHECK(hipMalloc(&d->d_wlast, wl.size() * sizeof(float)));
     SDFR_HIP_CHECK(hipMemcpy(d->d_Wf, Wf.data(), Wf.size() * sizeof(float), hipMemcpyHostToDevice));
     SDFR_HIP_CHECK(hipMemcpy(d->d_Wb, Wb.data(), Wb.size() * sizeof(float), hipMemcpyHostToDevice));
     SDFR_HIP_CHECK(hipMemcpy(d->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     SDFR_HIP_CHECK(hipMemcpy(d->d_wlast, wl.data(), wl.size() * sizeof(float), hipMemcpyHostToDevice));
-    P.Wf = d->d_Wf; P.Wb = d->d_Wb; P.Wh = d->d_Wh; P.bias = d->d_bias; P.w_last = d->d_wlast; P.fwd_np = 2;
+    P.Wf = d->d_Wf; P.Wb = d->d_Wb; P.Wh = d->d_Wh; P.Ws = d->d_Ws; P.bias = d->d_bias; P.w_last = d->d_wlast; P.fwd_np = 2;
     *out = d;
     return SDFR_OK;
 }
 
 extern "C" int sdfr_decoder_destroy(sdfr_decoder* d) {
     if (!d) return SDFR_OK;
-    hipFree(d->d_Wf); hipFree(d->d_Wb); hipFree(d->d_Wh); hipFree(d->d_bias); hipFree(d->d_wlast);
-    hipFree(d->d_lng); hipFree(d->d_lnb); hipFree(d->ln_ws);
+    void* bufs[] = {d->d_Wf, d->d_Wb, d->d_Wh, d->d_Ws, d->d_bias, d->d_wlast, d->d_lng, d->d_lnb, d->ln_ws};
+    for (void* b : bufs) (void)hipFree(b);
     delete d;
     return SDFR_OK;
 }
@@ -139,6 +147,23 @@ extern "C" int sdfr_mlp_forward_f16(const sdfr_decoder* d, const float* inputs, 
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws;
     sdfr_launch_fwd_f16_512(P, sdfr_cdiv(n, 128), mask_ws != nullptr, (hipStream_t)stream);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// forward with error-compensated float16 operands: every float32 operand x is carried as the pair  hi = half(x),
+// lo = half((x - hi) * 2^11)  (22 significand bits) and each product as  hi*hi + (hi*lo + lo*hi) * 2^-11  on the f16 matrix cores with
+// float32 accumulation -- three f16 MFMAs replace sixteen f32 MFMA passes.  Results agree with sdfr_mlp_forward to float32 rounding
+// noise (the same order as a change of summation order); masks are saved in the f32 forward's layout.
+extern "C" int sdfr_mlp_forward_split(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream) {
+    SDFR_REQUIRE(d && inputs && sdf, "sdfr_mlp_forward_split: NULL argument");
+    SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward_split: n=%lld out of range", (long long)n);
+    SDFR_REQUIRE(d->HP == 512, "sdfr_mlp_forward_split: built for hidden widths 257..512 (padded width %d)", d->HP);
+    SDFR_REQUIRE(!d->has_ln, "sdfr_mlp_forward_split: LayerNorm decoders run in float32");
+    if (n == 0) return SDFR_OK;
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws;
+    sdfr_launch_fwd_split_512(P, n, mask_ws != nullptr, (hipStream_t)stream);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

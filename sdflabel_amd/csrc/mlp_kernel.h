@@ -36,6 +36,7 @@ struct MlpLayer {
     int inj_n, inj_off;     // input columns concatenated BEFORE this layer
     int kp_f, kp_b, kp_h;   // padded K extents: forward f32 (in_dim -> x16), backward f32 (out_dim -> x16), forward f16 (in_dim -> x32)
     int off_f, off_b, off_h;// 16-byte-vector offsets of the layer's image in Wf / Wb / Wh
+    int kp_s, off_s;        // split forward: K padded to x64, 16-byte-vector offset of the layer's image in Ws
     int ln;                 // LayerNorm (eps 1e-5, affine) between this layer's linear and its ReLU (deep_sdf_decoder_scale.py:56-57,99-101)
 };
 
@@ -43,6 +44,7 @@ struct MlpParams {
     const float4* Wf;       // forward image, float32:  [k/4][HP] float4
     const float4* Wb;       // backward (transposed) image, float32
     const void* Wh;         // forward image, float16:  [k/8][HP] 8 x half
+    const void* Ws;         // split-forward image: [k/8][HP][2] 8 x half -- hi = half(w) and lo = half((w - hi) * 2^11) side by side
     int fwd_np;             // MODE 3: point tiles per workgroup of the forward launch that saved the masks (2: f32, 4: f16)
     const float* bias;      // [n_mfma][HP]
     const float* ln_gamma;  // [n_mfma][HP] LayerNorm weight / bias (LN decoders only)
@@ -75,6 +77,7 @@ struct sdfr_decoder {
     float4* d_Wf;
     float4* d_Wb;
     void* d_Wh;
+    void* d_Ws;
     float* d_lng;           // LayerNorm weight / bias images [n_mfma][HP] (NULL without LN)
     float* d_lnb;
     int has_ln;
@@ -629,6 +632,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 void sdfr_launch_fwd_f32_512(const MlpParams& P, int64_t n, bool save_masks, hipStream_t s);    // mlp_fwd32.hip
 int sdfr_fwd_f32_512_np();                                                                        // its point tiles per workgroup
 void sdfr_launch_fwd_f16_512(const MlpParams& P, int grid, bool save_masks, hipStream_t s);      // mlp_fwd16.hip
+void sdfr_launch_fwd_split_512(const MlpParams& P, int64_t n, bool save_masks, hipStream_t s);  // mlp_split.hip
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s); // mlp_jac.hip
 void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)
 void sdfr_launch_ln(const MlpParams& P, int HP, bool jac, int grid_x, int grid_y, hipStream_t s);        // mlp_ln.hip (LayerNorm decoders)

@@ -41,6 +41,8 @@ class _DecoderHandle:
         self.h = h
         self.n_inputs = n_inputs
         self.macs = int(L.sdfr_decoder_macs(h))
+        width = max(max(int(W.shape[0]) for W, _ in layers[:-1]), max(int(W.shape[1]) for W, _ in layers))
+        self.hp = 128 if width <= 128 else (256 if width <= 256 else 512)       # padded hidden width the kernels were built for
         self._keep = None
 
     def __del__(self):
@@ -67,6 +69,7 @@ class SdfState:
         self.sdf = None               # (G,) decoder output of the forward launch
         self.mask_ws = None           # ReLU masks saved by the forward launch (int32 words)
         self.f16 = False              # the forward launch used float16 operands
+        self.split = False            # the forward launch used error-compensated float16 operand pairs (float32-equivalent)
 
 
 def mlp_jacobian(state, idx, n, use_masks=True):
@@ -91,7 +94,7 @@ class _DeepSDFFn(torch.autograd.Function):
         if not state.handle.has_ln:
             nw = int(L.sdfr_decoder_mask_words(state.handle.h, state.G))
             state.mask_ws = torch.empty((nw,), dtype=torch.int32, device=inputs.device)
-        fwd = L.sdfr_mlp_forward_f16 if state.f16 else L.sdfr_mlp_forward
+        fwd = L.sdfr_mlp_forward_f16 if state.f16 else (L.sdfr_mlp_forward_split if state.split else L.sdfr_mlp_forward)
         _lib.check(fwd(state.handle.h, _lib.ptr(state.inputs), state.G, _lib.ptr(sdf), _lib.ptr(state.mask_ws), _lib.stream_ptr()),
                    "sdfr_mlp_forward")
         state.sdf = sdf.view(-1)
@@ -157,8 +160,9 @@ class Decoder(nn.Module):
         self.scale_net = nn.Sequential(nn.Linear(latent_size, 3), nn.ReLU(True), nn.Linear(3, 3), nn.ReLU(True), nn.Linear(3, 1))
         self._handle = None
         self._handle_key = None
-        # arithmetic of the hidden layers: torch.float32 (exact-f32 MFMA) or torch.float16 (half operands, f32 accumulate) -- what
-        # setup_dsdf(precision=...) selects; tensors at the module boundary stay float32 either way
+        # arithmetic of the hidden layers: torch.float32 (exact-f32 MFMA), torch.float16 (half operands, f32 accumulate) or
+        # "float32_split" (hi/lo half operand pairs, float32-equivalent) -- what setup_dsdf(precision=...) selects; tensors at the
+        # module boundary stay float32 either way
         self.mlp_precision = torch.float32
 
     # -- effective weights ---------------------------------------------------------------------------------------------
@@ -214,6 +218,7 @@ class Decoder(nn.Module):
         x32 = input if in_dtype == torch.float32 else input.float()          # half tensors are widened at the boundary
         state = SdfState(self.handle(input.device), x32.detach().contiguous())
         state.f16 = self.mlp_precision == torch.float16 and not state.handle.has_ln     # LayerNorm decoders compute in float32
+        state.split = self.mlp_precision == "float32_split" and not state.handle.has_ln and state.handle.hp == 512
         x = _DeepSDFFn.apply(x32, state)
         if in_dtype != torch.float32:
             x = x.to(in_dtype)

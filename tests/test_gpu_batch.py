@@ -229,3 +229,12 @@ def test_refinement_converges_from_perturbed_pose(dec):
     err1 = np.abs(N(rows)[:, 0] - 0.6)
     assert (err1 < 0.5 * err0).all(), (err0, err1)
     assert np.abs(N(rows)[:, 1:4] - np.array([0.0, 0.0, 3.5])).max() < 0.06
+
+
+def test_split_decoder_batched_path_passes_the_float32_goldens():
+    """BatchRenderer / BatchRefiner on the error-compensated f16 decoder against the float32 goldens (G7 gradients, G8 trajectory)"""
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_split")
+    d = d.to(DEV)
+    for tag in ("a", "b"):
+        test_batch_gradients_golden(d, tag)
+    test_batch_refiner_trajectory_golden(d, 2, True)

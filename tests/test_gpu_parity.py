@@ -709,3 +709,49 @@ def test_half_precision_callers_are_served(dec):
     assert abs(n16 - n32) < 0.1 * n32
     assert (m16 != m32).mean() < 0.02 and (np.abs(c16 - c32).max(axis=0) > 2e-2).mean() < 0.05
     assert abs(g16[0][0] - g32[0][0]) < 0.3 * max(1.0, abs(g32[0][0]))
+
+
+# ---- error-compensated f16 decoder ("float32_split"): float32 results from the f16 matrix cores -----------------------------------
+
+@pytest.fixture(scope="module")
+def dec_split():
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_split")
+    return d.to(DEV)
+
+
+def test_split_decoder_is_float32_accurate(dec, dec_split, oracle_layers):
+    """hi/lo half operand pairs, three f16 MFMAs per product: the output must sit as close to a float64 evaluation of the network as the
+    exact-f32 kernel does, the band must be the same rows and the saved ReLU masks (same layout) may differ only in a handful of bits"""
+    layers, spec = oracle_layers
+    grid = sdflabel_amd.Grid3D(40, DEV)
+    lat = F.normalize(torch.tensor([0.3, -0.5, 0.8], device=DEV), p=2, dim=0)
+    inputs = torch.cat([lat.expand(grid.points.size(0), -1), grid.points.detach()], 1).contiguous()
+    with torch.no_grad():
+        s32, _ = dec(inputs)
+        ssp, _ = dec_split(inputs)
+    assert ssp._sdfr_state.split and not s32._sdfr_state.split
+    sel = np.arange(0, inputs.shape[0], 9)
+    ref = O.decoder_forward(layers, spec, N(inputs)[sel].astype(np.float64)).reshape(-1)      # the oracle evaluated in float64
+    e32 = np.abs(N(s32).reshape(-1)[sel] - ref).max()
+    esp = np.abs(N(ssp).reshape(-1)[sel] - ref).max()
+    assert esp < 5e-7 and esp < 2.0 * e32 + 1e-7, (esp, e32)
+    assert float((s32 - ssp).abs().max()) < 1e-6
+    assert int(((s32.abs() < 0.03) != (ssp.abs() < 0.03)).sum()) <= 2
+    m32, msp = s32._sdfr_state.mask_ws, ssp._sdfr_state.mask_ws
+    assert m32.numel() == msp.numel()
+    x = m32 ^ msp
+    flips = int(sum(int(((x >> b) & 1).sum()) for b in range(32)))
+    assert flips <= 1e-6 * 32 * m32.numel() + 64, flips
+
+
+def test_split_decoder_passes_the_float32_goldens(dec_split, oracle_layers):
+    """the same golden vectors and tolerances as the exact-f32 path, through the drop-in modules"""
+    test_mlp_forward_golden_fitted(dec_split)
+    test_mlp_backward_golden_fitted(dec_split)
+    for n in (1, 63, 65, 1000):
+        test_mlp_forward_ragged_sizes_vs_oracle(dec_split, oracle_layers, n)
+    for tag in ("a", "b"):
+        test_surface_points_golden(dec_split, tag)
+        test_end_to_end_gradients_golden(dec_split, tag)
+    test_full_size_crop_vs_oracle_sample(dec_split, oracle_layers)
+    test_refinement_trajectory_golden(dec_split)

@@ -10,6 +10,7 @@ grid = sdflabel_amd.Grid3D(40, dev)
 lat = F.normalize(torch.tensor([0.3, -0.5, 0.8], device=dev), dim=0)
 inputs = torch.cat([lat.expand(grid.points.size(0), -1), grid.points], 1).contiguous()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+dec.mlp_precision = {"f32": torch.float32, "f16": torch.float16, "split": "float32_split"}[sys.argv[2] if len(sys.argv) > 2 else "f32"]
 with torch.no_grad():
     for _ in range(n):
         dec(inputs)

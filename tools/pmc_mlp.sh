@@ -1,8 +1,8 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; TAG=${1:-x}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; TAG=${1:-x}; PREC=${2:-f32}
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq_$TAG -o pmc -- python $R/tools/mlp_only.py 6 > $O/pmc_sq_$TAG.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $O/pmc_sq2_$TAG -o pmc -- python $R/tools/mlp_only.py 6 > $O/pmc_sq2_$TAG.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq_$TAG -o pmc -- python $R/tools/mlp_only.py 6 $PREC > $O/pmc_sq_$TAG.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $O/pmc_sq2_$TAG -o pmc -- python $R/tools/mlp_only.py 6 $PREC > $O/pmc_sq2_$TAG.log 2>&1
 tail -3 $O/pmc_sq_$TAG.log; tail -3 $O/pmc_sq2_$TAG.log
 python - <<PY
 import csv, collections

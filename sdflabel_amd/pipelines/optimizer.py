@@ -1,0 +1,89 @@
+"""Optimizer -- same constructor and `optimize` call as the reference's refinement loop object (pipelines/optimizer.py:43-164), run by
+the device-resident BatchRefiner (one crop): the caller (pipelines/refine_css_demo.py:157-191, refine_css.py) keeps building its `params`
+dict, constructing `Optimizer(params, device, weights)` and calling `optimize(...)`, then reads the refined `params[...]` tensors.
+
+What differs from the reference is only how an iteration executes: no per-iteration host work (the lidar cloud is uploaded once, the 3-D
+nearest-neighbour loss and the 2-D NOCS window loss run in HIP kernels, the Adam/SGD update and the reference's skip rules
+(optimizer.py:127-129,149-151) are one kernel), and the iterations are replayed from a HIP graph.  The arithmetic per iteration is the
+reference's (trajectory-tested against its own Optimizer, golden G8).  `get_opt_params` (optimizer.py:26-40) turns the caller's arrays into
+float32 leaf tensors in place; so does this class, and after `optimize` those tensors hold the refined values.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..grid import Grid3D
+from ..refine import BatchRefiner
+
+
+def get_opt_params(params, device):
+    """optimizer.py:26-40: every entry of `params` becomes a float32 leaf tensor on `device` (in place); returns the parameter groups with
+    the reference's learning rates (yaw .01, trans .01 -> Adam; scale .01, latent 3e-5 -> SGD)."""
+    for key, value in params.items():
+        params[key] = torch.as_tensor(np.asarray(value.detach().cpu() if torch.is_tensor(value) else value, dtype=np.float32)).to(device).requires_grad_(True)
+    groups = [{'params': params['yaw'], 'lr': 0.01}, {'params': params['trans'], 'lr': 0.01},
+              {'params': params['scale'], 'lr': 0.01}, {'params': params['latent'], 'lr': 0.00003}]
+    return params, groups
+
+
+class Optimizer:
+    def __init__(self, params, device, weights, rot='dcm'):
+        if rot != 'dcm':
+            raise NotImplementedError("the refinement loop optimises a yaw angle (rot='dcm', optimizer.py:44,86-90); the quaternion "
+                                      "variant is commented out in the reference (optimizer.py:92-93)")
+        self.params, self.optim_params = get_opt_params(params, device)
+        self.weights = weights
+        self.rot = rot
+        self.log = []             # per-iteration (weighted 2-D loss, weighted 3-D loss, total) when optimize(..., verbose=True)
+        self._refiner = None
+        self._key = None
+
+    def _refiner_for(self, dsdf, grid, K, crop_size, n_lidar):
+        G = int(grid.points.size(0))
+        D = int(round(G ** (1.0 / 3.0)))
+        if D ** 3 != G:
+            raise _lib.SdfrError("grid of %d points is not a D^3 Grid3D" % G)
+        dev = grid.points.device
+        cap = max(256, 1 << (max(n_lidar, 1) - 1).bit_length())       # lidar capacity, rounded up so that a refiner is reused across crops
+        Kn = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32)
+        key = (id(dsdf), D, tuple(int(c) for c in crop_size), cap, Kn.tobytes(), str(dev), dsdf._param_key(dev))
+        if self._key != key:
+            rf = BatchRefiner(dsdf, D, Kn, crop_size, 1, lidar_cap=cap, weights=self.weights, device=dev)
+            if not torch.equal(rf.br.grid, grid.points.detach().to(torch.float32)):
+                raise _lib.SdfrError("grid.points is not the Grid3D(%d) point set the kernels index" % D)
+            self._refiner, self._key = rf, key
+        return self._refiner
+
+    def optimize(self, iters_optim, nocs_pred, pcd_frustum_np, dsdf, grid, K, crop_size, viz_type=None, frame_vis=None, verbose=False):
+        """optimizer.py:56-164.  nocs_pred (3,h,w) CSS prediction, pcd_frustum_np (M,3) lidar points of the frustum (camera frame),
+        dsdf the decoder, grid a Grid3D, K (3,3), crop_size (H,W).  viz_type must be None (visualisation is not on the path).
+        verbose=True prints the reference's per-iteration loss line (one host synchronisation per iteration, as the reference has)."""
+        if viz_type is not None:
+            raise NotImplementedError("visualisation (open3d / matplotlib, optimizer.py:75-77,158-163) is outside the renderer path; "
+                                      "call with viz_type=None")
+        lidar = np.asarray(pcd_frustum_np, dtype=np.float32).reshape(-1, 3)
+        rf = self._refiner_for(dsdf, grid, K, crop_size, lidar.shape[0])
+        p = self.params
+        with torch.no_grad():
+            rf.set_crops({'yaw': p['yaw'].detach().reshape(1, -1), 'trans': p['trans'].detach().reshape(1, 3),
+                          'scale': p['scale'].detach().reshape(1, -1), 'latent': p['latent'].detach().reshape(1, -1)},
+                         torch.as_tensor(nocs_pred, dtype=torch.float32)[None], [lidar])
+            self.log = []
+            if verbose:
+                for e in range(iters_optim):
+                    rf.iteration()
+                    l2, l3 = float(rf.loss2d[0]) * rf.w2, float(rf.loss3d[0]) * rf.w3
+                    if int(rf.stepped[0]):
+                        print('ITER {} | Losses: 2D - {}, 3D - {}, Total - {}'.format(e, l2, l3, l2 + l3))
+                    else:
+                        print('Skip frame')
+                    self.log.append((l2, l3, l2 + l3))
+            else:
+                if iters_optim > 3:
+                    rf.capture()
+                rf.optimize(iters_optim)
+            p['yaw'].copy_(rf.yaw.view_as(p['yaw']))
+            p['trans'].copy_(rf.trans.view_as(p['trans']))
+            p['scale'].copy_(rf.scale.view_as(p['scale']))
+            p['latent'].copy_(rf.latent.view_as(p['latent']))
+        return self.params

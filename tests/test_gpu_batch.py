@@ -238,3 +238,34 @@ def test_split_decoder_batched_path_passes_the_float32_goldens():
     for tag in ("a", "b"):
         test_batch_gradients_golden(d, tag)
     test_batch_refiner_trajectory_golden(d, 2, True)
+
+
+@pytest.mark.parametrize("verbose", [False, True])
+def test_optimizer_mirror_reaches_the_reference_optimizers_parameters(dec, verbose, capsys):
+    """sdflabel_amd.pipelines.optimizer.Optimizer, called the way refine_css_demo.py:157-191 calls the reference's: after 10 iterations the
+    caller's params dict holds what the reference's own Optimizer produced (golden G8); verbose=True prints its per-iteration line."""
+    from sdflabel_amd.pipelines.optimizer import Optimizer
+    z = gold("g8_optimizer.npz")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    params = {"yaw": init[0:1].copy(), "trans": init[1:4].copy(), "scale": init[4:5].copy(), "latent": init[5:8].copy()}
+    opt = Optimizer(params, DEV, {"2d": 0.3, "3d": 0.5})
+    assert all(torch.is_tensor(v) and v.requires_grad and v.dtype == torch.float32 for v in params.values())
+    grid = sdflabel_amd.Grid3D(D, DEV)
+    out = opt.optimize(10, T(z["nocs_target"]), z["lidar"], dec, grid, T(z["K"]), (H, W), verbose=verbose)
+    assert out is params
+    got = np.concatenate([N(params[k]).reshape(-1) for k in ("yaw", "trans", "scale", "latent")])
+    assert np.abs(got - z["traj"][-1]).max() < 5e-4, np.abs(got - z["traj"][-1])
+    if verbose:
+        l = np.asarray(opt.log)
+        assert np.abs(l[:, 0] - z["loss2d_weighted"]).max() < 2e-4 and np.abs(l[:, 1] - z["loss3d_weighted"]).max() < 2e-4
+        assert capsys.readouterr().out.count("ITER") == 10
+    # a second crop through the same object reuses the refiner (same decoder, grid, K, crop size)
+    rf = opt._refiner
+    for k, sl in (("yaw", slice(0, 1)), ("trans", slice(1, 4)), ("scale", slice(4, 5)), ("latent", slice(5, 8))):
+        with torch.no_grad():
+            params[k].copy_(T(init[sl]).view_as(params[k]))
+    opt.optimize(10, T(z["nocs_target"]), z["lidar"], dec, grid, T(z["K"]), (H, W))
+    assert opt._refiner is rf
+    got2 = np.concatenate([N(params[k]).reshape(-1) for k in ("yaw", "trans", "scale", "latent")])
+    assert np.abs(got2 - z["traj"][-1]).max() < 5e-4

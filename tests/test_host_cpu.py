@@ -124,3 +124,19 @@ def test_ctypes_prototypes_match_the_header():
                 assert a is ctypes.c_int64, (name, p)
             else:
                 assert a is ctypes.c_int, (name, p, a)
+
+
+def test_optimizer_mirror_constructor_and_refusals():
+    """pipelines/optimizer.py:26-54: params become float32 leaf tensors in place; what is off the path is refused loudly"""
+    import pytest
+    from sdflabel_amd.pipelines.optimizer import Optimizer, get_opt_params
+    params = {"yaw": np.array([0.5]), "trans": np.array([0.1, 0.2, 3.0]), "scale": np.array([2.0]), "latent": np.zeros(3)}
+    opt = Optimizer(params, "cpu", {"2d": 0.3, "3d": 0.5})
+    assert opt.params is params
+    for k, n in (("yaw", 1), ("trans", 3), ("scale", 1), ("latent", 3)):
+        assert torch.is_tensor(params[k]) and params[k].dtype == torch.float32 and params[k].requires_grad and params[k].numel() == n
+    assert [g["lr"] for g in opt.optim_params] == [0.01, 0.01, 0.01, 0.00003]
+    with pytest.raises(NotImplementedError):
+        Optimizer(dict(params), "cpu", {}, rot="quat")
+    with pytest.raises(NotImplementedError):
+        opt.optimize(1, None, np.zeros((1, 3)), None, None, None, (8, 8), viz_type="2d")

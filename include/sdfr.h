@@ -89,7 +89,7 @@ int64_t sdfr_decoder_mask_words(const sdfr_decoder* dec, int64_t n);
  *   for crop b < B, slot s < cnt[b]:  r = row_base + b*rows_per_crop + idx[b*cap+s]
  *     J[b][s][:]      = d sdf(inputs[r,:]) / d inputs[r,:]      (n_inputs values)
  *     sdf_sel[b][s]   = sdf(inputs[r,:])                         (may be NULL)
- * J is zero-filled by the call itself (stream-ordered memset).
+ * Rows s < cnt[b] are fully written by the call (no prior initialisation needed); rows s >= cnt[b] are left untouched.
  * Reference: the xyz columns are what grid.py:55-56 captures through its hook for the band points; the latent
  * columns give d sdf/d latent, which autograd recomputes at optimizer.py:156. */
 int sdfr_mlp_jacobian(const sdfr_decoder* dec, const float* inputs, int64_t rows_per_crop, int B,
@@ -134,20 +134,25 @@ int sdfr_sdf_input_grad(const float* g_sdf, const int32_t* slot, const float* J,
 /* ------------------------------------------------------------------------------------------------
  * Projection to the camera frame  --  replaces project_in_2D (sdfrenderer/renderer/projection.py:7-101), rot='dcm'
  *   pose [B][16] row-major 4x4 (only the top 3 rows are used, :34); K [B][9]
- *   in : points, normals, colors [B][cap][3]  (colors ignored when output_nocs != 0: 1 -> c = p*(-1,1,1), :53-55; 2 -> c = p, :147-149)
+ *   in : points, normals, colors [B][cap][3]  (colors ignored when output_nocs != 0: 1 -> c = p*(-1,1,1), :53-55; 2 -> c = p, :147-149;
+ *        5 / 6 = 1 / 2 with the compositing map (c+1)/2 of rasterer.py:113-114 already applied, so that col feeds sdfr_splat_* directly)
  *   out: p_cam, n_cam, col [B][cap][3]; uv [B][cap][2] (clamped, :88-93; may be NULL)
- *        front-facing filter n_cam.p_cam < 0 (:61-70): fidx [B][cap] ascending slots, fcnt [B]
- *        (fidx/fcnt may be NULL).
+ *        front-facing filter n_cam.p_cam < 0 (:61-70): fidx [B][cap] ascending slots, fcnt [B]  (fidx/fcnt may be NULL);
+ *        optional with fidx: xyzf [B][cap][3] = p_cam rows of the front-facing surfels in fidx order (points['xyzf'], rasterer.py:151)
+ *        and fslot [B][cap] = position of each surfel in fidx or -1 (what the backward needs to route g_xyzf).
  */
 int sdfr_project_dcm(const float* pose, const float* K, const float* points, const float* normals, const float* colors,
                      int B, int cap, const int32_t* cnt, int output_nocs, int res_x, int res_y,
-                     float* p_cam, float* n_cam, float* col, float* uv, int32_t* fidx, int32_t* fcnt, void* stream);
+                     float* p_cam, float* n_cam, float* col, float* uv, int32_t* fidx, int32_t* fcnt, float* xyzf, int32_t* fslot,
+                     void* stream);
 
-/* Backward: g_points, g_normals, g_colors [B][cap][3] (g_colors NULL when output_nocs), g_pose [B][16]. */
+/* Backward: g_points, g_normals, g_colors [B][cap][3] (g_colors NULL when output_nocs), g_pose [B][16].  g_xyzf [B][cap][3] (may be
+ * NULL): gradient w.r.t. the xyzf rows, added to g_p_cam through fslot. */
 int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* normals,
                          const float* g_p_cam, const float* g_n_cam, const float* g_col,
                          int B, int cap, const int32_t* cnt, int output_nocs,
-                         float* g_points, float* g_normals, float* g_colors, float* g_pose, void* stream);
+                         float* g_points, float* g_normals, float* g_colors, float* g_pose, const float* g_xyzf, const int32_t* fslot,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Surfel splat + depth-softmax composite  --  replaces the primitives of sdfrenderer/renderer/primitives.py and the compositing of

@@ -65,14 +65,14 @@ class BatchRenderer:
         self.idx, self.cnt, self.scratch = i(B, cap), i(B), i(B * ((G + 255) // 256) + 1)
         self.J, self.sdf_band = f(B, cap, NI), f(B, cap)
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
-        self.p_cam, self.n_cam, self.col, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
-        self.fidx, self.fcnt = i(B, cap), i(B)
+        self.p_cam, self.n_cam, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
+        self.fidx, self.fcnt, self.fslot = i(B, cap), i(B), i(B, cap)
         self.bbox = i(B, cap, 4)
         self.color, self.mask, self.depth, self.nimg = f(B, 3, H, W), f(B, 1, H, W), f(B, 1, H, W), f(B, 3, H, W)
         self.aux = f(B, H * W, 4)
         self.xyzf = f(B, cap, 3)
         # backward
-        self.g_p, self.g_n, self.g_a, self.g_col = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
+        self.g_p, self.g_n, self.g_a = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.g_points, self.g_normals, self.g_pose = f(B, cap, 3), f(B, cap, 3), f(B, 16)
         self.g_latn = f(B, self.L)
         self.g_yaw, self.g_trans, self.g_latent = f(B), f(B, 3), f(B, self.L)
@@ -105,14 +105,13 @@ class BatchRenderer:
         xyz = self.inputs[:, self.NI - 3:]
         ck(L.sdfr_surface_project(P(xyz), self.NI, P(self.sdf), G, B, P(self.idx), cap, P(self.cnt), P(self.J), self.NI, self.NI - 3,
                                   P(self.points), P(self.nocs), P(self.normals), st), "sdfr_surface_project")
-        ck(L.sdfr_project_dcm(P(self.pose), P(self.K), P(self.points), P(self.normals), None, B, cap, P(self.cnt), self.nocs_mode, W, H,
-                              P(self.p_cam), P(self.n_cam), P(self.col), None, P(self.fidx), P(self.fcnt), st), "sdfr_project_dcm")
-        torch.add(self.col, 1.0, out=self.attr)                                   # attr = (col + 1) / 2, rasterer.py:113-114
-        self.attr.mul_(0.5)
+        # nocs_mode | 4: the projection writes the composited attribute (col + 1) / 2 (rasterer.py:113-114) and the front-facing xyzf rows
+        ck(L.sdfr_project_dcm(P(self.pose), P(self.K), P(self.points), P(self.normals), None, B, cap, P(self.cnt), self.nocs_mode | 4, W, H,
+                              P(self.p_cam), P(self.n_cam), P(self.attr), None, P(self.fidx), P(self.fcnt), P(self.xyzf), P(self.fslot), st),
+           "sdfr_project_dcm")
         ck(L.sdfr_splat_forward(0, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
                                 _DEPTH_CONSTANT, P(self.bbox), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(self.aux), st),
            "sdfr_splat_forward")
-        ck(L.sdfr_gather_rows3(P(self.xyzf), P(self.p_cam), P(self.fidx), B, cap, P(self.fcnt), st), "sdfr_gather_rows3")
         return {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.nimg, "xyzf": self.xyzf, "nf": self.fcnt,
                 "n": self.cnt}
 
@@ -132,13 +131,12 @@ class BatchRenderer:
         ck(L.sdfr_splat_backward(0, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
                                  _DEPTH_CONSTANT, P(self.aux), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(g_color),
                                  P(g_mask), P(g_depth), P(g_normals), P(self.g_p), P(self.g_n), P(self.g_a), st), "sdfr_splat_backward")
-        torch.mul(self.g_a, 0.5, out=self.g_col)                                   # attr = (col + 1) / 2
         if g_xyzf is not None:
             g_xyzf = c(g_xyzf, self.xyzf.shape)
-            ck(L.sdfr_scatter_add_rows3(P(self.g_p), P(g_xyzf), P(self.fidx), B, cap, P(self.fcnt), st), "sdfr_scatter_add_rows3")
-        ck(L.sdfr_project_dcm_bwd(P(self.pose), P(self.points), P(self.normals), P(self.g_p), P(self.g_n), P(self.g_col), B, cap,
-                                  P(self.cnt), self.nocs_mode, P(self.g_points), P(self.g_normals), None, P(self.g_pose), st),
-           "sdfr_project_dcm_bwd")
+        # the projection backward folds in the (col + 1) / 2 map of the attribute and the gradient arriving through xyzf
+        ck(L.sdfr_project_dcm_bwd(P(self.pose), P(self.points), P(self.normals), P(self.g_p), P(self.g_n), P(self.g_a), B, cap,
+                                  P(self.cnt), self.nocs_mode | 4, P(self.g_points), P(self.g_normals), None, P(self.g_pose), P(g_xyzf),
+                                  P(self.fslot), st), "sdfr_project_dcm_bwd")
         ck(L.sdfr_surface_latent_grad(P(self.g_points), None, P(self.normals), P(self.J), self.NI, self.L, B, cap, P(self.cnt),
                                       P(self.g_latn), st), "sdfr_surface_latent_grad")
         ck(L.sdfr_params_backward(P(self.yaw), P(self.latent), self.L, P(self.latnorm), P(self.g_pose), P(self.g_latn), B, P(self.g_yaw),

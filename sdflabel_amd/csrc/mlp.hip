@@ -176,7 +176,6 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     SDFR_REQUIRE(mask_ws == nullptr || sdf_full != nullptr, "sdfr_mlp_jacobian: mask_ws needs sdf_full");
     if (B == 0 || cap == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
-    SDFR_HIP_CHECK(hipMemsetAsync(J, 0, (size_t)B * cap * d->n_inputs * sizeof(float), s));
     MlpParams P = d->proto;
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
     P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.fwd_np = mask_from_f16 ? 4 : (d->HP == 512 ? sdfr_fwd_f32_512_np() : 2);

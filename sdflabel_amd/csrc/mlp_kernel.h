@@ -207,6 +207,14 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         if (tid < PT) rows[tid] = (int)(r0 + (tid < n_valid ? tid : 0));
     }
     __syncthreads();
+    if (JAC) {
+        // J rows of this tile start at zero: every contribution to them (layer-0 in-gradient, re-injected columns) is an atomicAdd issued by
+        // this workgroup after later barriers, so no separate memset launch is needed
+        for (int e = tid; e < PT * NI; e += NT) {
+            const int pt = e / NI;
+            if (slots[pt] >= 0) P.J[(int64_t)slots[pt] * NI + (e - pt * NI)] = 0.f;
+        }
+    }
 
     // ---- layer-0 operand: act[k][pt] = inputs[row(pt)][k], zero padded to the K tile ---------------------
     if (!GMASK) {

@@ -14,7 +14,8 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
     const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ points,
     const float* __restrict__ normals, const float* __restrict__ colors, int cap, const int32_t* __restrict__ cnt,
     int output_nocs, float res_x, float res_y, float* __restrict__ p_cam, float* __restrict__ n_cam, float* __restrict__ col,
-    float* __restrict__ uv, int32_t* __restrict__ fidx, int32_t* __restrict__ fcnt) {
+    float* __restrict__ uv, int32_t* __restrict__ fidx, int32_t* __restrict__ fcnt, float* __restrict__ xyzf,
+    int32_t* __restrict__ fslot) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
     for (int s0 = 0; s0 < count; s0 += PROJ_THREADS) {
         const int s = s0 + tid;
         bool front = false;
+        float fx = 0.f, fy = 0.f, fz = 0.f;
         if (s < count) {
             const int64_t e = ((int64_t)b * cap + s) * 3;
             const float x = points[e], y = points[e + 1], z = points[e + 2];
@@ -44,8 +46,12 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
             const float ncz = fmaf(r22, nz, fmaf(r21, ny, r20 * nx));
             p_cam[e] = pcx; p_cam[e + 1] = pcy; p_cam[e + 2] = pcz;
             n_cam[e] = ncx; n_cam[e + 1] = ncy; n_cam[e + 2] = ncz;
-            if (output_nocs) { col[e] = (output_nocs == 2) ? x : -x; col[e + 1] = y; col[e + 2] = z; }   // :53-55 (2: quat path, no flip :147-149)
-            else { col[e] = colors[e]; col[e + 1] = colors[e + 1]; col[e + 2] = colors[e + 2]; }
+            fx = pcx; fy = pcy; fz = pcz;
+            if (output_nocs) {                      // :53-55 (2: quat path, no flip :147-149); +4: the compositing map (c+1)/2 applied here
+                float c0 = ((output_nocs & 3) == 2) ? x : -x, c1 = y, c2 = z;
+                if (output_nocs & 4) { c0 = (c0 + 1.f) * 0.5f; c1 = (c1 + 1.f) * 0.5f; c2 = (c2 + 1.f) * 0.5f; }      // rasterer.py:113-114
+                col[e] = c0; col[e + 1] = c1; col[e + 2] = c2;
+            } else { col[e] = colors[e]; col[e + 1] = colors[e + 1]; col[e + 2] = colors[e + 2]; }
             const float dot = ncx * pcx + ncy * pcy + ncz * pcz;                          // :62
             front = dot < 0.f;
             if (uv) {
@@ -65,7 +71,12 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
             int woff = 0;
             for (int w = 0; w < wv; ++w) woff += wc[w];
             const int base = s_base;
-            if (front) fidx[(int64_t)b * cap + base + woff + __popcll(bal & ((1ull << lane) - 1ull))] = s;
+            const int slot = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+            if (front) {
+                fidx[(int64_t)b * cap + slot] = s;
+                if (xyzf) { const int64_t f = ((int64_t)b * cap + slot) * 3; xyzf[f] = fx; xyzf[f + 1] = fy; xyzf[f + 2] = fz; }   // points['xyzf'], rasterer.py:151
+            }
+            if (fslot && s < count) fslot[(int64_t)b * cap + s] = front ? slot : -1;
             __syncthreads();
             if (tid == 0) {
                 int tot = 0;
@@ -80,13 +91,17 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
 
 extern "C" int sdfr_project_dcm(const float* pose, const float* K, const float* points, const float* normals,
                                 const float* colors, int B, int cap, const int32_t* cnt, int output_nocs, int res_x, int res_y,
-                                float* p_cam, float* n_cam, float* col, float* uv, int32_t* fidx, int32_t* fcnt, void* stream) {
+                                float* p_cam, float* n_cam, float* col, float* uv, int32_t* fidx, int32_t* fcnt, float* xyzf,
+                                int32_t* fslot, void* stream) {
     SDFR_REQUIRE(pose && K && points && normals && p_cam && n_cam && col, "sdfr_project_dcm: NULL argument");
     SDFR_REQUIRE(output_nocs || colors, "sdfr_project_dcm: colors required when output_nocs == 0");
     SDFR_REQUIRE((fidx == nullptr) == (fcnt == nullptr), "sdfr_project_dcm: fidx and fcnt must be given together");
+    SDFR_REQUIRE(fidx || (!xyzf && !fslot), "sdfr_project_dcm: xyzf / fslot need fidx and fcnt");
+    SDFR_REQUIRE(output_nocs >= 0 && output_nocs <= 6 && output_nocs != 3 && output_nocs != 4, "sdfr_project_dcm: output_nocs %d unknown",
+                 output_nocs);
     if (B <= 0) return SDFR_OK;
     hipLaunchKernelGGL(sdfr_project_dcm_kernel, dim3(B), dim3(PROJ_THREADS), 0, (hipStream_t)stream, pose, K, points, normals,
-                       colors, cap, cnt, output_nocs, (float)res_x, (float)res_y, p_cam, n_cam, col, uv, fidx, fcnt);
+                       colors, cap, cnt, output_nocs, (float)res_x, (float)res_y, p_cam, n_cam, col, uv, fidx, fcnt, xyzf, fslot);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -99,7 +114,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_bwd_kernel(
     const float* __restrict__ pose, const float* __restrict__ points, const float* __restrict__ normals,
     const float* __restrict__ g_pc, const float* __restrict__ g_nc, const float* __restrict__ g_col, int cap,
     const int32_t* __restrict__ cnt, int output_nocs, float* __restrict__ g_points, float* __restrict__ g_normals,
-    float* __restrict__ g_colors, float* __restrict__ g_pose) {
+    float* __restrict__ g_colors, float* __restrict__ g_pose, const float* __restrict__ g_xyzf, const int32_t* __restrict__ fslot) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int count = sdfr_count(cnt, b, cap);
@@ -114,13 +129,21 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_bwd_kernel(
         const int64_t e = ((int64_t)b * cap + s) * 3;
         const float x = points[e], y = points[e + 1], z = points[e + 2];
         const float nx = normals[e], ny = normals[e + 1], nz = normals[e + 2];
-        const float ax = g_pc ? g_pc[e] : 0.f, ay = g_pc ? g_pc[e + 1] : 0.f, az = g_pc ? g_pc[e + 2] : 0.f;
+        float ax = g_pc ? g_pc[e] : 0.f, ay = g_pc ? g_pc[e + 1] : 0.f, az = g_pc ? g_pc[e + 2] : 0.f;
+        if (g_xyzf) {                                   // gradient arriving through points['xyzf'] (the 3-D loss), added to the renderer's
+            const int fs = fslot[(int64_t)b * cap + s];
+            if (fs >= 0) { const int64_t f = ((int64_t)b * cap + fs) * 3; ax += g_xyzf[f]; ay += g_xyzf[f + 1]; az += g_xyzf[f + 2]; }
+        }
         const float bx = g_nc ? g_nc[e] : 0.f, by = g_nc ? g_nc[e + 1] : 0.f, bz = g_nc ? g_nc[e + 2] : 0.f;
         float gx = r00 * ax + r10 * ay + r20 * az;
         float gy = r01 * ax + r11 * ay + r21 * az;
         float gz = r02 * ax + r12 * ay + r22 * az;
         if (g_col) {
-            if (output_nocs) { gx += (output_nocs == 2) ? g_col[e] : -g_col[e]; gy += g_col[e + 1]; gz += g_col[e + 2]; }
+            if (output_nocs) {
+                float c0 = g_col[e], c1 = g_col[e + 1], c2 = g_col[e + 2];
+                if (output_nocs & 4) { c0 *= 0.5f; c1 *= 0.5f; c2 *= 0.5f; }
+                gx += ((output_nocs & 3) == 2) ? c0 : -c0; gy += c1; gz += c2;
+            }
             else if (g_colors) { g_colors[e] = g_col[e]; g_colors[e + 1] = g_col[e + 1]; g_colors[e + 2] = g_col[e + 2]; }
         } else if (!output_nocs && g_colors) { g_colors[e] = 0.f; g_colors[e + 1] = 0.f; g_colors[e + 2] = 0.f; }
         g_points[e] = gx; g_points[e + 1] = gy; g_points[e + 2] = gz;
@@ -149,11 +172,13 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_bwd_kernel(
 
 extern "C" int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* normals, const float* g_p_cam,
                                     const float* g_n_cam, const float* g_col, int B, int cap, const int32_t* cnt, int output_nocs,
-                                    float* g_points, float* g_normals, float* g_colors, float* g_pose, void* stream) {
+                                    float* g_points, float* g_normals, float* g_colors, float* g_pose, const float* g_xyzf,
+                                    const int32_t* fslot, void* stream) {
     SDFR_REQUIRE(pose && points && normals && g_points && g_normals && g_pose, "sdfr_project_dcm_bwd: NULL argument");
+    SDFR_REQUIRE(!g_xyzf || fslot, "sdfr_project_dcm_bwd: g_xyzf needs the fslot array sdfr_project_dcm wrote");
     if (B <= 0) return SDFR_OK;
     hipLaunchKernelGGL(sdfr_project_dcm_bwd_kernel, dim3(B), dim3(PROJ_THREADS), 0, (hipStream_t)stream, pose, points, normals,
-                       g_p_cam, g_n_cam, g_col, cap, cnt, output_nocs, g_points, g_normals, g_colors, g_pose);
+                       g_p_cam, g_n_cam, g_col, cap, cnt, output_nocs, g_points, g_normals, g_colors, g_pose, g_xyzf, fslot);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

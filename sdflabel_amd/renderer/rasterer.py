@@ -41,7 +41,7 @@ class _RasterFn(torch.autograd.Function):
         if n > 0:
             _lib.check(L.sdfr_project_dcm(_lib.ptr(pose_c), _lib.ptr(K), _lib.ptr(coords_c), _lib.ptr(normals_c), _lib.ptr(colors_c), 1, n,
                                           None, int(nocs_mode), W, H, _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(col), _lib.ptr(uv),
-                                          _lib.ptr(fidx), _lib.ptr(fcnt), st), "sdfr_project_dcm")
+                                          _lib.ptr(fidx), _lib.ptr(fcnt), None, None, st), "sdfr_project_dcm")
         attr = ((col + 1) / 2) if half_attr else col                       # rasterer.py:108-109,113-116
         attr = attr.contiguous()
         # per-crop scalars of the secondary primitives / the background row (tiny host-layer reductions)
@@ -149,7 +149,7 @@ class _RasterFn(torch.autograd.Function):
         if n > 0:
             _lib.check(L.sdfr_project_dcm_bwd(_lib.ptr(pose), _lib.ptr(coords), _lib.ptr(normals), _lib.ptr(g_p), _lib.ptr(g_n),
                                               _lib.ptr(g_col), 1, n, None, int(nocs_mode), _lib.ptr(g_points), _lib.ptr(g_normals),
-                                              _lib.ptr(g_colors), _lib.ptr(g_pose), st), "sdfr_project_dcm_bwd")
+                                              _lib.ptr(g_colors), _lib.ptr(g_pose), None, None, st), "sdfr_project_dcm_bwd")
         return (g_points[:n], g_normals[:n], None if nocs_mode else g_colors[:n], g_pose, None) + (None,) * 11
 
 

@@ -294,9 +294,21 @@ def test_project_golden_poses():
             p_cam = torch.empty((n, 3), device=DEV); n_cam = torch.empty((n, 3), device=DEV); col = torch.empty((n, 3), device=DEV)
             uv = torch.empty((n, 2), device=DEV)
             fidx = torch.empty((n,), dtype=torch.int32, device=DEV); fcnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+            xyzf = torch.zeros((n, 3), device=DEV); fslot = torch.full((n,), -7, dtype=torch.int32, device=DEV)
             _lib.check(L.sdfr_project_dcm(_lib.ptr(pose), _lib.ptr(K), _lib.ptr(pts), _lib.ptr(nrm), _lib.ptr(nrm), 1, n, None, mode,
                                           32, 32, _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(col), _lib.ptr(uv), _lib.ptr(fidx),
-                                          _lib.ptr(fcnt), _lib.stream_ptr()), "project")
+                                          _lib.ptr(fcnt), _lib.ptr(xyzf), _lib.ptr(fslot), _lib.stream_ptr()), "project")
+            nf = int(fcnt[0]); fi = fidx[:nf].long()
+            assert torch.equal(xyzf[:nf], p_cam[fi])                                   # fused points['xyzf'] gather
+            inv = torch.full((n,), -1, dtype=torch.int32, device=DEV); inv[fi] = torch.arange(nf, dtype=torch.int32, device=DEV)
+            assert torch.equal(fslot, inv)
+            # modes 5 / 6: the same colours with the compositing map (c+1)/2 applied in the kernel
+            if mode:
+                col2 = torch.empty_like(col)
+                _lib.check(L.sdfr_project_dcm(_lib.ptr(pose), _lib.ptr(K), _lib.ptr(pts), _lib.ptr(nrm), _lib.ptr(nrm), 1, n, None, mode | 4,
+                                              32, 32, _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(col2), None, None, None, None, None,
+                                              _lib.stream_ptr()), "project")
+                assert torch.equal(col2, (col + 1) / 2)
             assert np.abs(N(p_cam) - z[t + "points_3d"]).max() < 1e-5
             assert np.abs(N(n_cam) - z[t + "normals_3d"]).max() < 1e-5
             assert np.abs(N(col) - z[t + "colors_3d"]).max() < 1e-6

@@ -171,15 +171,24 @@ __global__ __launch_bounds__(256) void sdfr_splat_bbox_kernel(const SplatArgs A,
 
 // ---- forward ----------------------------------------------------------------------------------------------------
 
+#define SPL_NW 4               // waves per 8x8 pixel tile (the forward is a latency chain over the tile's candidates: they are split 4 ways)
+
+// One workgroup of SPL_NW waves per 8x8 pixel tile; lane = pixel.  (1) The waves scan the crop's surfel boxes together, 64*SPL_NW per
+// step, and merge their ballots in surfel order into the tile's candidate list (ascending, deterministic).  (2) Every wave takes a
+// contiguous share of each round of 64*SPL_NW candidates, stages it in its own LDS slice and walks it for its 64 pixels; the per-pixel
+// partial states (nu^2; then the online-softmax running maximum and sums) are merged across the waves in a fixed order, so the result is
+// reproducible bit for bit.  disc: the first sweep also records which pixels each candidate covers (one 64-bit ballot per candidate);
+// the second sweep skips candidates that cover no pixel of the tile and re-evaluates only the plane hit for the others.
 template <int PRIM>
-__global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const SplatArgs A, const int4* __restrict__ bbox, float* __restrict__ color,
-                                                           float* __restrict__ mask, float* __restrict__ depth,
-                                                           float* __restrict__ normals, float* __restrict__ aux) {
+__global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const SplatArgs A, const int4* __restrict__ bbox, float* __restrict__ color,
+                                                                    float* __restrict__ mask, float* __restrict__ depth,
+                                                                    float* __restrict__ normals, float* __restrict__ aux) {
     const int b = blockIdx.y;
     const int W = A.W, H = A.H;
     const int tilesX = (W + 7) >> 3;
     const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int X0 = tx * 8, Y0 = ty * 8;
     const int X1 = min(X0 + 7, W - 1), Y1 = min(Y0 + 7, H - 1);
     const int x = X0 + (lane & 7), y = Y0 + (lane >> 3);
@@ -189,90 +198,115 @@ __global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const SplatArgs A, c
     const float diam = A.diam, C = A.depth_constant;
 
     __shared__ int list[SPL_LC];
-    __shared__ float sd[11][64];
+    __shared__ unsigned long long cov[SPL_LC];
+    __shared__ float sd[SPL_NW][11][64];
+    __shared__ float red[SPL_NW][11][64];
+    __shared__ int wc[2][SPL_NW];
 
-    // candidate list: surfels whose conservative box overlaps this tile, ascending order
+    // ---- (1) candidate list: surfels whose conservative box overlaps this tile, ascending order --------------------------------
     int nc = 0;
-    for (int s0 = 0; s0 < count; s0 += 64) {
-        const int s = s0 + lane;
-        bool ov = false;
-        if (s < count) {
+    {
+        auto overlaps = [&](int s) {
+            if (s >= count) return false;
             const int4 bb = bbox[sb + s];
-            ov = !(bb.x > X1 || bb.z < X0 || bb.y > Y1 || bb.w < Y0);
+            return !(bb.x > X1 || bb.z < X0 || bb.y > Y1 || bb.w < Y0);
+        };
+        bool ov = overlaps(wave * 64 + lane);
+        int par = 0;
+        for (int s0 = 0; s0 < count; s0 += 64 * SPL_NW, par ^= 1) {
+            const int s = s0 + wave * 64 + lane;
+            const bool ovn = overlaps(s + 64 * SPL_NW);              // next step's boxes are in flight across the barrier
+            const unsigned long long bal = __ballot(ov);
+            if (lane == 0) wc[par][wave] = __popcll(bal);
+            __syncthreads();
+            int off = nc, tot = 0;
+#pragma unroll
+            for (int w = 0; w < SPL_NW; ++w) { const int c = wc[par][w]; off += (w < wave) ? c : 0; tot += c; }
+            if (ov) {
+                const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < SPL_LC) list[pos] = s;
+            }
+            nc += tot;
+            ov = ovn;
         }
-        const unsigned long long bal = __ballot(ov);
-        if (ov) {
-            const int pos = nc + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < SPL_LC) list[pos] = s;
-        }
-        nc += __popcll(bal);
     }
     const bool overflow = nc > SPL_LC;
     const int total = overflow ? count : nc;
     __syncthreads();
+    if (total == 0 && !A.bg && !(PRIM == 1 && count > 0)) {          // nothing can touch this tile: all outputs are zero
+        if (wave != 0 || !inside) return;
+        const int P0 = W * H, pix0 = y * W + x;
+        if (color) { float* o = color + (int64_t)b * 3 * P0 + pix0; o[0] = 0.f; o[P0] = 0.f; o[2 * P0] = 0.f; }
+        if (mask) mask[(int64_t)b * P0 + pix0] = 0.f;
+        if (depth) depth[(int64_t)b * P0 + pix0] = 0.f;
+        if (normals) { float* o = normals + (int64_t)b * 3 * P0 + pix0; o[0] = 0.f; o[P0] = 0.f; o[2 * P0] = 0.f; }
+        if (aux) {
+            const unsigned gates0 = 127u;
+            reinterpret_cast<float4*>(aux)[(int64_t)b * P0 + pix0] = make_float4(0.f, 0.f, 0.f, __uint_as_float(gates0));
+        }
+        return;
+    }
 
     float rx = 0.f, ry = 0.f, rz = 0.f;
     if (PRIM == 0) pixel_ray(A.Kinv + (int64_t)b * 9, (float)x, (float)y, rx, ry, rz);
     const float zn = (PRIM != 0) ? A.znorm[b] : 0.f;
     const float k00 = A.K[(int64_t)b * 9];
+    float (*sdw)[64] = sd[wave];
 
-    // walk all candidates: stage 64 at a time into LDS (lane = candidate), then broadcast-read them.  A tile with at most 64
-    // candidates (the common case) stages them once and keeps them resident for both sweeps.
+    // ---- (2) walk the candidates in rounds of 64*SPL_NW: this wave's contiguous share of a round is staged in its LDS slice (lane =
+    // candidate) and broadcast-read.  A tile with at most 64*SPL_NW candidates stages once and keeps them for both sweeps.
     bool resident = false;
     auto for_each = [&](auto&& body) {
-        for (int c0 = 0; c0 < total; c0 += 64) {
-            const int c = c0 + lane;
+        for (int r0 = 0; r0 < total; r0 += 64 * SPL_NW) {
+            const int nr = min(64 * SPL_NW, total - r0);
+            const int q = (nr + SPL_NW - 1) / SPL_NW;                // share per wave (<= 64)
+            const int c0w = r0 + wave * q;
+            const int kn = max(0, min(q, r0 + nr - c0w));
             if (!resident) {
                 __syncthreads();
-                if (c < total) {
-                    const int s = overflow ? c : list[c];
+                if (lane < kn) {
+                    const int s = overflow ? (c0w + lane) : list[c0w + lane];
                     const int64_t e = (sb + s) * 3;
                     const float px = A.p_cam[e], py = A.p_cam[e + 1], pz = A.p_cam[e + 2];
                     const float nx = A.n_cam[e], ny = A.n_cam[e + 1], nz = A.n_cam[e + 2];
-                    sd[2][lane] = pz;
-                    sd[3][lane] = nx; sd[4][lane] = ny; sd[5][lane] = nz;
-                    sd[7][lane] = A.attr[e]; sd[8][lane] = A.attr[e + 1]; sd[9][lane] = A.attr[e + 2];
+                    sdw[2][lane] = pz;
+                    sdw[3][lane] = nx; sdw[4][lane] = ny; sdw[5][lane] = nz;
+                    sdw[7][lane] = A.attr[e]; sdw[8][lane] = A.attr[e + 1]; sdw[9][lane] = A.attr[e + 2];
                     if (PRIM == 0) {
-                        sd[0][lane] = px; sd[1][lane] = py;
-                        sd[6][lane] = nx * px + ny * py + nz * pz;                  // :202
+                        sdw[0][lane] = px; sdw[1][lane] = py;
+                        sdw[6][lane] = nx * px + ny * py + nz * pz;                  // :202
                     } else {
-                        sd[0][lane] = A.uv[(sb + s) * 2]; sd[1][lane] = A.uv[(sb + s) * 2 + 1];
-                        sd[6][lane] = fabsf(k00 * diam / (pz + FLT_EPSILON));       // :47 / :115
-                        sd[10][lane] = depth_logit(pz, zn, C, nullptr);
+                        sdw[0][lane] = A.uv[(sb + s) * 2]; sdw[1][lane] = A.uv[(sb + s) * 2 + 1];
+                        sdw[6][lane] = fabsf(k00 * diam / (pz + FLT_EPSILON));       // :47 / :115
+                        sdw[10][lane] = depth_logit(pz, zn, C, nullptr);
                     }
                 }
                 __syncthreads();
             }
-            const int kn = min(64, total - c0);
-            for (int k = 0; k < kn; ++k) body(k);
+            for (int k = 0; k < kn; ++k) body(k, c0w + k);
         }
-        resident = total <= 64;
-    };
-    // coverage + logit of candidate k for this lane's pixel
-    float nue = 1.f;
-    auto eval = [&](int k, float& logit) -> bool {
-        if (PRIM == 0) {
-            const Hit h = disc_eval(sd[0][k], sd[1][k], sd[2][k], sd[3][k], sd[4][k], sd[5][k], sd[6][k], rx, ry, rz, diam);
-            logit = fmaxf((-h.t) / nue + 1.f, 0.f) * C;                          // :227-230
-            return h.m;
-        } else if (PRIM == 1) {
-            logit = sd[10][k];
-            return circle_cover(sd[0][k], sd[1][k], sd[6][k], (float)x, (float)y);
-        } else {
-            logit = sd[10][k];
-            return stamp_axis(sd[0][k], x, W) && stamp_axis(sd[1][k], y, H);
-        }
+        resident = total <= 64 * SPL_NW;
     };
 
-    float nu = 0.f;
+    float nu = 0.f, nue = 1.f;
     if (PRIM == 0) {   // per-pixel norm nu = || -t * mask ||_2 over the surfels  (:227-228)
         float nu2 = 0.f;
-        for_each([&](int k) {
-            const Hit h = disc_eval(sd[0][k], sd[1][k], sd[2][k], sd[3][k], sd[4][k], sd[5][k], sd[6][k], rx, ry, rz, diam);
+        for_each([&](int k, int c) {
+            const Hit h = disc_eval(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, diam);
             if (h.m) nu2 += h.t * h.t;
+            if (!overflow) {
+                const unsigned long long cm = __ballot(h.m);
+                if (lane == 0) cov[c] = cm;
+            }
         });
+        red[wave][0][lane] = nu2;
+        __syncthreads();
+        nu2 = red[0][0][lane];
+#pragma unroll
+        for (int w = 1; w < SPL_NW; ++w) nu2 += red[w][0][lane];
         nu = sqrtf(nu2);
         nue = nu + FLT_EPSILON;
+        __syncthreads();                                           // red is reused by the second sweep
     }
     // one sweep with a running maximum (online softmax): max logit, softmax sums and composites (rasterer.py:119-144)
     float lmax = -FLT_MAX;
@@ -283,18 +317,60 @@ __global__ __launch_bounds__(64) void sdfr_splat_fwd_kernel(const SplatArgs A, c
         cs *= f; c0 *= f; c1 *= f; c2 *= f; dz *= f; n0 *= f; n1 *= f; n2 *= f;
         lmax = newmax;
     };
-    for_each([&](int k) {
+    for_each([&](int k, int c) {
+        bool hit;
         float l;
-        if (eval(k, l)) {
+        if (PRIM == 0) {
+            if (!overflow) {
+                const unsigned long long cm = cov[c];            // wave-uniform
+                if (cm == 0ull) return;                           // covers no pixel of this tile
+                hit = (cm >> lane) & 1ull;
+                // the plane hit alone, with disc_eval's arithmetic (:209-211)
+                const float b0 = rx * sdw[3][k] + ry * sdw[4][k] + rz * sdw[5][k];
+                const float bb = (fabsf(b0) < 0.01f) ? FLT_EPSILON : b0;
+                const float t = sdw[6][k] / bb;
+                l = fmaxf((-t) / nue + 1.f, 0.f) * C;                             // :227-230
+            } else {
+                const Hit h = disc_eval(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, diam);
+                l = fmaxf((-h.t) / nue + 1.f, 0.f) * C;
+                hit = h.m;
+            }
+        } else if (PRIM == 1) {
+            l = sdw[10][k];
+            hit = circle_cover(sdw[0][k], sdw[1][k], sdw[6][k], (float)x, (float)y);
+        } else {
+            l = sdw[10][k];
+            hit = stamp_axis(sdw[0][k], x, W) && stamp_axis(sdw[1][k], y, H);
+        }
+        if (hit) {
             ++ncov;
             if (l > lmax) rescale(l);
             const float e = expf(l - lmax);
             cs += e;
-            c0 += e * sd[7][k]; c1 += e * sd[8][k]; c2 += e * sd[9][k];
-            dz += e * sd[2][k];
-            n0 += e * ((sd[3][k] + 1.f) / 2.f); n1 += e * ((sd[4][k] + 1.f) / 2.f); n2 += e * ((sd[5][k] + 1.f) / 2.f);
+            c0 += e * sdw[7][k]; c1 += e * sdw[8][k]; c2 += e * sdw[9][k];
+            dz += e * sdw[2][k];
+            n0 += e * ((sdw[3][k] + 1.f) / 2.f); n1 += e * ((sdw[4][k] + 1.f) / 2.f); n2 += e * ((sdw[5][k] + 1.f) / 2.f);
         }
     });
+    // merge the waves' partial states, in wave order
+    {
+        float (*rw)[64] = red[wave];
+        rw[0][lane] = lmax; rw[1][lane] = cs; rw[2][lane] = c0; rw[3][lane] = c1; rw[4][lane] = c2; rw[5][lane] = dz;
+        rw[6][lane] = n0; rw[7][lane] = n1; rw[8][lane] = n2; rw[9][lane] = __int_as_float(ncov);
+        __syncthreads();
+        if (wave != 0) return;
+        float M = lmax;
+#pragma unroll
+        for (int w = 1; w < SPL_NW; ++w) M = fmaxf(M, red[w][0][lane]);
+        if (M > lmax) rescale(M);
+#pragma unroll
+        for (int w = 1; w < SPL_NW; ++w) {
+            const float f = expf(red[w][0][lane] - M);          // a wave without hits holds lmax = -FLT_MAX and zero sums
+            cs += f * red[w][1][lane]; c0 += f * red[w][2][lane]; c1 += f * red[w][3][lane]; c2 += f * red[w][4][lane];
+            dz += f * red[w][5][lane]; n0 += f * red[w][6][lane]; n1 += f * red[w][7][lane]; n2 += f * red[w][8][lane];
+            ncov += __float_as_int(red[w][9][lane]);
+        }
+    }
     const int nunc = count - ncov;
     if (PRIM == 1 && nunc > 0 && 0.f > lmax) rescale(0.f);                        // uncovered surfels keep logit 0 (:70)
     const float lbg = A.bg ? A.bg_logit[b] : 0.f;
@@ -493,15 +569,15 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
     switch (primitive) {
         case 0:
             if (cap > 0) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<0>, gb, dim3(256), 0, s, A, bb);
-            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<0>, gt, dim3(64), 0, s, A, bb, color, mask, depth, normals, aux);
+            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<0>, gt, dim3(64 * SPL_NW), 0, s, A, bb, color, mask, depth, normals, aux);
             break;
         case 1:
             if (cap > 0) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<1>, gb, dim3(256), 0, s, A, bb);
-            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<1>, gt, dim3(64), 0, s, A, bb, color, mask, depth, normals, aux);
+            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<1>, gt, dim3(64 * SPL_NW), 0, s, A, bb, color, mask, depth, normals, aux);
             break;
         default:
             if (cap > 0) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<2>, gb, dim3(256), 0, s, A, bb);
-            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<2>, gt, dim3(64), 0, s, A, bb, color, mask, depth, normals, aux);
+            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<2>, gt, dim3(64 * SPL_NW), 0, s, A, bb, color, mask, depth, normals, aux);
             break;
     }
     SDFR_LAUNCH_CHECK();

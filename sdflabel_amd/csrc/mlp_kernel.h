@@ -487,29 +487,42 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 
     // ---- backward: d out / d inputs for every point of the tile ---------------------------------------------
     // in-gradient of layer l (features k = in-features of layer l) -> masked operand for layer l-1, or J
-    auto store_in_grad = [&](int l, auto&& value) {
+    // MODE 3: the saved mask words of layer l-1 for this lane's features and point, fetched from HBM/L2.  Issued BEFORE the product of
+    // layer l (they do not depend on it), so their latency is hidden behind the K loop instead of sitting in front of the epilogue.
+    // Forward launch layout (32x32 tiles, P.fwd_np point tiles per workgroup): feature jr of this wave, point q of the forward tile ->
+    // bit ((jr/32 * np + q/32)*4 + (jr%32)/8)*4 + jr%4 of thread wave*64 + ((jr%32)/4 % 2)*32 + q%32
+    auto fetch_masks = [&](int l, uint32_t* raw) {
+        const int np = P.fwd_np;
+        const int r = rows[lp];
+        const int tile = r / (32 * np), q = r - tile * (32 * np);
+        const int mwf = FT32 * np / 2;                                   // mask words per thread of the forward kernel
+        const uint32_t* src = P.maskbuf + (((int64_t)tile * P.n_mfma + (l - 1)) * mwf) * NT + wave * 64 + (q & 31);
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) {
+                const int jr = f * MS + rg * (4 * NLG) + 4 * lg;
+                const int fbit = (((jr >> 5) * np + (q >> 5)) * 4 + ((jr & 31) >> 3)) * 4;
+                raw[f * RG + rg] = src[(fbit >> 5) * NT + (((jr & 31) >> 2) & 1) * 32];
+            }
+    };
+    auto store_in_grad = [&](int l, const uint32_t* raw, auto&& value) {
         const MlpLayer L = P.L[l];
         const int prev_out = P.L[l - 1].out_dim;
         const int inj_hi = prev_out + L.inj_n;
         uint32_t mw[MW];
         if (GMASK) {
-            // decode the forward launch's layout (32x32 tiles, P.fwd_np point tiles per workgroup): feature jr of this wave, point q of
-            // the forward tile -> bit ((jr/32 * np + q/32)*4 + (jr%32)/8)*4 + jr%4 of thread wave*64 + ((jr%32)/4 % 2)*32 + q%32
 #pragma unroll
             for (int w = 0; w < MW; ++w) mw[w] = 0u;
             const int np = P.fwd_np;
-            const int r = rows[lp];
-            const int tile = r / (32 * np), q = r - tile * (32 * np);
-            const int mwf = FT32 * np / 2;                                   // mask words per thread of the forward kernel
-            const uint32_t* src = P.maskbuf + (((int64_t)tile * P.n_mfma + (l - 1)) * mwf) * NT + wave * 64 + (q & 31);
+            const int q = rows[lp] % (32 * np);
 #pragma unroll
             for (int f = 0; f < FT; ++f)
 #pragma unroll
                 for (int rg = 0; rg < RG; ++rg) {
                     const int jr = f * MS + rg * (4 * NLG) + 4 * lg;
                     const int fbit = (((jr >> 5) * np + (q >> 5)) * 4 + ((jr & 31) >> 3)) * 4;
-                    const uint32_t word = src[(fbit >> 5) * NT + (((jr & 31) >> 2) & 1) * 32];
-                    const uint32_t nib = (word >> (fbit & 31)) & 0xFu;
+                    const uint32_t nib = (raw[f * RG + rg] >> (fbit & 31)) & 0xFu;
                     const int bit = ((f * NP + 0) * RG + rg) * 4;
                     mw[bit >> 5] |= nib << (bit & 31);
                 }
@@ -604,14 +617,17 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     };
 
     // top: in-gradient of the last linear = w_last[k] * gy[pt]
-    store_in_grad(P.n_mfma, [&](int, int, int, int, int k, int pt) { return P.w_last[k] * gy[pt]; });
+    uint32_t raw[FT * RG];
+    if (GMASK) fetch_masks(P.n_mfma, raw);
+    store_in_grad(P.n_mfma, raw, [&](int, int, int, int, int k, int pt) { return P.w_last[k] * gy[pt]; });
     __syncthreads();
     for (int l = P.n_mfma - 1; l >= 0; --l) {
         const MlpLayer L = P.L[l];
+        if (GMASK && l > 0) fetch_masks(l, raw);
         gemm(reinterpret_cast<const vec_t*>(P.Wb) + L.off_b, L.kp_b, L.in_dim);
         __syncthreads();
         if (l > 0) {
-            store_in_grad(l, [&](int f, int p, int rg, int i, int, int) { return acc[f][p][rg * 4 + i]; });
+            store_in_grad(l, raw, [&](int f, int p, int rg, int i, int, int) { return acc[f][p][rg * 4 + i]; });
             __syncthreads();
         } else {
 #pragma unroll

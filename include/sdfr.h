@@ -96,7 +96,8 @@ int sdfr_mlp_jacobian(const sdfr_decoder* dec, const float* inputs, int64_t rows
                       const int32_t* idx, int cap, const int32_t* cnt, float* J, float* sdf_sel,
                       const float* sdf_full /* optional: output of the sdfr_mlp_forward call over the same rows */,
                       const uint32_t* mask_ws /* optional: masks that call saved; with both, no forward recomputation */,
-                      int mask_from_f16 /* 1 if mask_ws was written by sdfr_mlp_forward_f16 */,
+                      int mask_from_f16 /* 0: mask_ws from sdfr_mlp_forward(_split); 1: from sdfr_mlp_forward_f16, float32 backward;
+                                            2: from sdfr_mlp_forward_f16 and the backward also runs with half operands */,
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -101,7 +101,7 @@ class BatchRenderer:
             mlp_events[1].record()
         ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
         ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.idx), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.sdf),
-                               P(self.mask_ws), int(self.f16), st), "sdfr_mlp_jacobian")
+                               P(self.mask_ws), 2 if self.f16 else 0, st), "sdfr_mlp_jacobian")
         xyz = self.inputs[:, self.NI - 3:]
         ck(L.sdfr_surface_project(P(xyz), self.NI, P(self.sdf), G, B, P(self.idx), cap, P(self.cnt), P(self.J), self.NI, self.NI - 3,
                                   P(self.points), P(self.nocs), P(self.normals), st), "sdfr_surface_project")

@@ -12,6 +12,7 @@ $HIPCC $COMMON -c "$HERE/mlp.hip"     -o "$HERE/obj/mlp.o" &
 $HIPCC $COMMON $SDFR_FWD_DEFS -c "$HERE/mlp_fwd32.hip" -o "$HERE/obj/mlp_fwd32.o" &
 $HIPCC $COMMON $SDFR_F16_DEFS -c "$HERE/mlp_fwd16.hip" -o "$HERE/obj/mlp_fwd16.o" &
 $HIPCC $COMMON $SDFR_SPLIT_DEFS -c "$HERE/mlp_split.hip" -o "$HERE/obj/mlp_split.o" &
+$HIPCC $COMMON $SDFR_J16_DEFS -c "$HERE/mlp_jac16.hip" -o "$HERE/obj/mlp_jac16.o" &
 $HIPCC $COMMON -c "$HERE/mlp_jac.hip"   -o "$HERE/obj/mlp_jac.o" &
 $HIPCC $COMMON -c "$HERE/mlp_small.hip" -o "$HERE/obj/mlp_small.o" &
 $HIPCC $COMMON -c "$HERE/mlp_ln.hip"    -o "$HERE/obj/mlp_ln.o" &
@@ -21,5 +22,5 @@ $HIPCC $COMMON -ffp-contract=off -c "$HERE/splat.hip"   -o "$HERE/obj/splat.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/params.hip"  -o "$HERE/obj/params.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/losses.hip"  -o "$HERE/obj/losses.o" &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${SDFR_LIBNAME:-libsdfr_hip.so}" "$HERE"/obj/{common,mlp,mlp_fwd32,mlp_fwd16,mlp_split,mlp_jac,mlp_small,mlp_ln,surface,project,splat,params,losses}.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${SDFR_LIBNAME:-libsdfr_hip.so}" "$HERE"/obj/{common,mlp,mlp_fwd32,mlp_fwd16,mlp_split,mlp_jac,mlp_jac16,mlp_small,mlp_ln,surface,project,splat,params,losses}.o
 echo "built $OUT/${SDFR_LIBNAME:-libsdfr_hip.so}"

@@ -35,7 +35,7 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
     d->device = device; d->n_lin = n_lin; d->n_inputs = n_inputs; d->use_tanh = use_tanh; d->HP = HP;
     MlpParams& P = d->proto;
     P.n_mfma = n_lin - 1; P.n_inputs = n_inputs; P.use_tanh = use_tanh;
-    int64_t off_f = 0, off_b = 0, off_h = 0, off_s = 0;
+    int64_t off_f = 0, off_b = 0, off_h = 0, off_s = 0, off_bh = 0;
     for (int l = 0; l < n_lin; ++l) {
         MlpLayer& L = P.L[l];
         L.in_dim = in_dim[l]; L.out_dim = out_dim[l]; L.inj_n = inj_n[l]; L.inj_off = inj_off[l];
@@ -44,13 +44,14 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
         L.kp_f = 16 * ((in_dim[l] + 15) / 16); L.kp_b = 16 * ((out_dim[l] + 15) / 16); L.kp_h = 32 * ((in_dim[l] + 31) / 32);
         L.off_f = (int)off_f; L.off_b = (int)off_b; L.off_h = (int)off_h;
         L.kp_s = 64 * ((in_dim[l] + 63) / 64); L.off_s = (int)off_s;
+        L.kp_bh = 128 * ((out_dim[l] + 127) / 128); L.off_bh = (int)off_bh;
         d->macs += (int64_t)in_dim[l] * out_dim[l];
         if (l < n_lin - 1) { off_f += (int64_t)(L.kp_f / 4) * HP; off_b += (int64_t)(L.kp_b / 4) * HP; off_h += (int64_t)(L.kp_h / 8) * HP;
-                             off_s += (int64_t)(L.kp_s / 8) * HP * 2; }
+                             off_s += (int64_t)(L.kp_s / 8) * HP * 2; off_bh += (int64_t)(L.kp_bh / 8) * HP; }
     }
     // images: vector index [k / KV][row], KV consecutive k per 16-byte vector (KV = 4 floats or 8 halfs); zero padded
     std::vector<float> Wf((size_t)off_f * 4, 0.f), Wb((size_t)off_b * 4, 0.f), bias((size_t)(n_lin - 1) * HP, 0.f), wl(HP, 0.f);
-    std::vector<_Float16> Wh((size_t)off_h * 8, (_Float16)0.f), Ws((size_t)off_s * 8, (_Float16)0.f);
+    std::vector<_Float16> Wh((size_t)off_h * 8, (_Float16)0.f), Ws((size_t)off_s * 8, (_Float16)0.f), Wbh((size_t)off_bh * 8, (_Float16)0.f);
     for (int l = 0; l < n_lin - 1; ++l) {
         const MlpLayer& L = P.L[l];
         const float* W = h_W[l];
@@ -64,6 +65,7 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
                 Ws[es] = wh;
                 Ws[es + 8] = (_Float16)((w - (float)wh) * 2048.f);
                 Wb[((size_t)L.off_b + (size_t)(r / 4) * HP + k) * 4 + (r % 4)] = w;          // transposed: rows = in-features, k = out-features
+                Wbh[((size_t)L.off_bh + (size_t)(r / 8) * HP + k) * 8 + (r % 8)] = wh;
             }
         for (int r = 0; r < L.out_dim; ++r) bias[(size_t)l * HP + r] = h_b[l][r];
     }
@@ -85,6 +87,8 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
     }
     SDFR_HIP_CHECK(hipMalloc(&d->d_Wh, Wh.size() * sizeof(_Float16)));
     SDFR_HIP_CHECK(hipMemcpy(d->d_Wh, Wh.data(), Wh.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    SDFR_HIP_CHECK(hipMalloc(&d->d_Wbh, Wbh.size() * sizeof(_Float16)));
+    SDFR_HIP_CHECK(hipMemcpy(d->d_Wbh, Wbh.data(), Wbh.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     SDFR_HIP_CHECK(hipMalloc(&d->d_Ws, Ws.size() * sizeof(_Float16)));
     SDFR_HIP_CHECK(hipMemcpy(d->d_Ws, Ws.data(), Ws.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     SDFR_HIP_CHECK(hipMalloc(&d->d_bias, bias.size() * sizeof(float)));
@@ -93,14 +97,14 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
     SDFR_HIP_CHECK(hipMemcpy(d->d_Wb, Wb.data(), Wb.size() * sizeof(float), hipMemcpyHostToDevice));
     SDFR_HIP_CHECK(hipMemcpy(d->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     SDFR_HIP_CHECK(hipMemcpy(d->d_wlast, wl.data(), wl.size() * sizeof(float), hipMemcpyHostToDevice));
-    P.Wf = d->d_Wf; P.Wb = d->d_Wb; P.Wh = d->d_Wh; P.Ws = d->d_Ws; P.bias = d->d_bias; P.w_last = d->d_wlast; P.fwd_np = 2;
+    P.Wf = d->d_Wf; P.Wb = d->d_Wb; P.Wh = d->d_Wh; P.Ws = d->d_Ws; P.Wbh = d->d_Wbh; P.bias = d->d_bias; P.w_last = d->d_wlast; P.fwd_np = 2;
     *out = d;
     return SDFR_OK;
 }
 
 extern "C" int sdfr_decoder_destroy(sdfr_decoder* d) {
     if (!d) return SDFR_OK;
-    void* bufs[] = {d->d_Wf, d->d_Wb, d->d_Wh, d->d_Ws, d->d_bias, d->d_wlast, d->d_lng, d->d_lnb, d->ln_ws};
+    void* bufs[] = {d->d_Wf, d->d_Wb, d->d_Wh, d->d_Ws, d->d_Wbh, d->d_bias, d->d_wlast, d->d_lng, d->d_lnb, d->ln_ws};
     for (void* b : bufs) (void)hipFree(b);
     delete d;
     return SDFR_OK;
@@ -179,6 +183,7 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     MlpParams P = d->proto;
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
     P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.fwd_np = mask_from_f16 ? 4 : (d->HP == 512 ? sdfr_fwd_f32_512_np() : 2);
+    SDFR_REQUIRE(mask_from_f16 >= 0 && mask_from_f16 <= 2, "sdfr_mlp_jacobian: mask_from_f16 = %d (0, 1 or 2)", mask_from_f16);
     // masks saved by the forward launch make the recomputation unnecessary (not for use_tanh decoders: their output
     // derivative needs the pre-tanh value)
     const bool from_masks = mask_ws && sdf_full && !d->use_tanh && !d->has_ln;
@@ -196,7 +201,8 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
         }
         P.ln_ws = d->ln_ws;
         sdfr_launch_ln(P, d->HP, true, gx, B, s);
-    } else if (d->HP == 512) sdfr_launch_jac_f32_512(P, cap, B, from_masks, s);
+    } else if (d->HP == 512 && mask_from_f16 == 2 && from_masks) sdfr_launch_jac_f16_512(P, cap, B, s);      // half operands, like the forward
+    else if (d->HP == 512) sdfr_launch_jac_f32_512(P, cap, B, from_masks, s);
     else sdfr_launch_small(P, d->HP, from_masks ? 3 : 2, sdfr_cdiv(cap, 32), B, s);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;

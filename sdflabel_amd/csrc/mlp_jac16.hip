@@ -1,0 +1,11 @@
+// Band Jacobian of the float16 decoder, padded hidden width 512: mask-fed backward (MODE 3) with half operands on
+// v_mfma_f32_16x16x32_f16 (float32 accumulation), 16-point workgroups.  The in-gradients are rounded to half between layers like the
+// forward's activations; the transposed half weight image is half the bytes of the float32 one, and the kernel is paced by that stream.
+#include "mlp_kernel.h"
+#ifndef SDFR_J16_PF
+#define SDFR_J16_PF 4
+#endif
+void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s) {
+    const dim3 grid(sdfr_cdiv(cap, 16), B);
+    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, 4, 1, 8, SDFR_J16_PF, 3>), grid, dim3(512), 0, s, P);
+}

@@ -36,6 +36,7 @@ struct MlpLayer {
     int inj_n, inj_off;     // input columns concatenated BEFORE this layer
     int kp_f, kp_b, kp_h;   // padded K extents: forward f32 (in_dim -> x16), backward f32 (out_dim -> x16), forward f16 (in_dim -> x32)
     int off_f, off_b, off_h;// 16-byte-vector offsets of the layer's image in Wf / Wb / Wh
+    int kp_bh, off_bh;      // float16 backward: out_dim padded to x128, 16-byte-vector offset of the layer's image in Wbh
     int kp_s, off_s;        // split forward: K padded to x64, 16-byte-vector offset of the layer's image in Ws
     int ln;                 // LayerNorm (eps 1e-5, affine) between this layer's linear and its ReLU (deep_sdf_decoder_scale.py:56-57,99-101)
 };
@@ -44,6 +45,7 @@ struct MlpParams {
     const float4* Wf;       // forward image, float32:  [k/4][HP] float4
     const float4* Wb;       // backward (transposed) image, float32
     const void* Wh;         // forward image, float16:  [k/8][HP] 8 x half
+    const void* Wbh;        // backward (transposed) image, float16:  [j/8][HP] 8 x half (the float16 decoder's mask-fed Jacobian)
     const void* Ws;         // split-forward image: [k/8][HP][2] 8 x half -- hi = half(w) and lo = half((w - hi) * 2^11) side by side
     int fwd_np;             // MODE 3: point tiles per workgroup of the forward launch that saved the masks (2: f32, 4: f16)
     const float* bias;      // [n_mfma][HP]
@@ -78,6 +80,7 @@ struct sdfr_decoder {
     float4* d_Wb;
     void* d_Wh;
     void* d_Ws;
+    void* d_Wbh;
     float* d_lng;           // LayerNorm weight / bias images [n_mfma][HP] (NULL without LN)
     float* d_lnb;
     int has_ln;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     constexpr bool GMASK = MODE == 3;
     static_assert(!SAVE || MS == 32, "mask layout assumes 32x32 forward tiles");
     static_assert(!SAVE || (FT * NP) % 2 == 0, "mask words: FT*NP*16 bits per thread and layer must fill whole words");
-    static_assert(!HALF || !JAC, "the Jacobian modes are float32");
+    static_assert(!HALF || !JAC || MODE == 3, "with half operands only the mask-fed Jacobian exists (MODE 3)");
     static_assert(!LN || (!HALF && MODE != 1 && MODE != 3), "LayerNorm decoders: float32 forward (MODE 0) and recomputing Jacobian (MODE 2)");
     constexpr int KV = M::KV;                                      // operand elements per 16-byte fragment
     constexpr int NLG = 64 / MS;                                   // lane groups (k slots per MFMA)
@@ -624,7 +627,8 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     for (int l = P.n_mfma - 1; l >= 0; --l) {
         const MlpLayer L = P.L[l];
         if (GMASK && l > 0) fetch_masks(l, raw);
-        gemm(reinterpret_cast<const vec_t*>(P.Wb) + L.off_b, L.kp_b, L.in_dim);
+        gemm(reinterpret_cast<const vec_t*>(HALF ? (const void*)P.Wbh : (const void*)P.Wb) + (HALF ? L.off_bh : L.off_b), HALF ? L.kp_bh : L.kp_b,
+             L.in_dim);
         __syncthreads();
         if (l > 0) {
             store_in_grad(l, raw, [&](int f, int p, int rg, int i, int, int) { return acc[f][p][rg * 4 + i]; });
@@ -658,6 +662,7 @@ int sdfr_fwd_f32_512_np();                                                      
 void sdfr_launch_fwd_f16_512(const MlpParams& P, int grid, bool save_masks, hipStream_t s);      // mlp_fwd16.hip
 void sdfr_launch_fwd_split_512(const MlpParams& P, int64_t n, bool save_masks, hipStream_t s);  // mlp_split.hip
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s); // mlp_jac.hip
+void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s);                  // mlp_jac16.hip (mask-fed only)
 void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)
 void sdfr_launch_ln(const MlpParams& P, int HP, bool jac, int grid_x, int grid_y, hipStream_t s);        // mlp_ln.hip (LayerNorm decoders)
 int sdfr_ln_points_per_wg(int HP, bool jac);

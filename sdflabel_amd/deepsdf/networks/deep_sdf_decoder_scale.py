@@ -72,9 +72,10 @@ class SdfState:
         self.split = False            # the forward launch used error-compensated float16 operand pairs (float32-equivalent)
 
 
-def mlp_jacobian(state, idx, n, use_masks=True):
+def mlp_jacobian(state, idx, n, use_masks=True, half=None):
     """J (n, NI), sdf_sel (n,) for the rows idx[:n] of state.inputs.  With the masks the forward launch saved the Jacobian is a
-    backward-only pass; otherwise the kernel recomputes the forward for the selected rows."""
+    backward-only pass; otherwise the kernel recomputes the forward for the selected rows.  half: run the mask-fed backward with half
+    operands too (default: whatever the forward used; half=False keeps the float32 backward on top of a float16 forward)."""
     L = _lib.lib()
     J = torch.empty((max(n, 1), state.inputs.shape[1]), dtype=torch.float32, device=state.inputs.device)
     sel = torch.empty((max(n, 1),), dtype=torch.float32, device=state.inputs.device)
@@ -82,7 +83,8 @@ def mlp_jacobian(state, idx, n, use_masks=True):
         um = use_masks and state.mask_ws is not None and state.sdf is not None
         _lib.check(L.sdfr_mlp_jacobian(state.handle.h, _lib.ptr(state.inputs), state.G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
                                        _lib.ptr(sel), _lib.ptr(state.sdf) if um else None, _lib.ptr(state.mask_ws) if um else None,
-                                       int(state.f16), _lib.stream_ptr()), "sdfr_mlp_jacobian")
+                                       (2 if (state.f16 if half is None else half) else 1) if state.f16 else 0, _lib.stream_ptr()),
+                   "sdfr_mlp_jacobian")
     return J[:n], sel[:n]
 
 

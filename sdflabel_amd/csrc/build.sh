@@ -13,7 +13,7 @@ $HIPCC $COMMON $SDFR_FWD_DEFS -c "$HERE/mlp_fwd32.hip" -o "$HERE/obj/mlp_fwd32.o
 $HIPCC $COMMON $SDFR_F16_DEFS -c "$HERE/mlp_fwd16.hip" -o "$HERE/obj/mlp_fwd16.o" &
 $HIPCC $COMMON $SDFR_SPLIT_DEFS -c "$HERE/mlp_split.hip" -o "$HERE/obj/mlp_split.o" &
 $HIPCC $COMMON $SDFR_J16_DEFS -c "$HERE/mlp_jac16.hip" -o "$HERE/obj/mlp_jac16.o" &
-$HIPCC $COMMON -c "$HERE/mlp_jac.hip"   -o "$HERE/obj/mlp_jac.o" &
+$HIPCC $COMMON $SDFR_JAC_DEFS -c "$HERE/mlp_jac.hip"   -o "$HERE/obj/mlp_jac.o" &
 $HIPCC $COMMON -c "$HERE/mlp_small.hip" -o "$HERE/obj/mlp_small.o" &
 $HIPCC $COMMON -c "$HERE/mlp_ln.hip"    -o "$HERE/obj/mlp_ln.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/surface.hip" -o "$HERE/obj/surface.o" &

@@ -150,7 +150,7 @@ extern "C" int sdfr_mlp_forward_f16(const sdfr_decoder* d, const float* inputs, 
     if (n == 0) return SDFR_OK;
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws;
-    sdfr_launch_fwd_f16_512(P, sdfr_cdiv(n, 128), mask_ws != nullptr, (hipStream_t)stream);
+    sdfr_launch_fwd_f16_512(P, n, mask_ws != nullptr, (hipStream_t)stream);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -182,7 +182,7 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     hipStream_t s = (hipStream_t)stream;
     MlpParams P = d->proto;
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
-    P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.fwd_np = mask_from_f16 ? 4 : (d->HP == 512 ? sdfr_fwd_f32_512_np() : 2);
+    P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.fwd_np = mask_from_f16 ? sdfr_fwd_f16_512_np() : (d->HP == 512 ? sdfr_fwd_f32_512_np() : 2);
     SDFR_REQUIRE(mask_from_f16 >= 0 && mask_from_f16 <= 2, "sdfr_mlp_jacobian: mask_from_f16 = %d (0, 1 or 2)", mask_from_f16);
     // masks saved by the forward launch make the recomputation unnecessary (not for use_tanh decoders: their output
     // derivative needs the pre-tanh value)

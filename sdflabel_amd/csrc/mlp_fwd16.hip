@@ -7,10 +7,15 @@
 #define SDFR_H_PF 2
 #define SDFR_H_PFB 2
 #endif
-void sdfr_launch_fwd_f16_512(const MlpParams& P, int grid, bool save_masks, hipStream_t s) {
+#ifndef SDFR_H_NP
+#define SDFR_H_NP 4            // point tiles (32 points) per workgroup
+#endif
+int sdfr_fwd_f16_512_np() { return SDFR_H_NP; }
+void sdfr_launch_fwd_f16_512(const MlpParams& P, int64_t n, bool save_masks, hipStream_t s) {
+    const int grid = sdfr_cdiv(n, 32 * SDFR_H_NP);
     static_assert(SDFR_H_FT * SDFR_H_NW == 16, "padded width 512 = 32 * FT * NW");
     if (save_masks)
-        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, SDFR_H_FT, 4, SDFR_H_NW, SDFR_H_PF, 1, SDFR_H_PFB>), dim3(grid), dim3(64 * SDFR_H_NW), 0, s, P);
+        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, SDFR_H_FT, SDFR_H_NP, SDFR_H_NW, SDFR_H_PF, 1, SDFR_H_PFB>), dim3(grid), dim3(64 * SDFR_H_NW), 0, s, P);
     else
-        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, SDFR_H_FT, 4, SDFR_H_NW, SDFR_H_PF, 0, SDFR_H_PFB>), dim3(grid), dim3(64 * SDFR_H_NW), 0, s, P);
+        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, SDFR_H_FT, SDFR_H_NP, SDFR_H_NW, SDFR_H_PF, 0, SDFR_H_PFB>), dim3(grid), dim3(64 * SDFR_H_NW), 0, s, P);
 }

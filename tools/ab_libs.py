@@ -24,7 +24,7 @@ for r in range(5):
 print("%%.4f %%.4f %%.8f" %% (min(ts), sorted(ts)[2], float(out.double().sum())))
 ''' % ROOT
 libs = sorted(glob.glob(os.path.join(ROOT, "sdflabel_amd", "lib", "ab", "*.so")))
-for rnd in range(2):
+for rnd in range(int(os.environ.get("AB_ROUNDS", "2"))):
     for lib in libs:
         env = dict(os.environ, SDFR_LIB=lib)
         out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)

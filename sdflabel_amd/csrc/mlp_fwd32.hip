@@ -3,7 +3,7 @@
 // tiles (32 points each) per workgroup, weight-fragment ring SDFR_FWD_PF, activation-fragment ring SDFR_FWD_PFB.
 #include "mlp_kernel.h"
 #ifndef SDFR_FWD_PF
-#define SDFR_FWD_PF 8
+#define SDFR_FWD_PF 2
 #endif
 #ifndef SDFR_FWD_PFB
 #define SDFR_FWD_PFB 2

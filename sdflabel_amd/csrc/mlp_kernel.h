@@ -268,6 +268,33 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #pragma unroll
         for (int u = 0; u < PFB - 1; ++u)
             if (u < nkt) load_b(u, b[u]);
+#ifndef SDFR_STRAIGHT_KLOOP
+#define SDFR_STRAIGHT_KLOOP 1
+#endif
+        if (SDFR_STRAIGHT_KLOOP && FULL && nkt % PF == 0) {
+            // The common case (every 512-wide layer): a K loop WITHOUT branches.  Prefetch indices are clamped instead of guarded (the
+            // tail re-reads the last tile into ring slots nobody consumes), so the body is one basic block and the compiler's s_waitcnt
+            // counts stay exact: with the guarded form below it falls back to vmcnt(0) once per PF tiles -- a wait for loads it has just
+            // issued, i.e. a full L2 round trip exposed (the 16-point Jacobian lost 40 % of its matrix-pipe time to that).
+            const int last = nkt - 1;
+            for (int t = 0; t < nkt; t += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    load_a(min(t + u + PF - 1, last), a[(u + PF - 1) % PF]);
+                    load_b(min(t + u + PFB - 1, last), b[(u + PFB - 1) % PFB]);
+                    __builtin_amdgcn_sched_barrier(0);      // keep each stage's prefetch ahead of its products (the scheduler otherwise
+                                                            // gathers all loads of the unrolled body in one place and waits on them at once)
+#pragma unroll
+                    for (int ks = 0; ks < M::NSTEP; ++ks)
+#pragma unroll
+                        for (int f = 0; f < FT; ++f)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) acc[f][p] = M::step(a[u][f], b[u % PFB][p], acc[f][p], ks);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            return;
+        }
         for (int t = 0; t < nkt; t += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
@@ -633,7 +660,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         if (l > 0) {
             store_in_grad(l, raw, [&](int f, int p, int rg, int i, int, int) { return acc[f][p][rg * 4 + i]; });
             __syncthreads();
-        } else {
+            } else {
 #pragma unroll
             for (int f = 0; f < FT; ++f)
 #pragma unroll

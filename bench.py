@@ -353,7 +353,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_mlp_forward.json")
         if os.path.isfile(tpath) and CB == 1:      # the committed PMC passes profiled the single-crop launch
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        line["roofline"] = {"kernel": "sdfr_mlp_kernel<float,32,2,2,8,8,1,2> (fused decoder forward on the grid, saves ReLU masks)", "bound": "mfma",
+        line["roofline"] = {"kernel": "sdfr_mlp_kernel<float,32,2,2,8,2,1,2> (fused decoder forward on the grid, saves ReLU masks)", "bound": "mfma",
                             "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                             "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": mlp_ms}
         line["dropin_api"] = dropin

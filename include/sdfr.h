@@ -215,15 +215,17 @@ int sdfr_scatter_add_rows3(float* dst, const float* src, const int32_t* idx, int
 
 /* compute_loss_3d (optimizer.py:166-198): exact nearest lidar point (lidar/scale, :84) of every estimated point est[b][j], j < ecnt[b];
  * pairs with distance < threshold/scale[b]; loss[b] = mean pair distance (0 without pairs).  g_est [B][ecap][3] and g_scale [B] receive
- * weight * d loss / d(est, scale).  npairs[b] = number of pairs, or -1 when either cloud is empty (the loop skips the crop, :127-129). */
+ * weight * d loss / d(est, scale).  npairs[b] = number of pairs, or -1 when either cloud is empty (the loop skips the crop, :127-129).
+ * scratch: 3 * B * ceil(ecap / 64) floats (partial sums of the two-pass reduction). */
 int sdfr_loss_3d(const float* est, const int32_t* ecnt, int ecap, const float* lidar, const int32_t* lcnt, int lcap, const float* scale,
-                 float threshold, float weight, int B, float* loss, float* g_est, float* g_scale, int32_t* npairs, void* stream);
+                 float threshold, float weight, int B, float* loss, float* g_est, float* g_scale, int32_t* npairs, float* scratch,
+                 void* stream);
 
 /* compute_loss_2d (optimizer.py:200-237) on rend, target [B][3][H][W]: per rendered non-zero pixel the smallest distance to the target
  * weighted by clamp(diam - pixel distance, 0); loss[b] = mean of the minima below threshold_nocs (NaN if none, 0 without rendered pixels,
  * exactly as the reference); g_rend = weight * d loss / d rend; nvalid[b] = number of pixels in the mean. */
 int sdfr_loss_2d(const float* rend, const float* target, int B, int H, int W, float diam, float threshold_nocs, float weight,
-                 float* loss, float* g_rend, int32_t* nvalid, float* scratch /* float[B * ceil(H*W/256) * 3] */, void* stream);
+                 float* loss, float* g_rend, int32_t* nvalid, float* scratch /* float[3 * B * ceil(W/16) * ceil(H/16)] */, void* stream);
 
 /* MultipleOptimizer.step (optimizer.py:13-23,34-52): Adam(lr_adam, betas .9/.999, eps 1e-8) on yaw and trans, SGD on scale (lr_scale) and
  * latent (lr_latent).  params / grads are ONE flat structure-of-arrays buffer [ yaw(B) | trans(B,3) | scale(B) | latent(B,L) ].

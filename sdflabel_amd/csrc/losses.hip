@@ -10,83 +10,121 @@
 //                     outside the window, evaluated here per pixel.
 //   sdfr_solver_step  the MultipleOptimizer step (:13-23,44-52): Adam(lr .01) on yaw and trans, SGD(lr .01 / 3e-5) on scale / latent,
 //                     gated per crop by the loop's skip conditions (:127-129,149-151).
-// One workgroup per crop with fixed-order reductions: bit-repeatable.  Compiled with -ffp-contract=off.
+// Fixed-order reductions throughout: bit-repeatable.  Compiled with -ffp-contract=off.
 #include "sdfr_common.h"
 #include <float.h>
 
-#define L_THREADS 1024
-
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int w = 0; w < L_THREADS / 64; ++w) t += red[w];
-    return t;
-}
-
 // ---- 3-D loss ----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(L_THREADS) void sdfr_loss_3d_kernel(const float* __restrict__ est, const int32_t* __restrict__ ecnt, int ecap,
-                                                                const float* __restrict__ lidar, const int32_t* __restrict__ lcnt,
-                                                                int lcap, const float* __restrict__ scale, float threshold, float weight,
-                                                                float* __restrict__ loss, float* __restrict__ g_est,
-                                                                float* __restrict__ g_scale, int32_t* __restrict__ npairs) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+// pass 1: one workgroup of 4 waves per 64 estimated points (lane = point); wave w scans lidar points [w*nl/4, (w+1)*nl/4) out of an LDS
+//         tile, the four candidates are merged in wave order with a strict '<' (so ties resolve to the lowest lidar index, as a
+//         sequential scan would); the point's un-normalised gradient and the workgroup's partial sums (distance, d/dscale, pairs) are
+//         written in a fixed order;
+// pass 2: every workgroup re-reduces the partials in the same order and scales its share of the gradient; workgroup 0 writes the loss.
+#define L3_PTS 64
+#define L3_NW 4
+#define L3_TILE 1024
+__global__ __launch_bounds__(64 * L3_NW) void sdfr_loss_3d_pairs_kernel(const float* __restrict__ est, const int32_t* __restrict__ ecnt,
+                                                                       int ecap, const float* __restrict__ lidar,
+                                                                       const int32_t* __restrict__ lcnt, int lcap,
+                                                                       const float* __restrict__ scale, float threshold,
+                                                                       float* __restrict__ g_est, float* __restrict__ partial) {
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ne = sdfr_count(ecnt, b, ecap), nl = sdfr_count(lcnt, b, lcap);
     const float s = scale[b];
     const float thr = threshold / s;                                   // :184
-    __shared__ float tile[3][L_THREADS];
-    __shared__ float red[L_THREADS / 64];
-    float lsum = 0.f, gs = 0.f;
-    int cnt = 0;
+    __shared__ float tile[3][L3_TILE];
+    __shared__ float cd[L3_NW][L3_PTS];
+    __shared__ int ci[L3_NW][L3_PTS];
     const float* E = est + (int64_t)b * ecap * 3;
     const float* Lp = lidar + (int64_t)b * lcap * 3;
     float* G = g_est + (int64_t)b * ecap * 3;
-    for (int j0 = 0; j0 < ne; j0 += L_THREADS) {
-        const int j = j0 + tid;
-        const bool act = j < ne;
-        const float ex = act ? E[j * 3] : 0.f, ey = act ? E[j * 3 + 1] : 0.f, ez = act ? E[j * 3 + 2] : 0.f;
-        float best = FLT_MAX;
-        int bi = -1;
-        for (int m0 = 0; m0 < nl; m0 += L_THREADS) {
-            __syncthreads();
-            if (m0 + tid < nl) {                                        // lidar / scale (:84), staged once per tile
-                tile[0][tid] = Lp[(m0 + tid) * 3] / s; tile[1][tid] = Lp[(m0 + tid) * 3 + 1] / s; tile[2][tid] = Lp[(m0 + tid) * 3 + 2] / s;
-            }
-            __syncthreads();
-            const int mn = min(L_THREADS, nl - m0);
-            if (act)
-                for (int m = 0; m < mn; ++m) {
-                    const float dx = tile[0][m] - ex, dy = tile[1][m] - ey, dz = tile[2][m] - ez;
-                    const float d2 = dx * dx + dy * dy + dz * dz;
-                    if (d2 < best) { best = d2; bi = m0 + m; }
-                }
+    const int j = blockIdx.x * L3_PTS + lane;
+    if (blockIdx.x * L3_PTS >= ne || nl == 0) {                        // nothing to pair in this workgroup: zero rows, zero partials
+        if (wave == 0) {
+            if (j < ecap) { G[j * 3] = 0.f; G[j * 3 + 1] = 0.f; G[j * 3 + 2] = 0.f; }
+            if (lane < 3) partial[((int64_t)b * gridDim.x + blockIdx.x) * 3 + lane] = 0.f;
+        }
+        return;
+    }
+    const bool act = j < ne;
+    const float ex = act ? E[j * 3] : 0.f, ey = act ? E[j * 3 + 1] : 0.f, ez = act ? E[j * 3 + 2] : 0.f;
+    float best = FLT_MAX;
+    int bi = -1;
+    for (int m0 = 0; m0 < nl; m0 += L3_TILE) {
+        __syncthreads();
+        for (int m = tid; m < L3_TILE && m0 + m < nl; m += 64 * L3_NW) {      // lidar / scale (:84), staged once per tile
+            tile[0][m] = Lp[(m0 + m) * 3] / s; tile[1][m] = Lp[(m0 + m) * 3 + 1] / s; tile[2][m] = Lp[(m0 + m) * 3 + 2] / s;
+        }
+        __syncthreads();
+        const int mn = min(L3_TILE, nl - m0);
+        const int q = (mn + L3_NW - 1) / L3_NW;
+        const int lo = wave * q, hi = min(mn, lo + q);
+        for (int m = lo; m < hi; ++m) {
+            const float dx = tile[0][m] - ex, dy = tile[1][m] - ey, dz = tile[2][m] - ez;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < best) { best = d2; bi = m0 + m; }
+        }
+    }
+    cd[wave][lane] = best; ci[wave][lane] = bi;
+    __syncthreads();
+    float lsum = 0.f, gs = 0.f, cnt = 0.f;
+    if (wave == 0) {
+        // the waves scanned ascending, disjoint index ranges per tile; over several tiles a later tile may hold a smaller index range of
+        // another wave, so ties are broken on the index explicitly
+#pragma unroll
+        for (int w = 1; w < L3_NW; ++w) {
+            const float d2 = cd[w][lane];
+            const int i2 = ci[w][lane];
+            if (d2 < best || (d2 == best && i2 >= 0 && i2 < bi)) { best = d2; bi = i2; }
         }
         float gx = 0.f, gy = 0.f, gz = 0.f;
         if (act && bi >= 0 && sqrtf(best) < thr) {                       // :184
             const float lx = Lp[bi * 3] / s, ly = Lp[bi * 3 + 1] / s, lz = Lp[bi * 3 + 2] / s;
             const float dx = lx - ex, dy = ly - ey, dz = lz - ez;
             const float d = sqrtf(dx * dx + dy * dy + dz * dz);          // :185
-            lsum += d;
-            ++cnt;
+            lsum = d;
+            cnt = 1.f;
             if (d > 0.f) {
                 const float ux = dx / d, uy = dy / d, uz = dz / d;       // d||l/s - e|| / d(l/s)
                 gx = -ux; gy = -uy; gz = -uz;
-                gs += -(ux * lx + uy * ly + uz * lz) / s;                // d(l/s)/ds = -(l/s)/s
+                gs = -(ux * lx + uy * ly + uz * lz) / s;                 // d(l/s)/ds = -(l/s)/s
             }
         }
-        if (act) { G[j * 3] = gx; G[j * 3 + 1] = gy; G[j * 3 + 2] = gz; }
+        if (j < ecap) { G[j * 3] = gx; G[j * 3 + 1] = gy; G[j * 3 + 2] = gz; }     // rows beyond ne: zero
+        float v[3] = {lsum, gs, cnt};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float x = v[i];
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+            if (lane == 0) partial[((int64_t)b * gridDim.x + blockIdx.x) * 3 + i] = x;
+        }
     }
-    const float tot = block_sum(lsum, red);
-    const float gst = block_sum(gs, red);
-    const float cf = block_sum((float)cnt, red);
+}
+
+__global__ __launch_bounds__(256) void sdfr_loss_3d_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                                   const int32_t* __restrict__ ecnt, int ecap,
+                                                                   const int32_t* __restrict__ lcnt, int lcap, float weight,
+                                                                   float* __restrict__ loss, float* __restrict__ g_est,
+                                                                   float* __restrict__ g_scale, int32_t* __restrict__ npairs) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ float red[3][256];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = tid; i < nblk; i += 256) {
+        const float* p = partial + ((int64_t)b * nblk + i) * 3;
+        a0 += p[0]; a1 += p[1]; a2 += p[2];
+    }
+    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) { red[0][tid] += red[0][tid + st]; red[1][tid] += red[1][tid + st]; red[2][tid] += red[2][tid + st]; }
+        __syncthreads();
+    }
+    const float tot = red[0][0], gst = red[1][0], cf = red[2][0];
     const float inv = cf > 0.f ? 1.f / cf : 0.f;
-    for (int j = tid; j < ne; j += L_THREADS) {                          // mean over the pairs (:189), times the loss weight
-        G[j * 3] *= weight * inv; G[j * 3 + 1] *= weight * inv; G[j * 3 + 2] *= weight * inv;
-    }
-    for (int j = ne + tid; j < ecap; j += L_THREADS) { G[j * 3] = 0.f; G[j * 3 + 1] = 0.f; G[j * 3 + 2] = 0.f; }
-    if (tid == 0) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + tid;                   // mean over the pairs (:189), times the loss weight
+    if (e < (int64_t)3 * ecap) g_est[(int64_t)b * 3 * ecap + e] *= weight * inv;
+    if (blockIdx.x == 0 && tid == 0) {
+        const int ne = sdfr_count(ecnt, b, ecap), nl = sdfr_count(lcnt, b, lcap);
         loss[b] = cf > 0.f ? tot * inv : 0.f;                            // :188-191
         g_scale[b] = weight * gst * inv;
         npairs[b] = (ne > 0 && nl > 0) ? (int)cf : -1;                   // -1: a cloud is empty -> the loop skips the crop (:127-129)
@@ -95,34 +133,69 @@ __global__ __launch_bounds__(L_THREADS) void sdfr_loss_3d_kernel(const float* __
 
 extern "C" int sdfr_loss_3d(const float* est, const int32_t* ecnt, int ecap, const float* lidar, const int32_t* lcnt, int lcap,
                             const float* scale, float threshold, float weight, int B, float* loss, float* g_est, float* g_scale,
-                            int32_t* npairs, void* stream) {
-    SDFR_REQUIRE(est && lidar && scale && loss && g_est && g_scale && npairs, "sdfr_loss_3d: NULL argument");
+                            int32_t* npairs, float* scratch, void* stream) {
+    SDFR_REQUIRE(est && lidar && scale && loss && g_est && g_scale && npairs && scratch, "sdfr_loss_3d: NULL argument");
+    SDFR_REQUIRE(ecap > 0 && lcap >= 0, "sdfr_loss_3d: bad capacity");
     if (B <= 0) return SDFR_OK;
-    hipLaunchKernelGGL(sdfr_loss_3d_kernel, dim3(B), dim3(L_THREADS), 0, (hipStream_t)stream, est, ecnt, ecap, lidar, lcnt, lcap, scale,
-                       threshold, weight, loss, g_est, g_scale, npairs);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = sdfr_cdiv(ecap, L3_PTS);
+    hipLaunchKernelGGL(sdfr_loss_3d_pairs_kernel, dim3(nblk, B), dim3(64 * L3_NW), 0, s, est, ecnt, ecap, lidar, lcnt, lcap, scale, threshold,
+                       g_est, scratch);
+    SDFR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sdfr_loss_3d_finalize_kernel, dim3(sdfr_cdiv(3 * ecap, 256), B), dim3(256), 0, s, scratch, nblk, ecnt, ecap, lcnt, lcap,
+                       weight, loss, g_est, g_scale, npairs);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
 
 // ---- 2-D loss ----------------------------------------------------------------------------------------------------------
-// pass 1: one thread per pixel (window search, un-normalised gradient), fixed-order partial sums per 256-pixel block;
-// pass 2: every block re-reduces the (few hundred) partials in the same order, scales its share of the gradient; block 0 writes the loss.
-__global__ __launch_bounds__(256) void sdfr_loss_2d_pixels_kernel(const float* __restrict__ rend, const float* __restrict__ target, int H,
-                                                                 int W, float diam, float threshold_nocs, float* __restrict__ g_rend,
-                                                                 float* __restrict__ partial) {
+// pass 1: one thread per pixel, one workgroup per 16x16 pixel tile.  A tile that holds a rendered pixel stages the target window
+//         (tile + halo, all three channels) and the (2*rad+1)^2 tap weights in LDS; the window search then runs out of LDS in the
+//         reference's tap order.  Un-normalised gradient per pixel, fixed-order partial sums per tile;
+// pass 2: every workgroup re-reduces the partials in the same order, scales its share of the gradient; workgroup 0 writes the loss.
+#define L2_T 16
+#define L2_RMAX 8                       // window radius the LDS path is built for (diam <= 9); larger windows read the target from memory
+#define L2_S 48                         // LDS row pitch: consecutive tile rows fall 16 banks apart
+__global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const float* __restrict__ rend, const float* __restrict__ target,
+                                                                         int H, int W, float diam, float threshold_nocs,
+                                                                         float* __restrict__ g_rend, float* __restrict__ partial) {
     const int b = blockIdx.y, tid = threadIdx.x;
     const int P = H * W;
     const float* R = rend + (int64_t)b * 3 * P;
     const float* Tg = target + (int64_t)b * 3 * P;
     float* G = g_rend + (int64_t)b * 3 * P;
     const int rad = (int)ceilf(diam) - 1;                               // taps with clamp(diam - dist, 0) > 0 have |d| < diam
-    const int q = blockIdx.x * 256 + tid;
+    const int tilesX = (W + L2_T - 1) / L2_T;
+    const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
+    const int lx = tid & (L2_T - 1), ly = tid / L2_T;
+    const int w = tx * L2_T + lx, h = ty * L2_T + ly;
+    const bool inside = (w < W) && (h < H);
+    const int q = h * W + w;
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    if (inside) { r0 = R[q]; r1 = R[P + q]; r2 = R[2 * P + q]; }
+    const bool nz = inside && (r0 + r1 + r2 != 0.f);                    // rendering_nocs.sum(0).nonzero()  (:213)
+    __shared__ float tg[3][(L2_T + 2 * L2_RMAX) * L2_S];
+    __shared__ float wt[(2 * L2_RMAX + 1) * (2 * L2_RMAX + 1)];
+    const bool lds = rad <= L2_RMAX;
+    const int side = 2 * rad + 1, span = L2_T + 2 * rad;
+    if (__syncthreads_or(nz) && lds) {
+        for (int i = tid; i < span * span; i += L2_T * L2_T) {
+            const int yy = i / span, xx = i - yy * span;
+            const int hh = ty * L2_T - rad + yy, ww = tx * L2_T - rad + xx;
+            const bool in = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const int p = hh * W + ww;
+            tg[0][yy * L2_S + xx] = in ? Tg[p] : 0.f; tg[1][yy * L2_S + xx] = in ? Tg[P + p] : 0.f; tg[2][yy * L2_S + xx] = in ? Tg[2 * P + p] : 0.f;
+        }
+        for (int i = tid; i < side * side; i += L2_T * L2_T) {
+            const int dh = i / side - rad, dw = i % side - rad;
+            wt[i] = fmaxf(diam - sqrtf((float)(dh * dh) + (float)(dw * dw)), 0.f);                     // :224-225
+        }
+        __syncthreads();
+    }
     float lsum = 0.f, cnt = 0.f, any = 0.f;
-    if (q < P) {
-        const float r0 = R[q], r1 = R[P + q], r2 = R[2 * P + q];
+    if (inside) {
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        if (r0 + r1 + r2 != 0.f) {                                      // rendering_nocs.sum(0).nonzero()  (:213)
-            const int h = q / W, w = q - h * W;
+        if (nz) {
             any = ((h | w) != 0) ? 1.f : 0.f;                           // `if rendering_nonzero_idxs.sum()` (:214)
             // every pixel outside the window has weight 0: masked target 0, distance ||r||  (:223-231)
             float best = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
@@ -133,9 +206,17 @@ __global__ __launch_bounds__(256) void sdfr_loss_2d_pixels_kernel(const float* _
                 for (int dw = -rad; dw <= rad; ++dw) {
                     const int ww = w + dw;
                     if (ww < 0 || ww >= W) continue;
-                    const float wgt = fmaxf(diam - sqrtf((float)(dh * dh) + (float)(dw * dw)), 0.f);   // :224-225
-                    const int p = hh * W + ww;
-                    const float v0 = Tg[p] * wgt, v1 = Tg[P + p] * wgt, v2 = Tg[2 * P + p] * wgt;     // :227
+                    float wgt, t0, t1, t2;
+                    if (lds) {
+                        const int o = (ly + dh + rad) * L2_S + (lx + dw + rad);
+                        wgt = wt[(dh + rad) * side + (dw + rad)];
+                        t0 = tg[0][o]; t1 = tg[1][o]; t2 = tg[2][o];
+                    } else {
+                        const int p = hh * W + ww;
+                        wgt = fmaxf(diam - sqrtf((float)(dh * dh) + (float)(dw * dw)), 0.f);
+                        t0 = Tg[p]; t1 = Tg[P + p]; t2 = Tg[2 * P + p];
+                    }
+                    const float v0 = t0 * wgt, v1 = t1 * wgt, v2 = t2 * wgt;                           // :227
                     const float e0 = v0 - r0, e1 = v1 - r1, e2 = v2 - r2;
                     const float d = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);                                // :232
                     if (d < best) { best = d; b0 = v0; b1 = v1; b2 = v2; }
@@ -194,9 +275,10 @@ extern "C" int sdfr_loss_2d(const float* rend, const float* target, int B, int H
     SDFR_REQUIRE(rend && target && loss && g_rend && nvalid && scratch, "sdfr_loss_2d: NULL argument");
     SDFR_REQUIRE(H > 0 && W > 0 && diam > 0.f, "sdfr_loss_2d: bad size");
     if (B <= 0) return SDFR_OK;
-    const int P = H * W, nblk = sdfr_cdiv(P, 256);
+    const int P = H * W, nblk = sdfr_cdiv(W, L2_T) * sdfr_cdiv(H, L2_T);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sdfr_loss_2d_pixels_kernel, dim3(nblk, B), dim3(256), 0, s, rend, target, H, W, diam, threshold_nocs, g_rend, scratch);
+    hipLaunchKernelGGL(sdfr_loss_2d_pixels_kernel, dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, diam, threshold_nocs, g_rend,
+                       scratch);
     SDFR_LAUNCH_CHECK();
     hipLaunchKernelGGL(sdfr_loss_2d_finalize_kernel, dim3(sdfr_cdiv(3 * P, 256), B), dim3(256), 0, s, scratch, nblk, P, weight, loss, g_rend,
                        nvalid);

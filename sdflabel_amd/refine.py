@@ -52,7 +52,8 @@ class BatchRefiner:
         self.npairs = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.stepped = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.g_color = torch.zeros((B, 3, self.H, self.W), dtype=torch.float32, device=dev)
-        self.l2_scratch = torch.zeros((B * ((self.H * self.W + 255) // 256) * 3,), dtype=torch.float32, device=dev)
+        self.l2_scratch = torch.zeros((3 * B * ((self.W + 15) // 16) * ((self.H + 15) // 16),), dtype=torch.float32, device=dev)
+        self.l3_scratch = torch.zeros((3 * B * ((br.cap + 63) // 64),), dtype=torch.float32, device=dev)
         self.g_xyzf = torch.zeros((B, br.cap, 3), dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros((B, 4), dtype=torch.float32, device=dev)
         self.adam_v = torch.zeros((B, 4), dtype=torch.float32, device=dev)
@@ -90,7 +91,7 @@ class BatchRefiner:
         ck(L.sdfr_loss_2d(P(out["color"]), P(self.target), B, self.H, self.W, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color),
                           P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d")
         ck(L.sdfr_loss_3d(P(out["xyzf"]), P(br.fcnt), br.cap, P(self.lidar), P(self.lcnt), self.lidar_cap, P(self.scale), 0.2, self.w3, B,
-                          P(self.loss3d), P(self.g_xyzf), P(self.g_scale), P(self.npairs), st), "sdfr_loss_3d")
+                          P(self.loss3d), P(self.g_xyzf), P(self.g_scale), P(self.npairs), P(self.l3_scratch), st), "sdfr_loss_3d")
         br.backward(g_color=self.g_color, g_xyzf=self.g_xyzf)
         ck(L.sdfr_solver_step(P(self.params), P(self.grads), self.L, P(self.loss2d), P(self.loss3d), P(self.npairs), self.w2, self.w3,
                               P(self.adam_m), P(self.adam_v), P(self.adam_t), 0.01, 0.01, 0.00003, B, P(self.total), P(self.stepped), st),

@@ -160,7 +160,7 @@ def test_losses_vs_torch_restatement(dec):
     ref = loss_2d(rend, tgt)
     ref.backward()
     loss = torch.zeros(1, device=DEV); g = torch.zeros(1, 3, H, W, device=DEV); nv = torch.zeros(1, dtype=torch.int32, device=DEV)
-    scr = torch.zeros(((H * W + 255) // 256) * 3, device=DEV)
+    scr = torch.zeros(3 * ((W + 15) // 16) * ((H + 15) // 16), device=DEV)
     _lib.check(L.sdfr_loss_2d(_lib.ptr(rend.detach().contiguous()), _lib.ptr(tgt.contiguous()), 1, H, W, 5.0, 1.0, 1.0, _lib.ptr(loss),
                               _lib.ptr(g), _lib.ptr(nv), _lib.ptr(scr), _lib.stream_ptr()), "loss2d")
     assert abs(float(loss) - float(ref)) < 1e-5
@@ -177,9 +177,11 @@ def test_losses_vs_torch_restatement(dec):
     ec = torch.tensor([300], dtype=torch.int32, device=DEV); lc = torch.tensor([150], dtype=torch.int32, device=DEV)
     l3 = torch.zeros(1, device=DEV); ge = torch.zeros(1, cap, 3, device=DEV); gs = torch.zeros(1, device=DEV)
     npair = torch.zeros(1, dtype=torch.int32, device=DEV)
+    scr3 = torch.zeros(3 * ((cap + 63) // 64), device=DEV); ge += 7.0          # the call must overwrite every row of g_est
     _lib.check(L.sdfr_loss_3d(_lib.ptr(estp), _lib.ptr(ec), cap, _lib.ptr(lid), _lib.ptr(lc), 256, _lib.ptr(scale.detach()), 0.2, 1.0, 1,
-                              _lib.ptr(l3), _lib.ptr(ge), _lib.ptr(gs), _lib.ptr(npair), _lib.stream_ptr()), "loss3d")
+                              _lib.ptr(l3), _lib.ptr(ge), _lib.ptr(gs), _lib.ptr(npair), _lib.ptr(scr3), _lib.stream_ptr()), "loss3d")
     assert int(npair) > 10
+    assert float(ge[0, 300:].abs().max()) == 0.0                     # rows beyond the count carry no gradient
     assert abs(float(l3) - float(ref)) < 1e-6
     assert np.abs(N(ge[0, :300]) - N(est.grad)).max() < 1e-6
     assert abs(float(gs) - float(scale.grad)) < 1e-5

@@ -653,6 +653,38 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     __syncthreads();
     for (int l = P.n_mfma - 1; l >= 0; --l) {
         const MlpLayer L = P.L[l];
+        if (l == 0 && L.in_dim <= 8) {
+            // The first layer of a DeepSDF decoder has a handful of inputs (latent + xyz): its transposed product is 8 x HP x PT multiply-adds,
+            // which one wave would do alone on the matrix pipe, K tile after K tile (20 k cycles of exposed latency).  Here every thread
+            // takes one point and HP / (NT / PT) features on the VALU, and the partial sums are added in a fixed order.
+            constexpr int PARTS = NT / PT, JS = HP / PARTS;
+            static_assert(NT % PT == 0 && HP % PARTS == 0 && PARTS * 8 * PT * 4 <= KG * PT * 16, "first-layer reduction scratch fits the operand tile");
+            const int pt = tid % PT, part = tid / PT;
+            const float4* W0 = P.Wf + L.off_f;                   // forward image of layer 0: W0[(k/4)*HP + j] = W[j][k..k+3]
+            float s8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s8[k] = 0.f;
+#pragma unroll 4
+            for (int jj = 0; jj < JS; ++jj) {
+                const int j = part * JS + jj;
+                const float g = (float)act_e[((j / KV) * PT + pt) * KV + (j % KV)];
+                const float4 wa = W0[j], wb = (L.kp_f > 4) ? W0[HP + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                s8[0] = fmaf(wa.x, g, s8[0]); s8[1] = fmaf(wa.y, g, s8[1]); s8[2] = fmaf(wa.z, g, s8[2]); s8[3] = fmaf(wa.w, g, s8[3]);
+                s8[4] = fmaf(wb.x, g, s8[4]); s8[5] = fmaf(wb.y, g, s8[5]); s8[6] = fmaf(wb.z, g, s8[6]); s8[7] = fmaf(wb.w, g, s8[7]);
+            }
+            __syncthreads();                                    // every thread has read its in-gradients: the tile becomes scratch
+            float* scr = reinterpret_cast<float*>(lds4);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) scr[(part * 8 + k) * PT + pt] = s8[k];
+            __syncthreads();
+            if (tid < 8 * PT) {
+                const int k = tid / PT, q = tid % PT;
+                float t = 0.f;
+                for (int r = 0; r < PARTS; ++r) t += scr[(r * 8 + k) * PT + q];
+                if (k < NI && k < L.in_dim && slots[q] >= 0) atomicAdd(P.J + (int64_t)slots[q] * NI + k, t);
+            }
+            break;
+        }
         if (GMASK && l > 0) fetch_masks(l, raw);
         gemm(reinterpret_cast<const vec_t*>(HALF ? (const void*)P.Wbh : (const void*)P.Wb) + (HALF ? L.off_bh : L.off_b), HALF ? L.kp_bh : L.kp_b,
              L.in_dim);

@@ -46,7 +46,8 @@ class Optimizer:
         dev = grid.points.device
         cap = max(256, 1 << (max(n_lidar, 1) - 1).bit_length())       # lidar capacity, rounded up so that a refiner is reused across crops
         Kn = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32)
-        key = (id(dsdf), D, tuple(int(c) for c in crop_size), cap, Kn.tobytes(), str(dev), dsdf._param_key(dev))
+        key = (id(dsdf), D, tuple(int(c) for c in crop_size), cap, Kn.tobytes(), str(dev), dsdf._param_key(dev),
+               float(self.weights.get('2d', 0.3)), float(self.weights.get('3d', 0.5)), getattr(dsdf, 'mlp_precision', None))
         if self._key != key:
             rf = BatchRefiner(dsdf, D, Kn, crop_size, 1, lidar_cap=cap, weights=self.weights, device=dev)
             if not torch.equal(rf.br.grid, grid.points.detach().to(torch.float32)):

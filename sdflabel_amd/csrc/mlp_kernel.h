@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             // The common case (every 512-wide layer): a K loop WITHOUT branches.  Prefetch indices are clamped instead of guarded (the
             // tail re-reads the last tile into ring slots nobody consumes), so the body is one basic block and the compiler's s_waitcnt
             // counts stay exact: with the guarded form below it falls back to vmcnt(0) once per PF tiles -- a wait for loads it has just
-            // issued, i.e. a full L2 round trip exposed (the 16-point Jacobian lost 40 % of its matrix-pipe time to that).
+            // issued, i.e. a full L2 round trip exposed per ring turn (forward on the grid: 1.80 -> 1.71 ms with the branch-free body).
             const int last = nkt - 1;
             for (int t = 0; t < nkt; t += PF) {
 #pragma unroll

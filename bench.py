@@ -280,7 +280,7 @@ def main():
         del rf
     res = None
 
-    # the same crop-iteration with the two alternative decoder arithmetics.  Informational -- the headline and the 1e-4 parity claim
+    # the same crop-iteration with the alternative decoder arithmetics.  Informational -- the headline and the 1e-4 parity claim
     # are the exact-f32 path's.
     #   float16        half operands on the matrix cores, f32 accumulate (reference default precision, configs/config_refine.ini:19;
     #                  BASELINE configs[4]); everything else float32
@@ -318,6 +318,9 @@ def main():
 
     f16 = alt_decoder(torch.float16, "f16 decoder / f32 rest")
     split = alt_decoder("float32_split", "f32 results from error-compensated f16 operand pairs (3 f16 MFMAs per product) / f32 rest")
+    #   float32_prefilter  a float16 pass over the grid proposes candidates |sdf| < 0.03 + margin; band membership, sdf and Jacobian of the
+    #                  band come from the exact-f32 kernels run on the candidates only (decoder_forward_ms spans both passes incl. the Jacobian)
+    prefilter = alt_decoder("float32_prefilter", "exact f32 on the band candidates chosen by an f16 pass over the grid / f32 rest")
 
     # the same crop-iteration through the drop-in boundary (rank 0 only, informational)
     dropin = None
@@ -360,6 +363,7 @@ def main():
         line["refine_demo"] = refine
         line["f16_decoder"] = f16
         line["split_decoder"] = split
+        line["prefilter_decoder"] = prefilter
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

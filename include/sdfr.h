@@ -126,6 +126,15 @@ int sdfr_surface_project(const float* xyz, int xyz_stride, const float* sdf, int
 int sdfr_surface_project_bwd(const float* g_points, const float* g_nocs, const float* normals, int64_t G, int B,
                              const int32_t* idx, int cap, const int32_t* cnt, float* g_sdf, float* g_xyz, void* stream);
 
+/* Two-stage band selection (optional): a half-operand decoder pass over the grid + sdfr_band_select with a safety margin gives
+ * candidate rows; sdfr_mlp_jacobian without masks evaluates them exactly (float32 sdf + Jacobian).  sdfr_scatter_values writes the exact
+ * values back, dst[b*G + idx[b][s]] = src[b][s] for s < cnt[b], so that the ordinary sdfr_band_select on dst yields the exact band of
+ * grid.py:64; sdfr_gather_rows re-orders rows of ncol floats, out[b][e] = src[b][slot[b*G + idx[b][e]]] for e < cnt[b] (slot = the
+ * grid-row -> candidate-slot map sdfr_band_select wrote; src has src_cap rows per crop). */
+int sdfr_scatter_values(float* dst, const float* src, const int32_t* idx, int64_t G, int B, int cap, const int32_t* cnt, void* stream);
+int sdfr_gather_rows(float* out, const float* src, int ncol, const int32_t* idx, const int32_t* slot, int64_t G, int B, int cap,
+                     int src_cap, const int32_t* cnt, void* stream);
+
 /* g_inputs[r][:] = g_sdf[r] * J[slot[r]][:]  for rows with slot[r] >= 0, else 0   (DeepSDF backward through the
  * cached band Jacobian).  n_uncached (device int32, may be NULL) receives the number of rows with g_sdf != 0 and
  * slot < 0, i.e. rows the cache does not cover. */

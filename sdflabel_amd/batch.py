@@ -38,6 +38,10 @@ class BatchRenderer:
         prec = getattr(decoder, "mlp_precision", torch.float32)
         self.f16 = prec == torch.float16
         self.split = prec == "float32_split"
+        # two-stage evaluation: half-operand pass over the grid -> candidates |sdf| < threshold + margin -> exact float32 pass (sdf + Jacobian)
+        # on the candidates only -> exact band.  The margin must exceed the half pass's error (4e-4 on the shipped decoder).
+        self.prefilter = prec == "float32_prefilter"
+        self.margin = float(getattr(decoder, "prefilter_margin", 0.005))
         self.handle = decoder.handle(dev)
         self.L = decoder.latent_size
         self.NI = self.L + 3
@@ -64,6 +68,9 @@ class BatchRenderer:
         self.mask_ws = i(int(_lib.lib().sdfr_decoder_mask_words(self.handle.h, B * G)))
         self.idx, self.cnt, self.scratch = i(B, cap), i(B), i(B * ((G + 255) // 256) + 1)
         self.J, self.sdf_band = f(B, cap, NI), f(B, cap)
+        if self.prefilter:
+            self.cidx, self.ccnt, self.cslot = i(B, cap), i(B), i(B * G)
+            self.Jc = f(B, cap, NI)
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.p_cam, self.n_cam, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.fidx, self.fcnt, self.fslot = i(B, cap), i(B), i(B, cap)
@@ -95,13 +102,26 @@ class BatchRenderer:
                                  P(self.latnorm), st), "sdfr_params_forward")
         if mlp_events is not None:
             mlp_events[0].record()
-        fwd = L.sdfr_mlp_forward_f16 if self.f16 else (L.sdfr_mlp_forward_split if self.split else L.sdfr_mlp_forward)
-        ck(fwd(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.mask_ws), st), "sdfr_mlp_forward")
-        if mlp_events is not None:
-            mlp_events[1].record()
-        ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
-        ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.idx), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.sdf),
-                               P(self.mask_ws), 2 if self.f16 else 0, st), "sdfr_mlp_jacobian")
+        if self.prefilter:
+            ck(L.sdfr_mlp_forward_f16(self.handle.h, P(self.inputs), B * G, P(self.sdf), None, st), "sdfr_mlp_forward_f16")
+            ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr + self.margin, P(self.cidx), cap, P(self.ccnt), P(self.cslot), P(self.scratch), st),
+               "sdfr_band_select")
+            # exact float32 sdf and Jacobian of the candidates (recomputing kernel, 16-row tiles), patched into the grid array
+            ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.cidx), cap, P(self.ccnt), P(self.Jc), P(self.sdf_band), None, None,
+                                   0, st), "sdfr_mlp_jacobian")
+            ck(L.sdfr_scatter_values(P(self.sdf), P(self.sdf_band), P(self.cidx), G, B, cap, P(self.ccnt), st), "sdfr_scatter_values")
+            ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
+            ck(L.sdfr_gather_rows(P(self.J), P(self.Jc), self.NI, P(self.idx), P(self.cslot), G, B, cap, cap, P(self.cnt), st), "sdfr_gather_rows")
+            if mlp_events is not None:
+                mlp_events[1].record()
+        else:
+            fwd = L.sdfr_mlp_forward_f16 if self.f16 else (L.sdfr_mlp_forward_split if self.split else L.sdfr_mlp_forward)
+            ck(fwd(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.mask_ws), st), "sdfr_mlp_forward")
+            if mlp_events is not None:
+                mlp_events[1].record()
+            ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
+            ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.idx), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.sdf),
+                                   P(self.mask_ws), 2 if self.f16 else 0, st), "sdfr_mlp_jacobian")
         xyz = self.inputs[:, self.NI - 3:]
         ck(L.sdfr_surface_project(P(xyz), self.NI, P(self.sdf), G, B, P(self.idx), cap, P(self.cnt), P(self.J), self.NI, self.NI - 3,
                                   P(self.points), P(self.nocs), P(self.normals), st), "sdfr_surface_project")
@@ -146,7 +166,10 @@ class BatchRenderer:
     # ------------------------------------------------------------------------------------------------------------------
     def overflow(self):
         """True if some crop's band did not fit `cap` (its surplus surfels were dropped).  Synchronises."""
-        return bool((self.cnt > self.cap).any().item())
+        over = (self.cnt > self.cap).any()
+        if self.prefilter:
+            over = over | (self.ccnt > self.cap).any()
+        return bool(over.item())
 
     def capture(self, grads_fn):
         """Capture forward -> grads_fn(outputs) -> backward in a HIP graph.  grads_fn maps the output dict to the keyword arguments of

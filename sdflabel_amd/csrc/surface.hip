@@ -77,6 +77,54 @@ extern "C" int sdfr_band_select(const float* sdf, int64_t G, int B, float thr, i
     return SDFR_OK;
 }
 
+// ---- two-stage band selection: exact values patched into a prefiltered grid, Jacobian rows re-ordered ---------------------
+// A cheap (half-operand) decoder pass over the whole grid followed by band_select with a safety margin yields CANDIDATE rows; the
+// exact decoder pass runs on the candidates only (sdfr_mlp_jacobian without masks gives their float32 sdf and Jacobian).
+// sdfr_scatter_values writes those exact sdf values back into the grid array, so that the ordinary band_select on it returns the
+// exact band; sdfr_gather_rows then brings the candidates' Jacobian rows into band order.
+
+__global__ __launch_bounds__(256) void sdfr_scatter_values_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                                 const int32_t* __restrict__ idx, int64_t G, int cap,
+                                                                 const int32_t* __restrict__ cnt) {
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= sdfr_count(cnt, b, cap)) return;
+    const int64_t e = (int64_t)b * cap + s;
+    dst[(int64_t)b * G + idx[e]] = src[e];
+}
+
+extern "C" int sdfr_scatter_values(float* dst, const float* src, const int32_t* idx, int64_t G, int B, int cap, const int32_t* cnt,
+                                   void* stream) {
+    SDFR_REQUIRE(dst && src && idx, "sdfr_scatter_values: NULL argument");
+    if (B <= 0 || cap <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_scatter_values_kernel, dim3(sdfr_cdiv(cap, 256), B), dim3(256), 0, (hipStream_t)stream, dst, src, idx, G, cap,
+                       cnt);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// out[b][e][:] = src[b][slot[b*G + idx[b][e]]][:]  for e < cnt[b]  (ncol floats per row; rows whose slot is negative become zero)
+__global__ __launch_bounds__(256) void sdfr_gather_rows_kernel(float* __restrict__ out, const float* __restrict__ src, int ncol,
+                                                              const int32_t* __restrict__ idx, const int32_t* __restrict__ slot,
+                                                              int64_t G, int cap, int src_cap, const int32_t* __restrict__ cnt) {
+    const int b = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int e = (int)(t / ncol), c = (int)(t - (int64_t)e * ncol);
+    if (e >= sdfr_count(cnt, b, cap)) return;
+    const int sl = slot[(int64_t)b * G + idx[(int64_t)b * cap + e]];
+    out[((int64_t)b * cap + e) * ncol + c] = (sl >= 0 && sl < src_cap) ? src[((int64_t)b * src_cap + sl) * ncol + c] : 0.f;
+}
+
+extern "C" int sdfr_gather_rows(float* out, const float* src, int ncol, const int32_t* idx, const int32_t* slot, int64_t G, int B,
+                                int cap, int src_cap, const int32_t* cnt, void* stream) {
+    SDFR_REQUIRE(out && src && idx && slot && ncol > 0, "sdfr_gather_rows: bad argument");
+    if (B <= 0 || cap <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_gather_rows_kernel, dim3(sdfr_cdiv((int64_t)cap * ncol, 256), B), dim3(256), 0, (hipStream_t)stream, out, src,
+                       ncol, idx, slot, G, cap, src_cap, cnt);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
 // ---- projection onto the zero level set -----------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void sdfr_surface_project_kernel(const float* __restrict__ xyz, int xyz_stride,

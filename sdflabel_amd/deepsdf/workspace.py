@@ -14,7 +14,9 @@ def setup_dsdf(dir, mode='eval', precision=torch.float32):
     half operands on the matrix cores, float32 accumulation; parameters and the tensors at the module boundary stay float32 (the
     reference would hand back half tensors; ours are at least as accurate).  precision="float32_split": float32 results from the f16
     matrix cores by error compensation (every operand carried as a hi/lo pair of halves, 22 significand bits per product, float32
-    accumulation) -- agrees with the float32 path to summation-order noise at ~4x its speed.
+    accumulation) -- agrees with the float32 path to summation-order noise at ~4x its speed.  precision="float32_prefilter" (batched path
+    only; the module call itself stays exact float32): a float16 pass over the grid selects candidates |sdf| < threshold + margin
+    (decoder.prefilter_margin, default 0.005), and only those are evaluated with the exact-f32 kernels.
     """
     specs_filename = os.path.splitext(dir)[0] + '.json'
     if not os.path.isfile(specs_filename):
@@ -28,8 +30,9 @@ def setup_dsdf(dir, mode='eval', precision=torch.float32):
     saved = torch.load(dir, map_location="cpu")
     state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in saved["model_state_dict"].items()}
     decoder.load_state_dict(state)
-    if precision not in (torch.float32, torch.float16, "float32_split"):
-        raise NotImplementedError("sdflabel_amd decoders compute in float32, float16 or 'float32_split' (requested %s)" % precision)
+    if precision not in (torch.float32, torch.float16, "float32_split", "float32_prefilter"):
+        raise NotImplementedError("sdflabel_amd decoders compute in float32, float16, 'float32_split' or 'float32_prefilter' (requested %s)"
+                                  % precision)
     decoder.to(dtype=torch.float32)
     decoder.mlp_precision = precision
     if mode == 'train':

@@ -71,6 +71,20 @@ class BatchRenderer:
         if self.prefilter:
             self.cidx, self.ccnt, self.cslot = i(B, cap), i(B), i(B * G)
             self.Jc = f(B, cap, NI)
+            # calibrate the margin on this decoder: the half pass against the exact pass on the grid for a few unit latents (the optimizer
+            # normalises the latent, optimizer.py:96); the margin is at least 4x the largest deviation seen
+            Lh = _lib.lib()
+            gen = torch.Generator().manual_seed(0)
+            s32, s16 = f(G), f(G)
+            worst = 0.0
+            for _ in range(4):
+                lat = torch.nn.functional.normalize(torch.randn(self.L, generator=gen), dim=0).to(dev)
+                inp = torch.cat([lat.expand(G, -1), self.grid], 1).contiguous()
+                _lib.check(Lh.sdfr_mlp_forward(self.handle.h, _lib.ptr(inp), G, _lib.ptr(s32), None, _lib.stream_ptr()), "sdfr_mlp_forward")
+                _lib.check(Lh.sdfr_mlp_forward_f16(self.handle.h, _lib.ptr(inp), G, _lib.ptr(s16), None, _lib.stream_ptr()), "sdfr_mlp_forward_f16")
+                worst = max(worst, float((s32 - s16).abs().max()))
+            self.f16_error = worst
+            self.margin = max(self.margin, 4.0 * worst)
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.p_cam, self.n_cam, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.fidx, self.fcnt, self.fslot = i(B, cap), i(B), i(B, cap)

@@ -287,6 +287,8 @@ def test_prefilter_two_stage_evaluation_reproduces_the_exact_path(dec):
     for d in (dec, dp):
         br = sdflabel_amd.BatchRenderer(d, D, K, (W, H), B, device=DEV)
         assert br.prefilter == (d is dp)
+        if br.prefilter:
+            assert 0.0 < br.f16_error < 2e-3 and br.margin >= 4.0 * br.f16_error       # calibrated on this decoder at construction
         o = br.forward(yaw, trans, lat)
         g = br.backward(g_color=torch.ones(B, 3, H, W, device=DEV), g_mask=torch.ones(B, 1, H, W, device=DEV),
                         g_xyzf=torch.ones(B, br.cap, 3, device=DEV))

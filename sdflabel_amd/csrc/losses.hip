@@ -156,6 +156,8 @@ extern "C" int sdfr_loss_3d(const float* est, const int32_t* ecnt, int ecap, con
 #define L2_T 16
 #define L2_RMAX 8                       // window radius the LDS path is built for (diam <= 9); larger windows read the target from memory
 #define L2_S 48                         // LDS row pitch: consecutive tile rows fall 16 banks apart
+template <bool LDS, int RADC>       // RADC > 0: window radius known at compile time (the loops unroll and the LDS reads of a row batch up); LDS: window radius <= L2_RMAX, taps come from the staged tile (two instantiations: a run-time choice per tap would
+                          // turn the loads into flat accesses with a full wait after each)
 __global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const float* __restrict__ rend, const float* __restrict__ target,
                                                                          int H, int W, float diam, float threshold_nocs,
                                                                          float* __restrict__ g_rend, float* __restrict__ partial) {
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const 
     const float* R = rend + (int64_t)b * 3 * P;
     const float* Tg = target + (int64_t)b * 3 * P;
     float* G = g_rend + (int64_t)b * 3 * P;
-    const int rad = (int)ceilf(diam) - 1;                               // taps with clamp(diam - dist, 0) > 0 have |d| < diam
+    const int rad = RADC > 0 ? RADC : (int)ceilf(diam) - 1;             // taps with clamp(diam - dist, 0) > 0 have |d| < diam
     const int tilesX = (W + L2_T - 1) / L2_T;
     const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
     const int lx = tid & (L2_T - 1), ly = tid / L2_T;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const 
     const bool nz = inside && (r0 + r1 + r2 != 0.f);                    // rendering_nocs.sum(0).nonzero()  (:213)
     __shared__ float tg[3][(L2_T + 2 * L2_RMAX) * L2_S];
     __shared__ float wt[(2 * L2_RMAX + 1) * (2 * L2_RMAX + 1)];
-    const bool lds = rad <= L2_RMAX;
+    constexpr bool lds = LDS;
     const int side = 2 * rad + 1, span = L2_T + 2 * rad;
     if (__syncthreads_or(nz) && lds) {
         for (int i = tid; i < span * span; i += L2_T * L2_T) {
@@ -200,9 +202,11 @@ __global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const 
             // every pixel outside the window has weight 0: masked target 0, distance ||r||  (:223-231)
             float best = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
             float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll (RADC > 0 ? 2 * RADC + 1 : 1)
             for (int dh = -rad; dh <= rad; ++dh) {
                 const int hh = h + dh;
                 if (hh < 0 || hh >= H) continue;
+#pragma unroll (RADC > 0 ? 2 * RADC + 1 : 1)
                 for (int dw = -rad; dw <= rad; ++dw) {
                     const int ww = w + dw;
                     if (ww < 0 || ww >= W) continue;
@@ -277,8 +281,16 @@ extern "C" int sdfr_loss_2d(const float* rend, const float* target, int B, int H
     if (B <= 0) return SDFR_OK;
     const int P = H * W, nblk = sdfr_cdiv(W, L2_T) * sdfr_cdiv(H, L2_T);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sdfr_loss_2d_pixels_kernel, dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, diam, threshold_nocs, g_rend,
-                       scratch);
+    const int rad = (int)ceilf(diam) - 1;
+    if (rad == 4)                                                        // the loop's diam = 5 (optimizer.py:200)
+        hipLaunchKernelGGL((sdfr_loss_2d_pixels_kernel<true, 4>), dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, diam,
+                           threshold_nocs, g_rend, scratch);
+    else if (rad <= L2_RMAX)
+        hipLaunchKernelGGL((sdfr_loss_2d_pixels_kernel<true, 0>), dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, diam,
+                           threshold_nocs, g_rend, scratch);
+    else
+        hipLaunchKernelGGL((sdfr_loss_2d_pixels_kernel<false, 0>), dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, diam,
+                           threshold_nocs, g_rend, scratch);
     SDFR_LAUNCH_CHECK();
     hipLaunchKernelGGL(sdfr_loss_2d_finalize_kernel, dim3(sdfr_cdiv(3 * P, 256), B), dim3(256), 0, s, scratch, nblk, P, weight, loss, g_rend,
                        nvalid);

@@ -165,6 +165,15 @@ def test_losses_vs_torch_restatement(dec):
                               _lib.ptr(g), _lib.ptr(nv), _lib.ptr(scr), _lib.stream_ptr()), "loss2d")
     assert abs(float(loss) - float(ref)) < 1e-5
     assert np.abs(N(g[0]) - N(rend.grad)).max() < 1e-5
+    # other window sizes: a generic LDS instantiation (diam 7) and, wider than the LDS tile's halo (diam > 9), the global-memory one
+    for dm in (7.0, 10.5):
+        rend2 = rend.detach().clone().requires_grad_(True)
+        ref2 = loss_2d(rend2, tgt, diam=dm)
+        ref2.backward()
+        _lib.check(L.sdfr_loss_2d(_lib.ptr(rend2.detach().contiguous()), _lib.ptr(tgt.contiguous()), 1, H, W, dm, 1.0, 1.0, _lib.ptr(loss),
+                                  _lib.ptr(g), _lib.ptr(nv), _lib.ptr(scr), _lib.stream_ptr()), "loss2d")
+        assert abs(float(loss) - float(ref2)) < 1e-5, dm
+        assert np.abs(N(g[0]) - N(rend2.grad)).max() < 1e-5, dm
     # 3-D
     est = torch.rand(300, 3, device=DEV).requires_grad_(True)
     lidar = torch.rand(150, 3, device=DEV) * 2.0

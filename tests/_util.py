@@ -29,3 +29,17 @@ def K_for(H, W):
 
 def state_from_npz(z, prefix):
     return {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+
+
+def build_c_abi_smoke(out_dir):
+    """Compile tests/c_abi/abi_smoke.c (plain C99, gcc) against include/sdfr.h and the in-tree libsdfr_hip.so; returns the binary path."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c_abi", "abi_smoke.c")
+    exe = os.path.join(str(out_dir), "abi_smoke")
+    libdir = os.path.join(ROOT, "sdflabel_amd", "lib")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wno-unused-result", src, "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+           "-D__HIP_PLATFORM_AMD__", "-L" + libdir, "-lsdfr_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe

@@ -1,0 +1,98 @@
+/* The drop-in boundary used from plain C: no Python, no torch -- only include/sdfr.h, the HIP runtime for device memory, and libsdfr_hip.so.
+ * Builds a small weight-normed-free decoder (3 -> 96 -> 96 -> 1 with a tanh output, the layout of deep_sdf_decoder_scale.py:78-107 without
+ * latent re-injection), evaluates it with sdfr_mlp_forward on N rows and compares with a double-precision evaluation on the host; then asks
+ * sdfr_mlp_jacobian for d sdf / d input of a few rows and checks it against central differences of the host evaluation.
+ * Exit code 0 = parity.   gcc -std=c99 abi_smoke.c -I../../include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -L../../sdflabel_amd/lib -lsdfr_hip
+ *                              -L/opt/rocm/lib -lamdhip64 -lm */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <hip/hip_runtime_api.h>
+#include "sdfr.h"
+
+#define NI 3
+#define HID 96
+#define N 1000
+
+static float W0[HID * NI], b0[HID], W1[HID * HID], b1[HID], W2[HID], b2[1];
+
+static double host_eval(const double* x) {
+    double h0[HID], h1[HID];
+    for (int j = 0; j < HID; ++j) {
+        double s = b0[j];
+        for (int k = 0; k < NI; ++k) s += (double)W0[j * NI + k] * x[k];
+        h0[j] = s > 0 ? s : 0;
+    }
+    for (int j = 0; j < HID; ++j) {
+        double s = b1[j];
+        for (int k = 0; k < HID; ++k) s += (double)W1[j * HID + k] * h0[k];
+        h1[j] = s > 0 ? s : 0;
+    }
+    double s = b2[0];
+    for (int k = 0; k < HID; ++k) s += (double)W2[k] * h1[k];
+    return tanh(s);
+}
+
+static float frand(unsigned* st) { *st = *st * 1664525u + 1013904223u; return (float)((*st >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+
+#define CK(x) do { if ((x) != 0) { fprintf(stderr, "%s failed: %s\n", #x, sdfr_last_error()); return 2; } } while (0)
+#define HK(x) do { if ((x) != hipSuccess) { fprintf(stderr, "%s failed\n", #x); return 3; } } while (0)
+
+int main(void) {
+    unsigned st = 12345u;
+    for (int i = 0; i < HID * NI; ++i) W0[i] = 0.8f * frand(&st);
+    for (int i = 0; i < HID * HID; ++i) W1[i] = 0.15f * frand(&st);
+    for (int i = 0; i < HID; ++i) { b0[i] = 0.3f * frand(&st); b1[i] = 0.2f * frand(&st); W2[i] = 0.2f * frand(&st); }
+    b2[0] = 0.05f;
+    static float x[N * NI], y[N];
+    for (int i = 0; i < N * NI; ++i) x[i] = frand(&st);
+
+    const int in_dim[3] = {NI, HID, HID}, out_dim[3] = {HID, HID, 1}, inj_n[3] = {0, 0, 0}, inj_off[3] = {0, 0, 0};
+    const float* Ws[3] = {W0, W1, W2};
+    const float* bs[3] = {b0, b1, b2};
+    sdfr_decoder* dec = NULL;
+    CK(sdfr_decoder_create(&dec, 3, in_dim, out_dim, inj_n, inj_off, Ws, bs, NULL, NULL, NI, 0, 0));
+
+    float *dx = NULL, *dy = NULL, *dJ = NULL, *dsel = NULL;
+    int32_t* didx = NULL;
+    HK(hipMalloc((void**)&dx, sizeof(x))); HK(hipMalloc((void**)&dy, sizeof(y)));
+    HK(hipMemcpy(dx, x, sizeof(x), hipMemcpyHostToDevice));
+    CK(sdfr_mlp_forward(dec, dx, N, dy, NULL, NULL));
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(y, dy, sizeof(y), hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int i = 0; i < N; ++i) {
+        double xd[NI] = {x[i * NI], x[i * NI + 1], x[i * NI + 2]};
+        const double e = fabs(host_eval(xd) - (double)y[i]);
+        if (e > worst) worst = e;
+    }
+    printf("forward: max |gpu - host double| = %.3e over %d rows\n", worst, N);
+    if (!(worst < 5e-6)) return 1;
+
+    /* Jacobian of 8 selected rows (recomputing kernel: no saved masks) against central differences of the host evaluation */
+    const int32_t idx[8] = {0, 7, 63, 64, 65, 500, 998, 999};
+    float J[8 * NI], sel[8];
+    HK(hipMalloc((void**)&didx, sizeof(idx))); HK(hipMalloc((void**)&dJ, sizeof(J))); HK(hipMalloc((void**)&dsel, sizeof(sel)));
+    HK(hipMemcpy(didx, idx, sizeof(idx), hipMemcpyHostToDevice));
+    CK(sdfr_mlp_jacobian(dec, dx, N, 1, didx, 8, NULL, dJ, dsel, NULL, NULL, 0, NULL));
+    HK(hipDeviceSynchronize());
+    HK(hipMemcpy(J, dJ, sizeof(J), hipMemcpyDeviceToHost)); HK(hipMemcpy(sel, dsel, sizeof(sel), hipMemcpyDeviceToHost));
+    double worstJ = 0;
+    for (int r = 0; r < 8; ++r) {
+        const int i = idx[r];
+        if (fabs((double)sel[r] - (double)y[i]) > 1e-6) { fprintf(stderr, "sdf_sel mismatch at row %d\n", i); return 1; }
+        for (int c = 0; c < NI; ++c) {
+            double xp[NI] = {x[i * NI], x[i * NI + 1], x[i * NI + 2]}, xm[NI] = {x[i * NI], x[i * NI + 1], x[i * NI + 2]};
+            xp[c] += 1e-5; xm[c] -= 1e-5;
+            const double fd = (host_eval(xp) - host_eval(xm)) / 2e-5;
+            const double e = fabs(fd - (double)J[r * NI + c]);
+            if (e > worstJ) worstJ = e;
+        }
+    }
+    printf("jacobian: max |gpu - central difference| = %.3e over 8 rows\n", worstJ);
+    if (!(worstJ < 2e-3)) return 1;          /* a ReLU kink inside the 2e-5 stencil would show up here; none with this seed */
+    CK(sdfr_decoder_destroy(dec));
+    hipFree(dx); hipFree(dy); hipFree(dJ); hipFree(dsel); hipFree(didx);
+    printf("C ABI smoke: OK (library version %d)\n", sdfr_version());
+    return 0;
+}

@@ -773,3 +773,14 @@ def test_split_decoder_passes_the_float32_goldens(dec_split, oracle_layers):
         test_end_to_end_gradients_golden(dec_split, tag)
     test_full_size_crop_vs_oracle_sample(dec_split, oracle_layers)
     test_refinement_trajectory_golden(dec_split)
+
+
+def test_c_abi_smoke_binary_runs_without_python_or_torch(tmp_path):
+    """the boundary driven from plain C (tests/c_abi/abi_smoke.c): decoder create / forward / Jacobian / destroy against a double-precision
+    host evaluation, device memory from the HIP runtime directly"""
+    import subprocess
+    from tests._util import build_c_abi_smoke
+    exe = build_c_abi_smoke(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+    assert "C ABI smoke: OK" in r.stdout

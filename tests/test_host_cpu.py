@@ -140,3 +140,10 @@ def test_optimizer_mirror_constructor_and_refusals():
         Optimizer(dict(params), "cpu", {}, rot="quat")
     with pytest.raises(NotImplementedError):
         opt.optimize(1, None, np.zeros((1, 3)), None, None, None, (8, 8), viz_type="2d")
+
+
+def test_c_abi_compiles_and_links_from_plain_c(tmp_path):
+    """include/sdfr.h is a C header (no C++, no torch types): a C99 client compiles against it and links with the in-tree library"""
+    from tests._util import build_c_abi_smoke
+    exe = build_c_abi_smoke(tmp_path)
+    assert os.path.isfile(exe)

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const 
     const float* R = rend + (int64_t)b * 3 * P;
     const float* Tg = target + (int64_t)b * 3 * P;
     float* G = g_rend + (int64_t)b * 3 * P;
+    constexpr int UNR = RADC > 0 ? 2 * RADC + 1 : 1;                    // full unroll of the window loops when the radius is a constant
     const int rad = RADC > 0 ? RADC : (int)ceilf(diam) - 1;             // taps with clamp(diam - dist, 0) > 0 have |d| < diam
     const int tilesX = (W + L2_T - 1) / L2_T;
     const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
@@ -202,11 +203,11 @@ __global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const 
             // every pixel outside the window has weight 0: masked target 0, distance ||r||  (:223-231)
             float best = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
             float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-#pragma unroll (RADC > 0 ? 2 * RADC + 1 : 1)
+#pragma unroll UNR
             for (int dh = -rad; dh <= rad; ++dh) {
                 const int hh = h + dh;
                 if (hh < 0 || hh >= H) continue;
-#pragma unroll (RADC > 0 ? 2 * RADC + 1 : 1)
+#pragma unroll UNR
                 for (int dw = -rad; dw <= rad; ++dw) {
                     const int ww = w + dw;
                     if (ww < 0 || ww >= W) continue;

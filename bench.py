@@ -144,7 +144,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--crops-per-gpu", type=int, default=1, help="crops refined together per rank (1 = BASELINE configs[1]; 64 = configs[2])")
+    ap.add_argument("--crop-size", type=int, default=256, help="crop edge in pixels (256 = BASELINE configs[1..3]; 512 = configs[4], informational)")
     args = ap.parse_args()
+    global H, W
+    H = W = int(args.crop_size)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -345,7 +348,7 @@ def main():
             "metric": "rendered rays/sec (fwd+bwd)", "value": rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: single" if CB == 1 else "BASELINE configs[2]-style: %d" % CB) + " 256x256 crop per GPU, DeepSDF 8x512 decoder on a 40^3 grid, "
+            "config": {"workload": ("BASELINE configs[1]: single" if (CB == 1 and H == 256) else ("BASELINE configs[4]-style: %d" % CB if H == 512 else "BASELINE configs[2]-style: %d" % CB)) + " %dx%d crop per GPU, DeepSDF 8x512 decoder on a 40^3 grid, " % (H, W) +
                                    "fwd+bwd to yaw/trans/latent (BatchRenderer, B=%d), decoder re-evaluated every step" % CB,
                        "crops_per_gpu": CB, "rays_per_crop": H * W, "grid_points": G, "surfels": int(n_surf),
                        "front_facing": int(n_front), "march_steps": None, "parallelism": "crop-parallel x%d" % world},

@@ -323,3 +323,35 @@ def test_prefilter_two_stage_evaluation_reproduces_the_exact_path(dec):
     for tag in ("a", "b"):
         test_batch_gradients_golden(dp, tag)
     test_batch_refiner_trajectory_golden(dp, 1, True)
+
+
+@pytest.mark.parametrize("precision", [torch.float32, torch.float16, "float32_split", "float32_prefilter"])
+def test_empty_band_renders_nothing_and_skips_the_crop(precision):
+    """no grid point inside the band (threshold ~ 0): zero surfels -> zero images, zero finite gradients, and the refinement loop's skip
+    rule (optimizer.py:127-129) holds the crop's parameters still, in every decoder precision"""
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)
+    d = d.to(DEV)
+    D, H, W, B = 20, 40, 40, 2
+    K = K_for(H, W)
+    br = sdflabel_amd.BatchRenderer(d, D, K, (W, H), B, device=DEV, threshold=1e-12)
+    if br.prefilter:
+        br.margin = 0.0
+    o = br.forward(T(np.array([0.3, -0.2], np.float32)), T(np.array([[0, 0, 3.5], [0.1, 0, 3.2]], np.float32)),
+                   T(np.array([[0.3, -0.5, 0.8], [0.1, 0.2, 0.9]], np.float32)))
+    assert int(o["n"].max()) == 0 and int(o["nf"].max()) == 0
+    for k in ("color", "mask", "depth", "normals"):
+        assert float(o[k].abs().max()) == 0.0
+    g = br.backward(g_color=torch.ones(B, 3, H, W, device=DEV), g_mask=torch.ones(B, 1, H, W, device=DEV),
+                    g_xyzf=torch.ones(B, br.cap, 3, device=DEV))
+    for t in g:
+        assert torch.isfinite(t).all() and float(t.abs().max()) == 0.0
+    rf = sdflabel_amd.BatchRefiner(d, D, K, (H, W), B, lidar_cap=64, device=DEV)
+    rf.br.thr = 1e-12
+    if rf.br.prefilter:
+        rf.br.margin = 0.0
+    p0 = {"yaw": np.array([[0.3], [-0.2]], np.float32), "trans": np.array([[0, 0, 3.5], [0.1, 0, 3.2]], np.float32),
+          "scale": np.array([[2.0], [2.0]], np.float32), "latent": np.array([[0.3, -0.5, 0.8], [0.1, 0.2, 0.9]], np.float32)}
+    rf.set_crops(p0, np.random.default_rng(0).random((B, 3, H, W)).astype(np.float32), [np.random.default_rng(1).random((30, 3)).astype(np.float32)] * B)
+    before = rf.params.clone()
+    rf.optimize(3)
+    assert int(rf.stepped.sum()) == 0 and torch.equal(rf.params, before)

@@ -431,35 +431,46 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             lnl = L.ln != 0;
             if (lnl) ln_forward(l, L.out_dim);          // acc already holds gamma * x_hat + beta (bias included)
         }
+        // Re-injected input columns (latent_in / xyz_in_all) occupy a few features of ONE wave in ONE or few layers: whether this wave's
+        // feature block touches them is a scalar question, asked once, so that every other wave and layer runs an epilogue without the
+        // per-group lane-divergent range checks (32 saveexec/branch pairs per layer otherwise).
+        const bool inj_here = __builtin_amdgcn_readfirstlane((int)((Ln.inj_n > 0) && (fbase + MS * FT > inj_lo) && (fbase < inj_hi))) != 0;
+        auto epilogue = [&](auto inj_tag) {
+            constexpr bool INJ = decltype(inj_tag)::value;
 #pragma unroll
-        for (int f = 0; f < FT; ++f)
+            for (int f = 0; f < FT; ++f)
 #pragma unroll
-            for (int rg = 0; rg < RG; ++rg) {
-                const int j0 = feat0(f, rg);
-                const float4 b4 = lnl ? make_float4(0.f, 0.f, 0.f, 0.f) : b4s[f][rg];
+                for (int rg = 0; rg < RG; ++rg) {
+                    const int j0 = feat0(f, rg);
+                    const float4 b4 = lnl ? make_float4(0.f, 0.f, 0.f, 0.f) : b4s[f][rg];
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const int pt = p * MS + lp;
-                    float v[4];
+                    for (int p = 0; p < NP; ++p) {
+                        const int pt = p * MS + lp;
+                        float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float x = acc[f][p][rg * 4 + i] + f4c(b4, i);
-                        const bool pos = x > 0.f;
-                        v[i] = pos ? x : 0.f;
-                        if (LMASK || SAVE) {
-                            const int bit = ((f * NP + p) * RG + rg) * 4 + i;
-                            mw[bit >> 5] |= (pos ? 1u : 0u) << (bit & 31);
+                        for (int i = 0; i < 4; ++i) {
+                            const float x = acc[f][p][rg * 4 + i] + f4c(b4, i);
+                            const bool pos = x > 0.f;
+                            v[i] = pos ? x : 0.f;
+                            if (LMASK || SAVE) {
+                                const int bit = ((f * NP + p) * RG + rg) * 4 + i;
+                                mw[bit >> 5] |= (pos ? 1u : 0u) << (bit & 31);
+                            }
                         }
-                    }
-                    if (j0 + 3 >= inj_lo && j0 < inj_hi) {    // re-inject input columns for the next layer
-                        const float* src = P.inputs + (int64_t)rows[pt] * NI + Ln.inj_off - inj_lo;
+                        if (INJ) {
+                            if (j0 + 3 >= inj_lo && j0 < inj_hi) {    // re-inject input columns for the next layer
+                                const float* src = P.inputs + (int64_t)rows[pt] * NI + Ln.inj_off - inj_lo;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (j0 + i >= inj_lo && j0 + i < inj_hi) v[i] = src[j0 + i];
+                                for (int i = 0; i < 4; ++i)
+                                    if (j0 + i >= inj_lo && j0 + i < inj_hi) v[i] = src[j0 + i];
+                            }
+                        }
+                        store4(act_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV), v);
                     }
-                    store4(act_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV), v);
                 }
-            }
+        };
+        if (inj_here) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
         if (LMASK) {
 #pragma unroll
             for (int w = 0; w < MW; ++w) masks[(l * MW + w) * NT + tid] = mw[w];

@@ -132,7 +132,7 @@ __device__ __forceinline__ void store4(h16* dst, const float* v) {
     *reinterpret_cast<h16x4*>(dst) = t;
 }
 
-// ET   operand element type (float: exact f32; _Float16: half operands, f32 accumulate -- forward modes only)
+// ET   operand element type (float: exact f32; _Float16: half operands, f32 accumulate -- forward modes and the mask-fed Jacobian)
 // MS   MFMA tile (32: forward on the grid; 16: small tiles so that a few thousand band rows fill the chip)
 // FT   feature tiles (MS rows) per wave, NP point tiles (MS points) per workgroup, NW waves per workgroup (HP = MS*FT*NW padded width)
 // PF   weight/activation fragment buffers in flight per wave (prefetch distance PF-1 K tiles)

@@ -147,3 +147,14 @@ def test_c_abi_compiles_and_links_from_plain_c(tmp_path):
     from tests._util import build_c_abi_smoke
     exe = build_c_abi_smoke(tmp_path)
     assert os.path.isfile(exe)
+
+
+@pytest.mark.parametrize("compiler,std,ext", [("gcc", "-std=c99", ".c"), ("g++", "-std=c++11", ".cpp")])
+def test_public_header_is_strict_c_and_cxx(tmp_path, compiler, std, ext):
+    """include/sdfr.h alone, with -Wall -Wextra -pedantic -Werror: plain pointers and sizes only, usable from C and from C++"""
+    import subprocess
+    src = tmp_path / ("hdr" + ext)
+    src.write_text('#include "sdfr.h"\nint main(void) { return sdfr_version() > 0 ? 0 : 0; }\n')
+    r = subprocess.run([compiler, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]

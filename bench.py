@@ -312,12 +312,21 @@ def main():
             return {"error": err}
         (b2, ev2), dt2 = res
         m2 = float(np.mean([a.elapsed_time(b) for a, b in ev2]))
-        return {"value": H * W * CB * world * args.steps / dt2, "unit": "rays/s", "ms_per_step": dt2 / args.steps * 1e3,
-                "dtype": dtype_label, "decoder_forward_ms": m2,
-                "decoder_forward_tflops": 2.0 * macs * G * CB / (m2 * 1e-3) / 1e12, "f16_mfma_peak_tflops": 2500.0,
+        out = {"value": H * W * CB * world * args.steps / dt2, "unit": "rays/s", "ms_per_step": dt2 / args.steps * 1e3,
+               "dtype": dtype_label, "decoder_forward_ms": m2}
+        if getattr(b2, "prefilter", False):
+            # the two-stage mode does not execute the 2*M*G flops of a full-grid pass in f32: no flop rate is quoted for it
+            out.update({"decoder_forward_ms_covers": "f16 grid pass + candidate selection + exact-f32 sdf and Jacobian of the candidates",
+                        "candidates": int(b2.ccnt[0]), "prefilter_margin": b2.margin, "f16_pass_max_deviation_at_calibration": b2.f16_error})
+        else:
+            out.update({"decoder_forward_tflops": 2.0 * macs * G * CB / (m2 * 1e-3) / 1e12, "f16_mfma_peak_tflops": 2500.0})
+        out.update({
                 "surfels": int(b2.cnt[0]), "mask_pixels_differing_from_f32": float((b2.mask != br.mask).float().mean()),
-                "max_abs_sdf_diff_vs_f32": float((b2.sdf - br.sdf).abs().max()),
-                "max_abs_color_diff_vs_f32": float((b2.color - br.color).abs().max())}
+                "max_abs_sdf_diff_vs_f32": float((b2.sdf - br.sdf).abs().max()),          # whole grid (prefilter: rows outside the candidates keep f16 values)
+                "max_abs_sdf_diff_vs_f32_at_band_rows": float((b2.sdf[b2.idx[0, :int(b2.cnt[0])].long()] - br.sdf[b2.idx[0, :int(b2.cnt[0])].long()]).abs().max())
+                                                        if int(b2.cnt[0]) > 0 else 0.0,
+                "max_abs_color_diff_vs_f32": float((b2.color - br.color).abs().max())})
+        return out
 
     f16 = alt_decoder(torch.float16, "f16 decoder / f32 rest")
     split = alt_decoder("float32_split", "f32 results from error-compensated f16 operand pairs (3 f16 MFMAs per product) / f32 rest")

@@ -213,6 +213,16 @@ int sdfr_surface_latent_grad(const float* g_points, const float* g_nocs, const f
 int sdfr_params_backward(const float* yaw, const float* latent, int L, const float* latnorm, const float* g_pose, const float* g_latn,
                          int B, float* g_yaw, float* g_trans, float* g_latent, void* stream);
 
+/* The backward tail of the batched step in one launch (latent sizes 1..8): sdfr_project_dcm_bwd (with its optional g_xyzf / fslot and
+ * colour-map handling), sdfr_surface_latent_grad (g_latn[b][c] = sum_s -(g_points_s . normals_s) J[b][s][c]) and sdfr_params_backward,
+ * with the same fixed-order reductions -- the results are bit-identical to calling the three.  g_points may be NULL (not stored).
+ * Replaces the autograd of pipelines/optimizer.py:86-100 + sdfrenderer/renderer/projection.py:34-70 + sdfrenderer/grid.py:61. */
+int sdfr_pose_latent_backward(const float* pose, const float* points, const float* normals, const float* g_p_cam, const float* g_n_cam,
+                              const float* g_col, int B, int cap, const int32_t* cnt, int output_nocs, const float* g_xyzf,
+                              const int32_t* fslot, const float* J, int n_inputs, int L, const float* yaw, const float* latent,
+                              const float* latnorm, float* g_points, float* g_pose, float* g_latn, float* g_yaw, float* g_trans,
+                              float* g_latent, void* stream);
+
 /* padded front-facing selection (points['xyzf'], rasterer.py:151): out[b][j] = src[b][idx[b][j]] for j < cnt[b], 0 beyond;
  * and its backward dst[b][idx[b][j]] += src[b][j]. */
 int sdfr_gather_rows3(float* out, const float* src, const int32_t* idx, int B, int cap, const int32_t* cnt, void* stream);

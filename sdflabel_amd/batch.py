@@ -98,6 +98,7 @@ class BatchRenderer:
         self.g_latn = f(B, self.L)
         self.g_yaw, self.g_trans, self.g_latent = f(B), f(B, 3), f(B, self.L)
         self._graph = None
+        self.fused_tail = True      # one launch for the backward tail (False: the three separate kernels, same bits)
 
     # ------------------------------------------------------------------------------------------------------------------
     def set_params(self, yaw, trans, latent):
@@ -167,6 +168,14 @@ class BatchRenderer:
                                  P(g_mask), P(g_depth), P(g_normals), P(self.g_p), P(self.g_n), P(self.g_a), st), "sdfr_splat_backward")
         if g_xyzf is not None:
             g_xyzf = c(g_xyzf, self.xyzf.shape)
+        if self.L <= 8 and self.fused_tail:
+            # projection backward (with the (col + 1) / 2 map of the attribute and the gradient arriving through xyzf), latent gradient
+            # and parameter gradients in one launch
+            ck(L.sdfr_pose_latent_backward(P(self.pose), P(self.points), P(self.normals), P(self.g_p), P(self.g_n), P(self.g_a), B, cap,
+                                           P(self.cnt), self.nocs_mode | 4, P(g_xyzf), P(self.fslot), P(self.J), self.NI, self.L, P(self.yaw),
+                                           P(self.latent), P(self.latnorm), None, P(self.g_pose), P(self.g_latn), P(self.g_yaw),
+                                           P(self.g_trans), P(self.g_latent), st), "sdfr_pose_latent_backward")
+            return self.g_yaw, self.g_trans, self.g_latent
         # the projection backward folds in the (col + 1) / 2 map of the attribute and the gradient arriving through xyzf
         ck(L.sdfr_project_dcm_bwd(P(self.pose), P(self.points), P(self.normals), P(self.g_p), P(self.g_n), P(self.g_a), B, cap,
                                   P(self.cnt), self.nocs_mode | 4, P(self.g_points), P(self.g_normals), None, P(self.g_pose), P(g_xyzf),

@@ -170,3 +170,120 @@ extern "C" int sdfr_gather_rows3(float* out, const float* src, const int32_t* id
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
+
+// ---- fused backward tail of the batched step ----------------------------------------------------------------------------------
+// sdfr_project_dcm_bwd + sdfr_surface_latent_grad + sdfr_params_backward in ONE launch (one workgroup per crop; latent sizes up to
+// LAT_MAXL): per surfel the object-frame point gradient, its contraction with the normal (g_sdf) and with the Jacobian's latent columns,
+// the 12 pose sums; fixed-order reductions exactly as in the three separate kernels (bit-identical results), then the parameter
+// gradients.  Three launches of a few microseconds each become one.
+#define PLB_THREADS 1024
+__global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
+    const float* __restrict__ pose, const float* __restrict__ points, const float* __restrict__ normals, const float* __restrict__ g_pc,
+    const float* __restrict__ g_nc, const float* __restrict__ g_col, int cap, const int32_t* __restrict__ cnt, int output_nocs,
+    const float* __restrict__ g_xyzf, const int32_t* __restrict__ fslot, const float* __restrict__ J, int NI, int L,
+    const float* __restrict__ yaw, const float* __restrict__ latent, const float* __restrict__ latnorm, float* __restrict__ g_points,
+    float* __restrict__ g_pose, float* __restrict__ g_latn, float* __restrict__ g_yaw, float* __restrict__ g_trans,
+    float* __restrict__ g_latent) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int count = sdfr_count(cnt, b, cap);
+    const float* P = pose + (int64_t)b * 16;
+    const float r00 = P[0], r01 = P[1], r02 = P[2];
+    const float r10 = P[4], r11 = P[5], r12 = P[6];
+    const float r20 = P[8], r21 = P[9], r22 = P[10];
+    float acc[12], lat[LAT_MAXL];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < LAT_MAXL; ++i) lat[i] = 0.f;
+    for (int s = tid; s < count; s += PLB_THREADS) {
+        const int64_t e1 = (int64_t)b * cap + s;
+        const int64_t e = e1 * 3;
+        const float x = points[e], y = points[e + 1], z = points[e + 2];
+        const float nx = normals[e], ny = normals[e + 1], nz = normals[e + 2];
+        float ax = g_pc ? g_pc[e] : 0.f, ay = g_pc ? g_pc[e + 1] : 0.f, az = g_pc ? g_pc[e + 2] : 0.f;
+        if (g_xyzf) {
+            const int fs = fslot[e1];
+            if (fs >= 0) { const int64_t f = ((int64_t)b * cap + fs) * 3; ax += g_xyzf[f]; ay += g_xyzf[f + 1]; az += g_xyzf[f + 2]; }
+        }
+        const float bx = g_nc ? g_nc[e] : 0.f, by = g_nc ? g_nc[e + 1] : 0.f, bz = g_nc ? g_nc[e + 2] : 0.f;
+        float gx = r00 * ax + r10 * ay + r20 * az;
+        float gy = r01 * ax + r11 * ay + r21 * az;
+        float gz = r02 * ax + r12 * ay + r22 * az;
+        if (g_col && output_nocs) {
+            float c0 = g_col[e], c1 = g_col[e + 1], c2 = g_col[e + 2];
+            if (output_nocs & 4) { c0 *= 0.5f; c1 *= 0.5f; c2 *= 0.5f; }
+            gx += ((output_nocs & 3) == 2) ? c0 : -c0; gy += c1; gz += c2;
+        }
+        if (g_points) { g_points[e] = gx; g_points[e + 1] = gy; g_points[e + 2] = gz; }
+        acc[0] += ax * x + bx * nx; acc[1] += ax * y + bx * ny; acc[2] += ax * z + bx * nz; acc[3] += ax;
+        acc[4] += ay * x + by * nx; acc[5] += ay * y + by * ny; acc[6] += ay * z + by * nz; acc[7] += ay;
+        acc[8] += az * x + bz * nx; acc[9] += az * y + bz * ny; acc[10] += az * z + bz * nz; acc[11] += az;
+        const float gs = -(gx * nx + gy * ny + gz * nz);               // grid.py:61 backward: d p / d sdf = -n_hat
+#pragma unroll
+        for (int i = 0; i < LAT_MAXL; ++i)
+            if (i < L) lat[i] += gs * J[e1 * NI + i];
+    }
+    __shared__ float red[12][PLB_THREADS / 64];
+    __shared__ float redl[PLB_THREADS / 64];
+    __shared__ float s_latn[LAT_MAXL];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        float v = acc[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((tid & 63) == 0) red[i][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < 12) {
+        float v = 0.f;
+        for (int w = 0; w < PLB_THREADS / 64; ++w) v += red[tid][w];
+        g_pose[(int64_t)b * 16 + tid] = v;
+        red[tid][0] = v;                                               // the pose sums stay here for the parameter gradients below
+    } else if (tid < 16) {
+        g_pose[(int64_t)b * 16 + tid] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < LAT_MAXL; ++i) {
+        if (i >= L) break;
+        float v = lat[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) redl[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < PLB_THREADS / 64; ++w) t += redl[w];
+            g_latn[b * L + i] = t;
+            s_latn[i] = t;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float g0 = red[0][0], g2 = red[2][0], g8 = red[8][0], g10 = red[10][0];
+        const float c = cosf(yaw[b]), s = sinf(yaw[b]);
+        g_yaw[b] = (-s) * g0 + c * g2 + (-c) * g8 + (-s) * g10;
+        g_trans[b * 3] = red[3][0]; g_trans[b * 3 + 1] = red[7][0]; g_trans[b * 3 + 2] = red[11][0];
+        const float nrm = latnorm[b];
+        float dot = 0.f;
+        for (int i = 0; i < L; ++i) dot += (latent[b * L + i] / nrm) * s_latn[i];
+        for (int i = 0; i < L; ++i) g_latent[b * L + i] = (s_latn[i] - (latent[b * L + i] / nrm) * dot) / nrm;
+    }
+}
+
+extern "C" int sdfr_pose_latent_backward(const float* pose, const float* points, const float* normals, const float* g_p_cam,
+                                         const float* g_n_cam, const float* g_col, int B, int cap, const int32_t* cnt, int output_nocs,
+                                         const float* g_xyzf, const int32_t* fslot, const float* J, int n_inputs, int L, const float* yaw,
+                                         const float* latent, const float* latnorm, float* g_points, float* g_pose, float* g_latn,
+                                         float* g_yaw, float* g_trans, float* g_latent, void* stream) {
+    SDFR_REQUIRE(pose && points && normals && J && yaw && latent && latnorm && g_pose && g_latn && g_yaw && g_trans && g_latent,
+                 "sdfr_pose_latent_backward: NULL argument");
+    SDFR_REQUIRE(L >= 1 && L <= LAT_MAXL && L <= n_inputs, "sdfr_pose_latent_backward: latent size %d outside [1,%d] (use the separate kernels)", L,
+                 LAT_MAXL);
+    SDFR_REQUIRE(!g_xyzf || fslot, "sdfr_pose_latent_backward: g_xyzf needs fslot");
+    SDFR_REQUIRE(output_nocs != 0, "sdfr_pose_latent_backward: built for the NOCS colour modes of the refinement loop");
+    if (B <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_pose_latent_backward_kernel, dim3(B), dim3(PLB_THREADS), 0, (hipStream_t)stream, pose, points, normals, g_p_cam,
+                       g_n_cam, g_col, cap, cnt, output_nocs, g_xyzf, fslot, J, n_inputs, L, yaw, latent, latnorm, g_points, g_pose, g_latn,
+                       g_yaw, g_trans, g_latent);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}

@@ -355,3 +355,24 @@ def test_empty_band_renders_nothing_and_skips_the_crop(precision):
     before = rf.params.clone()
     rf.optimize(3)
     assert int(rf.stepped.sum()) == 0 and torch.equal(rf.params, before)
+
+
+def test_fused_backward_tail_is_bitwise_the_three_kernels(dec):
+    """sdfr_pose_latent_backward (one launch) against sdfr_project_dcm_bwd + sdfr_surface_latent_grad + sdfr_params_backward"""
+    D, H, W, B = 40, 64, 64, 3
+    K = K_for(H, W)
+    br = sdflabel_amd.BatchRenderer(dec, D, K, (W, H), B, device=DEV)
+    rng = np.random.default_rng(77)
+    br.forward(T(rng.uniform(-1, 1, B).astype(np.float32)),
+               T(np.stack([rng.uniform(-0.2, 0.2, B), rng.uniform(-0.1, 0.1, B), rng.uniform(3.0, 3.8, B)], 1).astype(np.float32)),
+               T(rng.standard_normal((B, 3)).astype(np.float32)))
+    gc = torch.randn(B, 3, H, W, device=DEV); gm = torch.randn(B, 1, H, W, device=DEV); gn = torch.randn(B, 3, H, W, device=DEV)
+    gx = torch.randn(B, br.cap, 3, device=DEV)
+    res = []
+    for fused in (True, False):
+        br.fused_tail = fused
+        g = br.backward(g_color=gc, g_mask=gm, g_normals=gn, g_xyzf=gx)
+        res.append([t.clone() for t in g] + [br.g_pose.clone(), br.g_latn.clone()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][0].abs().max()) > 0 and float(res[0][2].abs().max()) > 0

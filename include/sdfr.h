@@ -156,6 +156,14 @@ int sdfr_project_dcm(const float* pose, const float* K, const float* points, con
                      float* p_cam, float* n_cam, float* col, float* uv, int32_t* fidx, int32_t* fcnt, float* xyzf, int32_t* fslot,
                      void* stream);
 
+/* Batched path, one launch: sdfr_surface_project (band rows -> points, unit normals; grid.py:57-67) + sdfr_project_dcm in a NOCS colour
+ * mode (projection.py:34-70) + the conservative disc screen boxes sdfr_splat_forward would otherwise compute (bbox [B][cap][4] int32, pass
+ * primitive | SDFR_PRIM_BOXES_READY to it; bbox may be NULL).  Same arithmetic and outputs as the separate calls. */
+int sdfr_surfels_forward(const float* xyz, int xyz_stride, const float* sdf, int64_t G, const int32_t* idx, const float* J, int Jstride,
+                         int Joff, const float* pose, const float* K, int B, int cap, const int32_t* cnt, int output_nocs, int res_x,
+                         int res_y, float diam, float* points, float* normals, float* p_cam, float* n_cam, float* col, int32_t* fidx,
+                         int32_t* fcnt, float* xyzf, int32_t* fslot, int32_t* bbox, void* stream);
+
 /* Backward: g_points, g_normals, g_colors [B][cap][3] (g_colors NULL when output_nocs), g_pose [B][16].  g_xyzf [B][cap][3] (may be
  * NULL): gradient w.r.t. the xyzf rows, added to g_p_cam through fslot. */
 int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* normals,
@@ -178,6 +186,7 @@ int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* no
  *   images: color [B][3][H][W], mask [B][H][W], depth [B][H][W], normals [B][3][H][W] (any may be NULL)
  *   aux [B][H*W][4]: per-pixel state for the backward (nu, max logit, softmax denominator, clamp gates)
  */
+#define SDFR_PRIM_BOXES_READY 256   /* OR into `primitive` of sdfr_splat_forward: bbox_ws already holds the surfels' screen boxes */
 int sdfr_splat_forward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
                        const float* uv, const float* znorm, const float* bg, const float* bg_logit,
                        int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant,

@@ -99,6 +99,7 @@ class BatchRenderer:
         self.g_yaw, self.g_trans, self.g_latent = f(B), f(B, 3), f(B, self.L)
         self._graph = None
         self.fused_tail = True      # one launch for the backward tail (False: the three separate kernels, same bits)
+        self.fused_head = True      # one launch for surface projection + camera projection + screen boxes (False: three launches, same bits)
 
     # ------------------------------------------------------------------------------------------------------------------
     def set_params(self, yaw, trans, latent):
@@ -138,13 +139,23 @@ class BatchRenderer:
             ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.idx), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.sdf),
                                    P(self.mask_ws), 2 if self.f16 else 0, st), "sdfr_mlp_jacobian")
         xyz = self.inputs[:, self.NI - 3:]
-        ck(L.sdfr_surface_project(P(xyz), self.NI, P(self.sdf), G, B, P(self.idx), cap, P(self.cnt), P(self.J), self.NI, self.NI - 3,
-                                  P(self.points), P(self.nocs), P(self.normals), st), "sdfr_surface_project")
-        # nocs_mode | 4: the projection writes the composited attribute (col + 1) / 2 (rasterer.py:113-114) and the front-facing xyzf rows
-        ck(L.sdfr_project_dcm(P(self.pose), P(self.K), P(self.points), P(self.normals), None, B, cap, P(self.cnt), self.nocs_mode | 4, W, H,
-                              P(self.p_cam), P(self.n_cam), P(self.attr), None, P(self.fidx), P(self.fcnt), P(self.xyzf), P(self.fslot), st),
-           "sdfr_project_dcm")
-        ck(L.sdfr_splat_forward(0, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
+        prim = 0
+        if self.fused_head:
+            # band rows -> surfels -> camera frame -> front-facing list -> screen boxes in one launch; nocs_mode | 4: the composited
+            # attribute (col + 1) / 2 (rasterer.py:113-114) is written directly
+            ck(L.sdfr_surfels_forward(P(xyz), self.NI, P(self.sdf), G, P(self.idx), P(self.J), self.NI, self.NI - 3, P(self.pose), P(self.K), B,
+                                      cap, P(self.cnt), self.nocs_mode | 4, W, H, _DIAM_DISC, P(self.points), P(self.normals), P(self.p_cam),
+                                      P(self.n_cam), P(self.attr), P(self.fidx), P(self.fcnt), P(self.xyzf), P(self.fslot), P(self.bbox), st),
+               "sdfr_surfels_forward")
+            prim = 256                                                                # SDFR_PRIM_BOXES_READY
+        else:
+            ck(L.sdfr_surface_project(P(xyz), self.NI, P(self.sdf), G, B, P(self.idx), cap, P(self.cnt), P(self.J), self.NI, self.NI - 3,
+                                      P(self.points), P(self.nocs), P(self.normals), st), "sdfr_surface_project")
+            # nocs_mode | 4: the projection writes the composited attribute (col + 1) / 2 (rasterer.py:113-114) and the front-facing xyzf rows
+            ck(L.sdfr_project_dcm(P(self.pose), P(self.K), P(self.points), P(self.normals), None, B, cap, P(self.cnt), self.nocs_mode | 4, W, H,
+                                  P(self.p_cam), P(self.n_cam), P(self.attr), None, P(self.fidx), P(self.fcnt), P(self.xyzf), P(self.fslot), st),
+               "sdfr_project_dcm")
+        ck(L.sdfr_splat_forward(prim, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
                                 _DEPTH_CONSTANT, P(self.bbox), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(self.aux), st),
            "sdfr_splat_forward")
         return {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.nimg, "xyzf": self.xyzf, "nf": self.fcnt,

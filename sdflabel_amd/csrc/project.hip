@@ -6,16 +6,26 @@
 // projection K p_c / (z + eps) clamped to [-1,res] (:88-93).
 // Compiled with -ffp-contract=off; fused multiply-adds only where written explicitly.
 #include "sdfr_common.h"
+#include "splat_bbox.h"
 #include <float.h>
 
 #define PROJ_THREADS 1024
 
+// SURF: the surfels are produced here as well -- iso-surface projection of the band rows (Grid3D.get_surface_points, grid.py:57-67, the
+// arithmetic of sdfr_surface_project) -- and written to points / normals; their conservative disc screen boxes (what
+// sdfr_splat_forward would compute in a launch of its own) go to S.bbox.  One launch instead of three for the batched path.
+struct SurfArgs {
+    const float* xyz; int xyz_stride; const float* sdf; int64_t G; const int32_t* idx; const float* J; int Jstride, Joff;
+    float* points_w; float* normals_w; int4* bbox; float diam;
+};
+
+template <bool SURF>
 __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
     const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ points,
     const float* __restrict__ normals, const float* __restrict__ colors, int cap, const int32_t* __restrict__ cnt,
     int output_nocs, float res_x, float res_y, float* __restrict__ p_cam, float* __restrict__ n_cam, float* __restrict__ col,
     float* __restrict__ uv, int32_t* __restrict__ fidx, int32_t* __restrict__ fcnt, float* __restrict__ xyzf,
-    int32_t* __restrict__ fslot) {
+    int32_t* __restrict__ fslot, const SurfArgs S) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -35,8 +45,23 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
         float fx = 0.f, fy = 0.f, fz = 0.f;
         if (s < count) {
             const int64_t e = ((int64_t)b * cap + s) * 3;
-            const float x = points[e], y = points[e + 1], z = points[e + 2];
-            const float nx = normals[e], ny = normals[e + 1], nz = normals[e + 2];
+            float x, y, z, nx, ny, nz;
+            if (SURF) {
+                const int64_t e1 = (int64_t)b * cap + s;
+                const int64_t r = (int64_t)b * S.G + S.idx[e1];
+                const float* xg = S.xyz + r * S.xyz_stride;
+                const float* n = S.J + e1 * S.Jstride + S.Joff;
+                const float jx = n[0], jy = n[1], jz = n[2];
+                const float nrm = sqrtf(jx * jx + jy * jy + jz * jz);          // grid.py:57
+                nx = jx / nrm; ny = jy / nrm; nz = jz / nrm;                   // grid.py:58
+                const float sd = S.sdf[r];
+                x = xg[0] - sd * nx; y = xg[1] - sd * ny; z = xg[2] - sd * nz;   // grid.py:61
+                S.points_w[e] = x; S.points_w[e + 1] = y; S.points_w[e + 2] = z;
+                S.normals_w[e] = nx; S.normals_w[e + 1] = ny; S.normals_w[e + 2] = nz;
+            } else {
+                x = points[e]; y = points[e + 1]; z = points[e + 2];
+                nx = normals[e]; ny = normals[e + 1]; nz = normals[e + 2];
+            }
             // p_c = RT [p;1]  (:58)   n_c = R n  (:49)
             const float pcx = fmaf(r02, z, fmaf(r01, y, r00 * x)) + t0;
             const float pcy = fmaf(r12, z, fmaf(r11, y, r10 * x)) + t1;
@@ -47,6 +72,11 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
             p_cam[e] = pcx; p_cam[e + 1] = pcy; p_cam[e + 2] = pcz;
             n_cam[e] = ncx; n_cam[e + 1] = ncy; n_cam[e + 2] = ncz;
             fx = pcx; fy = pcy; fz = pcz;
+            if (SURF && S.bbox) {
+                int x0, y0, x1, y1;
+                const bool ok = disc_bbox(Kb, pcx, pcy, pcz, S.diam, (int)res_x, (int)res_y, x0, y0, x1, y1);
+                S.bbox[(int64_t)b * cap + s] = ok ? make_int4(x0, y0, x1, y1) : make_int4(1, 1, 0, 0);
+            }
             if (output_nocs) {                      // :53-55 (2: quat path, no flip :147-149); +4: the compositing map (c+1)/2 applied here
                 float c0 = ((output_nocs & 3) == 2) ? x : -x, c1 = y, c2 = z;
                 if (output_nocs & 4) { c0 = (c0 + 1.f) * 0.5f; c1 = (c1 + 1.f) * 0.5f; c2 = (c2 + 1.f) * 0.5f; }      // rasterer.py:113-114
@@ -100,8 +130,28 @@ extern "C" int sdfr_project_dcm(const float* pose, const float* K, const float* 
     SDFR_REQUIRE(output_nocs >= 0 && output_nocs <= 6 && output_nocs != 3 && output_nocs != 4, "sdfr_project_dcm: output_nocs %d unknown",
                  output_nocs);
     if (B <= 0) return SDFR_OK;
-    hipLaunchKernelGGL(sdfr_project_dcm_kernel, dim3(B), dim3(PROJ_THREADS), 0, (hipStream_t)stream, pose, K, points, normals,
-                       colors, cap, cnt, output_nocs, (float)res_x, (float)res_y, p_cam, n_cam, col, uv, fidx, fcnt, xyzf, fslot);
+    SurfArgs S = {};
+    hipLaunchKernelGGL(sdfr_project_dcm_kernel<false>, dim3(B), dim3(PROJ_THREADS), 0, (hipStream_t)stream, pose, K, points, normals,
+                       colors, cap, cnt, output_nocs, (float)res_x, (float)res_y, p_cam, n_cam, col, uv, fidx, fcnt, xyzf, fslot, S);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// Band rows -> surfels -> camera frame -> front-face list -> screen boxes in ONE launch (batched path): sdfr_surface_project +
+// sdfr_project_dcm (NOCS colour modes) + the box pass of sdfr_splat_forward (disc primitive), same arithmetic, same outputs.
+extern "C" int sdfr_surfels_forward(const float* xyz, int xyz_stride, const float* sdf, int64_t G, const int32_t* idx, const float* J,
+                                    int Jstride, int Joff, const float* pose, const float* K, int B, int cap, const int32_t* cnt,
+                                    int output_nocs, int res_x, int res_y, float diam, float* points, float* normals, float* p_cam,
+                                    float* n_cam, float* col, int32_t* fidx, int32_t* fcnt, float* xyzf, int32_t* fslot,
+                                    int32_t* bbox, void* stream) {
+    SDFR_REQUIRE(xyz && sdf && idx && J && pose && K && points && normals && p_cam && n_cam && col, "sdfr_surfels_forward: NULL argument");
+    SDFR_REQUIRE(output_nocs == 1 || output_nocs == 2 || output_nocs == 5 || output_nocs == 6, "sdfr_surfels_forward: NOCS colour modes only");
+    SDFR_REQUIRE((fidx == nullptr) == (fcnt == nullptr), "sdfr_surfels_forward: fidx and fcnt must be given together");
+    SDFR_REQUIRE(fidx || (!xyzf && !fslot), "sdfr_surfels_forward: xyzf / fslot need fidx and fcnt");
+    if (B <= 0) return SDFR_OK;
+    SurfArgs S = {xyz, xyz_stride, sdf, G, idx, J, Jstride, Joff, points, normals, reinterpret_cast<int4*>(bbox), diam};
+    hipLaunchKernelGGL(sdfr_project_dcm_kernel<true>, dim3(B), dim3(PROJ_THREADS), 0, (hipStream_t)stream, pose, K, nullptr, nullptr,
+                       nullptr, cap, cnt, output_nocs, (float)res_x, (float)res_y, p_cam, n_cam, col, nullptr, fidx, fcnt, xyzf, fslot, S);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

@@ -25,6 +25,7 @@
 // The background logit is treated as a constant (its weight is exactly 0 or 1 for disc and circle_opt; the circle's is handled by the
 // host layer).  Compiled with -ffp-contract=off so that products and sums round separately like the reference's ATen ops.
 #include "sdfr_common.h"
+#include "splat_bbox.h"
 #include <float.h>
 
 #define SPL_LC 1024            // LDS candidate-list capacity per tile (beyond it the tile walks every surfel)
@@ -98,27 +99,6 @@ __device__ __forceinline__ void pixel_ray(const float* __restrict__ Ki, float x,
     rz = fmaf(Ki[7], y, Ki[6] * x) + Ki[8];
 }
 
-// Conservative pixel interval of the rays that can pass within rho of a point, along one image axis.
-// A pixel is covered only if its ray passes closer than rho to the surfel centre, hence (projecting on the u-z plane)
-// (pu - r pz)^2 < rho^2 (1 + r^2) with r = ray_u / ray_z.  Returns false if the interval is empty on screen.
-__device__ __forceinline__ bool axis_range(float pu, float pz, float rho, float f, float c, int n, int& lo, int& hi) {
-    lo = 0; hi = n - 1;
-    const float A = pz * pz - rho * rho;
-    if (!(A > 1e-9f) || !(f != 0.f)) return true;             // near the camera plane (or NaN): whole axis
-    const float d2 = pu * pu + pz * pz;
-    const float sq = rho * sqrtf(fmaxf(d2 - rho * rho, 0.f));
-    const float r1 = (pu * pz - sq) / A, r2 = (pu * pz + sq) / A;
-    float u1 = c + f * r1, u2 = c + f * r2;
-    if (u1 > u2) { const float tmp = u1; u1 = u2; u2 = tmp; }
-    const float pad = 1.5f + 1e-3f * (fabsf(u1) + fabsf(u2));
-    u1 -= pad; u2 += pad;
-    if (isnan(u1) || isnan(u2)) return true;                  // undecidable: keep the whole axis
-    if (u2 < 0.f || u1 > (float)(n - 1)) return false;       // entirely off screen
-    lo = (int)fmaxf(floorf(u1), 0.f);
-    hi = (int)fminf(ceilf(u2), (float)(n - 1));
-    return lo <= hi;
-}
-
 __device__ __forceinline__ bool interval(float lo_f, float hi_f, int n, int& lo, int& hi) {
     lo = 0; hi = n - 1;
     if (isnan(lo_f) || isnan(hi_f)) return true;
@@ -134,12 +114,7 @@ __device__ __forceinline__ bool surfel_bbox(const SplatArgs& A, int b, int64_t e
     x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
     const float* K = A.K + (int64_t)b * 9;
     if (PRIM == 0) {
-        const bool standard = (K[1] == 0.f) && (K[3] == 0.f) && (K[6] == 0.f) && (K[7] == 0.f) && (K[8] == 1.f);
-        if (!standard) return true;
-        const float px = A.p_cam[e * 3], py = A.p_cam[e * 3 + 1], pz = A.p_cam[e * 3 + 2];
-        if (!axis_range(px, pz, A.diam, K[0], K[2], W, x0, x1)) return false;
-        if (!axis_range(py, pz, A.diam, K[4], K[5], H, y0, y1)) return false;
-        return true;
+        return disc_bbox(K, A.p_cam[e * 3], A.p_cam[e * 3 + 1], A.p_cam[e * 3 + 2], A.diam, W, H, x0, y0, x1, y1);
     } else if (PRIM == 1) {
         const float u = A.uv[e * 2], v = A.uv[e * 2 + 1];
         const float r = fabsf(K[0] * A.diam / (A.p_cam[e * 3 + 2] + FLT_EPSILON)) + SIGMOID_REACH + 1.f;
@@ -557,6 +532,8 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
                                   const float* attr, const float* uv, const float* znorm, const float* bg, const float* bg_logit, int B,
                                   int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant, int32_t* bbox_ws,
                                   float* color, float* mask, float* depth, float* normals, float* aux, void* stream) {
+    const bool boxes_ready = (primitive & SDFR_PRIM_BOXES_READY) != 0;      // bbox_ws already holds the screen boxes (sdfr_surfels_forward)
+    primitive &= ~SDFR_PRIM_BOXES_READY;
     SplatArgs A;
     int rc = fill_args(A, "sdfr_splat_forward", primitive, K, Kinv, p_cam, n_cam, attr, uv, znorm, bg, bg_logit, B, cap, cnt, W, H, diam,
                        depth_constant);
@@ -569,15 +546,15 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
     const dim3 gt(((W + 7) / 8) * ((H + 7) / 8), B);
     switch (primitive) {
         case 0:
-            if (cap > 0) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<0>, gb, dim3(256), 0, s, A, bb);
+            if (cap > 0 && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<0>, gb, dim3(256), 0, s, A, bb);
             hipLaunchKernelGGL(sdfr_splat_fwd_kernel<0>, gt, dim3(64 * SPL_NW), 0, s, A, bb, color, mask, depth, normals, aux);
             break;
         case 1:
-            if (cap > 0) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<1>, gb, dim3(256), 0, s, A, bb);
+            if (cap > 0 && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<1>, gb, dim3(256), 0, s, A, bb);
             hipLaunchKernelGGL(sdfr_splat_fwd_kernel<1>, gt, dim3(64 * SPL_NW), 0, s, A, bb, color, mask, depth, normals, aux);
             break;
         default:
-            if (cap > 0) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<2>, gb, dim3(256), 0, s, A, bb);
+            if (cap > 0 && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<2>, gb, dim3(256), 0, s, A, bb);
             hipLaunchKernelGGL(sdfr_splat_fwd_kernel<2>, gt, dim3(64 * SPL_NW), 0, s, A, bb, color, mask, depth, normals, aux);
             break;
     }

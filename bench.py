@@ -198,12 +198,16 @@ def main():
     for _ in range(args.warmup):
         step()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    import gc
+    gc.collect()
+    gc.disable()                  # no collector pause inside a timed region (the steps allocate nothing, but the interpreter may still run it)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(events[i])
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     assert not br.overflow()
     n_surf, n_front = int(br.cnt[0]), int(br.fcnt[0])
     loss = br.color[0].sum() + br.mask[0].sum() + br.nimg[0].sum() + br.xyzf[0].sum()
@@ -235,6 +239,8 @@ def main():
             err = repr(e)[:200]
         if not all_ok(err is None):
             return None, err or "failed on another rank"
+        gc.collect()
+        gc.disable()
         barrier()
         t_ = time.perf_counter()
         try:
@@ -243,6 +249,7 @@ def main():
             err = repr(e)[:200]
         barrier()
         d_ = time.perf_counter() - t_
+        gc.enable()
         if dist is not None:
             tt = torch.tensor([d_], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

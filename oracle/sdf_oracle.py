@@ -647,3 +647,71 @@ def project_backward_dcm(camera_pose, points, normals, g_p3, g_nrm, g_col, outpu
     g_pose[:3, :3] = g_p3.T @ points + g_nrm.astype(np.float64).T @ normals
     g_pose[:3, 3] = g_p3.sum(axis=0)
     return g_points.astype(dt), g_normals.astype(dt), g_colors_in, g_pose.astype(dt)
+
+
+# --------------------------------------------------------------------------------------
+# Losses of the refinement loop  (pipelines/optimizer.py:166-237)
+# --------------------------------------------------------------------------------------
+
+def loss_3d(pcd_est, pcd_lidar, scale, threshold=0.2, want_grad=False):
+    """optimizer.py:166-198 with pcd_frustum = pcd_lidar / scale (optimizer.py:84).  Nearest lidar point of every estimated point (exact
+    NN; the reference queries a sklearn KDTree, :180-181), pairs closer than threshold / scale (:189), mean pair distance (:190-194).
+    Returns loss [, d loss / d pcd_est, d loss / d scale, nn index, close mask]."""
+    est = np.asarray(pcd_est, np.float32)
+    lidar = np.asarray(pcd_lidar, np.float32)
+    if est.size == 0 or lidar.size == 0:
+        return (np.float32(0), np.zeros_like(est), np.float32(0), None, None) if want_grad else np.float32(0)
+    fr = (lidar / np.float32(scale)).astype(np.float32)
+    d2 = ((est.astype(np.float64)[:, None, :] - fr.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    idx = d2.argmin(1)
+    dist = np.sqrt(d2[np.arange(est.shape[0]), idx])
+    close = dist < threshold / float(scale)
+    if not close.any():
+        return (np.float32(0), np.zeros_like(est), np.float32(0), idx, close) if want_grad else np.float32(0)
+    diff = fr[idx[close]] - est[close]
+    d = np.sqrt((diff * diff).sum(1))
+    loss = d.mean(dtype=np.float32)
+    if not want_grad:
+        return loss
+    u = diff / d[:, None] / np.float32(close.sum())               # d loss / d (frustum point) of each pair
+    g_est = np.zeros_like(est)
+    g_est[close] = -u
+    g_scale = np.float32((u * (-lidar[idx[close]] / np.float32(scale) ** 2)).sum())
+    return loss, g_est, g_scale, idx, close
+
+
+def loss_2d(rendering_nocs, css_nocs, diam=5, threshold_nocs=1, want_grad=False):
+    """optimizer.py:200-237.  For every rendered pixel (non-zero channel sum, :213) the smallest NOCS distance between its colour and
+    the target image weighted by clamp(diam - pixel distance, 0) (:223-226) over ALL pixels (:231-232: outside the window the weighted
+    target is 0, so the candidate there is the norm of the rendered colour itself); mean over the pixels whose minimum is below
+    threshold_nocs (:233).  Returns loss [, d loss / d rendering_nocs]."""
+    r = np.asarray(rendering_nocs, np.float32)
+    t = np.asarray(css_nocs, np.float32)
+    H, W = r.shape[1:]
+    ys, xs = np.nonzero(r.sum(0))
+    if (ys.sum() + xs.sum()) == 0:                                   # `if rendering_nonzero_idxs.sum():` -- the SUM OF THE INDICES (:214)
+        return (np.float32(0), np.zeros_like(r)) if want_grad else np.float32(0)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    g = np.zeros_like(r)
+    dmins, args = [], []
+    for y, x in zip(ys, xs):
+        w = np.maximum(np.float32(diam) - np.sqrt((yy - np.float32(y)) ** 2 + (xx - np.float32(x)) ** 2), 0).astype(np.float32)
+        m = t * w[None]
+        v = r[:, y, x]
+        diff = np.sqrt(((m - v[:, None, None]) ** 2).sum(0))
+        a = int(diff.argmin())
+        dmins.append(diff.reshape(-1)[a])
+        args.append(a)
+    dmins = np.asarray(dmins, np.float32)
+    sel = dmins < threshold_nocs
+    loss = dmins[sel].mean(dtype=np.float32) if sel.any() else np.float32(np.nan)
+    if not want_grad:
+        return loss
+    cnt = np.float32(sel.sum())
+    for (y, x, a, dm, s) in zip(ys, xs, args, dmins, sel):
+        if not s:
+            continue
+        w = max(np.float32(diam) - np.sqrt(np.float32((a // W - y) ** 2 + (a % W - x) ** 2)), np.float32(0))
+        m = t[:, a // W, a % W] * w
+        g[:, y, x] = (r[:, y, x] - m) / dm / cnt
+    return loss, g

@@ -43,3 +43,13 @@ def build_c_abi_smoke(out_dir):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     return exe
+
+
+def pattern_weights(shape, salt):
+    """Deterministic pseudo-random weights in [-1, 1] (integer hash of the flat index: exact in float32 on every platform); the same
+    function as tools/make_golden.py's, so that the gradient functionals of the large goldens (G10) need no stored weight arrays."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.uint64)
+    h = (i * np.uint64(2654435761) + np.uint64(salt) * np.uint64(40503)) & np.uint64(0xFFFFFFFF)
+    h = (h >> np.uint64(7)) % np.uint64(2001)
+    return ((h.astype(np.int64) - 1000).astype(np.float32) / np.float32(1000.0)).reshape(shape)

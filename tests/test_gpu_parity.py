@@ -445,7 +445,8 @@ def test_end_to_end_gradients_golden(dec, tag):
 
 
 def test_full_size_crop_vs_oracle_sample(dec, oracle_layers):
-    """BASELINE configs[1] shape (D=40, 256x256): compare the rendered images with the oracle on the same surfels."""
+    """D = 40 grid, 128x128 crop: the rendered images against the oracle on the same surfels (the 256x256 size of BASELINE configs[1] is
+    tested against reference-held data in tests/test_gpu_configs.py)."""
     layers, spec = oracle_layers
     D, H, W = 40, 128, 128
     grid = sdflabel_amd.Grid3D(D, DEV)

@@ -15,6 +15,9 @@ seeds, torch version and threshold margins -- never reference source.
                      yaw, trans, latent, coords, normals                  (optimizer.py:79-123 graph)
   G8 optimizer       10-iteration Optimizer.optimize trajectory            (optimizer.py:56-164)
   G9 secondary       Rasterer.forward with primitives circle / circle_opt and bg, + gradients   (primitives.py:4-162)
+  G10 config1        BASELINE configs[1] at full size: 256x256, D=40, float32, images + surfels + gradients        (optimizer.py:79-123 graph)
+  G11 config4        the reference's own float16 run at 512x512, D=40, beside its float32 run (config_refine.ini:19)
+  G12 losses         compute_loss_2d / compute_loss_3d values and gradients                                        (optimizer.py:166-237)
 
 usage: python tools/make_golden.py [G1 G2 ...]
 """
@@ -402,7 +405,178 @@ def g9():
     save("g9_secondary.npz", **arrs)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G9": g9}
+def pattern_weights(shape, salt):
+    """Deterministic pseudo-random weights in [-1, 1] (integer hash of the flat index: exact in float32 on every platform), so that a
+    gradient functional over large outputs needs no stored weight arrays.  tests/_util.py holds the same function."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.uint64)
+    h = (i * np.uint64(2654435761) + np.uint64(salt) * np.uint64(40503)) & np.uint64(0xFFFFFFFF)
+    h = (h >> np.uint64(7)) % np.uint64(2001)
+    return ((h.astype(np.int64) - 1000).astype(np.float32) / np.float32(1000.0)).reshape(shape)
+
+
+def near_threshold_pixels(K, H, W, pose, pcd, normals):
+    """Pixels where some (pixel, surfel) pair sits within 1e-5 of a selection threshold of inside_surfel (disc edge, |n.ray| = 0.01):
+    computed with THIS project's oracle on the reference's surfels, stored so that a GPU test can attribute a rounding flip."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from oracle import sdf_oracle as O
+    Kn = K.numpy().astype(np.float32)
+    Kinv = np.linalg.inv(Kn).astype(np.float32)
+    proj = O.project_in_2D(Kn, pose, pcd, normals, normals, (W, H), output_nocs=True)
+    v3, nc = proj["points_3d"].astype(np.float32), proj["normals_3d"].astype(np.float32)
+    near = np.zeros(H * W, bool)
+    grid2d = O.pixel_grid((W, H)).reshape(H, W, 2)
+    for r0 in range(0, H, 32):
+        sub = grid2d[r0:r0 + 32].reshape(-1, 2)
+        _, aux = O.inside_surfel(Kinv, sub, v3, nc, diam=0.04, want_aux=True)
+        near[r0 * W:r0 * W + sub.shape[0]] = (aux["margin_disc"] < 1e-5) | (aux["margin_b"] < 1e-5)
+    return near
+
+
+def g10():
+    """BASELINE configs[1] at its stated size: ONE 256x256 crop, D = 40, float32, the optimizer's graph (optimizer.py:79-123) with every
+    output enabled and a deterministic linear functional as the loss; images, surfels and autograd gradients of the reference."""
+    D, H, W = 40, 256, 256
+    latent, yaw0, trans0 = [0.5, -0.3, 0.6], 0.7, [0.03, 0.02, 3.45]
+    dec = load_fitted()[0]
+    grid = ref_grid.Grid3D(D, "cpu", torch.float32)
+    lat = torch.tensor(latent, dtype=torch.float32, requires_grad=True)
+    yaw = torch.tensor([yaw0], requires_grad=True)
+    trans = torch.tensor(trans0, requires_grad=True)
+    K = K_for(H, W)
+    renderer = Rasterer(K, (W, H), precision=torch.float32)
+    lat_ = F.normalize(lat, p=2, dim=0)
+    inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1)
+    sdf, _ = dec(inputs)
+    pcd, _, normals = grid.get_surface_points(sdf)
+    lat.grad = None
+    dec.zero_grad()
+    grid.points.grad = None
+    pose = build_pose(yaw, trans)
+    rendering, points = renderer(pcd, normals, normals, pose, primitives="disc", rot="dcm", bg=None, output_depth=True,
+                                 output_normals=True, output_nocs=True, output_points=True, output_mask=True)
+    salts = {"color": 1, "mask": 2, "depth": 3, "normals": 4, "xyzf": 5}
+    loss = sum((rendering[k] * torch.from_numpy(pattern_weights(tuple(rendering[k].shape), salts[k]))).sum() for k in rendering)
+    loss = loss + (points["xyzf"] * torch.from_numpy(pattern_weights(tuple(points["xyzf"].shape), salts["xyzf"]))).sum()
+    loss.backward()
+    s = sdf.detach().numpy()
+    arrs = dict(cfg=np.array([D, H, W]), latent=np.asarray(latent, np.float32), yaw=np.asarray([yaw0], np.float32),
+                trans=np.asarray(trans0, np.float32), K=K.numpy(), pose=pose.detach().numpy(),
+                sdf_stride7=s[::7, 0], band_idx=np.nonzero(np.abs(s[:, 0]) < 0.03)[0].astype(np.int32),
+                band_margin=np.min(np.abs(np.abs(s[:, 0]) - 0.03)), pcd=pcd.detach().numpy(), normals=normals.detach().numpy(),
+                xyzf=points["xyzf"].detach().numpy(), loss=loss.detach().numpy(), g_yaw=yaw.grad.numpy(), g_trans=trans.grad.numpy(),
+                g_latent=lat.grad.numpy())
+    dot = ((normals.detach() @ pose.detach()[:3, :3].t()) * points["xyz"].detach()).sum(1)
+    arrs["filt_margin"] = dot.abs().min().numpy()
+    for k, v in rendering.items():
+        arrs["out_" + k] = v.detach().numpy()
+    arrs["near_threshold"] = np.packbits(near_threshold_pixels(K, H, W, pose.detach().numpy(), pcd.detach().numpy(), normals.detach().numpy()))
+    print("G10 N", pcd.shape[0], "Nf", points["xyzf"].shape[0], "loss", float(loss), "g_yaw", yaw.grad.numpy(), "g_trans", trans.grad.numpy(),
+          "g_lat", lat.grad.numpy(), "band margin", arrs["band_margin"], "filt margin", arrs["filt_margin"],
+          "near px", int(np.unpackbits(arrs["near_threshold"]).sum()))
+    save("g10_config1_256.npz", **arrs)
+
+
+def _ref_render_precision(prec, D, H, W, latent, yaw0, trans0):
+    """the reference's pipeline at one `precision` (config_refine.ini:19 -> refine_css.py:144-153: decoder, grid, K, pose, Rasterer all in it)"""
+    dec, _ = load_fitted(prec)
+    grid = ref_grid.Grid3D(D, "cpu", prec)
+    lat_ = F.normalize(torch.tensor(latent).to(prec), p=2, dim=0)                                    # optimizer.py:96
+    inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1).to(lat_.dtype)       # :99-100
+    sdf, _ = dec(inputs)
+    pcd, _, normals = grid.get_surface_points(sdf)
+    pose = torch.eye(4).to(prec)                                                                      # :86-90
+    pose[:3, :3] = rtools.rot_from_yaw(torch.tensor([yaw0])).to(prec)
+    pose[1] *= -1
+    pose[:3, 3] = torch.tensor(trans0).to(prec)
+    K = K_for(H, W).to(prec)
+    r = Rasterer(K, (W, H), precision=prec)
+    with torch.no_grad():
+        rend, pts = r(pcd.detach(), normals.detach(), normals.detach(), pose, primitives="disc", rot="dcm", bg=None, output_depth=True,
+                      output_normals=True, output_nocs=True, output_points=True, output_mask=True)
+    return sdf.detach(), pcd.detach(), normals.detach(), rend, pts
+
+
+def g11():
+    """BASELINE configs[4]: the reference's OWN float16 run (setup_dsdf(precision=float16), Grid3D(..., float16), half K / pose / Rasterer,
+    configs/config_refine.ini:19) at 512x512, D = 40, beside its float32 run of the same inputs.  Stored: the float16 decoder output on the
+    whole grid and its band, the float16 images (as float16, exact), the float32 images, and the per-image counts of pixels where the
+    reference's two precisions disagree by more than 1e-2 -- the yardstick for the tolerance stated in tests/test_gpu_configs.py."""
+    D, H, W = 40, 512, 512
+    latent, yaw0, trans0 = [0.3, -0.5, 0.8], 0.6, [0.0, 0.0, 3.5]
+    arrs = dict(cfg=np.array([D, H, W]), latent=np.asarray(latent, np.float32), yaw=np.asarray([yaw0], np.float32),
+                trans=np.asarray(trans0, np.float32), K=K_for(H, W).numpy())
+    res = {}
+    for tag, prec in (("f32", torch.float32), ("f16", torch.float16)):
+        sdf, pcd, normals, rend, pts = _ref_render_precision(prec, D, H, W, latent, yaw0, trans0)
+        res[tag] = (sdf.float().numpy(), {k: v.float().numpy() for k, v in rend.items()})
+        s = sdf.float().numpy()[:, 0]
+        store = np.float16 if prec == torch.float16 else np.float32
+        arrs[tag + "_sdf"] = sdf.numpy()[:, 0].astype(store)
+        arrs[tag + "_band_idx"] = np.nonzero(np.abs(s) < 0.03)[0].astype(np.int32)
+        arrs[tag + "_n_front"] = pts["xyzf"].shape[0]
+        for k, v in rend.items():
+            arrs[tag + "_out_" + k] = v.numpy().astype(store)
+    for k in res["f32"][1]:
+        d = np.abs(res["f32"][1][k] - res["f16"][1][k])
+        arrs["ref_pixels_beyond_1e-2_" + k] = int((d.reshape(d.shape[0], -1).max(0) > 1e-2).sum())
+        print("G11", k, "reference f16 vs f32: pixels beyond 1e-2:", arrs["ref_pixels_beyond_1e-2_" + k], "of", H * W)
+    arrs["ref_sdf_max_abs_diff"] = float(np.abs(res["f32"][0] - res["f16"][0]).max())
+    arrs["ref_sdf_mean_abs_diff"] = float(np.abs(res["f32"][0] - res["f16"][0]).mean())
+    b32, b16 = set(arrs["f32_band_idx"].tolist()), set(arrs["f16_band_idx"].tolist())
+    arrs["ref_band_symmetric_difference"] = len(b32 ^ b16)
+    print("G11 sdf max/mean diff", arrs["ref_sdf_max_abs_diff"], arrs["ref_sdf_mean_abs_diff"], "band", len(b32), len(b16), "sym diff", len(b32 ^ b16))
+    save("g11_config4_fp16_512.npz", **arrs)
+
+
+def g12():
+    """Standalone goldens of the two losses (pipelines/optimizer.py:166-237): values and autograd gradients w.r.t. the rendered NOCS image,
+    the estimated points and the scale (through pcd_frustum = lidar / scale, optimizer.py:84)."""
+    from pipelines.optimizer import Optimizer
+    arrs = {}
+    dec = load_fitted()[0]
+    for tag, D, H, W in (("a", 20, 32, 32), ("b", 27, 40, 56)):
+        K, nocs_t, lidar = synth_targets(dec, D, H, W, [0.3, -0.5, 0.8], 0.6, [0.0, 0.0, 3.5], 2.0)
+        # the rendering of a perturbed pose / shape = what the loss sees in the first iteration
+        grid = ref_grid.Grid3D(D, "cpu", torch.float32)
+        lat_ = F.normalize(torch.tensor([0.5, -0.3, 0.6]), p=2, dim=0)
+        inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1)
+        sdf, _ = dec(inputs)
+        pcd, _, normals = grid.get_surface_points(sdf)
+        pose = build_pose(torch.tensor([0.7]), torch.tensor([0.03, 0.02, 3.45]))
+        renderer = Rasterer(K, (W, H), precision=torch.float32)
+        rendering, points = renderer(pcd.detach(), normals.detach(), normals.detach(), pose, primitives="disc", rot="dcm", output_nocs=True,
+                                     output_points=True, output_mask=True)
+        opt = Optimizer({"yaw": [0.7], "trans": [0.03, 0.02, 3.45], "scale": [2.0], "latent": [0.5, -0.3, 0.6]}, "cpu", {"2d": 0.3, "3d": 0.5})
+        opt.device, opt.precision = torch.device("cpu"), torch.float32
+        for thr_tag, thr in (("", 1.0), ("_t03", 0.3)):
+            col = rendering["color"].detach().clone().requires_grad_(True)
+            l2 = opt.compute_loss_2d(col, nocs_t, diam=5, threshold_nocs=thr)
+            l2.backward()
+            arrs[tag + "_l2d" + thr_tag] = l2.detach().numpy()
+            arrs[tag + "_g_color" + thr_tag] = col.grad.numpy()
+        est = points["xyzf"].detach().clone().requires_grad_(True)
+        scale = opt.params["scale"]
+        frustum = torch.Tensor(lidar) / scale                                   # optimizer.py:84
+        l3, dists, idxs = opt.compute_loss_3d(est, frustum)
+        l3.backward()
+        arrs[tag + "_cfg"] = np.array([D, H, W])
+        arrs[tag + "_color"] = rendering["color"].detach().numpy()
+        arrs[tag + "_target"] = nocs_t.numpy()
+        arrs[tag + "_xyzf"] = est.detach().numpy()
+        arrs[tag + "_lidar"] = lidar
+        arrs[tag + "_scale"] = np.asarray([2.0], np.float32)
+        arrs[tag + "_l3d"] = l3.detach().numpy()
+        arrs[tag + "_g_xyzf"] = est.grad.numpy()
+        arrs[tag + "_g_scale"] = scale.grad.numpy()
+        arrs[tag + "_nn_idx"] = np.asarray(idxs, np.int32)
+        arrs[tag + "_n_pairs"] = int((np.asarray(dists) < 0.2 / 2.0).sum())
+        print("G12", tag, "l2d", float(arrs[tag + "_l2d"]), "l2d(thr .3)", float(arrs[tag + "_l2d_t03"]), "l3d", float(l3), "pairs", arrs[tag + "_n_pairs"], "of", est.shape[0],
+              "g_scale", scale.grad.numpy())
+    save("g12_losses.npz", **arrs)
+
+
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G9": g9, "G10": g10, "G11": g11, "G12": g12}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

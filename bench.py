@@ -171,7 +171,7 @@ def main():
             __graft_entry__.build()
         if dist is not None:
             dist.barrier()
-    dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt")
+    dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
     dec = dec.to(dev)
     CB = args.crops_per_gpu
     from sdflabel_amd.parallel import shard_crops

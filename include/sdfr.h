@@ -203,6 +203,21 @@ int sdfr_splat_backward(int primitive, const float* K, const float* Kinv, const 
                         const float* g_color, const float* g_mask, const float* g_depth, const float* g_normals,
                         float* g_p_cam, float* g_n_cam, float* g_attr, void* stream);
 
+/* The dense weight matrix the reference's standalone primitives return (prob_color[:, 0, :] of inside_surfel / inside_circle /
+ * inside_circle_opt, primitives.py:71,162,243): weights [B][rows][W*H], rows = cap (+1 background row when bg_logit != NULL), from the
+ * per-pixel state `aux` of a sdfr_splat_forward call over the same surfels (with the same bg_logit).  `weights` must be zero-filled; only
+ * covered (surfel, pixel) pairs are written.  Not used by the renderer itself. */
+int sdfr_splat_weights(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* uv,
+                       const float* znorm, const float* bg_logit, int B, int cap, const int32_t* cnt, int W, int H, float diam,
+                       float depth_constant, const float* aux, float* weights, void* stream);
+/* Its backward w.r.t. p_cam / n_cam given g_weights [B][rows][W*H] and wsum[b][pix] = sum_j weights_j * g_weights_j (the softmax-backward
+ * sum over ALL rows of the pixel, background row included).  Coverage masks, the per-pixel norm and the background logit are constants, as
+ * in the reference's autograd (primitives.py:55,59,226,228). */
+int sdfr_splat_weights_backward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* uv,
+                                const float* znorm, int has_bg_row, int B, int cap, const int32_t* cnt, int W, int H, float diam,
+                                float depth_constant, const float* aux, const float* g_weights, const float* wsum, float* g_p_cam,
+                                float* g_n_cam, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Batched refinement step glue  --  the per-iteration host tensor algebra of pipelines/optimizer.py:86-100, for B crops
  * at once and entirely on the device (no host synchronisation anywhere in a step).

@@ -44,6 +44,10 @@ _PROTOS = {
     "sdfr_splat_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_weights": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                   c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_weights_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                            c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_params_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_surface_latent_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sdfr_params_backward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
@@ -97,8 +101,18 @@ def ptr(t):
 
 
 def stream_ptr():
+    """the current stream of the CURRENT device: call it inside `with guard(tensor):` so that device is the tensors' one"""
     import torch
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def guard(t):
+    """Context manager making the device of tensor (or torch.device) `t` current, as every kernel launch needs: the launch stream
+    (stream_ptr) and any allocation inside the library then belong to the device that holds the data, whatever the caller's current
+    device is (the reference works on any device the tensors live on)."""
+    import torch
+    dev = t.device if hasattr(t, "device") else torch.device(t)
+    return torch.cuda.device(dev)
 
 
 def require_gpu_float(*tensors):

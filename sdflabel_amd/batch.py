@@ -109,6 +109,14 @@ class BatchRenderer:
 
     def forward(self, yaw=None, trans=None, latent=None, mlp_events=None):
         """mlp_events: optional (start, end) torch.cuda.Event pair recorded around the decoder-forward launch (bench.py roofline)."""
+        with _lib.guard(self.dev):
+            return self._forward(yaw, trans, latent, mlp_events)
+
+    def backward(self, g_color=None, g_mask=None, g_depth=None, g_normals=None, g_xyzf=None):
+        with _lib.guard(self.dev):
+            return self._backward(g_color, g_mask, g_depth, g_normals, g_xyzf)
+
+    def _forward(self, yaw, trans, latent, mlp_events):
         if yaw is not None:
             self.set_params(yaw, trans, latent)
         L = _lib.lib()
@@ -161,7 +169,7 @@ class BatchRenderer:
         return {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.nimg, "xyzf": self.xyzf, "nf": self.fcnt,
                 "n": self.cnt}
 
-    def backward(self, g_color=None, g_mask=None, g_depth=None, g_normals=None, g_xyzf=None):
+    def _backward(self, g_color, g_mask, g_depth, g_normals, g_xyzf):
         L = _lib.lib()
         P, st, ck = _lib.ptr, _lib.stream_ptr(), _lib.check
         B, cap, W, H = self.B, self.cap, self.W, self.H
@@ -204,6 +212,13 @@ class BatchRenderer:
         if self.prefilter:
             over = over | (self.ccnt > self.cap).any()
         return bool(over.item())
+
+    def check_overflow(self):
+        """Raise if the last forward dropped surfels (the reference has no capacity: a truncated shape must not pass silently).  One sync."""
+        if self.overflow():
+            worst = int(self.cnt.max()) if not self.prefilter else max(int(self.cnt.max()), int(self.ccnt.max()))
+            raise _lib.SdfrError("a crop's band holds %d surfels but BatchRenderer was built with cap=%d: rebuild it with a larger `cap` "
+                                 "(default max(256, G/8))" % (worst, self.cap))
 
     def capture(self, grads_fn):
         """Capture forward -> grads_fn(outputs) -> backward in a HIP graph.  grads_fn maps the output dict to the keyword arguments of

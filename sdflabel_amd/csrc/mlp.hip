@@ -28,7 +28,8 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
     }
     SDFR_REQUIRE(width <= 512, "sdfr_decoder_create: hidden width %d > 512 unsupported", width);
     const int HP = width <= 128 ? 128 : (width <= 256 ? 256 : 512);
-    SDFR_HIP_CHECK(hipSetDevice(device));
+    SdfrDeviceGuard dev_guard(device);              // allocations and copies below go to `device`; the caller's current device is restored
+    SDFR_HIP_CHECK(dev_guard.err);
 
     sdfr_decoder* d = new sdfr_decoder();
     memset(d, 0, sizeof(*d));

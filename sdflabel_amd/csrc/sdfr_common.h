@@ -26,6 +26,18 @@ void sdfr_set_error(const char* fmt, ...);
 
 #define SDFR_LAUNCH_CHECK() SDFR_HIP_CHECK(hipGetLastError())
 
+// makes `device` current for the lifetime of the guard and restores the caller's device afterwards (a library call must not change the
+// process' current device: PyTorch and other HIP users rely on it)
+struct SdfrDeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit SdfrDeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device); else if (err == hipSuccess) prev = -1;
+    }
+    ~SdfrDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 static inline int sdfr_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // number of valid items of crop b in a [B][cap] ragged array

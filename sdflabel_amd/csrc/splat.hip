@@ -395,13 +395,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <int PRIM>
+// DENSE: the upstream gradient is given per (surfel, pixel) weight -- gW [B][rows][P], rows = cap (+1 with a background row) -- together with
+// Sd[b][pix] = sum_j w_j gW_j (the softmax-backward sum), instead of through the composited images: the backward of the standalone
+// primitives (sdfr_splat_weights), which hand out the dense weight matrix as the reference's inside_* functions do.
+template <int PRIM, bool DENSE = false>
 __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, const float* __restrict__ aux,
                                                             const float* __restrict__ color, const float* __restrict__ mask,
                                                             const float* __restrict__ depth, const float* __restrict__ normals,
                                                             const float* __restrict__ g_color, const float* __restrict__ g_mask,
                                                             const float* __restrict__ g_depth, const float* __restrict__ g_normals,
-                                                            float* __restrict__ g_p, float* __restrict__ g_n, float* __restrict__ g_attr) {
+                                                            float* __restrict__ g_p, float* __restrict__ g_n, float* __restrict__ g_attr,
+                                                            const float* __restrict__ gW = nullptr, const float* __restrict__ Sd = nullptr,
+                                                            int rows = 0) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -457,21 +462,23 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
             const float w = expf(logit - ax.y) / ax.z;
             // gated upstream gradients and S = sum_j w_j dL/dw_j = <gated grads, composited outputs>
             float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, gm = 0.f, gd = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, S = 0.f;
-            if (g_color) {
+            if (DENSE) S = Sd[(int64_t)b * P + pix];
+            if (!DENSE && g_color) {
                 const float* g = g_color + (int64_t)b * 3 * P + pix;
                 const float* o = color + (int64_t)b * 3 * P + pix;
                 gc0 = (gates & 1u) ? g[0] : 0.f; gc1 = (gates & 2u) ? g[P] : 0.f; gc2 = (gates & 4u) ? g[2 * P] : 0.f;
                 S += gc0 * o[0] + gc1 * o[P] + gc2 * o[2 * P];
             }
-            if (g_mask) { gm = (gates & 8u) ? g_mask[(int64_t)b * P + pix] : 0.f; S += gm * mask[(int64_t)b * P + pix]; }
-            if (g_depth) { gd = g_depth[(int64_t)b * P + pix]; S += gd * depth[(int64_t)b * P + pix]; }
-            if (g_normals) {
+            if (!DENSE && g_mask) { gm = (gates & 8u) ? g_mask[(int64_t)b * P + pix] : 0.f; S += gm * mask[(int64_t)b * P + pix]; }
+            if (!DENSE && g_depth) { gd = g_depth[(int64_t)b * P + pix]; S += gd * depth[(int64_t)b * P + pix]; }
+            if (!DENSE && g_normals) {
                 const float* g = g_normals + (int64_t)b * 3 * P + pix;
                 const float* o = normals + (int64_t)b * 3 * P + pix;
                 gn0 = (gates & 16u) ? g[0] : 0.f; gn1 = (gates & 32u) ? g[P] : 0.f; gn2 = (gates & 64u) ? g[2 * P] : 0.f;
                 S += gn0 * o[0] + gn1 * o[P] + gn2 * o[2 * P];
             }
-            const float dLdw = gc0 * a0 + gc1 * a1 + gc2 * a2 + gm + gd * pz + gn0 * m0 + gn1 * m1 + gn2 * m2;
+            const float dLdw = DENSE ? gW[((int64_t)b * rows + s) * P + pix]
+                                     : gc0 * a0 + gc1 * a1 + gc2 * a2 + gm + gd * pz + gn0 * m0 + gn1 * m1 + gn2 * m2;
             sC0 += w * gc0; sC1 += w * gc1; sC2 += w * gc2;
             sN0 += w * gn0; sN1 += w * gn1; sN2 += w * gn2;
             sZ += w * gd;
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
     if (PRIM == 0) { sA = wave_sum(sA); sB0 = wave_sum(sB0); sB1 = wave_sum(sB1); sB2 = wave_sum(sB2); }
     else sL = wave_sum(sL);
     if (lane == 0) {
-        g_attr[e] = sC0; g_attr[e + 1] = sC1; g_attr[e + 2] = sC2;
+        if (g_attr) { g_attr[e] = sC0; g_attr[e + 1] = sC1; g_attr[e + 2] = sC2; }
         if (PRIM == 0) {
             g_n[e] = 0.5f * sN0 + sB0 + sA * px;
             g_n[e + 1] = 0.5f * sN1 + sB1 + sA * py;
@@ -510,6 +517,65 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
             g_p[e + 2] = sZ - dq / (zn + FLT_EPSILON);
         }
     }
+}
+
+// ---- dense weight matrix (the standalone primitives) ---------------------------------------------------------------------------
+// The reference's inside_surfel / inside_circle / inside_circle_opt RETURN the (N[+1], P) weight matrix (primitives.py:71,162,243).
+// Rasterer.forward never needs it here (the splat kernels composite on the fly), but a caller of the standalone functions does: the
+// per-pixel softmax state `aux` of a splat forward pass plus one more sweep over each surfel's screen box reproduces every entry.
+// One wavefront per surfel; W must be zero-filled by the caller (only covered pixels are written).
+template <int PRIM>
+__global__ __launch_bounds__(256) void sdfr_splat_weights_kernel(const SplatArgs A, const float* __restrict__ aux, float* __restrict__ Wout,
+                                                                int rows) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= sdfr_count(A.cnt, b, A.cap)) return;
+    const int W = A.W, H = A.H, P = W * H;
+    const int64_t e1 = (int64_t)b * A.cap + s, e = e1 * 3;
+    const float px = A.p_cam[e], py = A.p_cam[e + 1], pz = A.p_cam[e + 2];
+    const float nx = A.n_cam[e], ny = A.n_cam[e + 1], nz = A.n_cam[e + 2];
+    const float a = nx * px + ny * py + nz * pz;
+    const float* Ki = A.Kinv + (int64_t)b * 9;
+    float u = 0.f, v = 0.f, rad = 0.f, zl = 0.f;
+    if (PRIM != 0) {
+        u = A.uv[e1 * 2]; v = A.uv[e1 * 2 + 1];
+        rad = fabsf(A.K[(int64_t)b * 9] * A.diam / (pz + FLT_EPSILON));
+        zl = depth_logit(pz, A.znorm[b], A.depth_constant, nullptr);
+    }
+    int x0, y0, x1, y1;
+    if (!surfel_bbox<PRIM>(A, b, e1, x0, y0, x1, y1)) return;
+    const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+    float* row = Wout + ((int64_t)b * rows + s) * P;
+    for (int i = lane; i < bw * bh; i += 64) {
+        const int yy = i / bw;
+        const int x = x0 + (i - yy * bw), y = y0 + yy;
+        bool cov;
+        float logit = zl;
+        const int pix = y * W + x;
+        const float4 ax = reinterpret_cast<const float4*>(aux)[(int64_t)b * P + pix];
+        if (PRIM == 0) {
+            float rx, ry, rz;
+            pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
+            const Hit h = disc_eval(px, py, pz, nx, ny, nz, a, rx, ry, rz, A.diam);
+            cov = h.m;
+            logit = fmaxf((-h.t) / (ax.x + FLT_EPSILON) + 1.f, 0.f) * A.depth_constant;
+        } else if (PRIM == 1) {
+            cov = circle_cover(u, v, rad, (float)x, (float)y);
+        } else {
+            cov = stamp_axis(u, x, W) && stamp_axis(v, y, H);
+        }
+        if (cov) row[pix] = expf(logit - ax.y) / ax.z;
+    }
+}
+
+__global__ __launch_bounds__(256) void sdfr_splat_bgweights_kernel(const float* __restrict__ aux, const float* __restrict__ bg_logit,
+                                                                  float* __restrict__ Wout, int rows, int P) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= P) return;
+    const float4 ax = reinterpret_cast<const float4*>(aux)[(int64_t)b * P + pix];
+    Wout[((int64_t)b * rows + (rows - 1)) * P + pix] = expf(bg_logit[b] - ax.y) / ax.z;
 }
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------
@@ -585,6 +651,57 @@ extern "C" int sdfr_splat_backward(int primitive, const float* K, const float* K
                                    g_depth, g_normals, g_p_cam, g_n_cam, g_attr); break;
         default: hipLaunchKernelGGL(sdfr_splat_bwd_kernel<2>, g, dim3(256), 0, s, A, aux, color, mask, depth, normals, g_color, g_mask,
                                     g_depth, g_normals, g_p_cam, g_n_cam, g_attr); break;
+    }
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_splat_weights(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* uv,
+                                  const float* znorm, const float* bg_logit, int B, int cap, const int32_t* cnt, int W, int H, float diam,
+                                  float depth_constant, const float* aux, float* weights, void* stream) {
+    SplatArgs A;
+    int rc = fill_args(A, "sdfr_splat_weights", primitive, K, Kinv, p_cam, n_cam, p_cam /* attr unused */, uv, znorm, nullptr, nullptr, B, cap,
+                       cnt, W, H, diam, depth_constant);
+    if (rc) return rc;
+    SDFR_REQUIRE(aux && weights, "sdfr_splat_weights: NULL argument");
+    if (B == 0) return SDFR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = cap + (bg_logit ? 1 : 0);
+    if (cap > 0) {
+        const dim3 g(sdfr_cdiv(cap, 4), B);
+        switch (primitive) {
+            case 0: hipLaunchKernelGGL(sdfr_splat_weights_kernel<0>, g, dim3(256), 0, s, A, aux, weights, rows); break;
+            case 1: hipLaunchKernelGGL(sdfr_splat_weights_kernel<1>, g, dim3(256), 0, s, A, aux, weights, rows); break;
+            default: hipLaunchKernelGGL(sdfr_splat_weights_kernel<2>, g, dim3(256), 0, s, A, aux, weights, rows); break;
+        }
+    }
+    if (bg_logit) hipLaunchKernelGGL(sdfr_splat_bgweights_kernel, dim3(sdfr_cdiv(W * H, 256), B), dim3(256), 0, s, aux, bg_logit, weights, rows, W * H);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_splat_weights_backward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam,
+                                           const float* uv, const float* znorm, int has_bg_row, int B, int cap, const int32_t* cnt, int W,
+                                           int H, float diam, float depth_constant, const float* aux, const float* g_weights,
+                                           const float* wsum, float* g_p_cam, float* g_n_cam, void* stream) {
+    SplatArgs A;
+    int rc = fill_args(A, "sdfr_splat_weights_backward", primitive, K, Kinv, p_cam, n_cam, p_cam /* attr unused */, uv, znorm, nullptr, nullptr,
+                       B, cap, cnt, W, H, diam, depth_constant);
+    if (rc) return rc;
+    SDFR_REQUIRE(aux && g_weights && wsum && g_p_cam && g_n_cam, "sdfr_splat_weights_backward: NULL argument");
+    if (B == 0 || cap == 0) return SDFR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(sdfr_cdiv(cap, 4), B);
+    const int rows = cap + (has_bg_row ? 1 : 0);
+    const float* z = nullptr;
+    float* zo = nullptr;
+    switch (primitive) {
+        case 0: hipLaunchKernelGGL((sdfr_splat_bwd_kernel<0, true>), g, dim3(256), 0, s, A, aux, z, z, z, z, z, z, z, z, g_p_cam, g_n_cam, zo,
+                                   g_weights, wsum, rows); break;
+        case 1: hipLaunchKernelGGL((sdfr_splat_bwd_kernel<1, true>), g, dim3(256), 0, s, A, aux, z, z, z, z, z, z, z, z, g_p_cam, g_n_cam, zo,
+                                   g_weights, wsum, rows); break;
+        default: hipLaunchKernelGGL((sdfr_splat_bwd_kernel<2, true>), g, dim3(256), 0, s, A, aux, z, z, z, z, z, z, z, z, g_p_cam, g_n_cam, zo,
+                                    g_weights, wsum, rows); break;
     }
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;

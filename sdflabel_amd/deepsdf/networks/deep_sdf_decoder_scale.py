@@ -72,6 +72,36 @@ class SdfState:
         self.split = False            # the forward launch used error-compensated float16 operand pairs (float32-equivalent)
 
 
+# autograd nodes that hand their input's VALUES on unchanged (up to a dtype rounding): a tensor reached from the decoder output through
+# these only is still "the decoder output" for Grid3D.get_surface_points
+_PASS_THROUGH = ("CloneBackward", "ToCopyBackward", "ViewBackward", "UnsafeViewBackward", "ReshapeAliasBackward", "AliasBackward",
+                 "SqueezeBackward", "UnsqueezeBackward", "ExpandBackward")
+
+
+def sdf_state_of(t):
+    """The SdfState of the decoder call that produced tensor `t`, or None.  Found through the autograd graph -- the node of _DeepSDFFn IS
+    its ctx and carries `.state` -- walking back over value-preserving nodes, so `.clone()`, `.to(dtype)`, `.float()`, `.view(...)`
+    between dsdf() and get_surface_points() keep the fused band-only path (a Python attribute on the tensor would be dropped by them
+    and silently switch to the generic path that differentiates all G rows).  Any node that changes values ends the walk."""
+    st = getattr(t, "_sdfr_state", None)
+    if isinstance(st, SdfState):
+        return st
+    node = getattr(t, "grad_fn", None)
+    for _ in range(32):
+        if node is None:
+            return None
+        st = getattr(node, "state", None)
+        if isinstance(st, SdfState):
+            return st
+        if not type(node).__name__.startswith(_PASS_THROUGH):
+            return None
+        parents = [f for f, _ in node.next_functions if f is not None]
+        if len(parents) != 1:
+            return None
+        node = parents[0]
+    return None
+
+
 def mlp_jacobian(state, idx, n, use_masks=True, half=None):
     """J (n, NI), sdf_sel (n,) for the rows idx[:n] of state.inputs.  With the masks the forward launch saved the Jacobian is a
     backward-only pass; otherwise the kernel recomputes the forward for the selected rows.  half: run the mask-fed backward with half
@@ -80,6 +110,7 @@ def mlp_jacobian(state, idx, n, use_masks=True, half=None):
     J = torch.empty((max(n, 1), state.inputs.shape[1]), dtype=torch.float32, device=state.inputs.device)
     sel = torch.empty((max(n, 1),), dtype=torch.float32, device=state.inputs.device)
     if n > 0:
+      with _lib.guard(state.inputs):
         um = use_masks and state.mask_ws is not None and state.sdf is not None
         _lib.check(L.sdfr_mlp_jacobian(state.handle.h, _lib.ptr(state.inputs), state.G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
                                        _lib.ptr(sel), _lib.ptr(state.sdf) if um else None, _lib.ptr(state.mask_ws) if um else None,
@@ -97,8 +128,9 @@ class _DeepSDFFn(torch.autograd.Function):
             nw = int(L.sdfr_decoder_mask_words(state.handle.h, state.G))
             state.mask_ws = torch.empty((nw,), dtype=torch.int32, device=inputs.device)
         fwd = L.sdfr_mlp_forward_f16 if state.f16 else (L.sdfr_mlp_forward_split if state.split else L.sdfr_mlp_forward)
-        _lib.check(fwd(state.handle.h, _lib.ptr(state.inputs), state.G, _lib.ptr(sdf), _lib.ptr(state.mask_ws), _lib.stream_ptr()),
-                   "sdfr_mlp_forward")
+        with _lib.guard(inputs):
+            _lib.check(fwd(state.handle.h, _lib.ptr(state.inputs), state.G, _lib.ptr(sdf), _lib.ptr(state.mask_ws), _lib.stream_ptr()),
+                       "sdfr_mlp_forward")
         state.sdf = sdf.view(-1)
         ctx.state = state
         return sdf
@@ -110,10 +142,11 @@ class _DeepSDFFn(torch.autograd.Function):
         g_sdf = g_sdf.contiguous().float()
         NI = st.inputs.shape[1]
         g_in = torch.empty((st.G, NI), dtype=torch.float32, device=g_sdf.device)
-        if st.J is not None:
+        if st.J is not None and st.J.shape[0] > 0:
             miss = torch.zeros((1,), dtype=torch.int32, device=g_sdf.device)
-            _lib.check(L.sdfr_sdf_input_grad(_lib.ptr(g_sdf), _lib.ptr(st.slot), _lib.ptr(st.J), NI, st.G, 1, st.cap, _lib.ptr(g_in),
-                                             _lib.ptr(miss), _lib.stream_ptr()), "sdfr_sdf_input_grad")
+            with _lib.guard(g_sdf):
+                _lib.check(L.sdfr_sdf_input_grad(_lib.ptr(g_sdf), _lib.ptr(st.slot), _lib.ptr(st.J), NI, st.G, 1, st.cap, _lib.ptr(g_in),
+                                                 _lib.ptr(miss), _lib.stream_ptr()), "sdfr_sdf_input_grad")
             if int(miss.item()) == 0:
                 return g_in, None
         # rows outside the cached band carry gradient: evaluate the Jacobian exactly where it is needed

@@ -6,10 +6,11 @@ import os
 import torch
 
 
-def setup_dsdf(dir, mode='eval', precision=torch.float32):
+def setup_dsdf(dir, mode='eval', precision=torch.float16):
     """Load `<x>.json` specs + `<x>.pt` state (keys may carry the DataParallel 'module.' prefix, workspace.py:176-180).
 
-    Returns (decoder, latent_size).  precision=torch.float32: exact-f32 matrix instructions (the parity path, 1e-4 against the
+    Returns (decoder, latent_size).  The default `precision` is the reference's (workspace.py:167: torch.float16); pass torch.float32
+    for the 1e-4 parity path.  precision=torch.float32: exact-f32 matrix instructions (the parity path, 1e-4 against the
     reference).  precision=torch.float16 (the reference's default config, configs/config_refine.ini:19): the hidden layers run with
     half operands on the matrix cores, float32 accumulation; parameters and the tensors at the module boundary stay float32 (the
     reference would hand back half tensors; ours are at least as accurate).  precision="float32_split": float32 results from the f16

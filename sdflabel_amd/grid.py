@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .deepsdf.networks.deep_sdf_decoder_scale import mlp_jacobian
+from .deepsdf.networks.deep_sdf_decoder_scale import mlp_jacobian, sdf_state_of
 
 
 class _SurfaceFn(torch.autograd.Function):
@@ -26,9 +26,10 @@ class _SurfaceFn(torch.autograd.Function):
         nocs = torch.empty((n, 3), dtype=torch.float32, device=dev)
         nrm = torch.empty((n, 3), dtype=torch.float32, device=dev)
         if n > 0:
-            _lib.check(L.sdfr_surface_project(_lib.ptr(xyz_src), xyz_stride, _lib.ptr(sdf), G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
-                                              Jstride, Joff, _lib.ptr(pts), _lib.ptr(nocs), _lib.ptr(nrm), _lib.stream_ptr()),
-                       "sdfr_surface_project")
+            with _lib.guard(sdf):
+                _lib.check(L.sdfr_surface_project(_lib.ptr(xyz_src), xyz_stride, _lib.ptr(sdf), G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
+                                                  Jstride, Joff, _lib.ptr(pts), _lib.ptr(nocs), _lib.ptr(nrm), _lib.stream_ptr()),
+                           "sdfr_surface_project")
         ctx.save_for_backward(nrm, idx)
         ctx.n, ctx.G = n, G
         ctx.mark_non_differentiable(nrm)
@@ -40,14 +41,19 @@ class _SurfaceFn(torch.autograd.Function):
         nrm, idx = ctx.saved_tensors
         n, G = ctx.n, ctx.G
         dev = nrm.device
+        if n == 0:
+            # empty band: zero gradients, as the reference's ops on (0,3) tensors give (no kernel to launch; empty tensors have no address)
+            return (torch.zeros((G, 1), dtype=ctx.dtypes[0], device=dev),
+                    torch.zeros((G, 3), dtype=ctx.dtypes[1], device=dev) if ctx.needs_input_grad[1] else None) + (None,) * 8
         g_sdf = torch.empty((G, 1), dtype=torch.float32, device=dev)
         g_xyz = torch.empty((G, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         if g_pts is None:
             g_pts = torch.zeros((n, 3), dtype=torch.float32, device=dev)
         g_pts = g_pts.contiguous().float()
         g_nocs = None if g_nocs is None else g_nocs.contiguous().float()
-        _lib.check(L.sdfr_surface_project_bwd(_lib.ptr(g_pts), _lib.ptr(g_nocs), _lib.ptr(nrm), G, 1, _lib.ptr(idx), n, None,
-                                              _lib.ptr(g_sdf), _lib.ptr(g_xyz), _lib.stream_ptr()), "sdfr_surface_project_bwd")
+        with _lib.guard(nrm):
+            _lib.check(L.sdfr_surface_project_bwd(_lib.ptr(g_pts), _lib.ptr(g_nocs), _lib.ptr(nrm), G, 1, _lib.ptr(idx), n, None,
+                                                  _lib.ptr(g_sdf), _lib.ptr(g_xyz), _lib.stream_ptr()), "sdfr_surface_project_bwd")
         g_sdf = g_sdf.to(ctx.dtypes[0])
         g_xyz = None if g_xyz is None else g_xyz.to(ctx.dtypes[1])
         return g_sdf, g_xyz, None, None, None, None, None, None, None, None
@@ -63,8 +69,9 @@ def band_select(sdf_flat, threshold, want_slot=True):
     cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
     slot = torch.empty((max(G, 1),), dtype=torch.int32, device=dev) if want_slot else None
     scratch = torch.empty(((G + 255) // 256 + 1,), dtype=torch.int32, device=dev)
-    _lib.check(L.sdfr_band_select(_lib.ptr(sdf_flat), G, 1, float(threshold), _lib.ptr(idx), G, _lib.ptr(cnt), _lib.ptr(slot),
-                                  _lib.ptr(scratch), _lib.stream_ptr()), "sdfr_band_select")
+    with _lib.guard(sdf_flat):
+        _lib.check(L.sdfr_band_select(_lib.ptr(sdf_flat), G, 1, float(threshold), _lib.ptr(idx), G, _lib.ptr(cnt), _lib.ptr(slot),
+                                      _lib.ptr(scratch), _lib.stream_ptr()), "sdfr_band_select")
     n = int(cnt.item())
     return idx, n, slot
 
@@ -87,7 +94,8 @@ class Grid3D:
         if pred_sdf_grid.dim() != 2 or pred_sdf_grid.shape[1] != 1 or pred_sdf_grid.shape[0] != self.points.shape[0]:
             raise _lib.SdfrError("pred_sdf_grid must be (G,1) with G = number of grid points")
         out_dtype = pred_sdf_grid.dtype
-        state = getattr(pred_sdf_grid, "_sdfr_state", None)
+        # the decoder call behind this tensor, found through the autograd graph (survives .clone() / .to() / .view() of the output)
+        state = sdf_state_of(pred_sdf_grid)
         fused = state is not None and state.G == self.points.shape[0] and state.sdf is not None
         # float32 values for the kernels: the decoder's own output when available (a half `pred_sdf_grid` is a rounded copy of it)
         sdf_c = state.sdf if fused else pred_sdf_grid.detach().float().contiguous().view(-1)

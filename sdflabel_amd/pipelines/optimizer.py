@@ -8,12 +8,21 @@ nearest-neighbour loss and the 2-D NOCS window loss run in HIP kernels, the Adam
 reference's (trajectory-tested against its own Optimizer, golden G8).  `get_opt_params` (optimizer.py:26-40) turns the caller's arrays into
 float32 leaf tensors in place; so does this class, and after `optimize` those tensors hold the refined values.
 """
+import weakref
+
 import numpy as np
 import torch
 
 from .. import _lib
 from ..grid import Grid3D
 from ..refine import BatchRefiner
+
+
+# Refiners (device buffers + captured HIP graph) are shared by all Optimizer objects of a process: the reference's callers construct a new
+# Optimizer per crop (refine_css.py:203), and re-allocating / re-capturing for each would cost more than refining it.  Keyed by everything
+# the buffers and the captured launches depend on; a few entries at most.
+_REFINERS = {}
+_REFINERS_MAX = 4
 
 
 def get_opt_params(params, device):
@@ -49,8 +58,19 @@ class Optimizer:
         key = (id(dsdf), D, tuple(int(c) for c in crop_size), cap, Kn.tobytes(), str(dev), dsdf._param_key(dev),
                float(self.weights.get('2d', 0.3)), float(self.weights.get('3d', 0.5)), getattr(dsdf, 'mlp_precision', None))
         if self._key != key:
-            rf = BatchRefiner(dsdf, D, Kn, crop_size, 1, lidar_cap=cap, weights=self.weights, device=dev)
-            if not torch.equal(rf.br.grid, grid.points.detach().to(torch.float32)):
+            hit = _REFINERS.get(key)
+            if hit is not None and hit[0]() is dsdf:
+                rf = hit[1]
+            else:
+                rf = BatchRefiner(dsdf, D, Kn, crop_size, 1, lidar_cap=cap, weights=self.weights, device=dev)
+                while len(_REFINERS) >= _REFINERS_MAX:
+                    _REFINERS.pop(next(iter(_REFINERS)))
+                _REFINERS[key] = (weakref.ref(dsdf), rf)
+            # the caller's grid must be the Grid3D(D) point set the kernels index, in whatever precision it was built (the reference's
+            # callers pass Grid3D(grid_density, device, precision) with the config's float16 default, refine_css.py:148): compare in the
+            # caller's dtype -- the same float32 -> precision rounding produced both
+            pts = grid.points.detach()
+            if pts.shape != rf.br.grid.shape or not torch.equal(rf.br.grid.to(pts.dtype), pts.to(rf.br.grid.device)):
                 raise _lib.SdfrError("grid.points is not the Grid3D(%d) point set the kernels index" % D)
             self._refiner, self._key = rf, key
         return self._refiner
@@ -80,9 +100,10 @@ class Optimizer:
                         print('Skip frame')
                     self.log.append((l2, l3, l2 + l3))
             else:
-                if iters_optim > 3:
-                    rf.capture()
+                if iters_optim > 3 and rf._replay is None:
+                    rf.capture()                              # once per refiner: later crops replay the same graph
                 rf.optimize(iters_optim)
+            rf.br.check_overflow()                            # a truncated band must not pass silently (one sync, after the loop)
             p['yaw'].copy_(rf.yaw.view_as(p['yaw']))
             p['trans'].copy_(rf.trans.view_as(p['trans']))
             p['scale'].copy_(rf.scale.view_as(p['scale']))

@@ -80,10 +80,14 @@ class BatchRefiner:
             self.lidar[b, :l.shape[0]] = l
             self.lcnt[b] = l.shape[0]
         self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t.zero_()
-        self._replay = None
+        # a captured graph stays valid: every buffer it reads or writes is static and was updated in place above
 
     def iteration(self):
         """One refinement iteration of every crop (optimizer.py:79-157).  No host synchronisation."""
+        with _lib.guard(self.dev):
+            self._iteration()
+
+    def _iteration(self):
         L = _lib.lib()
         P, st, ck = _lib.ptr, _lib.stream_ptr(), _lib.check
         br, B = self.br, self.B
@@ -121,6 +125,8 @@ class BatchRefiner:
                 self.iteration()
 
     def results(self):
-        """(B, 5+L) rows [yaw, trans(3), scale, latent(L)] and the last (B,) weighted losses (2d, 3d).  Synchronises."""
+        """(B, 5+L) rows [yaw, trans(3), scale, latent(L)] and the last (B,) weighted losses (2d, 3d).  Synchronises; raises if a crop's
+        band overflowed the surfel capacity in the last iteration (its shape would have been truncated)."""
+        self.br.check_overflow()
         rows = torch.cat([self.yaw.view(-1, 1), self.trans, self.scale.view(-1, 1), self.latent], dim=1)
         return rows.clone(), (self.w2 * self.loss2d).clone(), (self.w3 * self.loss3d).clone()

@@ -18,8 +18,18 @@ class _RasterFn(torch.autograd.Function):
     """(coords, normals, colors, pose44, bg) -> color, mask, depth, normals_img, p_cam, n_cam, col  (+ fidx through `holder`)."""
 
     @staticmethod
-    def forward(ctx, coords, normals, colors, pose, bg, K, Kinv, res, nocs_mode, prim, half_attr, want_mask, want_depth, want_normals,
-                want_filter, holder):
+    def forward(ctx, coords, *args):
+        with _lib.guard(coords):                      # launch stream / allocations of the device that holds the surfels
+            return _RasterFn._forward(ctx, coords, *args)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        with _lib.guard(ctx.saved_tensors[0]):
+            return _RasterFn._backward(ctx, *grads)
+
+    @staticmethod
+    def _forward(ctx, coords, normals, colors, pose, bg, K, Kinv, res, nocs_mode, prim, half_attr, want_mask, want_depth, want_normals,
+                 want_filter, holder):
         L = _lib.lib()
         W, H = res
         pid, diam, dconst = _PRIMS[prim]
@@ -87,7 +97,7 @@ class _RasterFn(torch.autograd.Function):
         return outs
 
     @staticmethod
-    def backward(ctx, g_color, g_mask, g_depth, g_nimg, g_pcam_ext, _g_ncam, g_col_ext):
+    def _backward(ctx, g_color, g_mask, g_depth, g_nimg, g_pcam_ext, _g_ncam, g_col_ext):
         L = _lib.lib()
         (coords, normals, pose, K, Kinv, p_cam, n_cam, attr, aux, color, mask, depth, nimg, uv, znorm, bg_c, bg_logit) = ctx.saved_tensors
         n, W, H, nocs_mode, prim, half_attr, want_mask, want_depth, want_normals, has_bg, bg_argmin = ctx.cfg
@@ -114,9 +124,10 @@ class _RasterFn(torch.autograd.Function):
                                              _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(nimg), _lib.ptr(g_color),
                                              _lib.ptr(g_mask), _lib.ptr(g_depth), _lib.ptr(g_nimg), _lib.ptr(g_p), _lib.ptr(g_n),
                                              _lib.ptr(g_a), st), "sdfr_splat_backward")
-            if has_bg and pid == 1:
-                # inside_circle's background logit z.min() - 1 (primitives.py:65) competes with the surfels' logits, so its weight is
-                # not 0/1 and the gradient through the min reaches the farthest surfel's depth; a per-crop scalar, done here.
+            if has_bg and pid != 0:
+                # the circle primitives' background logit z.min() - 1 (primitives.py:65,147) competes with the surfels' logits (it sits one
+                # unit below the farthest surfel's), so its weight is not 0/1 and the gradient through the min reaches the farthest surfel's
+                # depth; a per-crop scalar, done here.  (disc: the background sits ~500 below every surfel logit -- weight exactly 0 or 1.)
                 eps = torch.finfo(torch.float32).eps
                 gates = aux[:, 3].contiguous().view(torch.int32)
                 w_bg = torch.exp(bg_logit - aux[:, 1]) / aux[:, 2]
@@ -160,6 +171,10 @@ class Rasterer(torch.nn.Module):
         self.res_x_px, self.res_y_px = resolution_px
         yy, xx = np.mgrid[0:self.res_y_px, 0:self.res_x_px]
         self.register_buffer('grid', torch.from_numpy(np.stack((xx, yy), axis=-1).reshape((1, -1, 2))))
+        # the 15x15 stamp offsets of inside_circle_opt (rasterer.py:29-32): the kernels generate them on the fly, the buffer exists so that
+        # state_dict() has the reference's keys (grid, grid_prim, K)
+        yy, xx = np.mgrid[-7:8, -7:8]
+        self.register_buffer('grid_prim', torch.from_numpy(np.stack((xx, yy), axis=-1).reshape((1, -1, 2))))
         if K is None:
             K = torch.from_numpy(calibration_matrix((self.res_x_px, self.res_y_px), diagonal_mm, focal_len_mm, skew=0))
         if precision not in (torch.float32, torch.float16):
@@ -169,7 +184,8 @@ class Rasterer(torch.nn.Module):
         K = K.detach().to(torch.float32)
         self.register_buffer('K', K.contiguous())
         # K^-1 in float32 exactly as the reference computes it on every call (primitives.py:204), once, on the host
-        self.register_buffer('Kinv', torch.linalg.inv(K.cpu().float()).contiguous())
+        # (not part of the state_dict: the reference has no such buffer)
+        self.register_buffer('Kinv', torch.linalg.inv(K.cpu().float()).contiguous(), persistent=False)
 
     def forward(self, coords, normals, colors, camera_matrix, rot='quat', primitives='disc', bg=None, output_mask=False,
                 output_depth=False, output_normals=False, output_nocs=False, output_points=True):

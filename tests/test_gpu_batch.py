@@ -15,7 +15,7 @@ DEV = "cuda"
 
 @pytest.fixture(scope="module")
 def dec():
-    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt")
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
     return d.to(DEV)
 
 

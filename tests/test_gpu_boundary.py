@@ -1,0 +1,220 @@
+"""GPU tests of the drop-in boundary's behaviour (round-2 review items): state hand-over through the autograd graph, empty bands, surfel
+capacity overflow, the Optimizer mirror called exactly as the reference's pipeline calls it (float16 default precision), module names of
+the reference's renderer package."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import sdflabel_amd
+from sdflabel_amd import _lib
+from tests._util import ASSET, K_for, gold
+from tests.test_gpu_parity import N, T, build_pose
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def dec():
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
+    return d.to(DEV)
+
+
+def _inputs(grid, lat):
+    lat_ = F.normalize(lat, p=2, dim=0)
+    return torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1)
+
+
+@pytest.mark.parametrize("how", ["clone", "to_half_and_back", "view", "contiguous_float"])
+def test_fused_band_path_survives_value_preserving_ops(dec, how):
+    """`.clone()` / `.to()` / `.view()` between dsdf() and get_surface_points() must not fall to the generic path (which differentiates all
+    G rows): the decoder state is found through the autograd graph, not through an attribute of the tensor object."""
+    from sdflabel_amd.deepsdf.networks.deep_sdf_decoder_scale import sdf_state_of
+    grid = sdflabel_amd.Grid3D(16, DEV)
+    lat = torch.tensor([0.3, -0.5, 0.8], device=DEV, requires_grad=True)
+    sdf, _ = dec(_inputs(grid, lat))
+    ref_pts, _, ref_nrm = grid.get_surface_points(sdf)
+    st = sdf_state_of(sdf)
+    assert st is not None and st.J is not None
+    lat2 = lat.detach().clone().requires_grad_(True)
+    sdf2, _ = dec(_inputs(grid, lat2))
+    moved = {"clone": lambda t: t.clone(), "to_half_and_back": lambda t: t.to(torch.float16).to(torch.float32),
+             "view": lambda t: t.view(-1).view(-1, 1), "contiguous_float": lambda t: t.contiguous().float().clone()}[how](sdf2)
+    assert not hasattr(moved, "_sdfr_state")
+    st2 = sdf_state_of(moved)
+    assert st2 is not None and st2.J is None
+    pts, _, nrm = grid.get_surface_points(moved)
+    assert st2.J is not None and st2.J.shape[0] == pts.shape[0]            # the band-only Jacobian ran (fused path)
+    assert torch.equal(pts, ref_pts) and torch.equal(nrm, ref_nrm)
+    pts.sum().backward()
+    ref_pts.sum().backward()
+    if how == "to_half_and_back":            # autograd rounds the gradient to half on its way back through the casts
+        assert torch.allclose(lat.grad, lat2.grad, rtol=5e-3, atol=1e-4)
+    else:
+        assert torch.equal(lat.grad, lat2.grad)
+    # a value-changing op is NOT followed: generic path, still correct
+    lat3 = lat.detach().clone().requires_grad_(True)
+    sdf3, _ = dec(_inputs(grid, lat3))
+    assert sdf_state_of(sdf3 * 1.0) is None
+    p3, _, _ = grid.get_surface_points(sdf3 * 1.0)
+    assert np.abs(N(p3) - N(ref_pts)).max() < 1e-5
+
+
+def test_empty_band_gives_empty_tensors_and_zero_gradients(dec):
+    """optimizer.py:127: the caller checks nelement() == 0; backward through an empty selection must give zeros, not raise"""
+    grid = sdflabel_amd.Grid3D(8, DEV)
+    lat = torch.tensor([0.3, -0.5, 0.8], device=DEV, requires_grad=True)
+    yaw = torch.tensor([0.6], device=DEV, requires_grad=True)
+    trans = torch.tensor([0.0, 0.0, 3.5], device=DEV, requires_grad=True)
+    sdf, _ = dec(_inputs(grid, lat))
+    pts, nocs, nrm = grid.get_surface_points(sdf, threshold=1e-12)
+    assert pts.shape == (0, 3) and nocs.shape == (0, 3) and nrm.shape == (0, 3)
+    r = sdflabel_amd.Rasterer(T(K_for(16, 16)), (16, 16)).to(DEV)
+    rend, points = r(pts, nrm, nrm, build_pose(yaw, trans), rot="dcm", output_mask=True, output_nocs=True)
+    assert points["xyzf"].nelement() == 0 and float(rend["color"].abs().max()) == 0.0
+    (rend["color"].sum() + rend["mask"].sum() + points["xyzf"].sum() + pts.sum() + nocs.sum()).backward()
+    assert lat.grad is not None and float(lat.grad.abs().max()) == 0.0
+    assert float(yaw.grad.abs().max()) == 0.0 and float(trans.grad.abs().max()) == 0.0
+
+
+def test_surfel_capacity_overflow_raises_in_the_refinement_loop(dec):
+    z = gold("g8_optimizer.npz")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    rf = sdflabel_amd.BatchRefiner(dec, D, z["K"], (H, W), 1, lidar_cap=256, cap=64, device=DEV)
+    rf.set_crops({"yaw": init[0:1], "trans": init[1:4][None], "scale": init[4:5], "latent": init[5:8][None]}, z["nocs_target"][None], [z["lidar"]])
+    rf.optimize(2)
+    with pytest.raises(_lib.SdfrError, match="cap"):
+        rf.results()
+
+
+def test_optimizer_mirror_with_the_reference_pipelines_float16_setup():
+    """refine_css.py:144-153 with the shipped config (precision = float16): setup_dsdf default precision, Grid3D(D, device, float16), half K.
+    The mirror must accept the half grid and refine towards the float32 trajectory's end state."""
+    from sdflabel_amd.pipelines.optimizer import Optimizer
+    z = gold("g8_optimizer.npz")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    precision = torch.float16
+    dsdf, latent_size = sdflabel_amd.setup_dsdf(ASSET + ".pt")                      # reference default: float16
+    assert dsdf.mlp_precision == torch.float16
+    dsdf = dsdf.to(DEV)
+    grid = sdflabel_amd.Grid3D(D, DEV, precision)
+    K = T(z["K"]).to(precision)
+    params = {"yaw": init[0:1].copy(), "trans": init[1:4].copy(), "scale": init[4:5].copy(), "latent": init[5:8].copy()}
+    opt = Optimizer(params, DEV, {"2d": 0.3, "3d": 0.5})
+    opt.optimize(10, T(z["nocs_target"]).to(precision), z["lidar"], dsdf, grid, K, (H, W))
+    got = np.concatenate([N(params[k]).reshape(-1) for k in ("yaw", "trans", "scale", "latent")])
+    assert np.isfinite(got).all()
+    assert np.abs(got - z["traj"][-1]).max() < 2e-2, np.abs(got - z["traj"][-1])       # float16 decoder: close to the float32 trajectory
+    assert abs(got[0] - init[0]) > 0.05
+    # a second Optimizer object (the reference constructs one per crop, refine_css.py:203) reuses the refiner and its captured graph
+    opt2 = Optimizer({k: np.asarray(v.detach().cpu()) for k, v in params.items()}, DEV, {"2d": 0.3, "3d": 0.5})
+    opt2.optimize(5, T(z["nocs_target"]).to(precision), z["lidar"], dsdf, grid, K, (H, W))
+    assert opt2._refiner is opt._refiner and opt._refiner._replay is not None
+    # a grid that is not the D^3 point set is refused
+    bad = sdflabel_amd.Grid3D(D, DEV, precision)
+    with torch.no_grad():
+        bad.points[5, 0] += 0.25
+    with pytest.raises(_lib.SdfrError):
+        Optimizer({k: np.asarray(v.detach().cpu()) for k, v in params.items()}, DEV, {"2d": 0.3, "3d": 0.5}).optimize(
+            2, T(z["nocs_target"]), z["lidar"], dsdf, bad, K, (H, W))
+
+
+def test_rasterer_state_dict_keys_match_the_reference():
+    r = sdflabel_amd.Rasterer(T(K_for(32, 24)), (32, 24))
+    assert list(r.state_dict().keys()) == ["grid", "grid_prim", "K"]              # rasterer.py:27,32,44
+    assert r.grid_prim.shape == (1, 225, 2) and r.grid.shape == (1, 32 * 24, 2)
+
+
+# ---- the reference's renderer.primitives / renderer.projection module functions (golden G13, captured from the reference) ------------
+
+def _call_primitive(name, bg, K, r, uv, p, n):
+    from sdflabel_amd.renderer import primitives as prim
+    if name == "disc":
+        return prim.inside_surfel(K, r.grid, uv, p, n, diam=0.04, softclamp=False, add_bg=bg)
+    if name == "circle":
+        return prim.inside_circle(K, r.grid, uv, p, n, diam=0.02, add_bg=bg)
+    return prim.inside_circle_opt(K, r.grid_prim, uv, p, n, diam=0.025, add_bg=bg)
+
+
+@pytest.mark.parametrize("name", ["disc", "circle", "circle_opt"])
+@pytest.mark.parametrize("bg", [False, True])
+def test_standalone_primitives_dense_weights_and_gradients_golden(name, bg):
+    z = gold("g13_primitives.npz")
+    W, H = [int(v) for v in z["res"]]
+    K = T(z["K"])
+    r = sdflabel_amd.Rasterer(K, (W, H)).to(DEV)
+    p = T(z["points"]).requires_grad_(True)
+    n = T(z["normals"]).requires_grad_(True)
+    t = "%s_bg%d_" % (name, int(bg))
+    w = _call_primitive(name, bg, K, r, T(z["uv"]), p, n)
+    ref = z[t + "w"]
+    assert w.shape == (ref.shape[0], 3, W * H)
+    assert torch.equal(w[:, 0], w[:, 1]) and torch.equal(w[:, 0], w[:, 2])
+    tol = 1e-3 if name == "circle_opt" else 1e-5          # circle_opt: logits scaled by 10000, one float32 ulp moves a weight by ~2e-4
+    assert np.abs(N(w[:, 0]) - ref).max() < tol
+    assert ((N(w[:, 0]) > 0) == (ref > 0)).all()
+    (w[:, 0, :] * T(z[t + "R"])).sum().backward()
+    gtol = 2e-2 if name == "circle_opt" else 2e-3
+    for got, key in ((p.grad, "g_points"), (n.grad, "g_normals")):
+        g = z[t + key]
+        got = torch.zeros_like(p) if got is None else got
+        assert np.abs(N(got) - g).max() < gtol * max(1.0, np.abs(g).max()), (key, np.abs(N(got) - g).max(), np.abs(g).max())
+
+
+def test_standalone_primitives_refuse_what_the_renderer_never_calls():
+    from sdflabel_amd.renderer import primitives as prim
+    K = T(K_for(16, 16))
+    r = sdflabel_amd.Rasterer(K, (16, 16)).to(DEV)
+    p = torch.rand(4, 3, device=DEV) + torch.tensor([0, 0, 1.0], device=DEV)
+    with pytest.raises(NotImplementedError):
+        prim.inside_surfel(K, r.grid, None, p, p)                                  # softclamp=True default
+    with pytest.raises(NotImplementedError):
+        prim.inside_surfel(K, r.grid[:, ::2], None, p, p, softclamp=False)         # not the full pixel grid
+
+
+@pytest.mark.parametrize("tag", ["dcm", "quat"])
+def test_standalone_projection_outputs_and_gradients_golden(tag):
+    from sdflabel_amd.renderer import projection as proj
+    z = gold("g13_primitives.npz")
+    K = T(z["proj_K"])
+    p = T(z["proj_points"]).requires_grad_(True)
+    n = T(z["proj_normals"]).requires_grad_(True)
+    cam = T(z["proj_%s_cam" % tag]).requires_grad_(True)
+    fn = proj.project_in_2D if tag == "dcm" else proj.project_in_2D_quat
+    o = fn(K, cam, p, n, n, (32, 32), output_nocs=True)
+    keys = sorted(k[len("proj_%s_out_" % tag):] for k in z.files if k.startswith("proj_%s_out_" % tag))
+    assert sorted(o) == keys
+    loss = 0
+    for k in keys:
+        ref = z["proj_%s_out_%s" % (tag, k)]
+        assert o[k].shape == ref.shape, k
+        assert np.abs(N(o[k]) - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), k
+        loss = loss + (o[k] * T(z["proj_%s_W_%s" % (tag, k)])).sum()
+    loss.backward()
+    for got, key in ((cam.grad, "g_cam"), (p.grad, "g_points"), (n.grad, "g_normals")):
+        ref = z["proj_%s_%s" % (tag, key)]
+        if tag == "dcm" and key == "g_cam":
+            got, ref = got[:3], ref[:3]                  # the homogeneous row is dropped (projection.py:34)
+        assert np.abs(N(got) - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), (key, np.abs(N(got) - ref).max())
+    with pytest.raises(NotImplementedError):
+        fn(K, cam, p, n, n, (32, 32), filter_hpr=True)
+
+
+def test_reference_module_names_resolve_through_the_compat_path():
+    import importlib
+    import os
+    import sys
+    compat = os.path.join(os.path.dirname(sdflabel_amd.__file__), "compat")
+    sys.path.insert(0, compat)
+    try:
+        for mod, names in (("renderer.rasterer", ["Rasterer"]), ("renderer.primitives", ["inside_circle", "inside_circle_opt", "inside_surfel"]),
+                           ("renderer.projection", ["project_in_2D", "project_in_2D_quat"]), ("grid", ["Grid3D"]),
+                           ("sdfrenderer.grid", ["Grid3D"]), ("deepsdf.workspace", ["setup_dsdf"]),
+                           ("sdfrenderer.deepsdf.workspace", ["setup_dsdf"]), ("sdfrenderer.renderer.primitives", ["inside_surfel"])):
+            m = importlib.import_module(mod)
+            assert all(hasattr(m, n) for n in names), mod
+    finally:
+        sys.path.remove(compat)

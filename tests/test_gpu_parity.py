@@ -29,7 +29,7 @@ def N(t):
 
 @pytest.fixture(scope="module")
 def dec():
-    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt")
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
     return d.to(DEV)
 
 

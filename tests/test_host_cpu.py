@@ -35,7 +35,7 @@ def test_grid_points_match_reference_golden():
 
 
 def test_setup_dsdf_loads_reference_format_and_folds_weight_norm():
-    dec, L = sdflabel_amd.setup_dsdf(ASSET + ".pt")
+    dec, L = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
     assert L == 3 and not dec.training
     st, spec = fitted_state()
     ref_layers = O.decoder_layers_from_state(st, spec)
@@ -52,7 +52,7 @@ def test_setup_dsdf_loads_reference_format_and_folds_weight_norm():
 
 
 def test_no_cpu_fallback():
-    dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt")
+    dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
     with pytest.raises(_lib.SdfrError):
         dec(torch.zeros(8, 6))
     g = sdflabel_amd.Grid3D(4)

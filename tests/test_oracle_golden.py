@@ -310,3 +310,21 @@ def test_g11_reference_float16_decoder_model():
     d = np.abs(got - ref)
     assert d.max() < 1e-3 and d.mean() < 1e-4 and (d == 0).mean() > 0.5      # measured: max 4.9e-4 (one half ulp), 77 % of the rows bit-equal
     assert float(z["ref_sdf_max_abs_diff"]) < 1e-3        # the reference's own f16-vs-f32 decoder deviation recorded with the golden
+
+
+@pytest.mark.parametrize("name", ["disc", "circle", "circle_opt"])
+@pytest.mark.parametrize("bg", [False, True])
+def test_g13_standalone_primitive_weights(name, bg):
+    z = gold("g13_primitives.npz")
+    W, H = [int(v) for v in z["res"]]
+    K = z["K"]
+    g2 = O.pixel_grid((W, H))
+    if name == "disc":
+        w = O.inside_surfel(np.linalg.inv(K).astype(np.float32), g2, z["points"], z["normals"], diam=0.04, add_bg=bg)
+    elif name == "circle":
+        w = O.inside_circle(K, g2, z["uv"], z["points"], diam=0.02, add_bg=bg)
+    else:
+        w = O.inside_circle_opt(K, z["uv"], z["points"], diam=0.025, add_bg=bg)
+    ref = z["%s_bg%d_w" % (name, int(bg))]
+    assert w.shape == ref.shape
+    assert np.abs(w - ref).max() < (1e-3 if name == "circle_opt" else 2e-6)

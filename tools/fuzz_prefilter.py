@@ -5,7 +5,7 @@ import numpy as np, torch
 import sdflabel_amd
 from tests._util import ASSET, K_for
 dev = "cuda"
-d0, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt"); d0 = d0.to(dev)
+d0, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32); d0 = d0.to(dev)
 d1, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter"); d1 = d1.to(dev)
 B, D, H, W = 8, 40, 64, 64
 K = K_for(H, W)

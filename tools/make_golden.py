@@ -17,6 +17,7 @@ seeds, torch version and threshold margins -- never reference source.
   G9 secondary       Rasterer.forward with primitives circle / circle_opt and bg, + gradients   (primitives.py:4-162)
   G10 config1        BASELINE configs[1] at full size: 256x256, D=40, float32, images + surfels + gradients        (optimizer.py:79-123 graph)
   G11 config4        the reference's own float16 run at 512x512, D=40, beside its float32 run (config_refine.ini:19)
+  G13 primitives     standalone inside_surfel / inside_circle / inside_circle_opt weights + gradients, project_in_2D(_quat) gradients
   G12 losses         compute_loss_2d / compute_loss_3d values and gradients                                        (optimizer.py:166-237)
 
 usage: python tools/make_golden.py [G1 G2 ...]
@@ -576,7 +577,76 @@ def g12():
     save("g12_losses.npz", **arrs)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G9": g9, "G10": g10, "G11": g11, "G12": g12}
+def g13():
+    """The three standalone primitives (primitives.py:4-242) as Rasterer.forward calls them (rasterer.py:92-104): dense weight matrices
+    and autograd gradients of a fixed random functional w.r.t. the camera-frame vertices and normals; plus project_in_2D(_quat) gradients."""
+    arrs = {}
+    torch.manual_seed(13)
+    H, W = 16, 24
+    K = K_for(H, W)
+    K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+    r = Rasterer(K, (W, H), precision=torch.float32)
+    N = 48
+    p = torch.stack([torch.rand(N) * 0.7 - 0.35, torch.rand(N) * 0.5 - 0.25, 1.0 + torch.rand(N) * 0.4], 1)
+    n = F.normalize(torch.randn(N, 3) * 0.4 + torch.tensor([0, 0, -1.0]), dim=1)
+    eps = torch.finfo(torch.float32).eps
+    h2 = (K @ p.t()).t()
+    uv = h2[:, :2] / (h2[:, 2:] + eps)
+    uv = torch.cat([torch.clamp(uv[:, 0:1], -1, W), torch.clamp(uv[:, 1:2], -1, H)], -1)
+    arrs.update(K=K.numpy(), points=p.numpy(), normals=n.numpy(), uv=uv.numpy(), res=np.array([W, H]))
+    gen = torch.Generator().manual_seed(14)
+    for name in ("disc", "circle", "circle_opt"):
+        for bg in (False, True):
+            pp = p.clone().requires_grad_(True)
+            nn_ = n.clone().requires_grad_(True)
+            if name == "disc":
+                w = ref_prim.inside_surfel(K, r.grid, uv, pp, nn_, diam=0.04, softclamp=False, add_bg=bg)
+            elif name == "circle":
+                w = ref_prim.inside_circle(K, r.grid, uv, pp, nn_, diam=0.02, add_bg=bg)
+            else:
+                w = ref_prim.inside_circle_opt(K, r.grid_prim, uv, pp, nn_, diam=0.025, add_bg=bg)
+            R = torch.randn(w.shape[0], w.shape[2], generator=gen)
+            (w[:, 0, :] * R).sum().backward()
+            t = "%s_bg%d_" % (name, int(bg))
+            arrs[t + "w"] = w[:, 0, :].detach().numpy()
+            arrs[t + "R"] = R.numpy()
+            arrs[t + "g_points"] = pp.grad.numpy()
+            arrs[t + "g_normals"] = nn_.grad.numpy() if nn_.grad is not None else np.zeros((N, 3), np.float32)
+            print("G13", t, "covered pairs", int((w[:, 0, :] > 0).sum()), "|g_p|max", float(pp.grad.abs().max()))
+    # projection gradients (object-frame inputs)
+    dec, grid, lat, sdf, pts, nocs, nrm = surface_case(16, [0.3, -0.5, 0.8])
+    pts0, nrm0 = pts.detach()[::3].clone(), nrm.detach()[::3].clone()
+    arrs["proj_points"], arrs["proj_normals"] = pts0.numpy(), nrm0.numpy()
+    K2 = K_for(32, 32)
+    arrs["proj_K"] = K2.numpy()
+    for tag in ("dcm", "quat"):
+        pp = pts0.clone().requires_grad_(True)
+        nn_ = nrm0.clone().requires_grad_(True)
+        if tag == "dcm":
+            yaw = torch.tensor([0.6], requires_grad=True)
+            trans = torch.tensor([0.05, -0.03, 3.4], requires_grad=True)
+            cam = build_pose(yaw, trans)
+            cam.retain_grad()
+            o = ref_proj.project_in_2D(K2, cam, pp, nn_, nn_, (32, 32), output_nocs=True)
+        else:
+            cam = torch.cat([F.normalize(torch.tensor([0.9, 0.1, 0.35, -0.2]), dim=0), torch.tensor([0.1, -0.05, 3.2])]).requires_grad_(True)
+            o = ref_proj.project_in_2D_quat(K2, cam, pp, nn_, nn_, (32, 32), output_nocs=True)
+        loss = 0
+        for k in sorted(o):
+            Wk = torch.randn(o[k].shape, generator=gen)
+            arrs["proj_%s_W_%s" % (tag, k)] = Wk.numpy()
+            arrs["proj_%s_out_%s" % (tag, k)] = o[k].detach().numpy()
+            loss = loss + (o[k] * Wk).sum()
+        loss.backward()
+        arrs["proj_%s_cam" % tag] = cam.detach().numpy()
+        arrs["proj_%s_g_cam" % tag] = cam.grad.numpy()
+        arrs["proj_%s_g_points" % tag] = pp.grad.numpy()
+        arrs["proj_%s_g_normals" % tag] = nn_.grad.numpy()
+        print("G13 proj", tag, "keys", sorted(o), "loss", float(loss))
+    save("g13_primitives.npz", **arrs)
+
+
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G9": g9, "G10": g10, "G11": g11, "G12": g12, "G13": g13}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -5,7 +5,7 @@ import torch
 import bench, sdflabel_amd
 from tests._util import ASSET
 dev = torch.device("cuda", 0)
-dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt"); dec = dec.to(dev)
+dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32); dec = dec.to(dev)
 grid = sdflabel_amd.Grid3D(bench.D, dev)
 renderer = sdflabel_amd.Rasterer(torch.from_numpy(bench.K_for(bench.H, bench.W)), (bench.W, bench.H)).to(dev)
 crop = bench.Crop(0, dev)

@@ -6,7 +6,7 @@ import numpy as np, torch, torch.nn.functional as F
 import sdflabel_amd
 from tests._util import ASSET
 dev = "cuda"
-dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt"); dec = dec.to(dev)
+dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32); dec = dec.to(dev)
 grid = sdflabel_amd.Grid3D(40, dev)
 lat = F.normalize(torch.tensor([0.3, -0.5, 0.8], device=dev), dim=0)
 inputs = torch.cat([lat.expand(grid.points.size(0), -1), grid.points.detach()], 1).contiguous()

@@ -44,6 +44,7 @@ _PROTOS = {
     "sdfr_splat_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_ws_words": (c_int64, [c_int, c_int, c_int, c_int]),
     "sdfr_splat_weights": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                    c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "sdfr_splat_weights_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
@@ -113,6 +114,12 @@ def guard(t):
     import torch
     dev = t.device if hasattr(t, "device") else torch.device(t)
     return torch.cuda.device(dev)
+
+
+def splat_ws(B, cap, W, H, device):
+    """workspace of sdfr_splat_forward / sdfr_surfels_forward: screen boxes + per-tile surfel lists (int32)"""
+    import torch
+    return torch.empty((int(lib().sdfr_splat_ws_words(int(B), max(int(cap), 1), int(W), int(H))),), dtype=torch.int32, device=device)
 
 
 def require_gpu_float(*tensors):

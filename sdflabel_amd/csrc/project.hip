@@ -17,6 +17,7 @@
 struct SurfArgs {
     const float* xyz; int xyz_stride; const float* sdf; int64_t G; const int32_t* idx; const float* J; int Jstride, Joff;
     float* points_w; float* normals_w; int4* bbox; float diam;
+    int32_t* bins;            // per-crop tile lists behind the boxes (splat_bbox.h), or NULL
 };
 
 template <bool SURF>
@@ -35,8 +36,9 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
     const float r00 = P[0], r01 = P[1], r02 = P[2], t0 = P[3];
     const float r10 = P[4], r11 = P[5], r12 = P[6], t1 = P[7];
     const float r20 = P[8], r21 = P[9], r22 = P[10], t2 = P[11];
-    __shared__ int wc[PROJ_THREADS / 64];
+    __shared__ int wc[PROJ_THREADS / 64 + 1];
     __shared__ int s_base;
+    __shared__ int tile_cnt[SURF ? SPL_BIN_MAX_TILES : 1];
     if (tid == 0) s_base = 0;
     __syncthreads();
     for (int s0 = 0; s0 < count; s0 += PROJ_THREADS) {
@@ -117,6 +119,13 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
         }
     }
     if (fcnt && tid == 0) fcnt[b] = s_base;
+    if (SURF && S.bbox && S.bins) {
+        // the crop's boxes (written above by this workgroup) -> per-tile surfel lists for the splat kernel
+        __threadfence_block();
+        __syncthreads();
+        sdfr_bin_boxes<PROJ_THREADS>(S.bbox + (int64_t)b * cap, count, (int)res_x, (int)res_y, cap,
+                                     S.bins + (int64_t)b * sdfr_splat_bin_stride(cap, (int)res_x, (int)res_y), tile_cnt, wc);
+    }
 }
 
 extern "C" int sdfr_project_dcm(const float* pose, const float* K, const float* points, const float* normals,
@@ -145,11 +154,14 @@ extern "C" int sdfr_surfels_forward(const float* xyz, int xyz_stride, const floa
                                     float* n_cam, float* col, int32_t* fidx, int32_t* fcnt, float* xyzf, int32_t* fslot,
                                     int32_t* bbox, void* stream) {
     SDFR_REQUIRE(xyz && sdf && idx && J && pose && K && points && normals && p_cam && n_cam && col, "sdfr_surfels_forward: NULL argument");
+    const bool no_bins = (output_nocs & 8) != 0;          // | 8: boxes only, no tile lists (pass SDFR_PRIM_NO_BINS to sdfr_splat_forward)
+    output_nocs &= ~8;
     SDFR_REQUIRE(output_nocs == 1 || output_nocs == 2 || output_nocs == 5 || output_nocs == 6, "sdfr_surfels_forward: NOCS colour modes only");
     SDFR_REQUIRE((fidx == nullptr) == (fcnt == nullptr), "sdfr_surfels_forward: fidx and fcnt must be given together");
     SDFR_REQUIRE(fidx || (!xyzf && !fslot), "sdfr_surfels_forward: xyzf / fslot need fidx and fcnt");
     if (B <= 0) return SDFR_OK;
-    SurfArgs S = {xyz, xyz_stride, sdf, G, idx, J, Jstride, Joff, points, normals, reinterpret_cast<int4*>(bbox), diam};
+    SurfArgs S = {xyz, xyz_stride, sdf, G, idx, J, Jstride, Joff, points, normals, reinterpret_cast<int4*>(bbox), diam,
+                  (bbox && !no_bins) ? bbox + (int64_t)B * cap * 4 : nullptr};
     hipLaunchKernelGGL(sdfr_project_dcm_kernel<true>, dim3(B), dim3(PROJ_THREADS), 0, (hipStream_t)stream, pose, K, nullptr, nullptr,
                        nullptr, cap, cnt, output_nocs, (float)res_x, (float)res_y, p_cam, n_cam, col, nullptr, fidx, fcnt, xyzf, fslot, S);
     SDFR_LAUNCH_CHECK();

@@ -144,6 +144,19 @@ __global__ __launch_bounds__(256) void sdfr_splat_bbox_kernel(const SplatArgs A,
     bbox[e] = ok ? make_int4(x0, y0, x1, y1) : make_int4(1, 1, 0, 0);
 }
 
+// screen boxes -> per-tile surfel lists, one workgroup per crop (the drop-in path; the batched path bins inside sdfr_surfels_forward)
+__global__ __launch_bounds__(1024) void sdfr_splat_bin_kernel(const SplatArgs A, const int4* __restrict__ bbox, int32_t* __restrict__ bins) {
+    __shared__ int tile_cnt[SPL_BIN_MAX_TILES];
+    __shared__ int wsum[1024 / 64 + 1];
+    const int b = blockIdx.x;
+    sdfr_bin_boxes<1024>(bbox + (int64_t)b * A.cap, sdfr_count(A.cnt, b, A.cap), A.W, A.H, A.cap,
+                         bins + (int64_t)b * sdfr_splat_bin_stride(A.cap, A.W, A.H), tile_cnt, wsum);
+}
+
+extern "C" int64_t sdfr_splat_ws_words(int B, int cap, int W, int H) {
+    return (int64_t)B * ((int64_t)cap * 4 + sdfr_splat_bin_stride(cap, W, H));
+}
+
 // ---- forward ----------------------------------------------------------------------------------------------------
 
 #define SPL_NW 8               // waves per 8x8 pixel tile (the forward is a latency chain over the tile's candidates: they are split SPL_NW ways;
@@ -156,7 +169,8 @@ __global__ __launch_bounds__(256) void sdfr_splat_bbox_kernel(const SplatArgs A,
 // reproducible bit for bit.  disc: the first sweep also records which pixels each candidate covers (one 64-bit ballot per candidate);
 // the second sweep skips candidates that cover no pixel of the tile and re-evaluates only the plane hit for the others.
 template <int PRIM>
-__global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const SplatArgs A, const int4* __restrict__ bbox, float* __restrict__ color,
+__global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const SplatArgs A, const int4* __restrict__ bbox,
+                                                                    const int32_t* __restrict__ bins, float* __restrict__ color,
                                                                     float* __restrict__ mask, float* __restrict__ depth,
                                                                     float* __restrict__ normals, float* __restrict__ aux) {
     const int b = blockIdx.y;
@@ -176,12 +190,38 @@ __global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const Splat
     __shared__ int list[SPL_LC];
     __shared__ unsigned long long cov[SPL_LC];
     __shared__ float sd[SPL_NW][11][64];
-    __shared__ float red[SPL_NW][11][64];
+    __shared__ float nured[SPL_NW][64];
     __shared__ int wc[2][SPL_NW];
+    float (*red)[11][64] = sd;        // the final merge reuses each wave's own staging slice (dead by then): 36 KiB of LDS, 4 tiles per CU
 
     // ---- (1) candidate list: surfels whose conservative box overlaps this tile, ascending order --------------------------------
+    // binned: the tile's entries of the per-crop tile lists (sdfr_bin_boxes: count -> scan -> fill, arbitrary order), sorted here by rank
+    // so that every sum below runs in ascending surfel order whatever the fill order was -- a tile touches its candidates, not all N boxes.
+    // Otherwise (no lists, or the crop's lists overflowed) the waves scan all boxes together.
     int nc = 0;
-    {
+    bool binned = false;
+    if (bins) {
+        const int T = tilesX * ((H + 7) >> 3);
+        const int32_t* toff = bins + (int64_t)b * sdfr_splat_bin_stride(A.cap, W, H);
+        if (toff[T + 1] == 1) {
+            binned = true;
+            const int o0 = toff[blockIdx.x];
+            nc = toff[blockIdx.x + 1] - o0;
+            if (nc > 0 && nc <= SPL_LC) {
+                int* tmp = reinterpret_cast<int*>(cov);
+                const int32_t* tl = toff + T + 2 + o0;
+                for (int i = threadIdx.x; i < nc; i += 64 * SPL_NW) tmp[i] = tl[i];
+                __syncthreads();
+                for (int i = threadIdx.x; i < nc; i += 64 * SPL_NW) {
+                    const int v = tmp[i];
+                    int r = 0;
+                    for (int j = 0; j < nc; ++j) r += (tmp[j] < v) ? 1 : 0;
+                    list[r] = v;
+                }
+            }
+        }
+    }
+    if (!binned) {
         auto overlaps = [&](int s) {
             if (s >= count) return false;
             const int4 bb = bbox[sb + s];
@@ -275,14 +315,13 @@ __global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const Splat
                 if (lane == 0) cov[c] = cm;
             }
         });
-        red[wave][0][lane] = nu2;
+        nured[wave][lane] = nu2;
         __syncthreads();
-        nu2 = red[0][0][lane];
+        nu2 = nured[0][lane];
 #pragma unroll
-        for (int w = 1; w < SPL_NW; ++w) nu2 += red[w][0][lane];
+        for (int w = 1; w < SPL_NW; ++w) nu2 += nured[w][lane];
         nu = sqrtf(nu2);
         nue = nu + FLT_EPSILON;
-        __syncthreads();                                           // red is reused by the second sweep
     }
     // one sweep with a running maximum (online softmax): max logit, softmax sums and composites (rasterer.py:119-144)
     float lmax = -FLT_MAX;
@@ -598,8 +637,9 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
                                   const float* attr, const float* uv, const float* znorm, const float* bg, const float* bg_logit, int B,
                                   int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant, int32_t* bbox_ws,
                                   float* color, float* mask, float* depth, float* normals, float* aux, void* stream) {
-    const bool boxes_ready = (primitive & SDFR_PRIM_BOXES_READY) != 0;      // bbox_ws already holds the screen boxes (sdfr_surfels_forward)
-    primitive &= ~SDFR_PRIM_BOXES_READY;
+    const bool boxes_ready = (primitive & SDFR_PRIM_BOXES_READY) != 0;      // bbox_ws already holds boxes and tile lists (sdfr_surfels_forward)
+    const bool no_bins = (primitive & SDFR_PRIM_NO_BINS) != 0;
+    primitive &= ~(SDFR_PRIM_BOXES_READY | SDFR_PRIM_NO_BINS);
     SplatArgs A;
     int rc = fill_args(A, "sdfr_splat_forward", primitive, K, Kinv, p_cam, n_cam, attr, uv, znorm, bg, bg_logit, B, cap, cnt, W, H, diam,
                        depth_constant);
@@ -608,20 +648,25 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
     int4* bb = reinterpret_cast<int4*>(bbox_ws);
+    // tile lists behind the boxes (splat_bbox.h).  SDFR_PRIM_NO_BINS: the workspace holds the boxes only -> every tile scans all boxes
+    int32_t* bins = (cap > 0 && !no_bins) ? bbox_ws + (int64_t)B * cap * 4 : nullptr;
     const dim3 gb(sdfr_cdiv(cap > 0 ? cap : 1, 256), B);
     const dim3 gt(((W + 7) / 8) * ((H + 7) / 8), B);
     switch (primitive) {
         case 0:
             if (cap > 0 && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<0>, gb, dim3(256), 0, s, A, bb);
-            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<0>, gt, dim3(64 * SPL_NW), 0, s, A, bb, color, mask, depth, normals, aux);
+            if (bins && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bin_kernel, dim3(B), dim3(1024), 0, s, A, bb, bins);
+            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<0>, gt, dim3(64 * SPL_NW), 0, s, A, bb, bins, color, mask, depth, normals, aux);
             break;
         case 1:
             if (cap > 0 && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<1>, gb, dim3(256), 0, s, A, bb);
-            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<1>, gt, dim3(64 * SPL_NW), 0, s, A, bb, color, mask, depth, normals, aux);
+            if (bins && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bin_kernel, dim3(B), dim3(1024), 0, s, A, bb, bins);
+            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<1>, gt, dim3(64 * SPL_NW), 0, s, A, bb, bins, color, mask, depth, normals, aux);
             break;
         default:
             if (cap > 0 && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<2>, gb, dim3(256), 0, s, A, bb);
-            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<2>, gt, dim3(64 * SPL_NW), 0, s, A, bb, color, mask, depth, normals, aux);
+            if (bins && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bin_kernel, dim3(B), dim3(1024), 0, s, A, bb, bins);
+            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<2>, gt, dim3(64 * SPL_NW), 0, s, A, bb, bins, color, mask, depth, normals, aux);
             break;
     }
     SDFR_LAUNCH_CHECK();

@@ -33,3 +33,68 @@ __device__ __forceinline__ bool disc_bbox(const float* __restrict__ K, float px,
     if (!axis_range(py, pz, diam, K[4], K[5], H, y0, y1)) return false;
     return true;
 }
+
+
+// ---- binning of the screen boxes into 8x8 pixel tiles ---------------------------------------------------------------------------------
+// Workspace of the splat forward pass (int32 words):  [B][cap][4] screen boxes, then per crop  tile_off[T + 2] | tile_list[SPL_LM * cap]
+// with T = ceil(W/8) * ceil(H/8):  tile_off[t] .. tile_off[t+1] delimit tile t's entries of tile_list (surfel slots, in NO particular
+// order: the consumer sorts them), tile_off[T] = total, tile_off[T + 1] = 1 if the lists are valid (0: too many tiles for the counters
+// or more entries than SPL_LM * cap -- the splat kernel then scans all boxes per tile instead).
+#define SPL_LM 32               // list capacity per crop = SPL_LM * cap entries
+#define SPL_BIN_MAX_TILES 8192  // LDS counters of the binning pass (32 KiB)
+
+__host__ __device__ __forceinline__ int64_t sdfr_splat_bin_stride(int cap, int W, int H) {
+    return (int64_t)((W + 7) / 8) * ((H + 7) / 8) + 2 + (int64_t)SPL_LM * cap;
+}
+
+// One workgroup of NT threads bins `count` boxes of ONE crop (bbox -> tile_off / tile_list).  lds_cnt: T ints, lds_w: NT/64 + 1 ints.
+// count -> exclusive scan -> fill, with LDS atomics (the per-tile order is whatever the atomics give; counts and offsets are exact).
+template <int NT>
+__device__ __forceinline__ void sdfr_bin_boxes(const int4* __restrict__ bbox, int count, int W, int H, int cap, int32_t* __restrict__ tile_off,
+                                               int* lds_cnt, int* lds_w) {
+    const int tid = threadIdx.x;
+    const int tilesX = (W + 7) >> 3, tilesY = (H + 7) >> 3, T = tilesX * tilesY;
+    int32_t* tile_list = tile_off + T + 2;
+    const int list_cap = SPL_LM * cap;
+    if (T > SPL_BIN_MAX_TILES) { if (tid == 0) { tile_off[T] = 0; tile_off[T + 1] = 0; } return; }
+    for (int t = tid; t < T; t += NT) lds_cnt[t] = 0;
+    __syncthreads();
+    for (int s = tid; s < count; s += NT) {
+        const int4 bb = bbox[s];
+        if (bb.x > bb.z || bb.y > bb.w) continue;
+        for (int ty = bb.y >> 3; ty <= (bb.w >> 3); ++ty)
+            for (int tx = bb.x >> 3; tx <= (bb.z >> 3); ++tx) atomicAdd(&lds_cnt[ty * tilesX + tx], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the tiles: thread tid owns the contiguous tiles [tid*per, tid*per + per)
+    const int per = (T + NT - 1) / NT;
+    int local = 0;
+    for (int k = 0; k < per; ++k) { const int t = tid * per + k; if (t < T) local += lds_cnt[t]; }
+    int incl = local;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) lds_w[wv] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < NT / 64; ++w) { const int c = lds_w[w]; lds_w[w] = run; run += c; }
+        lds_w[NT / 64] = run;
+    }
+    __syncthreads();
+    const int total = lds_w[NT / 64];
+    int run = lds_w[wv] + incl - local;
+    for (int k = 0; k < per; ++k) {
+        const int t = tid * per + k;
+        if (t < T) { const int c = lds_cnt[t]; tile_off[t] = run; lds_cnt[t] = run; run += c; }       // lds_cnt becomes the fill cursor
+    }
+    const bool ok = total <= list_cap;
+    if (tid == 0) { tile_off[T] = total; tile_off[T + 1] = ok ? 1 : 0; }
+    __syncthreads();
+    if (!ok) return;
+    for (int s = tid; s < count; s += NT) {
+        const int4 bb = bbox[s];
+        if (bb.x > bb.z || bb.y > bb.w) continue;
+        for (int ty = bb.y >> 3; ty <= (bb.w >> 3); ++ty)
+            for (int tx = bb.x >> 3; tx <= (bb.z >> 3); ++tx) tile_list[atomicAdd(&lds_cnt[ty * tilesX + tx], 1)] = s;
+    }
+}

@@ -387,19 +387,21 @@ def test_fused_surfel_forward_is_bitwise_the_three_launches(dec):
             T(np.stack([rng.uniform(-0.2, 0.2, B), rng.uniform(-0.1, 0.1, B), rng.uniform(3.0, 3.8, B)], 1).astype(np.float32)),
             T(rng.standard_normal((B, 3)).astype(np.float32)))
     snaps = []
-    for fused in (True, False):
+    for fused, binned in ((True, True), (False, True), (True, False), (False, False)):
         br = sdflabel_amd.BatchRenderer(dec, D, K, (W, H), B, device=DEV)
-        br.fused_head = fused
+        br.fused_head, br.binned = fused, binned
         o = br.forward(*args)
         n = [int(v) for v in br.cnt]; nf = [int(v) for v in br.fcnt]
         per = []
         for b in range(B):
-            per.append([t[b, :n[b]].clone() for t in (br.points, br.normals, br.p_cam, br.n_cam, br.attr, br.fslot, br.bbox)] +
+            per.append([t[b, :n[b]].clone() for t in (br.points, br.normals, br.p_cam, br.n_cam, br.attr, br.fslot, br.boxes)] +
                        [br.fidx[b, :nf[b]].clone(), br.xyzf[b, :nf[b]].clone()])
         snaps.append((n, nf, per, {k: o[k].clone() for k in ("color", "mask", "depth", "normals")}))
     assert snaps[0][0] == snaps[1][0] and snaps[0][1] == snaps[1][1] and min(snaps[0][0]) > 500
-    for pa, pb in zip(snaps[0][2], snaps[1][2]):
-        for a, b in zip(pa, pb):
-            assert torch.equal(a, b)
-    for k in snaps[0][3]:
-        assert torch.equal(snaps[0][3][k], snaps[1][3][k]), k
+    for other in snaps[1:]:
+        assert snaps[0][0] == other[0] and snaps[0][1] == other[1]
+        for pa, pb in zip(snaps[0][2], other[2]):
+            for a, b in zip(pa, pb):
+                assert torch.equal(a, b)
+        for k in snaps[0][3]:
+            assert torch.equal(snaps[0][3][k], other[3][k]), k

@@ -1,0 +1,94 @@
+"""GPU tests of the tile-binned splat forward (count -> scan -> fill lists of surfels per 8x8 pixel tile): identical bits to the
+all-boxes scan it replaces, and correct fall-backs when the lists do not fit."""
+import numpy as np
+import pytest
+import torch
+
+import sdflabel_amd
+from sdflabel_amd import _lib
+from oracle import sdf_oracle as O
+from tests._util import ASSET, K_for
+from tests.test_gpu_parity import N, T, images_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+NO_BINS = 512
+
+
+def _splat(prim_flags, K, Kinv, p, n, attr, W, H, B=1, cnt=None):
+    L = _lib.lib()
+    cap = p.shape[-2]
+    ws = _lib.splat_ws(B, cap, W, H, DEV)
+    ws.fill_(-7)
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=DEV)
+    color, mask, depth, nimg, aux = f(B, 3, H, W), f(B, 1, H, W), f(B, 1, H, W), f(B, 3, H, W), f(B, H * W, 4)
+    _lib.check(L.sdfr_splat_forward(prim_flags, _lib.ptr(K), _lib.ptr(Kinv), _lib.ptr(p), _lib.ptr(n), _lib.ptr(attr), None, None, None, None, B,
+                                    cap, _lib.ptr(cnt), W, H, 0.04, 150.0, _lib.ptr(ws), _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth),
+                                    _lib.ptr(nimg), _lib.ptr(aux), _lib.stream_ptr()), "sdfr_splat_forward")
+    return color, mask, depth, nimg, aux, ws
+
+
+def _surfels(rng, n, spread, z0, z1):
+    p = np.stack([rng.uniform(-spread, spread, n), rng.uniform(-spread, spread, n), rng.uniform(z0, z1, n)], 1).astype(np.float32)
+    nrm = rng.standard_normal((n, 3)).astype(np.float32) * 0.3 + np.array([0, 0, -1], np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return p, nrm, rng.uniform(0, 1, (n, 3)).astype(np.float32)
+
+
+@pytest.mark.parametrize("H,W,n", [(64, 64, 900), (72, 100, 2500), (256, 256, 3000)])
+def test_binned_forward_is_bitwise_the_unbinned_scan(H, W, n):
+    rng = np.random.default_rng(H + n)
+    p, nrm, col = _surfels(rng, n, 0.9, 3.0, 4.0)
+    K = K_for(H, W)
+    Kt, Ki = T(K).view(1, 9), T(np.linalg.inv(K).astype(np.float32)).view(1, 9)
+    a = _splat(0, Kt, Ki, T(p)[None], T(nrm)[None], T(col)[None], W, H)
+    b = _splat(NO_BINS, Kt, Ki, T(p)[None], T(nrm)[None], T(col)[None], W, H)
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+    assert float(a[1].sum()) > 50
+    # the lists: valid flag set, total = sum over surfels of the tiles their boxes overlap, offsets ascending
+    Tn = ((W + 7) // 8) * ((H + 7) // 8)
+    ws = N(a[5])
+    boxes = ws[:n * 4].reshape(n, 4)
+    toff = ws[n * 4:n * 4 + Tn + 2]
+    ok = boxes[:, 0] <= boxes[:, 2]
+    want = int((((boxes[ok, 2] >> 3) - (boxes[ok, 0] >> 3) + 1) * ((boxes[ok, 3] >> 3) - (boxes[ok, 1] >> 3) + 1)).sum())
+    assert toff[Tn + 1] == 1 and toff[Tn] == want and (np.diff(toff[:Tn + 1]) >= 0).all() and toff[0] == 0
+    lst = ws[n * 4 + Tn + 2:n * 4 + Tn + 2 + want]
+    assert lst.min() >= 0 and lst.max() < n
+
+
+def test_bin_list_overflow_falls_back_to_the_scan_and_matches_the_oracle():
+    """surfels so close to the camera that each covers most of the image: more list entries than 32 per surfel -> the crop is flagged
+    unbinned and every tile scans all boxes (and here also overflows its 1024-entry LDS list? no: N is small) -- same images"""
+    rng = np.random.default_rng(8)
+    H, W, n = 96, 96, 40
+    p, nrm, col = _surfels(rng, n, 0.01, 0.05, 0.06)          # disc radius 0.04 at z = 0.05: covers ~everything
+    K = K_for(H, W)
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    a = _splat(0, T(K).view(1, 9), T(Kinv).view(1, 9), T(p)[None], T(nrm)[None], T(col)[None], W, H)
+    Tn = ((W + 7) // 8) * ((H + 7) // 8)
+    toff = N(a[5])[n * 4:n * 4 + Tn + 2]
+    assert toff[Tn + 1] == 0 and toff[Tn] > 32 * n                    # overflow recorded, lists not used
+    b = _splat(NO_BINS, T(K).view(1, 9), T(Kinv).view(1, 9), T(p)[None], T(nrm)[None], T(col)[None], W, H)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    Wm, aux = O.inside_surfel(Kinv, O.pixel_grid((W, H)), p, nrm, diam=0.04, want_aux=True)
+    images_close(N(a[0][0]), np.minimum((Wm.T @ col).T, 1).reshape(3, H, W), aux)
+    images_close(N(a[1][0]), np.minimum(Wm.sum(0), 1).reshape(1, H, W), aux)
+
+
+def test_binned_ragged_batch_with_empty_and_full_crops():
+    """device-side counts: crop 0 empty, crop 1 partly filled, crop 2 full -- each equals the same crop splatted alone"""
+    rng = np.random.default_rng(3)
+    H, W, cap = 64, 80, 700
+    K = K_for(H, W)
+    Kt = T(np.tile(K.reshape(1, 9), (3, 1))); Ki = T(np.tile(np.linalg.inv(K).astype(np.float32).reshape(1, 9), (3, 1)))
+    p, nrm, col = _surfels(rng, 3 * cap, 0.8, 3.0, 4.0)
+    p, nrm, col = T(p).view(3, cap, 3), T(nrm).view(3, cap, 3), T(col).view(3, cap, 3)
+    cnt = torch.tensor([0, 311, cap], dtype=torch.int32, device=DEV)
+    a = _splat(0, Kt, Ki, p, nrm, col, W, H, B=3, cnt=cnt)
+    assert float(a[0][0].abs().max()) == 0.0 and float(a[1][0].abs().max()) == 0.0
+    for b, c in ((1, 311), (2, cap)):
+        one = _splat(0, Kt[b:b + 1], Ki[b:b + 1], p[b:b + 1, :c].contiguous(), nrm[b:b + 1, :c].contiguous(), col[b:b + 1, :c].contiguous(), W, H)
+        for x, y in zip(a[:5], one[:5]):
+            assert torch.equal(x[b], y[0]), b

@@ -328,3 +328,28 @@ def test_g13_standalone_primitive_weights(name, bg):
     ref = z["%s_bg%d_w" % (name, int(bg))]
     assert w.shape == ref.shape
     assert np.abs(w - ref).max() < (1e-3 if name == "circle_opt" else 2e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g7_torch_cpu_port_reproduces_the_reference(tag):
+    """the multi-threaded torch-CPU port timed by bench.py's cpu_baseline gives the reference's images and autograd gradients (golden G7)"""
+    import torch
+    from oracle import torch_cpu_port as TP
+    z = gold("g7_grads.npz")
+    D, H, W = [int(v) for v in z[tag + "_cfg"]]
+    st, spec = fitted_state()
+    dec = TP.DecoderPort(st, spec)
+    gp = TP.generate_point_grid(D).requires_grad_(True)
+    yaw = torch.tensor(z[tag + "_yaw"], requires_grad=True)
+    trans = torch.tensor(z[tag + "_trans"], requires_grad=True)
+    lat = torch.tensor(z[tag + "_latent"], requires_grad=True)
+    wts = {k: torch.from_numpy(z[tag + "_W_" + k]) for k in ("color", "mask", "depth", "normals")}
+    wts.update({k: torch.from_numpy(z[tag + "_Wp_" + k]) for k in ("xyzf", "rgbf", "xyz", "rgb")})
+    rend, pts, n, loss = TP.crop_iteration(dec, gp, torch.from_numpy(z[tag + "_K"]), (W, H), yaw, trans, lat, weights=wts, output_depth=True)
+    assert n == z[tag + "_pcd"].shape[0]
+    for k in ("color", "mask", "depth", "normals"):
+        assert np.abs(rend[k].detach().numpy() - z[tag + "_out_" + k]).max() < 1e-5, k
+    assert abs(float(loss) - float(z[tag + "_loss"])) < 1e-3 * max(1.0, abs(float(z[tag + "_loss"])))
+    for got, key in ((yaw.grad, "_g_yaw"), (trans.grad, "_g_trans"), (lat.grad, "_g_latent")):
+        ref = z[tag + key]
+        assert np.abs(got.numpy() - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), key

@@ -18,8 +18,12 @@ One ray = one pixel of one crop in one step; value = rays of all ranks / max-ove
 rank, no data-path collective; the per-crop results are all-gathered once after the timed region).
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (the fused decoder forward, MFMA-bound) timed with events on
-the launch stream inside the timed region, and `cpu_baseline`: the numpy oracle (oracle/sdf_oracle.py, a port of the
-reference's dense algorithm) timed on the host cores for one crop-iteration of the same workload (rank 0, N=1 only).
+the launch stream inside the timed region; `roofline_splat` (the splat forward+backward pair against the HBM roofline, at one crop and
+at 64 crops per launch); `cpu_baseline`: the reference's dense algorithm as a multi-threaded torch-CPU port (oracle/torch_cpu_port.py,
+pinned to the reference's golden G7) timed on the host cores for one full crop-iteration of the same workload (rank 0, N=1 only);
+`refine_sharded`: BASELINE configs[3] -- `--total-crops` (default 1024) crops sharded crop i -> rank i mod N, refined in chunks of 64 by
+BatchRefiner with the reference's losses and solver, one all_gather of the result rows: the strong-scaling figure of north_star
+(time at N ranks / time at 1 rank); labelled second lines `pose_only`, `f16_decoder`, `split_decoder`, `prefilter_decoder`.
 """
 import argparse
 import json
@@ -84,57 +88,46 @@ def crop_iteration(dec, grid, renderer, crop, ev=None):
 
 
 def cpu_baseline():
-    """The oracle timed on the host: one crop-iteration of the same workload, dense N x P formulation as the reference."""
-    from oracle import sdf_oracle as O
+    """The reference's dense algorithm on the host cores: ONE full crop-iteration (fwd+bwd) of the bench workload -- 256x256 rays, D = 40,
+    every pixel, nothing extrapolated -- with oracle/torch_cpu_port.py (torch CPU ops in the reference's order, autograd backward incl. the
+    decoder's unneeded weight gradients, dense N x P splat tensors; measured in the build container at the cost of the imported reference
+    itself: 14.4 s against 13.8 s on 8 cores).  Timed with 8 threads (the survey's probe configuration) and with 32."""
+    from oracle import torch_cpu_port as TP
     from tests._util import fitted_state
-    try:
-        from threadpoolctl import threadpool_info
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        blas_threads = os.cpu_count() or 1
     st, spec = fitted_state()
-    layers = O.decoder_layers_from_state(st, spec)
-    K = K_for(H, W)
-    Kinv = np.linalg.inv(K).astype(np.float32)
-    lat = np.array([0.3, -0.5, 0.8], np.float32)
-    lat = lat / np.linalg.norm(lat)
-    pts = O.generate_point_grid(D)
-    t0 = time.perf_counter()
-    inp = np.concatenate([np.broadcast_to(lat, (pts.shape[0], 3)), pts], 1).astype(np.float32)
-    sdf, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
-    Jall = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(sdf))
-    pm, _, nm, idx, n_hat = O.get_surface_points(pts, sdf, Jall[:, 3:], 0.03)
-    pose = O.render_pose(0.6, [0.0, 0.0, 3.5])
-    proj = O.project_in_2D(K, pose, pm, nm, nm, (W, H), output_nocs=True)
-    v3, nc = proj["points_3d"].astype(np.float32), proj["normals_3d"].astype(np.float32)
-    c_attr = ((proj["colors_3d"] + 1) / 2).astype(np.float32)
-    t_mlp = time.perf_counter() - t0
-    # dense splat + composite + backward on a quarter of the image (rows H*3/8 .. H*5/8, through the object), extrapolated x4:
-    # the dense N x P formulation costs the same for every pixel
-    sub = O.pixel_grid((W, H)).reshape(H, W, 2)[H * 3 // 8:H * 5 // 8].reshape(-1, 2)
-    t1 = time.perf_counter()
-    Wm = O.inside_surfel(Kinv, sub, v3, nc, diam=0.04)
-    color = np.minimum((Wm.T @ c_attr).T, 1)
-    mask = np.minimum(Wm.sum(0), 1)
-    nimg = np.minimum((Wm.T @ ((nc + 1) / 2)).T, 1)
-    del Wm
-    P = sub.shape[0]
-    g_v3, g_n, g_c = O.splat_backward(Kinv, (W, H), v3, nc, c_attr, np.ones((3, P), np.float32), np.ones((1, P), np.float32), None,
-                                      np.ones((3, P), np.float32), grid_2d=sub)
-    t_rast = (time.perf_counter() - t1) * (H * W / float(P))
-    t2 = time.perf_counter()
-    g_points, _, _, g_pose = O.project_backward_dcm(pose, pm, nm, g_v3, g_n, g_c * 0.5, output_nocs=True, filt_idx=proj["filt_idx"],
-                                                    g_p3_filt=np.ones_like(proj["points_3d_filt"]))
-    g_sdf, _ = O.get_surface_points_backward(sdf, n_hat, idx, g_points)
-    g_lat = (Jall * g_sdf)[:, :3].sum(0)
-    dt = t_mlp + t_rast + (time.perf_counter() - t2)
-    assert color.shape[1] == P and mask.shape[0] == P and nimg.shape[1] == P
-    assert np.isfinite(g_lat).all() and np.isfinite(g_pose).all()
-    return {"value": H * W / dt, "unit": "rays/s", "cores": int(blas_threads), "kind": "port",
-            "sample": "1 crop-iteration (fwd+bwd) of the bench workload (256x256 rays, D=40, N=%d surfels) with the numpy oracle, dense "
-                      "N x P as the reference: decoder fwd + input-Jacobian on all 64000 grid points and projection timed in full "
-                      "(%.1f s), dense splat/composite fwd+bwd timed on the central quarter of the image and extrapolated x4 (%.1f s); "
-                      "BLAS matmuls on %d threads, elementwise passes single-threaded" % (pm.shape[0], t_mlp, t_rast, blas_threads)}
+    decoder = TP.DecoderPort(st, spec)
+    gp = TP.generate_point_grid(D).requires_grad_(True)
+    K = torch.from_numpy(K_for(H, W))
+    ncpu = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    out, n_surf = {}, 0
+
+    def run():
+        yaw = torch.tensor([0.6], requires_grad=True)
+        trans = torch.tensor([0.0, 0.0, 3.5], requires_grad=True)
+        lat = torch.tensor([0.3, -0.5, 0.8], requires_grad=True)
+        t0 = time.perf_counter()
+        rend, pts, n, loss = TP.crop_iteration(decoder, gp, K, (W, H), yaw, trans, lat)
+        dt = time.perf_counter() - t0
+        assert bool(torch.isfinite(yaw.grad).all() and torch.isfinite(trans.grad).all() and torch.isfinite(lat.grad).all())
+        return dt, n
+
+    # 8 threads = the survey's probe configuration; 32 = a quarter of a socket.  (Every hardware thread of the 256-thread GPU box measured
+    # 1.08 k rays/s, 60 s per iteration: the dense passes are memory-bound and oversubscribe -- not timed by default, see DESIGN.md 5.)
+    for threads in sorted({min(8, ncpu), min(32, ncpu)}, reverse=True):
+        torch.set_num_threads(threads)
+        if not out:
+            run()                                   # one warm-up iteration (allocator, thread pool) at the first setting
+        dt, n_surf = run()
+        out[threads] = (H * W / dt, dt)
+    torch.set_num_threads(prev)
+    best = max(out, key=lambda k: out[k][0])
+    return {"value": out[best][0], "unit": "rays/s", "cores": int(best), "kind": "port",
+            "by_threads": {str(k): {"rays_per_s": v[0], "seconds_per_crop_iteration": v[1]} for k, v in out.items()},
+            "host_cores": ncpu,
+            "sample": "1 full crop-iteration (fwd+bwd to yaw/trans/latent) of the bench workload, all %dx%d rays, D=%d, N=%d surfels, dense "
+                      "N x P formulation as the reference, torch CPU ops + autograd (oracle/torch_cpu_port.py); 1 warm-up + 1 timed "
+                      "iteration per thread setting; value = the faster setting" % (H, W, D, n_surf)}
 
 
 def main():
@@ -145,6 +138,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--crops-per-gpu", type=int, default=1, help="crops refined together per rank (1 = BASELINE configs[1]; 64 = configs[2])")
     ap.add_argument("--crop-size", type=int, default=256, help="crop edge in pixels (256 = BASELINE configs[1..3]; 512 = configs[4], informational)")
+    ap.add_argument("--total-crops", type=int, default=1024, help="crops of the sharded refinement (BASELINE configs[3]); 0 skips the section")
+    ap.add_argument("--sharded-iters", type=int, default=10, help="refinement iterations per crop in the sharded section (the reference runs 60, "
+                    "configs/config_refine.ini:15: pass 60 for the literal refine run; every iteration costs the same)")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline loop (+ cpu_baseline): skip the informational sections")
     args = ap.parse_args()
     global H, W
     H = W = int(args.crop_size)
@@ -156,12 +153,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:                                              # each rank its share of the host cores
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     dist = None
     if world > 1 or "RANK" in os.environ:          # under torch.distributed.run: always take the distributed path
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_mod.init_process_group("nccl", device_id=dev)
         dist = dist_mod
+        if dist.get_world_size() != world or args.gpus != world:
+            raise SystemExit("--gpus %d, WORLD_SIZE %d, process group of %d ranks: they must agree" % (args.gpus, world, dist.get_world_size()))
 
     import sdflabel_amd
     from tests._util import ASSET
@@ -186,9 +187,9 @@ def main():
     ones1 = torch.ones(CB, 1, H, W, device=dev)
     onesx = torch.ones(CB, br.cap, 3, device=dev)
 
-    def step(ev=None):
-        br.forward(mlp_events=ev)
-        br.backward(g_color=ones3, g_mask=ones1, g_normals=ones3, g_xyzf=onesx)     # d/d(out) of the plain sums used as the loss
+    def step(ev=None, evs=None):
+        br.forward(mlp_events=ev, events=evs)
+        br.backward(g_color=ones3, g_mask=ones1, g_normals=ones3, g_xyzf=onesx, events=evs)     # d/d(out) of the plain sums used as the loss
 
     def barrier():
         if dist is not None:
@@ -197,14 +198,18 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    def ev_pair():
+        return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    events = [ev_pair() for _ in range(args.steps)]
+    kev = [{"jacobian": ev_pair(), "splat_fwd": ev_pair(), "splat_bwd": ev_pair()} for _ in range(args.steps)]
     import gc
     gc.collect()
     gc.disable()                  # no collector pause inside a timed region (the steps allocate nothing, but the interpreter may still run it)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(events[i])
+        step(events[i], kev[i])
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -221,6 +226,7 @@ def main():
         table = gather_crop_results(res, CB * world, rank, world)
         assert table.shape == (CB * world, 8) and bool(torch.isfinite(table).all())
     mlp_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    kms = {k: float(np.mean([e[k][0].elapsed_time(e[k][1]) for e in kev])) for k in kev[0]}
 
     def all_ok(flag):
         if dist is None:
@@ -278,7 +284,7 @@ def main():
         rf.capture()
         return rf, p0["yaw"].to(dev).clone()
 
-    res, err = timed_section(refine_setup, lambda st: st[0].optimize(iters))
+    res, err = timed_section(refine_setup, lambda st: st[0].optimize(iters)) if not args.no_extras else (None, "skipped (--no-extras)")
     if res is None:
         refine = {"error": err}
     else:
@@ -289,6 +295,121 @@ def main():
                   "crops_stepped_last_iteration": int(rf.stepped.sum())}
         del rf
     res = None
+
+    # ---- BASELINE configs[3]: `--total-crops` crops sharded over the ranks (crop i -> rank i mod N), refined in chunks of 64 by BatchRefiner,
+    # ONE all_gather of the per-crop result rows at the end.  Strong scaling: the total is fixed, so seconds(N=1) / seconds(N)
+    # is the north_star's "x at 8 GPUs over 1 GPU on a 1024-crop batch".
+    CHUNK = 64
+
+    def crop_params(indices):
+        ys, ts, ls = [], [], []
+        for i in indices:                                      # the same per-crop jitter as Crop(i), generated on the host
+            jit = torch.rand(7, generator=torch.Generator().manual_seed(1 + i))
+            ys.append(0.6 + 0.1 + 0.1 * jit[0:1])
+            ts.append(torch.tensor([0.0, 0.0, 3.5]) + torch.tensor([0.1, 0.05, -0.3]) * jit[1:4])
+            ls.append(torch.tensor([0.3, -0.5, 0.8]) + 0.2 * (jit[4:7] - 0.5))
+        return {"yaw": torch.cat(ys), "trans": torch.stack(ts), "scale": torch.full((len(indices),), 2.0), "latent": torch.stack(ls)}
+
+    def sharded_setup():
+        mine = shard_crops(args.total_crops, rank, world)
+        rf = sdflabel_amd.BatchRefiner(dec, D, K_for(H, W), (H, W), CHUNK, lidar_cap=4096, device=dev)
+        gt = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), 1, device=dev)
+        o = gt.forward(torch.tensor([0.6], device=dev), torch.tensor([[0.0, 0.0, 3.5]], device=dev), torch.tensor([[0.3, -0.5, 0.8]], device=dev))
+        lidar = (o["xyzf"][0, :int(o["nf"][0])] * 2.0)[::2].cpu().numpy()
+        nocs_t = o["color"].expand(CHUNK, 3, H, W).clone()
+        params = crop_params(mine) if mine else None
+        warm = crop_params(list(range(CHUNK)))
+        rf.set_crops(warm, nocs_t, [lidar] * CHUNK)
+        rf.capture()
+        rf.optimize(2)                                         # warm-up (graph instantiation, allocator)
+        return rf, mine, params, nocs_t, lidar
+
+    def sharded_run(st):
+        rf, mine, params, nocs_t, lidar = st
+        rows = []
+        for c0 in range(0, len(mine), CHUNK):
+            n = min(CHUNK, len(mine) - c0)
+            sel = list(range(c0, c0 + n)) + [c0 + n - 1] * (CHUNK - n)          # a short last chunk is padded with copies of its last crop
+            rf.set_crops({k: v[sel] for k, v in params.items()}, nocs_t, [lidar] * CHUNK)
+            rf.optimize(args.sharded_iters)
+            rows.append(rf.results()[0][:n])
+        local = torch.cat(rows) if rows else torch.zeros((0, 5 + rf.L), device=dev)
+        st.append(gather_crop_results(local, args.total_crops, rank, world) if dist is not None else local)
+
+    sharded = None
+    if args.total_crops > 0 and not args.no_extras and CB == 1:
+        from sdflabel_amd.parallel import gather_crop_results
+        res, err = timed_section(lambda: list(sharded_setup()), sharded_run)
+        if res is None:
+            sharded = {"error": err}
+        else:
+            st, dt_s = res
+            table = st[-1]
+            ok = tuple(table.shape) == (args.total_crops, 5 + st[0].L) and bool(torch.isfinite(table).all())
+            sharded = {"workload": "BASELINE configs[3]: %d crops of %dx%d rays sharded crop i -> rank i mod %d, chunks of %d through BatchRefiner "
+                                   "(reference losses + solver, HIP-graph replay), one all_gather of the result rows" % (args.total_crops, H, W, world, CHUNK),
+                       "total_crops": args.total_crops, "iterations_per_crop": args.sharded_iters, "world_size": world, "seconds": dt_s,
+                       "crop_iterations_per_s": args.total_crops * args.sharded_iters / dt_s,
+                       "crops_per_s_at_this_iteration_count": args.total_crops / dt_s,
+                       "mean_abs_yaw_error_after": float((table[:, 0] - 0.6).abs().mean()), "gathered_table_ok": ok,
+                       "scaling": "strong (total crops fixed): speed-up at N ranks = seconds(N=1) / seconds(N)"}
+            del st
+        res = None
+
+    # ---- labelled second line: pose-only refinement (BASELINE configs[1] says "pose-only refinement"; SURVEY.md 8d: "latent frozen -- MLP
+    # result may be cached; state whether it was").  The HEADLINE above caches nothing.  Here the latent is fixed, so decoder, band and Jacobian
+    # are evaluated once (BatchRenderer.freeze_shape) and a step is: pose -> re-projection -> splat -> backward to yaw and trans.
+    def pose_only_setup():
+        b2 = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), CB, device=dev)
+        b2.freeze_shape = True
+        b2.set_params(br.yaw, br.trans, br.latent)
+        for _ in range(args.warmup + 1):
+            b2.forward()
+            b2.backward(g_color=ones3, g_mask=ones1, g_normals=ones3, g_xyzf=onesx)
+        return b2
+
+    def pose_only_run(b2):
+        for _ in range(args.steps):
+            b2.yaw.add_(1e-3)                                  # the pose moves every step, as under a solver; the latent does not
+            b2.forward()
+            b2.backward(g_color=ones3, g_mask=ones1, g_normals=ones3, g_xyzf=onesx)
+
+    pose_only = None
+    if not args.no_extras:
+        res, err = timed_section(pose_only_setup, pose_only_run)
+        if res is None:
+            pose_only = {"error": err}
+        else:
+            b2, dt_p = res
+            pose_only = {"workload": "pose-only crop-iteration: latent frozen, decoder/band/Jacobian evaluated ONCE and cached; per step pose -> "
+                                     "re-projection -> splat -> backward to yaw/trans (%d crop(s) of %dx%d per GPU)" % (CB, H, W),
+                         "value": H * W * CB * world * args.steps / dt_p, "unit": "rays/s", "ms_per_step": dt_p / args.steps * 1e3,
+                         "decoder_cached": True, "surfels": int(b2.cnt[0])}
+            del b2
+        res = None
+
+    # ---- the splat pair at 64 crops per launch (BASELINE configs[2] shape), for roofline_splat (rank 0 only, a few steps)
+    splat64 = None
+    if rank == 0 and CB == 1 and H == 256 and not args.no_extras:
+        try:
+            b64 = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), 64, device=dev)
+            p64 = crop_params(list(range(64)))
+            b64.set_params(p64["yaw"].to(dev), p64["trans"].to(dev), p64["latent"].to(dev))
+            o3, o1, ox = torch.ones(64, 3, H, W, device=dev), torch.ones(64, 1, H, W, device=dev), torch.ones(64, b64.cap, 3, device=dev)
+            e64 = [{"jacobian": ev_pair(), "splat_fwd": ev_pair(), "splat_bwd": ev_pair()} for _ in range(4)]
+            for e in e64:
+                b64.forward(events=e)
+                b64.backward(g_color=o3, g_mask=o1, g_normals=o3, g_xyzf=ox, events=e)
+            torch.cuda.synchronize()
+            ms = {k: float(np.mean([e[k][0].elapsed_time(e[k][1]) for e in e64[1:]])) for k in e64[0]}
+            nb = 64.0 * H * W * 64 + 72.0 * float(b64.cnt.sum()) + 48.0 * float(b64.fcnt.sum())
+            splat64 = {"crops_per_launch": 64, "fwd_ms": ms["splat_fwd"], "bwd_ms": ms["splat_bwd"], "algorithmic_bytes": nb,
+                       "achieved": nb / ((ms["splat_fwd"] + ms["splat_bwd"]) * 1e-3) / 1e9, "jacobian_ms": ms["jacobian"],
+                       "jacobian_tflops": 2.0 * macs * float(b64.cnt.sum()) / (ms["jacobian"] * 1e-3) / 1e12}
+            splat64["frac"] = splat64["achieved"] / 8000.0
+            del b64, o3, o1, ox
+        except Exception as e:                                 # informational only
+            splat64 = {"error": repr(e)[:200]}
 
     # the same crop-iteration with the alternative decoder arithmetics.  Informational -- the headline and the 1e-4 parity claim
     # are the exact-f32 path's.
@@ -335,15 +456,18 @@ def main():
                 "max_abs_color_diff_vs_f32": float((b2.color - br.color).abs().max())})
         return out
 
-    f16 = alt_decoder(torch.float16, "f16 decoder / f32 rest")
-    split = alt_decoder("float32_split", "f32 results from error-compensated f16 operand pairs (3 f16 MFMAs per product) / f32 rest")
+    f16 = split = prefilter = None
+    if not args.no_extras:
+        f16 = alt_decoder(torch.float16, "f16 decoder / f32 rest")
+        split = alt_decoder("float32_split", "f32 results from error-compensated f16 operand pairs (3 f16 MFMAs per product) / f32 rest")
     #   float32_prefilter  a float16 pass over the grid proposes candidates |sdf| < 0.03 + margin; band membership, sdf and Jacobian of the
     #                  band come from the exact-f32 kernels run on the candidates only (decoder_forward_ms spans both passes incl. the Jacobian)
-    prefilter = alt_decoder("float32_prefilter", "exact f32 on the band candidates chosen by an f16 pass over the grid / f32 rest")
+    if not args.no_extras:
+        prefilter = alt_decoder("float32_prefilter", "exact f32 on the band candidates chosen by an f16 pass over the grid / f32 rest")
 
     # the same crop-iteration through the drop-in boundary (rank 0 only, informational)
     dropin = None
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         grid = sdflabel_amd.Grid3D(D, dev)
         renderer = sdflabel_amd.Rasterer(torch.from_numpy(K_for(H, W)), (W, H)).to(dev)
         for _ in range(3):
@@ -378,8 +502,20 @@ def main():
         line["roofline"] = {"kernel": "sdfr_mlp_kernel<float,32,2,2,8,2,1,2> (fused decoder forward on the grid, saves ReLU masks)", "bound": "mfma",
                             "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                             "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": mlp_ms}
+        nbytes = 64.0 * H * W * CB + 72.0 * float(br.cnt.sum()) + 48.0 * float(br.fcnt.sum())          # 64 P + 72 N + 48 N_f per crop, fwd+bwd
+        ach_s = nbytes / ((kms["splat_fwd"] + kms["splat_bwd"]) * 1e-3) / 1e9
+        line["roofline_splat"] = {"kernel": "sdfr_splat_fwd_kernel<0> + sdfr_splat_bwd_kernel<0> (surfel splat / depth-softmax composite and its backward)",
+                                  "bound": "hbm", "achieved": ach_s, "peak": 8000.0, "unit": "GB/s", "frac": ach_s / 8000.0, "traffic": None,
+                                  "algorithmic_bytes_per_launch_pair": nbytes, "fwd_ms": kms["splat_fwd"], "bwd_ms": kms["splat_bwd"],
+                                  "crops_per_launch": CB, "at_64_crops_per_launch": splat64,
+                                  "note": "latency-bound at one crop (candidate evaluation chains, not bytes); see DESIGN.md 3.4"}
+        line["jacobian"] = {"avg_launch_ms": kms["jacobian"], "tflops": 2.0 * macs * float(br.cnt.sum()) / (kms["jacobian"] * 1e-3) / 1e12,
+                            "f32_mfma_peak_tflops": F32_MFMA_PEAK_TFLOPS, "rows": int(br.cnt.sum())}
         line["dropin_api"] = dropin
         line["refine_demo"] = refine
+        line["refine_sharded"] = sharded
+        line["pose_only"] = pose_only
+        line["world_size"] = world
         line["f16_decoder"] = f16
         line["split_decoder"] = split
         line["prefilter_decoder"] = prefilter

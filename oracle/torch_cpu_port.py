@@ -100,11 +100,11 @@ def inside_surfel(K, grid_2d, vertex_3d, normals, diam=0.04, depth_constant=150)
     b[b.abs() < 0.01] = eps                                                              # :210 (in place: no gradient through the overwritten entries)
     z = n_v3d.unsqueeze(-1) / b                                                          # :211
     g3 = rays.unsqueeze(0) * z.unsqueeze(-1)                                             # :212  (N, P, 3)
-    d = (vertex_3d.unsqueeze(1) - g3).norm(p=2, dim=-1)                                  # :215
+    d = (vertex_3d.view(-1, 1, 3) - g3).pow(2).sum(-1).sqrt()                            # :215,:220
     dist = torch.clamp(diam - d, min=0)                                                  # :220
     mask = (dist > 0).detach().to(dt)                                                    # :226
     zz = -z * mask                                                                       # :227
-    zn = zz.norm(p=2, dim=0, keepdim=True).detach()                                      # :228
+    zn = torch.norm(zz, p=2, dim=0).detach().unsqueeze(0)                                # :228
     zz = torch.clamp(zz / (zn + eps) + 1, min=0) * depth_constant                        # :229-230
     zz = zz.masked_fill(mask == 0, torch.finfo(dt).min)                                  # :240
     return F.softmax(zz, dim=0) * mask                                                   # :240

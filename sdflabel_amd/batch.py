@@ -102,6 +102,11 @@ class BatchRenderer:
         self.g_latn = f(B, self.L)
         self.g_yaw, self.g_trans, self.g_latent = f(B), f(B, 3), f(B, self.L)
         self._graph = None
+        # pose-only refinement (BASELINE configs[1] wording): with the latent fixed, sdf, band, Jacobian and surfels do not change between
+        # iterations -- freeze_shape=True evaluates the decoder stages once (until the latent is set again) and every later forward() only
+        # re-projects and splats.  Exact: the skipped kernels would reproduce the cached arrays bit for bit.
+        self.freeze_shape = False
+        self._shape_valid = False
         self.fused_tail = True      # one launch for the backward tail (False: the three separate kernels, same bits)
         self.fused_head = True      # one launch for surface projection + camera projection + screen boxes (False: three launches, same bits)
 
@@ -115,17 +120,23 @@ class BatchRenderer:
         self.yaw.copy_(yaw.reshape(self.B))
         self.trans.copy_(trans.reshape(self.B, 3))
         self.latent.copy_(latent.reshape(self.B, self.L))
+        self._shape_valid = False
 
-    def forward(self, yaw=None, trans=None, latent=None, mlp_events=None):
-        """mlp_events: optional (start, end) torch.cuda.Event pair recorded around the decoder-forward launch (bench.py roofline)."""
+    def invalidate_shape(self):
+        """call after changing self.latent in place (freeze_shape mode): the next forward() re-evaluates decoder, band and Jacobian"""
+        self._shape_valid = False
+
+    def forward(self, yaw=None, trans=None, latent=None, mlp_events=None, events=None):
+        """mlp_events: optional (start, end) torch.cuda.Event pair recorded around the decoder-forward launch (bench.py roofline).
+        events: optional dict of such pairs for other launches of the step: 'jacobian', 'splat_fwd' (and 'splat_bwd' in backward())."""
         with _lib.guard(self.dev):
-            return self._forward(yaw, trans, latent, mlp_events)
+            return self._forward(yaw, trans, latent, mlp_events, events or {})
 
-    def backward(self, g_color=None, g_mask=None, g_depth=None, g_normals=None, g_xyzf=None):
+    def backward(self, g_color=None, g_mask=None, g_depth=None, g_normals=None, g_xyzf=None, events=None):
         with _lib.guard(self.dev):
-            return self._backward(g_color, g_mask, g_depth, g_normals, g_xyzf)
+            return self._backward(g_color, g_mask, g_depth, g_normals, g_xyzf, events or {})
 
-    def _forward(self, yaw, trans, latent, mlp_events):
+    def _forward(self, yaw, trans, latent, mlp_events, events):
         if yaw is not None:
             self.set_params(yaw, trans, latent)
         L = _lib.lib()
@@ -135,7 +146,10 @@ class BatchRenderer:
                                  P(self.latnorm), st), "sdfr_params_forward")
         if mlp_events is not None:
             mlp_events[0].record()
-        if self.prefilter:
+        if self.freeze_shape and self._shape_valid:
+            if mlp_events is not None:
+                mlp_events[1].record()
+        elif self.prefilter:
             ck(L.sdfr_mlp_forward_f16(self.handle.h, P(self.inputs), B * G, P(self.sdf), None, st), "sdfr_mlp_forward_f16")
             ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr + self.margin, P(self.cidx), cap, P(self.ccnt), P(self.cslot), P(self.scratch), st),
                "sdfr_band_select")
@@ -153,8 +167,13 @@ class BatchRenderer:
             if mlp_events is not None:
                 mlp_events[1].record()
             ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
+            if "jacobian" in events:
+                events["jacobian"][0].record()
             ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.idx), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.sdf),
                                    P(self.mask_ws), 2 if self.f16 else 0, st), "sdfr_mlp_jacobian")
+            if "jacobian" in events:
+                events["jacobian"][1].record()
+        self._shape_valid = True
         xyz = self.inputs[:, self.NI - 3:]
         prim = 0 if self.binned else 512                                              # [SDFR_PRIM_NO_BINS]
         if self.fused_head:
@@ -172,13 +191,17 @@ class BatchRenderer:
             ck(L.sdfr_project_dcm(P(self.pose), P(self.K), P(self.points), P(self.normals), None, B, cap, P(self.cnt), self.nocs_mode | 4, W, H,
                                   P(self.p_cam), P(self.n_cam), P(self.attr), None, P(self.fidx), P(self.fcnt), P(self.xyzf), P(self.fslot), st),
                "sdfr_project_dcm")
+        if "splat_fwd" in events:
+            events["splat_fwd"][0].record()
         ck(L.sdfr_splat_forward(prim, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
                                 _DEPTH_CONSTANT, P(self.bbox), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(self.aux), st),
            "sdfr_splat_forward")
+        if "splat_fwd" in events:
+            events["splat_fwd"][1].record()
         return {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.nimg, "xyzf": self.xyzf, "nf": self.fcnt,
                 "n": self.cnt}
 
-    def _backward(self, g_color, g_mask, g_depth, g_normals, g_xyzf):
+    def _backward(self, g_color, g_mask, g_depth, g_normals, g_xyzf, events):
         L = _lib.lib()
         P, st, ck = _lib.ptr, _lib.stream_ptr(), _lib.check
         B, cap, W, H = self.B, self.cap, self.W, self.H
@@ -191,9 +214,13 @@ class BatchRenderer:
 
         g_color, g_mask = c(g_color, self.color.shape), c(g_mask, self.mask.shape)
         g_depth, g_normals = c(g_depth, self.depth.shape), c(g_normals, self.nimg.shape)
+        if "splat_bwd" in events:
+            events["splat_bwd"][0].record()
         ck(L.sdfr_splat_backward(0, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
                                  _DEPTH_CONSTANT, P(self.aux), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(g_color),
                                  P(g_mask), P(g_depth), P(g_normals), P(self.g_p), P(self.g_n), P(self.g_a), st), "sdfr_splat_backward")
+        if "splat_bwd" in events:
+            events["splat_bwd"][1].record()
         if g_xyzf is not None:
             g_xyzf = c(g_xyzf, self.xyzf.shape)
         if self.L <= 8 and self.fused_tail:

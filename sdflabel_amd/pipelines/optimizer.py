@@ -47,7 +47,7 @@ class Optimizer:
         self._refiner = None
         self._key = None
 
-    def _refiner_for(self, dsdf, grid, K, crop_size, n_lidar):
+    def _refiner_for(self, dsdf, grid, K, crop_size, n_lidar, optimize_latent=True):
         G = int(grid.points.size(0))
         D = int(round(G ** (1.0 / 3.0)))
         if D ** 3 != G:
@@ -56,13 +56,13 @@ class Optimizer:
         cap = max(256, 1 << (max(n_lidar, 1) - 1).bit_length())       # lidar capacity, rounded up so that a refiner is reused across crops
         Kn = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32)
         key = (id(dsdf), D, tuple(int(c) for c in crop_size), cap, Kn.tobytes(), str(dev), dsdf._param_key(dev),
-               float(self.weights.get('2d', 0.3)), float(self.weights.get('3d', 0.5)), getattr(dsdf, 'mlp_precision', None))
+               float(self.weights.get('2d', 0.3)), float(self.weights.get('3d', 0.5)), getattr(dsdf, 'mlp_precision', None), bool(optimize_latent))
         if self._key != key:
             hit = _REFINERS.get(key)
             if hit is not None and hit[0]() is dsdf:
                 rf = hit[1]
             else:
-                rf = BatchRefiner(dsdf, D, Kn, crop_size, 1, lidar_cap=cap, weights=self.weights, device=dev)
+                rf = BatchRefiner(dsdf, D, Kn, crop_size, 1, lidar_cap=cap, weights=self.weights, device=dev, optimize_latent=optimize_latent)
                 while len(_REFINERS) >= _REFINERS_MAX:
                     _REFINERS.pop(next(iter(_REFINERS)))
                 _REFINERS[key] = (weakref.ref(dsdf), rf)
@@ -75,15 +75,17 @@ class Optimizer:
             self._refiner, self._key = rf, key
         return self._refiner
 
-    def optimize(self, iters_optim, nocs_pred, pcd_frustum_np, dsdf, grid, K, crop_size, viz_type=None, frame_vis=None, verbose=False):
+    def optimize(self, iters_optim, nocs_pred, pcd_frustum_np, dsdf, grid, K, crop_size, viz_type=None, frame_vis=None, verbose=False,
+                 optimize_latent=True):
         """optimizer.py:56-164.  nocs_pred (3,h,w) CSS prediction, pcd_frustum_np (M,3) lidar points of the frustum (camera frame),
         dsdf the decoder, grid a Grid3D, K (3,3), crop_size (H,W).  viz_type must be None (visualisation is not on the path).
-        verbose=True prints the reference's per-iteration loss line (one host synchronisation per iteration, as the reference has)."""
+        verbose=True prints the reference's per-iteration loss line (one host synchronisation per iteration, as the reference has).
+        optimize_latent=False (extension): pose-only refinement -- the latent group gets no update and the shape is evaluated once."""
         if viz_type is not None:
             raise NotImplementedError("visualisation (open3d / matplotlib, optimizer.py:75-77,158-163) is outside the renderer path; "
                                       "call with viz_type=None")
         lidar = np.asarray(pcd_frustum_np, dtype=np.float32).reshape(-1, 3)
-        rf = self._refiner_for(dsdf, grid, K, crop_size, lidar.shape[0])
+        rf = self._refiner_for(dsdf, grid, K, crop_size, lidar.shape[0], optimize_latent)
         p = self.params
         with torch.no_grad():
             rf.set_crops({'yaw': p['yaw'].detach().reshape(1, -1), 'trans': p['trans'].detach().reshape(1, 3),

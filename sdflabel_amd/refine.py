@@ -18,13 +18,17 @@ from .batch import BatchRenderer
 
 
 class BatchRefiner:
-    def __init__(self, decoder, density, K, crop_size, batch, lidar_cap, weights=None, cap=None, device="cuda"):
-        """crop_size = (H, W) as the reference passes it (optimizer.py:56,72 builds the Rasterer with crop_size[::-1])."""
+    def __init__(self, decoder, density, K, crop_size, batch, lidar_cap, weights=None, cap=None, device="cuda", optimize_latent=True):
+        """crop_size = (H, W) as the reference passes it (optimizer.py:56,72 builds the Rasterer with crop_size[::-1]).
+        optimize_latent=False: pose-only refinement (yaw, trans, scale; the latent parameter group of optimizer.py:38 gets no update), so
+        the shape is evaluated once per set_crops() and every iteration only re-projects, splats and differentiates the pose."""
         self.H, self.W = int(crop_size[0]), int(crop_size[1])
         self.B = int(batch)
         self.w2 = float((weights or {}).get('2d', 0.3))          # configs/config_refine.ini:26-27
         self.w3 = float((weights or {}).get('3d', 0.5))
         self.br = BatchRenderer(decoder, density, K, (self.W, self.H), batch, cap=cap, device=device)
+        self.optimize_latent = bool(optimize_latent)
+        self.br.freeze_shape = not self.optimize_latent
         br, B = self.br, self.B
         dev = br.dev
         self.dev = dev
@@ -80,6 +84,7 @@ class BatchRefiner:
             self.lidar[b, :l.shape[0]] = l
             self.lcnt[b] = l.shape[0]
         self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t.zero_()
+        self.br.invalidate_shape()
         # a captured graph stays valid: every buffer it reads or writes is static and was updated in place above
 
     def iteration(self):
@@ -97,9 +102,11 @@ class BatchRefiner:
         ck(L.sdfr_loss_3d(P(out["xyzf"]), P(br.fcnt), br.cap, P(self.lidar), P(self.lcnt), self.lidar_cap, P(self.scale), 0.2, self.w3, B,
                           P(self.loss3d), P(self.g_xyzf), P(self.g_scale), P(self.npairs), P(self.l3_scratch), st), "sdfr_loss_3d")
         br.backward(g_color=self.g_color, g_xyzf=self.g_xyzf)
+        if not self.optimize_latent:
+            self.g_latent.zero_()                       # no latent parameter group: exactly no update (lr * 0)
         ck(L.sdfr_solver_step(P(self.params), P(self.grads), self.L, P(self.loss2d), P(self.loss3d), P(self.npairs), self.w2, self.w3,
-                              P(self.adam_m), P(self.adam_v), P(self.adam_t), 0.01, 0.01, 0.00003, B, P(self.total), P(self.stepped), st),
-           "sdfr_solver_step")
+                              P(self.adam_m), P(self.adam_v), P(self.adam_t), 0.01, 0.01, 0.00003 if self.optimize_latent else 0.0, B,
+                              P(self.total), P(self.stepped), st), "sdfr_solver_step")
 
     def capture(self):
         """Capture one iteration in a HIP graph; optimize() then replays it."""
@@ -119,6 +126,9 @@ class BatchRefiner:
 
     def optimize(self, iters_optim):
         for _ in range(iters_optim):
+            if self._replay is not None and self.br.freeze_shape and not self.br._shape_valid:
+                self.iteration()                        # pose-only: the captured graph holds the steady state; a new latent needs one full pass
+                continue
             if self._replay is not None:
                 self._replay()
             else:

@@ -405,3 +405,41 @@ def test_fused_surfel_forward_is_bitwise_the_three_launches(dec):
                 assert torch.equal(a, b)
         for k in snaps[0][3]:
             assert torch.equal(snaps[0][3][k], other[3][k]), k
+
+
+def test_pose_only_refinement_caches_the_shape_exactly(dec):
+    """optimize_latent=False (BASELINE configs[1]: "pose-only refinement"): decoder, band and Jacobian are evaluated once per set_crops();
+    the trajectory is bit-identical to re-evaluating them every iteration with the latent held fixed, eager and through the HIP graph,
+    and the latent does not move."""
+    z = gold("g8_optimizer.npz")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    B = 2
+    rep = lambda a: np.tile(np.asarray(a, np.float32).reshape(1, -1), (B, 1))
+    p0 = {"yaw": rep(init[0:1]) + np.array([[0.0], [0.05]], np.float32), "trans": rep(init[1:4]), "scale": rep(init[4:5]), "latent": rep(init[5:8])}
+    runs = []
+    for freeze, graph in ((False, False), (True, False), (True, True)):
+        rf = sdflabel_amd.BatchRefiner(dec, D, z["K"], (H, W), B, lidar_cap=256, device=DEV, optimize_latent=False)
+        rf.br.freeze_shape = freeze
+        rf.set_crops(p0, np.tile(z["nocs_target"][None], (B, 1, 1, 1)), [z["lidar"]] * B)
+        if graph:
+            rf.capture()
+        rf.optimize(8)
+        rows, l2, l3 = rf.results()
+        runs.append((N(rows), N(l2), N(l3)))
+        if freeze:                                   # a second set of crops through the same (captured) refiner: the new latent is picked up
+            p1 = dict(p0); p1["latent"] = rep([0.2, 0.6, -0.4])
+            rf.set_crops(p1, np.tile(z["nocs_target"][None], (B, 1, 1, 1)), [z["lidar"]] * B)
+            rf.optimize(3)
+            r1 = N(rf.results()[0])
+            assert np.array_equal(r1[:, 5:8], p1["latent"]) and not np.array_equal(r1[:, 0], runs[-1][0][:, 0])
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert np.array_equal(a, b)
+    assert np.array_equal(runs[0][0][:, 5:8], p0["latent"])                      # latent untouched
+    assert np.abs(runs[0][0][:, 0] - p0["yaw"][:, 0]).min() > 0.02               # the pose moved
+    # and the pose trajectory differs from the joint refinement's only through the (tiny, lr 3e-5) latent updates
+    rj = sdflabel_amd.BatchRefiner(dec, D, z["K"], (H, W), B, lidar_cap=256, device=DEV)
+    rj.set_crops(p0, np.tile(z["nocs_target"][None], (B, 1, 1, 1)), [z["lidar"]] * B)
+    rj.optimize(8)
+    assert np.abs(N(rj.results()[0])[:, :5] - runs[0][0][:, :5]).max() < 5e-3

@@ -46,9 +46,10 @@ def test_shard_is_a_partition():
         shard_crops(4, 2, 2)
 
 
-@pytest.mark.parametrize("n_crops", [2, 5])
-def test_gather_two_ranks_gloo(n_crops):
-    world = 2
+@pytest.mark.parametrize("world,n_crops", [(2, 2), (2, 5), (8, 1021), (8, 5)])
+def test_gather_ranks_gloo(world, n_crops):
+    """world 2 and the 8-rank layout of BASELINE configs[3] with an uneven split (1021 crops: five ranks own 128, three own 127) and a
+    split with idle ranks (5 crops on 8 ranks)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

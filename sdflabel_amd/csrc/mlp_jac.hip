@@ -1,10 +1,36 @@
-// Band Jacobian, float32, padded hidden width 512: 16x16x4 MFMA tiles, 16-point workgroups; mask-fed (MODE 3) or recomputing (MODE 2).
+// Band Jacobian, float32, padded hidden width 512; mask-fed (MODE 3) or recomputing (MODE 2).
+//   few crops per launch   16-row tiles (16x16x4 MFMA), 4 waves each owning 128 features (one wave per SIMD): a few thousand band rows of ONE
+//                          crop give ~170 workgroups for 256 CUs; every workgroup streams the whole transposed weight image, so the kernel
+//                          sits between its matrix floor (111 us) and its L2 stream (172 x 7.2 MB): 136 us (8 waves of 64 features: 158 us)
+//   many crops per launch  32-row tiles (32x32x2 MFMA, paired K order = the 16-row kernel's, see gemm_pair), 4 waves of 128 features:
+//                          half the weight stream per row, 118 TFLOP/s = 75 % of the f32 MFMA peak at 64 crops (16-row tiles: 93-108)
+// The two return identical bits (same k order, same first-layer partition), so the choice is invisible in the results.
+// Geometry macros (tools/ab_variant.sh A/B builds): SDFR_JAC_MS/_FT/_NP/_NW/_PF override the many-crops variant, SDFR_JAC_SMALL_* the other.
 #include "mlp_kernel.h"
-#ifndef SDFR_JAC_PF
-#define SDFR_JAC_PF 4
+#ifndef SDFR_JAC_MS
+#define SDFR_JAC_MS 32
+#define SDFR_JAC_FT 4
+#define SDFR_JAC_NP 1
+#define SDFR_JAC_NW 4
+#define SDFR_JAC_PF 2
+#endif
+#ifndef SDFR_JAC_SMALL_FT
+#define SDFR_JAC_SMALL_FT 8
+#define SDFR_JAC_SMALL_NW 4
+#define SDFR_JAC_SMALL_PF 4
+#endif
+#ifndef SDFR_JAC_SWITCH_ROWS
+#define SDFR_JAC_SWITCH_ROWS 8       // 32-row tiles from this many crops per launch (measured: 6 crops 665 vs 705 us, 8 crops 798 vs 712 us)
 #endif
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s) {
-    const dim3 grid(sdfr_cdiv(cap, 16), B);
-    if (from_masks) hipLaunchKernelGGL((sdfr_mlp_kernel<float, 16, 4, 1, 8, SDFR_JAC_PF, 3>), grid, dim3(512), 0, s, P);
-    else hipLaunchKernelGGL((sdfr_mlp_kernel<float, 16, 4, 1, 8, SDFR_JAC_PF, 2>), grid, dim3(512), 0, s, P);
+    static_assert(SDFR_JAC_MS * SDFR_JAC_FT * SDFR_JAC_NW == 512 && 16 * SDFR_JAC_SMALL_FT * SDFR_JAC_SMALL_NW == 512, "padded width 512 = MS * FT * NW");
+    if (!from_masks) {
+        hipLaunchKernelGGL((sdfr_mlp_kernel<float, 16, 4, 1, 8, 4, 2>), dim3(sdfr_cdiv(cap, 16), B), dim3(512), 0, s, P);
+    } else if (B >= SDFR_JAC_SWITCH_ROWS) {
+        hipLaunchKernelGGL((sdfr_mlp_kernel<float, SDFR_JAC_MS, SDFR_JAC_FT, SDFR_JAC_NP, SDFR_JAC_NW, SDFR_JAC_PF, 3>),
+                           dim3(sdfr_cdiv(cap, SDFR_JAC_MS * SDFR_JAC_NP), B), dim3(64 * SDFR_JAC_NW), 0, s, P);
+    } else {
+        hipLaunchKernelGGL((sdfr_mlp_kernel<float, 16, SDFR_JAC_SMALL_FT, 1, SDFR_JAC_SMALL_NW, SDFR_JAC_SMALL_PF, 3>), dim3(sdfr_cdiv(cap, 16), B),
+                           dim3(64 * SDFR_JAC_SMALL_NW), 0, s, P);
+    }
 }

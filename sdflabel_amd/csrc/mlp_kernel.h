@@ -313,6 +313,69 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             }
         }
     };
+    // K order of the 16x16x4 kernels, reproduced with 32x32x2 instructions.  A 16x16x4 MFMA sums the four k values of its four lane groups in
+    // lane-group order, so a 16-row kernel accumulates k = 16t + 4g + s in the order (t, s, g).  A 32x32x2 instruction holds two lane groups
+    // (fragment tile u: k = 8u + 4g + s); walking fragment tiles in PAIRS with the component s as the outer loop -- (u = 2t, s), (u = 2t+1, s)
+    // -- visits the same k sequence, so the 32-row Jacobian kernel (many crops per launch) returns bit for bit what the 16-row one (few crops)
+    // does, and results stay independent of the batch size.  Ring of two pairs; branch-free when the pair count is even.
+    auto gemm_pair = [&](const vec_t* __restrict__ Wl, int kpad, int nact, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int npair = kpad / (2 * KT);
+        const vec_t* aptr = Wl + lg * HP + fbase + lp;
+        const vec_t* bptr = act + lg * PT + lp;
+        vec_t a[4][FT], b[4][NP];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int i = 0; i < KV; ++i) a[u][f][i] = (ET)0;
+        auto load_pair = [&](int pr, int slot) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const vec_t* ap = aptr + (int64_t)(2 * pr + h) * (NLG * HP);
+                const vec_t* bp = bptr + (2 * pr + h) * (NLG * PT);
+#pragma unroll
+                for (int f = 0; f < FT; ++f)
+                    if (FULL || f < nact) a[slot + h][f] = ap[f * MS];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) b[slot + h][p] = bp[p * MS];
+            }
+        };
+        auto compute = [&](int slot) {
+#pragma unroll
+            for (int ks = 0; ks < M::NSTEP; ++ks)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)          // per accumulator the order stays (s, first tile), (s, second tile); the accumulators alternate
+#pragma unroll
+                    for (int f = 0; f < FT; ++f)
+                        if (FULL || f < nact) {
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) acc[f][p] = M::step(a[slot + h][f], b[slot + h][p], acc[f][p], ks);
+                        }
+        };
+        if (npair <= 0) return;
+        load_pair(0, 0);
+        if (FULL && (npair % 2 == 0)) {
+            const int lastp = npair - 1;
+            for (int pr = 0; pr < npair; pr += 2) {
+                load_pair(pr + 1, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_pair(min(pr + 2, lastp), 0);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
+        for (int pr = 0; pr < npair; ++pr) {           // thin or odd layers: plain loop, same order
+            if (pr > 0) load_pair(pr, 0);
+            compute(0);
+        }
+    };
+    constexpr bool KPAIR = (MS == 32) && (MODE == 3) && !HALF && (HP == 512);
     auto gemm = [&](const vec_t* __restrict__ Wl, int kpad, int rows_active) {
 #pragma unroll
         for (int f = 0; f < FT; ++f)
@@ -323,8 +386,13 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         int nact = (rows_active - fbase + MS - 1) / MS;
         nact = nact < 0 ? 0 : (nact > FT ? FT : nact);
         nact = __builtin_amdgcn_readfirstlane(nact);
-        if (nact == FT) gemm_body(Wl, kpad, FT, std::true_type{});
-        else if (nact > 0) gemm_body(Wl, kpad, nact, std::false_type{});
+        if constexpr (KPAIR) {
+            if (nact == FT) gemm_pair(Wl, kpad, FT, std::true_type{});
+            else if (nact > 0) gemm_pair(Wl, kpad, nact, std::false_type{});
+        } else {
+            if (nact == FT) gemm_body(Wl, kpad, FT, std::true_type{});
+            else if (nact > 0) gemm_body(Wl, kpad, nact, std::false_type{});
+        }
     };
     // first feature of the 4-register group rg of feature tile f held by this lane
     auto feat0 = [&](int f, int rg) { return fbase + f * MS + rg * (4 * NLG) + 4 * lg; };
@@ -530,22 +598,30 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     // in-gradient of layer l (features k = in-features of layer l) -> masked operand for layer l-1, or J
     // MODE 3: the saved mask words of layer l-1 for this lane's features and point, fetched from HBM/L2.  Issued BEFORE the product of
     // layer l (they do not depend on it), so their latency is hidden behind the K loop instead of sitting in front of the epilogue.
-    // Forward launch layout (32x32 tiles, P.fwd_np point tiles per workgroup): feature jr of this wave, point q of the forward tile ->
-    // bit ((jr/32 * np + q/32)*4 + (jr%32)/8)*4 + jr%4 of thread wave*64 + ((jr%32)/4 % 2)*32 + q%32
-    auto fetch_masks = [&](int l, uint32_t* raw) {
+    // Forward launch layout (32x32 tiles, P.fwd_np point tiles per workgroup, NWF waves of FTF feature tiles): feature j, point q of the
+    // forward tile -> bit (((j/32) % FTF * np + q/32)*4 + (j%32)/8)*4 + j%4 of thread (j / (32*FTF))*64 + ((j%32)/4 % 2)*32 + q%32
+    constexpr int NWF = (HP == 512) ? 8 : 4;                            // waves of the forward kernel for this padded width (mlp.hip mask_geometry)
+    constexpr int FTF = HP / (32 * NWF), NTF = 64 * NWF;
+    auto mask_addr = [&](int j, int r, int l, int& shift) -> int64_t {
         const int np = P.fwd_np;
-        const int r = rows[lp];
         const int tile = r / (32 * np), q = r - tile * (32 * np);
-        const int mwf = FT32 * np / 2;                                   // mask words per thread of the forward kernel
-        const uint32_t* src = P.maskbuf + (((int64_t)tile * P.n_mfma + (l - 1)) * mwf) * NT + wave * 64 + (q & 31);
+        const int mwf = FTF * np / 2;                                   // mask words per thread of the forward kernel
+        const int fbit = ((((j >> 5) % FTF) * np + (q >> 5)) * 4 + ((j & 31) >> 3)) * 4;
+        shift = fbit & 31;
+        return (((int64_t)tile * P.n_mfma + (l - 1)) * mwf + (fbit >> 5)) * NTF + (j / (32 * FTF)) * 64 + (((j & 31) >> 2) & 1) * 32 + (q & 31);
+    };
+    auto fetch_masks = [&](int l, uint32_t* raw) {
 #pragma unroll
-        for (int f = 0; f < FT; ++f)
+        for (int p = 0; p < NP; ++p) {
+            const int r = rows[p * MS + lp];
 #pragma unroll
-            for (int rg = 0; rg < RG; ++rg) {
-                const int jr = f * MS + rg * (4 * NLG) + 4 * lg;
-                const int fbit = (((jr >> 5) * np + (q >> 5)) * 4 + ((jr & 31) >> 3)) * 4;
-                raw[f * RG + rg] = src[(fbit >> 5) * NT + (((jr & 31) >> 2) & 1) * 32];
-            }
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) {
+                    int shift;
+                    raw[(p * FT + f) * RG + rg] = P.maskbuf[mask_addr(feat0(f, rg), r, l, shift)];
+                }
+        }
     };
     auto store_in_grad = [&](int l, const uint32_t* raw, auto&& value) {
         const MlpLayer L = P.L[l];
@@ -555,47 +631,58 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         if (GMASK) {
 #pragma unroll
             for (int w = 0; w < MW; ++w) mw[w] = 0u;
-            const int np = P.fwd_np;
-            const int q = rows[lp] % (32 * np);
 #pragma unroll
-            for (int f = 0; f < FT; ++f)
+            for (int p = 0; p < NP; ++p) {
+                const int r = rows[p * MS + lp];
 #pragma unroll
-                for (int rg = 0; rg < RG; ++rg) {
-                    const int jr = f * MS + rg * (4 * NLG) + 4 * lg;
-                    const int fbit = (((jr >> 5) * np + (q >> 5)) * 4 + ((jr & 31) >> 3)) * 4;
-                    const uint32_t nib = (raw[f * RG + rg] >> (fbit & 31)) & 0xFu;
-                    const int bit = ((f * NP + 0) * RG + rg) * 4;
-                    mw[bit >> 5] |= nib << (bit & 31);
-                }
+                for (int f = 0; f < FT; ++f)
+#pragma unroll
+                    for (int rg = 0; rg < RG; ++rg) {
+                        int shift;
+                        (void)mask_addr(feat0(f, rg), r, l, shift);
+                        const uint32_t nib = (raw[(p * FT + f) * RG + rg] >> shift) & 0xFu;
+                        const int bit = ((f * NP + p) * RG + rg) * 4;
+                        mw[bit >> 5] |= nib << (bit & 31);
+                    }
+            }
         } else {
 #pragma unroll
             for (int w = 0; w < MW; ++w) mw[w] = masks[((l - 1) * MW + w) * NT + tid];
         }
-        // 1) ReLU mask of layer l-1 (its output features), re-injected input columns -> J
+        // 1) ReLU mask of layer l-1 (its output features), re-injected input columns -> J.  Features >= prev_out (padding and the
+        // re-injected input columns of latent_in / xyz_in_all layers) sit in the last wave's block of one or two layers: whether this wave's
+        // block reaches them is a scalar question asked once, so every other wave and layer runs the plain masking without per-element range
+        // checks and lane-divergent atomics.
+        const bool tail_here = __builtin_amdgcn_readfirstlane((int)(fbase + MS * FT > prev_out)) != 0;
+        auto apply_masks = [&](auto tail_tag) {
+            constexpr bool TAIL = decltype(tail_tag)::value;
 #pragma unroll
-        for (int f = 0; f < FT; ++f)
+            for (int f = 0; f < FT; ++f)
 #pragma unroll
-            for (int rg = 0; rg < RG; ++rg) {
-                const int j0 = feat0(f, rg);
+                for (int rg = 0; rg < RG; ++rg) {
+                    const int j0 = feat0(f, rg);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const int pt = p * MS + lp;
+                    for (int p = 0; p < NP; ++p) {
+                        const int pt = p * MS + lp;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int k = j0 + i;
-                        const int bit = ((f * NP + p) * RG + rg) * 4 + i;
-                        float x = value(f, p, rg, i, k, pt);
-                        if (k < prev_out) {
-                            x = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? x : 0.f;
-                        } else {
-                            if (k < inj_hi && slots[pt] >= 0)
-                                atomicAdd(P.J + (int64_t)slots[pt] * NI + L.inj_off + (k - prev_out), x);
-                            x = 0.f;
+                        for (int i = 0; i < 4; ++i) {
+                            const int k = j0 + i;
+                            const int bit = ((f * NP + p) * RG + rg) * 4 + i;
+                            float x = value(f, p, rg, i, k, pt);
+                            if (!TAIL || k < prev_out) {
+                                x = ((mw[bit >> 5] >> (bit & 31)) & 1u) ? x : 0.f;
+                            } else {
+                                if (k < inj_hi && slots[pt] >= 0)
+                                    atomicAdd(P.J + (int64_t)slots[pt] * NI + L.inj_off + (k - prev_out), x);
+                                x = 0.f;
+                            }
+                            acc[f][p][rg * 4 + i] = x;
                         }
-                        acc[f][p][rg * 4 + i] = x;
                     }
                 }
-            }
+        };
+        if (tail_here) apply_masks(std::true_type{});
+        else apply_masks(std::false_type{});
         // 2) LayerNorm backward of layer l-1:  g_x = rstd * (g*gamma - mean(g*gamma) - x_hat * mean(g*gamma*x_hat))
         if constexpr (LN) {
             if (P.L[l - 1].ln) {
@@ -658,7 +745,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     };
 
     // top: in-gradient of the last linear = w_last[k] * gy[pt]
-    uint32_t raw[FT * RG];
+    uint32_t raw[NP * FT * RG];
     if (GMASK) fetch_masks(P.n_mfma, raw);
     store_in_grad(P.n_mfma, raw, [&](int, int, int, int, int k, int pt) { return P.w_last[k] * gy[pt]; });
     __syncthreads();
@@ -668,25 +755,36 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             // The first layer of a DeepSDF decoder has a handful of inputs (latent + xyz): its transposed product is 8 x HP x PT multiply-adds,
             // which one wave would do alone on the matrix pipe, K tile after K tile (20 k cycles of exposed latency).  Here every thread
             // takes one point and HP / (NT / PT) features on the VALU, and the partial sums are added in a fixed order.
-            constexpr int PARTS = NT / PT, JS = HP / PARTS;
-            static_assert(NT % PT == 0 && HP % PARTS == 0 && PARTS * 8 * PT * 4 <= KG * PT * 16, "first-layer reduction scratch fits the operand tile");
-            const int pt = tid % PT, part = tid / PT;
+            // Partition of the HP in-gradients of a point into PARTS contiguous blocks summed in order, then the blocks in order: for the
+            // 512-wide Jacobian variants the partition is fixed at 16 blocks whatever the workgroup shape (threads per point TPP = 16 or 8),
+            // so that all of them round identically.
+            constexpr int TPP = NT / PT;
+            constexpr int PARTS = (HP == 512 && TPP < 16) ? 16 : TPP, PPT = PARTS / TPP, JS = HP / PARTS;
+            static_assert(NT % PT == 0 && HP % PARTS == 0 && PARTS % TPP == 0 && 8 * PT <= NT && PARTS * 8 * PT * 4 <= KG * PT * 16,
+                          "first-layer reduction scratch fits the operand tile");
+            const int pt = tid % PT, t0 = tid / PT;
             const float4* W0 = P.Wf + L.off_f;                   // forward image of layer 0: W0[(k/4)*HP + j] = W[j][k..k+3]
-            float s8[8];
+            float s8[PPT][8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s8[k] = 0.f;
+            for (int q = 0; q < PPT; ++q) {
+                const int part = t0 * PPT + q;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s8[q][k] = 0.f;
 #pragma unroll 4
-            for (int jj = 0; jj < JS; ++jj) {
-                const int j = part * JS + jj;
-                const float g = (float)act_e[((j / KV) * PT + pt) * KV + (j % KV)];
-                const float4 wa = W0[j], wb = (L.kp_f > 4) ? W0[HP + j] : make_float4(0.f, 0.f, 0.f, 0.f);
-                s8[0] = fmaf(wa.x, g, s8[0]); s8[1] = fmaf(wa.y, g, s8[1]); s8[2] = fmaf(wa.z, g, s8[2]); s8[3] = fmaf(wa.w, g, s8[3]);
-                s8[4] = fmaf(wb.x, g, s8[4]); s8[5] = fmaf(wb.y, g, s8[5]); s8[6] = fmaf(wb.z, g, s8[6]); s8[7] = fmaf(wb.w, g, s8[7]);
+                for (int jj = 0; jj < JS; ++jj) {
+                    const int j = part * JS + jj;
+                    const float g = (float)act_e[((j / KV) * PT + pt) * KV + (j % KV)];
+                    const float4 wa = W0[j], wb = (L.kp_f > 4) ? W0[HP + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    s8[q][0] = fmaf(wa.x, g, s8[q][0]); s8[q][1] = fmaf(wa.y, g, s8[q][1]); s8[q][2] = fmaf(wa.z, g, s8[q][2]); s8[q][3] = fmaf(wa.w, g, s8[q][3]);
+                    s8[q][4] = fmaf(wb.x, g, s8[q][4]); s8[q][5] = fmaf(wb.y, g, s8[q][5]); s8[q][6] = fmaf(wb.z, g, s8[q][6]); s8[q][7] = fmaf(wb.w, g, s8[q][7]);
+                }
             }
             __syncthreads();                                    // every thread has read its in-gradients: the tile becomes scratch
             float* scr = reinterpret_cast<float*>(lds4);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) scr[(part * 8 + k) * PT + pt] = s8[k];
+            for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) scr[((t0 * PPT + q) * 8 + k) * PT + pt] = s8[q][k];
             __syncthreads();
             if (tid < 8 * PT) {
                 const int k = tid / PT, q = tid % PT;

@@ -443,3 +443,22 @@ def test_pose_only_refinement_caches_the_shape_exactly(dec):
     rj.set_crops(p0, np.tile(z["nocs_target"][None], (B, 1, 1, 1)), [z["lidar"]] * B)
     rj.optimize(8)
     assert np.abs(N(rj.results()[0])[:, :5] - runs[0][0][:, :5]).max() < 5e-3
+
+
+def test_band_jacobian_variants_return_identical_bits(dec):
+    """the band Jacobian runs 16-row tiles for few crops per launch and 32-row tiles (32x32x2 MFMA, paired K order) from 8 crops: the
+    rows of a crop must be the same bits whichever kernel produced them"""
+    D, H, W = 40, 32, 32
+    rng = np.random.default_rng(11)
+    B = 9
+    yaws = rng.uniform(-1.0, 1.0, B).astype(np.float32)
+    trans = np.tile(np.array([[0.0, 0.0, 3.5]], np.float32), (B, 1))
+    lats = rng.standard_normal((B, 3)).astype(np.float32)
+    big = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), B, device=DEV)
+    one = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), 1, device=DEV)
+    big.forward(T(yaws), T(trans), T(lats))
+    for b in (0, 4, 8):
+        one.forward(T(yaws[b:b + 1]), T(trans[b:b + 1]), T(lats[b:b + 1]))
+        n = int(one.cnt[0])
+        assert n == int(big.cnt[b]) and n > 1000
+        assert torch.equal(one.J[0, :n], big.J[b, :n]) and torch.equal(one.sdf_band[0, :n], big.sdf_band[b, :n])

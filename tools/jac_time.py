@@ -1,4 +1,4 @@
-"""Time the mask-fed band Jacobian alone (after one decoder forward): python tools/jac_time.py"""
+"""Time the mask-fed band Jacobian alone (after one decoder forward): python tools/jac_time.py [B ...]   (SDFR_LIB selects a variant library)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,16 +6,28 @@ import sdflabel_amd
 from tests._util import ASSET, K_for
 dev = "cuda"
 dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32); dec = dec.to(dev)
-br = sdflabel_amd.BatchRenderer(dec, 40, K_for(256, 256), (256, 256), 1, device=dev)
-br.set_params(torch.tensor([0.7], device=dev), torch.tensor([[0.05, 0.02, 3.3]], device=dev), torch.tensor([[0.3, -0.5, 0.8]], device=dev))
-br.forward(); torch.cuda.synchronize()
 L = sdflabel_amd._lib.lib(); P = sdflabel_amd._lib.ptr
-def jac():
-    L.sdfr_mlp_jacobian(br.handle.h, P(br.inputs), br.G, 1, P(br.idx), br.cap, P(br.cnt), P(br.J), P(br.sdf_band), P(br.sdf), P(br.mask_ws), 0,
-                        sdflabel_amd._lib.stream_ptr())
-for _ in range(5): jac()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(50): jac()
-e1.record(); torch.cuda.synchronize()
-print("jacobian %.1f us  (N = %d rows)" % (e0.elapsed_time(e1) / 50 * 1e3, int(br.cnt[0])))
+out = []
+for B in [int(a) for a in sys.argv[1:]] or [1]:
+    br = sdflabel_amd.BatchRenderer(dec, 40, K_for(64, 64), (64, 64), B, device=dev)
+    g = torch.Generator().manual_seed(1)
+    lat = torch.tensor([[0.3, -0.5, 0.8]]) + 0.2 * (torch.rand(B, 3, generator=g) - 0.5)
+    br.set_params(torch.full((B,), 0.7, device=dev), torch.tensor([[0.05, 0.02, 3.3]], device=dev).expand(B, 3), lat.to(dev))
+    br.forward(); torch.cuda.synchronize()
+    def jac():
+        L.sdfr_mlp_jacobian(br.handle.h, P(br.inputs), br.G, B, P(br.idx), br.cap, P(br.cnt), P(br.J), P(br.sdf_band), P(br.sdf), P(br.mask_ws), 0,
+                            sdflabel_amd._lib.stream_ptr())
+    for _ in range(3): jac()
+    n = 50 if B < 16 else 10
+    ts = []
+    for r in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): jac()
+        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / n * 1e3)
+    rows = int(br.cnt.sum())
+    t = min(ts)
+    cs = float(sum(br.J[b, :int(br.cnt[b])].double().sum() for b in range(B)))
+    out.append("B=%d: %.1f us (%.1f us/crop, %d rows, %.1f TFLOP/s) J checksum %.10g" % (B, t, t / B, rows, 2 * 1835520 * rows / (t * 1e-6) / 1e12, cs))
+    del br
+print(os.path.basename(os.environ.get("SDFR_LIB", "default")), " | ".join(out))

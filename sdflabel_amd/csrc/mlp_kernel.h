@@ -537,7 +537,53 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                     }
                 }
         };
+        // Half-operand forward, plain layers (no re-injection in this wave, no LayerNorm): the epilogue is VALU-issue bound (two waves per
+        // SIMD, ~7 instructions per value in the generic form above against 16 k cycles of matrix work per layer), so it is written for
+        // instruction count: bias add, ONE v_alignbit per value shifting its sign bit into the mask word (bit = "not negative"; the words are
+        // bit-reversed and inverted once per 32 values), packed f32->f16 conversion and a packed half max for the ReLU (max(rne(x), 0) =
+        // rne(max(x, 0))).  Loop order f, p, rg, i = ascending mask bit.
+        auto epilogue_half_fast = [&]() {
+            uint32_t run = 0u;
+#pragma unroll
+            for (int f = 0; f < FT; ++f)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int pt = p * MS + lp;
+#pragma unroll
+                    for (int rg = 0; rg < RG; ++rg) {
+                        const int j0 = feat0(f, rg);
+                        const float4 b4 = b4s[f][rg];
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+                        float x[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            x[i] = acc[f][p][rg * 4 + i] + f4c(b4, i);
+                            if (LMASK || SAVE) {
+                                run = __builtin_amdgcn_alignbit(run, __float_as_uint(x[i]), 31);      // run = run << 1 | sign(x)
+                                const int bit = ((f * NP + p) * RG + rg) * 4 + i;
+                                if ((bit & 31) == 31) mw[bit >> 5] = ~__builtin_bitreverse32(run);
+                            }
+                        }
+                        f32x2 lo2 = {x[0], x[1]}, hi2 = {x[2], x[3]};
+                        h16x2 lo = __builtin_convertvector(lo2, h16x2), hi = __builtin_convertvector(hi2, h16x2);
+                        const h16x2 z = {(h16)0, (h16)0};
+                        lo = __builtin_elementwise_max(lo, z);
+                        hi = __builtin_elementwise_max(hi, z);
+                        h16x4 t;
+                        t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
+                        *reinterpret_cast<h16x4*>(act_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV)) = t;
+                    }
+                }
+        };
         if (inj_here) epilogue(std::true_type{});
+#ifndef SDFR_H_FAST_EPI
+#define SDFR_H_FAST_EPI 1
+#endif
+        else if constexpr (SDFR_H_FAST_EPI && HALF && !LN && (MODE == 0 || MODE == 1)) {
+            if (!lnl) epilogue_half_fast();
+            else epilogue(std::false_type{});
+        }
         else epilogue(std::false_type{});
         if (LMASK) {
 #pragma unroll

@@ -284,6 +284,10 @@ int sdfr_solver_step(float* params, const float* grads, int L, const float* loss
                      float w2, float w3, float* adam_m, float* adam_v, int32_t* adam_t, float lr_adam, float lr_scale, float lr_latent,
                      int B, float* total, int32_t* stepped, void* stream);
 
+/* Debug only: forward kernels of a library built with -DSDFR_MLP_TRACE write cycle stamps of their workgroup 0 into this device buffer
+ * (2 * SDFR_MAX_LAYERS * 5 uint64; see tools/cycle_trace.py); pass NULL to disable.  Production builds ignore it. */
+int sdfr_debug_set_trace(void* device_buffer);
+
 #ifdef __cplusplus
 }
 #endif

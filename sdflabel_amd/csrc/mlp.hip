@@ -37,6 +37,8 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
     MlpParams& P = d->proto;
     P.n_mfma = n_lin - 1; P.n_inputs = n_inputs; P.use_tanh = use_tanh;
     int64_t off_f = 0, off_b = 0, off_h = 0, off_s = 0, off_bh = 0;
+    const bool kinj = (n_inputs <= 8) && (HP == 512);
+    P.kinj = kinj ? 1 : 0;
     for (int l = 0; l < n_lin; ++l) {
         MlpLayer& L = P.L[l];
         L.in_dim = in_dim[l]; L.out_dim = out_dim[l]; L.inj_n = inj_n[l]; L.inj_off = inj_off[l];
@@ -44,6 +46,9 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
         if (L.ln) { SDFR_REQUIRE(h_ln_b && h_ln_b[l], "sdfr_decoder_create: LayerNorm weight without bias at layer %d", l); d->has_ln = 1; }
         L.kp_f = 16 * ((in_dim[l] + 15) / 16); L.kp_b = 16 * ((out_dim[l] + 15) / 16); L.kp_h = 32 * ((in_dim[l] + 31) / 32);
         L.off_f = (int)off_f; L.off_b = (int)off_b; L.off_h = (int)off_h;
+        // half forward image: the re-injected input columns of a layer (latent_in / xyz_in_all) move behind the HP feature slots, k = HP +
+        // input column, where the kernel keeps the tile's input rows (two more K tiles, zero padded): no operand patching between layers
+        if (kinj && l > 0 && inj_n[l] > 0) L.kp_h = HP + 32;
         L.kp_s = 64 * ((in_dim[l] + 63) / 64); L.off_s = (int)off_s;
         L.kp_bh = 128 * ((out_dim[l] + 127) / 128); L.off_bh = (int)off_bh;
         d->macs += (int64_t)in_dim[l] * out_dim[l];
@@ -61,7 +66,9 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
                 const float w = W[(size_t)r * L.in_dim + k];
                 Wf[((size_t)L.off_f + (size_t)(k / 4) * HP + r) * 4 + (k % 4)] = w;
                 const _Float16 wh = (_Float16)w;
-                Wh[((size_t)L.off_h + (size_t)(k / 8) * HP + r) * 8 + (k % 8)] = wh;
+                const int prev_out = l > 0 ? P.L[l - 1].out_dim : 0;
+                const int kh = (kinj && l > 0 && L.inj_n > 0 && k >= prev_out) ? HP + L.inj_off + (k - prev_out) : k;
+                Wh[((size_t)L.off_h + (size_t)(kh / 8) * HP + r) * 8 + (kh % 8)] = wh;
                 const size_t es = ((size_t)L.off_s + ((size_t)(k / 8) * HP + r) * 2) * 8 + (k % 8);        // split forward: hi | lo
                 Ws[es] = wh;
                 Ws[es + 8] = (_Float16)((w - (float)wh) * 2048.f);
@@ -103,6 +110,11 @@ extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_
     return SDFR_OK;
 }
 
+// Debug: device buffer (2 * SDFR_MAX_LAYERS * 5 uint64) that forward kernels built with -DSDFR_MLP_TRACE fill with cycle stamps of their
+// workgroup 0 (tools/cycle_trace.py); NULL (the default) disables it.  Not part of the renderer path.
+static unsigned long long* g_trace = nullptr;
+extern "C" int sdfr_debug_set_trace(void* device_buffer) { g_trace = (unsigned long long*)device_buffer; return SDFR_OK; }
+
 extern "C" int sdfr_decoder_destroy(sdfr_decoder* d) {
     if (!d) return SDFR_OK;
     void* bufs[] = {d->d_Wf, d->d_Wb, d->d_Wh, d->d_Ws, d->d_Wbh, d->d_bias, d->d_wlast, d->d_lng, d->d_lnb, d->ln_ws};
@@ -133,7 +145,7 @@ extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int6
     SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward: n=%lld out of range", (long long)n);
     if (n == 0) return SDFR_OK;
     MlpParams P = d->proto;
-    P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws;
+    P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws; P.trace = g_trace;
     const int grid = sdfr_cdiv(n, 64);
     if (d->has_ln) sdfr_launch_ln(P, d->HP, false, grid, 1, (hipStream_t)stream);        // LayerNorm decoders: no mask saving
     else if (d->HP == 512) sdfr_launch_fwd_f32_512(P, n, mask_ws != nullptr, (hipStream_t)stream);
@@ -150,7 +162,7 @@ extern "C" int sdfr_mlp_forward_f16(const sdfr_decoder* d, const float* inputs, 
     SDFR_REQUIRE(!d->has_ln, "sdfr_mlp_forward_f16: LayerNorm decoders run in float32");
     if (n == 0) return SDFR_OK;
     MlpParams P = d->proto;
-    P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws;
+    P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws; P.trace = g_trace;
     sdfr_launch_fwd_f16_512(P, n, mask_ws != nullptr, (hipStream_t)stream);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
@@ -167,7 +179,7 @@ extern "C" int sdfr_mlp_forward_split(const sdfr_decoder* d, const float* inputs
     SDFR_REQUIRE(!d->has_ln, "sdfr_mlp_forward_split: LayerNorm decoders run in float32");
     if (n == 0) return SDFR_OK;
     MlpParams P = d->proto;
-    P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws;
+    P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = mask_ws; P.trace = g_trace;
     sdfr_launch_fwd_split_512(P, n, mask_ws != nullptr, (hipStream_t)stream);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;

@@ -47,6 +47,7 @@ struct MlpParams {
     const void* Wh;         // forward image, float16:  [k/8][HP] 8 x half
     const void* Wbh;        // backward (transposed) image, float16:  [j/8][HP] 8 x half (the float16 decoder's mask-fed Jacobian)
     const void* Ws;         // split-forward image: [k/8][HP][2] 8 x half -- hi = half(w) and lo = half((w - hi) * 2^11) side by side
+    int kinj;               // half forward image Wh: re-injected input columns sit at k = HP + input column (K-side injection, n_inputs <= 8)
     int fwd_np;             // MODE 3: point tiles per workgroup of the forward launch that saved the masks (2: f32, 4: f16)
     const float* bias;      // [n_mfma][HP]
     const float* ln_gamma;  // [n_mfma][HP] LayerNorm weight / bias (LN decoders only)
@@ -71,6 +72,7 @@ struct MlpParams {
     float* sdf_sel;
     const float* sdf_in;    // MODE 3: decoder output of the forward launch that saved the masks
     uint32_t* maskbuf;      // MODE 1 (write) / MODE 3 (read): ReLU masks [tile64][layer][word][thread]
+    unsigned long long* trace;   // builds with -DSDFR_MLP_TRACE: cycle stamps of workgroup 0 (sdfr_debug_set_trace), else unused
 };
 
 struct sdfr_decoder {
@@ -172,15 +174,19 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     constexpr int MASK_WORDS = LMASK ? (SDFR_MAX_LAYERS * MW * NT) : 1;
     // single LDS object, carved by hand (16-byte aligned pieces first)
     constexpr int LN_F4 = LN ? (NW * PT + SDFR_MAX_LAYERS * PT + 3) / 4 : 0;   // cross-wave partial sums + rstd per layer
-    __shared__ float4 lds4[KG * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4 + LN_F4];
+    // half forward: four more k groups behind the HP feature slots hold the tile's input rows (k = HP + input column; zero beyond), so that
+    // layers which re-inject input columns (latent_in / xyz_in_all) find them in the operand at a fixed place and no epilogue has to patch
+    // them in (the generic per-element injection path cost the one wave that ran it 12 k cycles per layer, everybody else waiting)
+    constexpr int KGX = KG + ((HALF && MODE <= 1) ? 4 : 0);
+    __shared__ float4 lds4[KGX * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4 + LN_F4];
     vec_t* act = reinterpret_cast<vec_t*>(lds4);                  // [KG][PT] 16-byte vectors: act[k/KV][point][k%KV]
     ET* act_e = reinterpret_cast<ET*>(lds4);
-    float* red = reinterpret_cast<float*>(lds4 + KG * PT);        // [NT]
-    int* rows = reinterpret_cast<int*>(lds4 + KG * PT + NT / 4);  // [PT] source row of each point (128 ints max)
-    float* gy = reinterpret_cast<float*>(lds4 + KG * PT + NT / 4 + 32);   // [PT] d out / d y_last
-    int* slots = reinterpret_cast<int*>(lds4 + KG * PT + NT / 4 + 32 + (PT + 3) / 4);   // [PT] J slot or -1
-    uint32_t* masks = reinterpret_cast<uint32_t*>(lds4 + KG * PT + NT / 4 + 32 + (PT + 3) / 4 * 2);
-    float* lnred = reinterpret_cast<float*>(lds4 + KG * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4);   // [NW][PT]
+    float* red = reinterpret_cast<float*>(lds4 + KGX * PT);        // [NT]
+    int* rows = reinterpret_cast<int*>(lds4 + KGX * PT + NT / 4);  // [PT] source row of each point (128 ints max)
+    float* gy = reinterpret_cast<float*>(lds4 + KGX * PT + NT / 4 + 32);   // [PT] d out / d y_last
+    int* slots = reinterpret_cast<int*>(lds4 + KGX * PT + NT / 4 + 32 + (PT + 3) / 4);   // [PT] J slot or -1
+    uint32_t* masks = reinterpret_cast<uint32_t*>(lds4 + KGX * PT + NT / 4 + 32 + (PT + 3) / 4 * 2);
+    float* lnred = reinterpret_cast<float*>(lds4 + KGX * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4);   // [NW][PT]
     float* lnrstd = lnred + NW * PT;                                                                                   // [layers][PT]
 
     const int tid = threadIdx.x;
@@ -226,6 +232,14 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             const int pt = e / k0pad, k = e - pt * k0pad;
             const float v = (k < NI) ? P.inputs[(int64_t)rows[pt] * NI + k] : 0.f;
             act_e[((k / KV) * PT + pt) * KV + (k % KV)] = (ET)v;
+
+        }
+    }
+    if (KGX > KG) {
+        for (int e = tid; e < PT * 4 * KV; e += NT) {
+            const int pt = e / (4 * KV), k = e - pt * (4 * KV);
+            const float v = (P.kinj && k < NI) ? P.inputs[(int64_t)rows[pt] * NI + k] : 0.f;
+            act_e[((KG + k / KV) * PT + pt) * KV + (k % KV)] = (ET)v;
         }
     }
     __syncthreads();
@@ -246,6 +260,9 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         const vec_t* bptr = act + lg * PT + lp;
         vec_t a[PF][FT], b[PFB][NP];
         auto load_a = [&](int tile, vec_t* aa) {
+#ifdef SDFR_PIN_WEIGHTS
+            tile &= 1;            // ablation (timing only, wrong results): the weight stream hits L1 -- what the product loop costs without its L2 traffic
+#endif
             const vec_t* ap = aptr + (int64_t)tile * (NLG * HP);
 #pragma unroll
             for (int f = 0; f < FT; ++f)
@@ -477,10 +494,23 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     };
 
     // ---- forward through the MFMA layers -------------------------------------------------------------------
+#ifdef SDFR_MLP_TRACE
+    // cycle stamps of workgroup 0, waves 0 and NW-1, lane 0:  trace[(wave ? 1 : 0)][layer][5] = layer start, product loop done, first barrier
+    // passed, epilogue done, second barrier passed (s_memtime ticks = shader cycles)
+#define SDFR_STAMP(l, i)                                                                                                   \
+    do {                                                                                                                   \
+        if (P.trace && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == NW - 1))                   \
+            P.trace[((wave ? 1 : 0) * SDFR_MAX_LAYERS + (l)) * 5 + (i)] = __builtin_amdgcn_s_memtime();                    \
+    } while (0)
+#else
+#define SDFR_STAMP(l, i) do { } while (0)
+#endif
     for (int l = 0; !GMASK && l < P.n_mfma; ++l) {
         const MlpLayer L = P.L[l];
         const MlpLayer Ln = P.L[l + 1];
+        SDFR_STAMP(l, 0);
         gemm(Wfwd + (HALF ? L.off_h : L.off_f), HALF ? L.kp_h : L.kp_f, L.out_dim);
+        SDFR_STAMP(l, 1);
         // all bias vectors of this lane are requested before the barrier, so their L2 latency overlaps the wait for the other waves
         // (left inside the store loop the compiler serialises them: one exposed round trip per register group)
         const float* bias = P.bias + l * HP;
@@ -490,6 +520,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) b4s[f][rg] = *reinterpret_cast<const float4*>(bias + feat0(f, rg));
         __syncthreads();                                  // every wave is done reading act
+        SDFR_STAMP(l, 2);
         uint32_t mw[MW];
 #pragma unroll
         for (int w = 0; w < MW; ++w) mw[w] = 0u;
@@ -502,7 +533,8 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         // Re-injected input columns (latent_in / xyz_in_all) occupy a few features of ONE wave in ONE or few layers: whether this wave's
         // feature block touches them is a scalar question, asked once, so that every other wave and layer runs an epilogue without the
         // per-group lane-divergent range checks (32 saveexec/branch pairs per layer otherwise).
-        const bool inj_here = __builtin_amdgcn_readfirstlane((int)((Ln.inj_n > 0) && (fbase + MS * FT > inj_lo) && (fbase < inj_hi))) != 0;
+        const bool inj_here = __builtin_amdgcn_readfirstlane((int)((Ln.inj_n > 0) && !(KGX > KG && P.kinj) && (fbase + MS * FT > inj_lo) &&
+                                                                    (fbase < inj_hi))) != 0;
         auto epilogue = [&](auto inj_tag) {
             constexpr bool INJ = decltype(inj_tag)::value;
 #pragma unroll
@@ -576,14 +608,14 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                     }
                 }
         };
-        if (inj_here) epilogue(std::true_type{});
 #ifndef SDFR_H_FAST_EPI
 #define SDFR_H_FAST_EPI 1
 #endif
-        else if constexpr (SDFR_H_FAST_EPI && HALF && !LN && (MODE == 0 || MODE == 1)) {
-            if (!lnl) epilogue_half_fast();
-            else epilogue(std::false_type{});
+        if constexpr (SDFR_H_FAST_EPI && HALF && !LN && (MODE == 0 || MODE == 1)) {
+            if (inj_here) epilogue(std::true_type{});          // decoders with more than 8 input columns: generic injection
+            else epilogue_half_fast();
         }
+        else if (inj_here) epilogue(std::true_type{});
         else epilogue(std::false_type{});
         if (LMASK) {
 #pragma unroll
@@ -595,7 +627,9 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #pragma unroll
             for (int w = 0; w < MW; ++w) dst[w * NT] = mw[w];
         }
+        SDFR_STAMP(l, 3);
         __syncthreads();
+        SDFR_STAMP(l, 4);
     }
 
     // ---- last linear (H -> 1) + tanh -----------------------------------------------------------------------

@@ -132,6 +132,15 @@ int sdfr_surface_project_bwd(const float* g_points, const float* g_nocs, const f
  * grid.py:64; sdfr_gather_rows re-orders rows of ncol floats, out[b][e] = src[b][slot[b*G + idx[b][e]]] for e < cnt[b] (slot = the
  * grid-row -> candidate-slot map sdfr_band_select wrote; src has src_cap rows per crop). */
 int sdfr_scatter_values(float* dst, const float* src, const int32_t* idx, int64_t G, int B, int cap, const int32_t* cnt, void* stream);
+/* sdfr_band_select with a per-crop addition to the threshold (thr + thr_extra[b]): the candidate selection with a device-resident margin. */
+int sdfr_band_select_margin(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, int32_t* idx, int cap, int32_t* cnt,
+                            int32_t* slot, int32_t* scratch, void* stream);
+/* sdfr_scatter_values plus the run-time guard of the two-stage evaluation: max_dev[b] = max over the crop's candidates of
+ * |sdf_grid (half pass) - sdf_exact|, measured while the exact values are patched in.  max_dev > margin[b]/2: violations[2b] += 1 and
+ * margin[b] = max(margin[b], 4 max_dev) for the following selections; max_dev >= margin[b]: violations[2b+1] += 1 as well (a band row may
+ * have been excluded in this step).  margin float[B] in/out, violations int32[B][2] in/out; no host synchronisation. */
+int sdfr_prefilter_guard(float* sdf_grid, const float* sdf_exact, const int32_t* idx, int64_t G, int B, int cap, const int32_t* cnt,
+                         float* margin, float* max_dev, int32_t* violations, void* stream);
 int sdfr_gather_rows(float* out, const float* src, int ncol, const int32_t* idx, const int32_t* slot, int64_t G, int B, int cap,
                      int src_cap, const int32_t* cnt, void* stream);
 

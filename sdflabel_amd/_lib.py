@@ -27,6 +27,8 @@ _PROTOS = {
     "sdfr_mlp_jacobian": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_int, c_void_p]),
     "sdfr_band_select": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_band_select_margin": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_prefilter_guard": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_surface_project": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_surface_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -85,6 +85,11 @@ class BatchRenderer:
                 worst = max(worst, float((s32 - s16).abs().max()))
             self.f16_error = worst
             self.margin = max(self.margin, 4.0 * worst)
+            # run-time guard (sdfr_prefilter_guard): the margin lives on the device, per crop; every step measures the half pass's deviation
+            # at the candidates, grows a crop's margin to 4x the deviation when it exceeds half of it, and counts such steps
+            self.margin_dev = torch.full((B,), self.margin, dtype=torch.float32, device=dev)
+            self.max_dev = f(B)
+            self.violations = i(B, 2)
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.p_cam, self.n_cam, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.fidx, self.fcnt, self.fslot = i(B, cap), i(B), i(B, cap)
@@ -151,12 +156,14 @@ class BatchRenderer:
                 mlp_events[1].record()
         elif self.prefilter:
             ck(L.sdfr_mlp_forward_f16(self.handle.h, P(self.inputs), B * G, P(self.sdf), None, st), "sdfr_mlp_forward_f16")
-            ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr + self.margin, P(self.cidx), cap, P(self.ccnt), P(self.cslot), P(self.scratch), st),
-               "sdfr_band_select")
+            ck(L.sdfr_band_select_margin(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.cidx), cap, P(self.ccnt), P(self.cslot),
+                                         P(self.scratch), st), "sdfr_band_select_margin")
             # exact float32 sdf and Jacobian of the candidates (recomputing kernel, 16-row tiles), patched into the grid array
             ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.cidx), cap, P(self.ccnt), P(self.Jc), P(self.sdf_band), None, None,
                                    0, st), "sdfr_mlp_jacobian")
-            ck(L.sdfr_scatter_values(P(self.sdf), P(self.sdf_band), P(self.cidx), G, B, cap, P(self.ccnt), st), "sdfr_scatter_values")
+            # exact values patched into the grid array + guard (deviation of the half pass at the candidates -> margin / violation counters)
+            ck(L.sdfr_prefilter_guard(P(self.sdf), P(self.sdf_band), P(self.cidx), G, B, cap, P(self.ccnt), P(self.margin_dev), P(self.max_dev),
+                                      P(self.violations), st), "sdfr_prefilter_guard")
             ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
             ck(L.sdfr_gather_rows(P(self.J), P(self.Jc), self.NI, P(self.idx), P(self.cslot), G, B, cap, cap, P(self.cnt), st), "sdfr_gather_rows")
             if mlp_events is not None:
@@ -249,12 +256,26 @@ class BatchRenderer:
             over = over | (self.ccnt > self.cap).any()
         return bool(over.item())
 
+    def prefilter_report(self):
+        """float32_prefilter only: {'violations': soft count, 'hard_violations': steps in which the half pass deviated by more than the
+        margin at a candidate (a band row may have been missed), 'max_deviation': last step's, 'margin': current per-crop maximum}.
+        One synchronisation."""
+        if not self.prefilter:
+            return None
+        v = self.violations.sum(0).tolist()
+        return {"violations": int(v[0]), "hard_violations": int(v[1]), "max_deviation": float(self.max_dev.max()),
+                "margin": float(self.margin_dev.max())}
+
     def check_overflow(self):
         """Raise if the last forward dropped surfels (the reference has no capacity: a truncated shape must not pass silently).  One sync."""
         if self.overflow():
             worst = int(self.cnt.max()) if not self.prefilter else max(int(self.cnt.max()), int(self.ccnt.max()))
             raise _lib.SdfrError("a crop's band holds %d surfels but BatchRenderer was built with cap=%d: rebuild it with a larger `cap` "
                                  "(default max(256, G/8))" % (worst, self.cap))
+        if self.prefilter and int(self.violations[:, 1].sum()) > 0:
+            raise _lib.SdfrError("float32_prefilter: the half-operand pass deviated from the exact values by more than the safety margin "
+                                 "(max deviation %g) in %d step(s): band rows may have been excluded; use precision=torch.float32 or a larger "
+                                 "decoder.prefilter_margin" % (float(self.max_dev.max()), int(self.violations[:, 1].sum())))
 
     def capture(self, grads_fn):
         """Capture forward -> grads_fn(outputs) -> backward in a HIP graph.  grads_fn maps the output dict to the keyword arguments of

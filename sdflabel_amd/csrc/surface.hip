@@ -11,8 +11,9 @@
 // rank inside the block from ballot/popcount prefix.  No inter-workgroup hand-off inside a launch.
 
 __global__ __launch_bounds__(256) void sdfr_band_count_kernel(const float* __restrict__ sdf, int64_t G, float thr,
-                                                             int32_t* __restrict__ blockcnt) {
+                                                             const float* __restrict__ thr_extra, int32_t* __restrict__ blockcnt) {
     const int b = blockIdx.y;
+    if (thr_extra) thr += thr_extra[b];
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool in = false;
     if (g < G) in = fabsf(sdf[(int64_t)b * G + g]) < thr;
@@ -24,9 +25,11 @@ __global__ __launch_bounds__(256) void sdfr_band_count_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256) void sdfr_band_scatter_kernel(const float* __restrict__ sdf, int64_t G, float thr,
+                                                               const float* __restrict__ thr_extra,
                                                                const int32_t* __restrict__ blockcnt, int32_t* __restrict__ idx,
                                                                int cap, int32_t* __restrict__ cnt, int32_t* __restrict__ slot) {
     const int b = blockIdx.y;
+    if (thr_extra) thr += thr_extra[b];
     const int nblk = gridDim.x;
     const int tid = threadIdx.x;
     __shared__ int part[256];
@@ -62,17 +65,26 @@ __global__ __launch_bounds__(256) void sdfr_band_scatter_kernel(const float* __r
     if (blockIdx.x == nblk - 1 && tid == 0) cnt[b] = base + wc[0] + wc[1] + wc[2] + wc[3];
 }
 
+extern "C" int sdfr_band_select_margin(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, int32_t* idx, int cap,
+                                       int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream);
 extern "C" int sdfr_band_select(const float* sdf, int64_t G, int B, float thr, int32_t* idx, int cap, int32_t* cnt,
                                 int32_t* slot, int32_t* scratch, void* stream) {
+    return sdfr_band_select_margin(sdf, G, B, thr, nullptr, idx, cap, cnt, slot, scratch, stream);
+}
+
+// the same with a per-crop addition to the threshold (thr + thr_extra[b]; thr_extra may be NULL): the candidate selection of the
+// two-stage evaluation, whose safety margin is kept per crop on the device (sdfr_prefilter_guard)
+extern "C" int sdfr_band_select_margin(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, int32_t* idx, int cap,
+                                       int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream) {
     SDFR_REQUIRE(sdf && idx && cnt && scratch, "sdfr_band_select: NULL argument");
     SDFR_REQUIRE(G >= 0 && B >= 0 && cap >= 0, "sdfr_band_select: negative size");
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
     if (G == 0) { SDFR_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * B, s)); return SDFR_OK; }
     dim3 grid(sdfr_cdiv(G, 256), B);
-    hipLaunchKernelGGL(sdfr_band_count_kernel, grid, dim3(256), 0, s, sdf, G, thr, scratch);
+    hipLaunchKernelGGL(sdfr_band_count_kernel, grid, dim3(256), 0, s, sdf, G, thr, thr_extra, scratch);
     SDFR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sdfr_band_scatter_kernel, grid, dim3(256), 0, s, sdf, G, thr, scratch, idx, cap, cnt, slot);
+    hipLaunchKernelGGL(sdfr_band_scatter_kernel, grid, dim3(256), 0, s, sdf, G, thr, thr_extra, scratch, idx, cap, cnt, slot);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -99,6 +111,52 @@ extern "C" int sdfr_scatter_values(float* dst, const float* src, const int32_t* 
     if (B <= 0 || cap <= 0) return SDFR_OK;
     hipLaunchKernelGGL(sdfr_scatter_values_kernel, dim3(sdfr_cdiv(cap, 256), B), dim3(256), 0, (hipStream_t)stream, dst, src, idx, G, cap,
                        cnt);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// sdfr_scatter_values + the run-time guard of the two-stage evaluation, one workgroup per crop.  The exclusion test of the half pass is only
+// valid while its error stays below the margin; the error is observable exactly where it matters -- at the candidates, whose exact values
+// have just been computed.  dev = max |half-pass value - exact value| over the crop's candidates:
+//   dev > margin / 2   "soft" violation: counted, and the crop's margin grows to 4 * dev for the following selections
+//   dev >= margin      "hard" violation: counted separately -- a row may have been excluded wrongly in THIS step
+// Everything stays on the device (no host synchronisation; graph-capturable); the host reads the counters when convenient.
+__global__ __launch_bounds__(1024) void sdfr_prefilter_guard_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                                   const int32_t* __restrict__ idx, int64_t G, int cap,
+                                                                   const int32_t* __restrict__ cnt, float* __restrict__ margin,
+                                                                   float* __restrict__ max_dev, int32_t* __restrict__ violations) {
+    const int b = blockIdx.x;
+    const int n = sdfr_count(cnt, b, cap);
+    float dev = 0.f;
+    for (int s = threadIdx.x; s < n; s += 1024) {
+        const int64_t e = (int64_t)b * cap + s;
+        const int64_t r = (int64_t)b * G + idx[e];
+        const float v = src[e];
+        dev = fmaxf(dev, fabsf(dst[r] - v));
+        dst[r] = v;
+    }
+    for (int o = 32; o > 0; o >>= 1) dev = fmaxf(dev, __shfl_xor(dev, o, 64));
+    __shared__ float wmax[16];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = dev;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) dev = fmaxf(dev, wmax[w]);
+        const float m = margin[b];
+        max_dev[b] = dev;
+        if (!(dev <= 0.5f * m)) {                         // also catches NaN
+            violations[2 * b] += 1;
+            if (!(dev < m)) violations[2 * b + 1] += 1;
+            margin[b] = fmaxf(m, 4.f * dev);
+        }
+    }
+}
+
+extern "C" int sdfr_prefilter_guard(float* sdf_grid, const float* sdf_exact, const int32_t* idx, int64_t G, int B, int cap,
+                                    const int32_t* cnt, float* margin, float* max_dev, int32_t* violations, void* stream) {
+    SDFR_REQUIRE(sdf_grid && sdf_exact && idx && margin && max_dev && violations, "sdfr_prefilter_guard: NULL argument");
+    if (B <= 0 || cap <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_prefilter_guard_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, sdf_grid, sdf_exact, idx, G, cap, cnt, margin,
+                       max_dev, violations);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

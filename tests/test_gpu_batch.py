@@ -462,3 +462,61 @@ def test_band_jacobian_variants_return_identical_bits(dec):
         n = int(one.cnt[0])
         assert n == int(big.cnt[b]) and n > 1000
         assert torch.equal(one.J[0, :n], big.J[b, :n]) and torch.equal(one.sdf_band[0, :n], big.sdf_band[b, :n])
+
+
+def test_prefilter_fuzz_1000_latents_band_equals_exact_and_guard_stays_quiet(dec):
+    """float32_prefilter over 1000 random latents (any direction and norm: the optimizer normalises, optimizer.py:96) and poses at the
+    BASELINE grid (D = 40): the band must be the exact path's rows for every crop, the run-time guard must record no violation, and the
+    half pass's largest deviation at the candidates must stay far below the margin."""
+    dp, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter")
+    dp = dp.to(DEV)
+    B, D, H, W = 8, 40, 32, 32
+    K = K_for(H, W)
+    b0 = sdflabel_amd.BatchRenderer(dec, D, K, (W, H), B, device=DEV)
+    b1 = sdflabel_amd.BatchRenderer(dp, D, K, (W, H), B, device=DEV)
+    rng = np.random.default_rng(1000)
+    worst, n_crops = 0.0, 0
+    for it in range(125):
+        lat = (rng.standard_normal((B, 3)) * rng.choice([1e-3, 0.3, 1.0, 30.0], (B, 1))).astype(np.float32)
+        if it % 10 == 0:
+            lat[0] = np.eye(3, dtype=np.float32)[it // 10 % 3] * (1 if it % 20 else -1)            # axis-aligned extremes
+        yaw = rng.uniform(-3, 3, B).astype(np.float32)
+        tr = np.stack([rng.uniform(-0.3, 0.3, B), rng.uniform(-0.2, 0.2, B), rng.uniform(2.5, 4.5, B)], 1).astype(np.float32)
+        a = [T(x) for x in (yaw, tr, lat)]
+        b0.forward(*a)
+        b1.forward(*a)
+        n0, n1 = N(b0.cnt), N(b1.cnt)
+        assert np.array_equal(n0, n1), (it, n0, n1)
+        for b in range(B):
+            assert torch.equal(b0.idx[b, :n0[b]], b1.idx[b, :n1[b]]), (it, b)
+        worst = max(worst, float(b1.max_dev.max()))
+        n_crops += B
+    rep = b1.prefilter_report()
+    assert n_crops == 1000 and rep["violations"] == 0 and rep["hard_violations"] == 0, rep
+    assert worst < 0.25 * b1.margin, (worst, b1.margin)
+    b1.check_overflow()
+
+
+def test_prefilter_guard_trips_grows_the_margin_and_raises(dec):
+    """force the situation the guard exists for: a margin smaller than the half pass's deviation.  The guard must count the steps, grow
+    the per-crop margin on the device (so that the next selection is safe again) and check_overflow()/results() must refuse the result."""
+    dp, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter")
+    dp = dp.to(DEV)
+    B, D, H, W = 2, 40, 32, 32
+    br = sdflabel_amd.BatchRenderer(dp, D, K_for(H, W), (W, H), B, device=DEV)
+    a = [T(np.array([0.6, -0.4], np.float32)), T(np.array([[0.0, 0.0, 3.5], [0.1, -0.05, 3.2]], np.float32)),
+         T(np.array([[0.3, -0.5, 0.8], [-0.2, 0.6, 0.4]], np.float32))]
+    br.forward(*a)
+    dev0 = float(br.max_dev.max())
+    assert 0 < dev0 < br.margin / 4 and br.prefilter_report()["violations"] == 0
+    br.margin_dev.fill_(dev0 * 0.2)                        # an (artificially) unsafe margin
+    br.forward(*a)
+    rep = br.prefilter_report()
+    assert rep["violations"] >= 1 and rep["hard_violations"] >= 1
+    grown, devs = N(br.margin_dev), N(br.max_dev)
+    assert (grown >= np.maximum(dev0 * 0.2, 4.0 * devs) * 0.999).all() and grown.max() > dev0 * 0.2     # grown to 4x the observed deviation
+    with pytest.raises(sdflabel_amd.SdfrError, match="prefilter"):
+        br.check_overflow()
+    before = br.prefilter_report()["violations"]
+    br.forward(*a)                                         # with the grown margin the next step is quiet
+    assert br.prefilter_report()["violations"] == before

@@ -167,9 +167,10 @@ int sdfr_project_dcm(const float* pose, const float* K, const float* points, con
 
 /* Batched path, one launch: sdfr_surface_project (band rows -> points, unit normals; grid.py:57-67) + sdfr_project_dcm in a NOCS colour
  * mode (projection.py:34-70) + the conservative disc screen boxes and their 8x8-pixel tile lists that sdfr_splat_forward would otherwise
- * build (bbox = its workspace of sdfr_splat_ws_words(B, cap, res_x, res_y) words; pass primitive | SDFR_PRIM_BOXES_READY to it; bbox may be
- * NULL).  output_nocs | 8: boxes only, no tile lists (then also pass SDFR_PRIM_NO_BINS to sdfr_splat_forward; building the lists costs one
- * workgroup per crop ~13 us, which pays from about four crops per launch).  Same arithmetic and outputs as the separate calls. */
+ * build (bbox = its workspace; pass primitive | SDFR_PRIM_BOXES_READY to it; bbox may be NULL).  output_nocs | 8: bbox is the large
+ * workspace of sdfr_splat_ws_words(B, cap, res_x, res_y) words and the tile lists are built too (then also pass SDFR_PRIM_BINS to
+ * sdfr_splat_forward; building the lists costs one workgroup per crop ~13 us, which pays from about four crops per launch); without it
+ * bbox is int32[B][cap][4].  Same arithmetic and outputs as the separate calls. */
 int sdfr_surfels_forward(const float* xyz, int xyz_stride, const float* sdf, int64_t G, const int32_t* idx, const float* J, int Jstride,
                          int Joff, const float* pose, const float* K, int B, int cap, const int32_t* cnt, int output_nocs, int res_x,
                          int res_y, float diam, float* points, float* normals, float* p_cam, float* n_cam, float* col, int32_t* fidx,
@@ -198,14 +199,16 @@ int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* no
  *   aux [B][H*W][4]: per-pixel state for the backward (nu, max logit, softmax denominator, clamp gates)
  */
 #define SDFR_PRIM_BOXES_READY 256   /* OR into `primitive` of sdfr_splat_forward: bbox_ws already holds the surfels' screen boxes and tile lists */
-#define SDFR_PRIM_NO_BINS 512       /* OR into `primitive`: bbox_ws is only int32[B][cap][4] (boxes); every 8x8 tile then scans all boxes */
-/* words of the splat workspace: the conservative screen boxes int32[B][cap][4] followed, per crop, by the 8x8-pixel tile lists built from
- * them (count -> scan -> fill): tile_off[T+2] | tile_list[32*cap], T = ceil(W/8)*ceil(H/8) */
+#define SDFR_PRIM_BINS 512          /* OR into `primitive`: bbox_ws is the LARGE workspace of sdfr_splat_ws_words() and per-tile surfel lists are
+                                       built in it and used; without the flag bbox_ws only needs int32[B][cap][4] (boxes) and every 8x8 tile
+                                       scans all boxes -- same bits either way */
+/* words of the large splat workspace: the conservative screen boxes int32[B][cap][4] followed, per crop, by the 8x8-pixel tile lists built
+ * from them (count -> scan -> fill): tile_off[T+2] | tile_list[32*cap], T = ceil(W/8)*ceil(H/8) */
 int64_t sdfr_splat_ws_words(int B, int cap, int W, int H);
 int sdfr_splat_forward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
                        const float* uv, const float* znorm, const float* bg, const float* bg_logit,
                        int B, int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant,
-                       int32_t* bbox_ws /* workspace of sdfr_splat_ws_words(B, cap, W, H) int32 words */,
+                       int32_t* bbox_ws /* workspace: int32[B][cap][4], or sdfr_splat_ws_words(B, cap, W, H) words with SDFR_PRIM_BINS */,
                        float* color, float* mask, float* depth, float* normals, float* aux, void* stream);
 
 /* Backward w.r.t. p_cam, n_cam, attr given the gradients of the four images (any may be NULL; a non-NULL gradient

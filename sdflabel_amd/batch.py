@@ -93,7 +93,7 @@ class BatchRenderer:
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.p_cam, self.n_cam, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.fidx, self.fcnt, self.fslot = i(B, cap), i(B), i(B, cap)
-        self.bbox = _lib.splat_ws(B, cap, W, H, dev)          # screen boxes + per-tile surfel lists
+        self.bbox = _lib.splat_ws(B, cap, W, H, dev)          # screen boxes + per-tile surfel lists (SDFR_PRIM_BINS workspace)
         # per-tile surfel lists (count -> scan -> fill, one workgroup per crop inside sdfr_surfels_forward) instead of every tile scanning
         # all boxes: same bits either way; the lists pay from a few crops per launch (B=64: splat forward 947 -> 551 us), at one crop the
         # distributed scan is the faster of the two (building the lists is a 13 us latency chain on one CU)
@@ -182,12 +182,12 @@ class BatchRenderer:
                 events["jacobian"][1].record()
         self._shape_valid = True
         xyz = self.inputs[:, self.NI - 3:]
-        prim = 0 if self.binned else 512                                              # [SDFR_PRIM_NO_BINS]
+        prim = 512 if self.binned else 0                                              # [SDFR_PRIM_BINS]
         if self.fused_head:
             # band rows -> surfels -> camera frame -> front-facing list -> screen boxes in one launch; nocs_mode | 4: the composited
             # attribute (col + 1) / 2 (rasterer.py:113-114) is written directly
             ck(L.sdfr_surfels_forward(P(xyz), self.NI, P(self.sdf), G, P(self.idx), P(self.J), self.NI, self.NI - 3, P(self.pose), P(self.K), B,
-                                      cap, P(self.cnt), self.nocs_mode | 4 | (0 if self.binned else 8), W, H, _DIAM_DISC, P(self.points), P(self.normals), P(self.p_cam),
+                                      cap, P(self.cnt), self.nocs_mode | 4 | (8 if self.binned else 0), W, H, _DIAM_DISC, P(self.points), P(self.normals), P(self.p_cam),
                                       P(self.n_cam), P(self.attr), P(self.fidx), P(self.fcnt), P(self.xyzf), P(self.fslot), P(self.bbox), st),
                "sdfr_surfels_forward")
             prim |= 256                                                               # SDFR_PRIM_BOXES_READY

@@ -154,7 +154,7 @@ extern "C" int sdfr_surfels_forward(const float* xyz, int xyz_stride, const floa
                                     float* n_cam, float* col, int32_t* fidx, int32_t* fcnt, float* xyzf, int32_t* fslot,
                                     int32_t* bbox, void* stream) {
     SDFR_REQUIRE(xyz && sdf && idx && J && pose && K && points && normals && p_cam && n_cam && col, "sdfr_surfels_forward: NULL argument");
-    const bool no_bins = (output_nocs & 8) != 0;          // | 8: boxes only, no tile lists (pass SDFR_PRIM_NO_BINS to sdfr_splat_forward)
+    const bool no_bins = (output_nocs & 8) == 0;          // | 8: bbox is the large workspace, build the tile lists too (SDFR_PRIM_BINS)
     output_nocs &= ~8;
     SDFR_REQUIRE(output_nocs == 1 || output_nocs == 2 || output_nocs == 5 || output_nocs == 6, "sdfr_surfels_forward: NOCS colour modes only");
     SDFR_REQUIRE((fidx == nullptr) == (fcnt == nullptr), "sdfr_surfels_forward: fidx and fcnt must be given together");

@@ -638,8 +638,8 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
                                   int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant, int32_t* bbox_ws,
                                   float* color, float* mask, float* depth, float* normals, float* aux, void* stream) {
     const bool boxes_ready = (primitive & SDFR_PRIM_BOXES_READY) != 0;      // bbox_ws already holds boxes and tile lists (sdfr_surfels_forward)
-    const bool no_bins = (primitive & SDFR_PRIM_NO_BINS) != 0;
-    primitive &= ~(SDFR_PRIM_BOXES_READY | SDFR_PRIM_NO_BINS);
+    const bool use_bins = (primitive & SDFR_PRIM_BINS) != 0;
+    primitive &= ~(SDFR_PRIM_BOXES_READY | SDFR_PRIM_BINS);
     SplatArgs A;
     int rc = fill_args(A, "sdfr_splat_forward", primitive, K, Kinv, p_cam, n_cam, attr, uv, znorm, bg, bg_logit, B, cap, cnt, W, H, diam,
                        depth_constant);
@@ -648,8 +648,8 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
     int4* bb = reinterpret_cast<int4*>(bbox_ws);
-    // tile lists behind the boxes (splat_bbox.h).  SDFR_PRIM_NO_BINS: the workspace holds the boxes only -> every tile scans all boxes
-    int32_t* bins = (cap > 0 && !no_bins) ? bbox_ws + (int64_t)B * cap * 4 : nullptr;
+    // SDFR_PRIM_BINS: tile lists behind the boxes (splat_bbox.h); otherwise the workspace holds the boxes only and every tile scans all boxes
+    int32_t* bins = (cap > 0 && use_bins) ? bbox_ws + (int64_t)B * cap * 4 : nullptr;
     const dim3 gb(sdfr_cdiv(cap > 0 ? cap : 1, 256), B);
     const dim3 gt(((W + 7) / 8) * ((H + 7) / 8), B);
     switch (primitive) {

@@ -48,10 +48,10 @@ class _WeightsFn(torch.autograd.Function):
         weights = torch.zeros((rows, P), **f32)
         aux = torch.empty((P, 4), **f32)
         if n > 0:
-            bbox = torch.empty((n, 4), dtype=torch.int32, device=dev)   # boxes only: SDFR_PRIM_NO_BINS
+            bbox = torch.empty((n, 4), dtype=torch.int32, device=dev)   # boxes only (no SDFR_PRIM_BINS)
             bg_img = torch.zeros((3, H, W), **f32) if add_bg else None
             st = _lib.stream_ptr()
-            _lib.check(L.sdfr_splat_forward(pid | 512, _lib.ptr(Kf), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(p_cam), _lib.ptr(uv),
+            _lib.check(L.sdfr_splat_forward(pid, _lib.ptr(Kf), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(p_cam), _lib.ptr(uv),
                                             _lib.ptr(znorm), _lib.ptr(bg_img), _lib.ptr(bg_logit), 1, n, None, W, H, diam, dconst, _lib.ptr(bbox),
                                             None, None, None, None, _lib.ptr(aux), st), "sdfr_splat_forward")
             _lib.check(L.sdfr_splat_weights(pid, _lib.ptr(Kf), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(uv), _lib.ptr(znorm),

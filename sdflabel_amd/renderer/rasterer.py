@@ -78,8 +78,8 @@ class _RasterFn(torch.autograd.Function):
         depth = torch.empty((1, H, W), **f32) if want_depth else None
         nimg = torch.empty((3, H, W), **f32) if want_normals else None
         aux = torch.empty((H * W, 4), **f32)
-        bbox = torch.empty((m, 4), dtype=torch.int32, device=dev)       # boxes only: SDFR_PRIM_NO_BINS (one crop per call)
-        _lib.check(L.sdfr_splat_forward(pid | 512, _lib.ptr(K), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(attr), _lib.ptr(uv),
+        bbox = torch.empty((m, 4), dtype=torch.int32, device=dev)       # boxes only (no SDFR_PRIM_BINS: one crop per call)
+        _lib.check(L.sdfr_splat_forward(pid, _lib.ptr(K), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(attr), _lib.ptr(uv),
                                         _lib.ptr(znorm), _lib.ptr(bg_c), _lib.ptr(bg_logit), 1, n, None, W, H, diam, dconst,
                                         _lib.ptr(bbox), _lib.ptr(color), _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(nimg), _lib.ptr(aux), st),
                    "sdfr_splat_forward")

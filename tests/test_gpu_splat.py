@@ -12,7 +12,7 @@ from tests.test_gpu_parity import N, T, images_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-NO_BINS = 512
+BINS = 512
 
 
 def _splat(prim_flags, K, Kinv, p, n, attr, W, H, B=1, cnt=None):
@@ -41,8 +41,8 @@ def test_binned_forward_is_bitwise_the_unbinned_scan(H, W, n):
     p, nrm, col = _surfels(rng, n, 0.9, 3.0, 4.0)
     K = K_for(H, W)
     Kt, Ki = T(K).view(1, 9), T(np.linalg.inv(K).astype(np.float32)).view(1, 9)
-    a = _splat(0, Kt, Ki, T(p)[None], T(nrm)[None], T(col)[None], W, H)
-    b = _splat(NO_BINS, Kt, Ki, T(p)[None], T(nrm)[None], T(col)[None], W, H)
+    a = _splat(BINS, Kt, Ki, T(p)[None], T(nrm)[None], T(col)[None], W, H)
+    b = _splat(0, Kt, Ki, T(p)[None], T(nrm)[None], T(col)[None], W, H)
     for x, y in zip(a[:5], b[:5]):
         assert torch.equal(x, y)
     assert float(a[1].sum()) > 50
@@ -66,11 +66,11 @@ def test_bin_list_overflow_falls_back_to_the_scan_and_matches_the_oracle():
     p, nrm, col = _surfels(rng, n, 0.01, 0.05, 0.06)          # disc radius 0.04 at z = 0.05: covers ~everything
     K = K_for(H, W)
     Kinv = np.linalg.inv(K).astype(np.float32)
-    a = _splat(0, T(K).view(1, 9), T(Kinv).view(1, 9), T(p)[None], T(nrm)[None], T(col)[None], W, H)
+    a = _splat(BINS, T(K).view(1, 9), T(Kinv).view(1, 9), T(p)[None], T(nrm)[None], T(col)[None], W, H)
     Tn = ((W + 7) // 8) * ((H + 7) // 8)
     toff = N(a[5])[n * 4:n * 4 + Tn + 2]
     assert toff[Tn + 1] == 0 and toff[Tn] > 32 * n                    # overflow recorded, lists not used
-    b = _splat(NO_BINS, T(K).view(1, 9), T(Kinv).view(1, 9), T(p)[None], T(nrm)[None], T(col)[None], W, H)
+    b = _splat(0, T(K).view(1, 9), T(Kinv).view(1, 9), T(p)[None], T(nrm)[None], T(col)[None], W, H)
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
     Wm, aux = O.inside_surfel(Kinv, O.pixel_grid((W, H)), p, nrm, diam=0.04, want_aux=True)
     images_close(N(a[0][0]), np.minimum((Wm.T @ col).T, 1).reshape(3, H, W), aux)
@@ -86,9 +86,9 @@ def test_binned_ragged_batch_with_empty_and_full_crops():
     p, nrm, col = _surfels(rng, 3 * cap, 0.8, 3.0, 4.0)
     p, nrm, col = T(p).view(3, cap, 3), T(nrm).view(3, cap, 3), T(col).view(3, cap, 3)
     cnt = torch.tensor([0, 311, cap], dtype=torch.int32, device=DEV)
-    a = _splat(0, Kt, Ki, p, nrm, col, W, H, B=3, cnt=cnt)
+    a = _splat(BINS, Kt, Ki, p, nrm, col, W, H, B=3, cnt=cnt)
     assert float(a[0][0].abs().max()) == 0.0 and float(a[1][0].abs().max()) == 0.0
     for b, c in ((1, 311), (2, cap)):
-        one = _splat(0, Kt[b:b + 1], Ki[b:b + 1], p[b:b + 1, :c].contiguous(), nrm[b:b + 1, :c].contiguous(), col[b:b + 1, :c].contiguous(), W, H)
+        one = _splat(BINS, Kt[b:b + 1], Ki[b:b + 1], p[b:b + 1, :c].contiguous(), nrm[b:b + 1, :c].contiguous(), col[b:b + 1, :c].contiguous(), W, H)
         for x, y in zip(a[:5], one[:5]):
             assert torch.equal(x[b], y[0]), b

@@ -30,7 +30,7 @@ def timeit(fn, n=50):
 W = H = HW
 xyz = br.inputs[:, br.NI - 3:]
 def surf():
-    _lib.check(L.sdfr_surfels_forward(P(xyz), br.NI, P(br.sdf), br.G, P(br.idx), P(br.J), br.NI, br.NI - 3, P(br.pose), P(br.K), B, br.cap, P(br.cnt), br.nocs_mode | 4, W, H, 0.04,
+    _lib.check(L.sdfr_surfels_forward(P(xyz), br.NI, P(br.sdf), br.G, P(br.idx), P(br.J), br.NI, br.NI - 3, P(br.pose), P(br.K), B, br.cap, P(br.cnt), br.nocs_mode | 4 | 8, W, H, 0.04,
                P(br.points), P(br.normals), P(br.p_cam), P(br.n_cam), P(br.attr), P(br.fidx), P(br.fcnt), P(br.xyzf), P(br.fslot), P(br.bbox), _lib.stream_ptr()), "surf")
 def splat(flags):
     def f():
@@ -43,8 +43,8 @@ def bwd():
 n, nf = int(br.cnt[0]), int(br.fcnt[0])
 print("B=%d %dx%d N=%d Nf=%d" % (B, HW, HW, n, nf))
 print("surfels_forward (projection + boxes + bins)  median %.1f us  min %.1f" % timeit(surf))
-print("splat fwd, lists ready (256)                  median %.1f us  min %.1f" % timeit(splat(256)))
-print("splat fwd, boxes+bins rebuilt (0)             median %.1f us  min %.1f" % timeit(splat(0)))
-print("splat fwd, unbinned scan (256|512)            median %.1f us  min %.1f" % timeit(splat(256 | 512)))
+print("splat fwd, lists ready (256|512)              median %.1f us  min %.1f" % timeit(splat(256 | 512)))
+print("splat fwd, boxes+bins rebuilt (512)           median %.1f us  min %.1f" % timeit(splat(512)))
+print("splat fwd, unbinned scan (256)                median %.1f us  min %.1f" % timeit(splat(256)))
 print("splat bwd                                     median %.1f us  min %.1f" % timeit(bwd))
 surf()

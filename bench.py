@@ -505,8 +505,12 @@ def main():
                             "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": mlp_ms}
         nbytes = 64.0 * H * W * CB + 72.0 * float(br.cnt.sum()) + 48.0 * float(br.fcnt.sum())          # 64 P + 72 N + 48 N_f per crop, fwd+bwd
         ach_s = nbytes / ((kms["splat_fwd"] + kms["splat_bwd"]) * 1e-3) / 1e9
+        tsp = os.path.join(ROOT, "profiles", "traffic_splat.json")
+        tsplat = json.load(open(tsp)) if os.path.isfile(tsp) else {}
+        if splat64 is not None and "error" not in splat64:
+            splat64["traffic"] = tsplat.get("crops_64")
         line["roofline_splat"] = {"kernel": "sdfr_splat_fwd_kernel<0> + sdfr_splat_bwd_kernel<0> (surfel splat / depth-softmax composite and its backward)",
-                                  "bound": "hbm", "achieved": ach_s, "peak": 8000.0, "unit": "GB/s", "frac": ach_s / 8000.0, "traffic": None,
+                                  "bound": "hbm", "achieved": ach_s, "peak": 8000.0, "unit": "GB/s", "frac": ach_s / 8000.0, "traffic": tsplat.get("crops_1") if CB == 1 else None,
                                   "algorithmic_bytes_per_launch_pair": nbytes, "fwd_ms": kms["splat_fwd"], "bwd_ms": kms["splat_bwd"],
                                   "crops_per_launch": CB, "at_64_crops_per_launch": splat64,
                                   "note": "latency-bound at one crop (candidate evaluation chains, not bytes); see DESIGN.md 3.4"}

@@ -8,8 +8,10 @@ cd $R
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/pytest_$TAG.log
 timeout 900 python bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
 cd /tmp && export TMPDIR=/tmp
-# kernel trace + stats of the same command (the sharded-refinement section shortened: its kernels are the refine_demo's)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --total-crops 128 > $O/prof_$TAG.log 2>&1
+# kernel trace + stats of the headline loop alone (--no-extras: every decoder-forward launch is the single-crop one the roofline is quoted on)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_$TAG.log 2>&1
+# ... and of the whole default run (all informational sections; the sharded refinement shortened: its kernels are the refine_demo's at 64 crops)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/proffull_$TAG -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --total-crops 128 > $O/proffull_$TAG.log 2>&1
 # HBM traffic: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), headline loop only
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$TAG -o pmc -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_fetch_$TAG.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$TAG -o pmc -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_write_$TAG.log 2>&1

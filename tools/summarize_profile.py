@@ -30,6 +30,14 @@ with open(os.path.join(P, "%s_kernel_stats.csv" % rnd), "w") as f:
         name = r["Name"].split("(")[0][:100]
         w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 
+srcf = os.path.join(G, "proffull_%s" % tag, "trace_kernel_stats.csv")
+if os.path.isfile(srcf):
+    with open(os.path.join(P, "%s_kernel_stats_all_sections.csv" % rnd), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in csv.DictReader(open(srcf)):
+            w.writerow([r["Name"].split("(")[0][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
 pmc = {}
 for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     path = os.path.join(G, "pmc_%s_%s" % (kind, tag), "pmc_counter_collection.csv")
@@ -51,6 +59,35 @@ key = sorted([k for k in pmc if "sdfr_mlp_kernel" in k], key=lambda k: -pmc[k].g
 if key:
     json.dump({"kernel": key[0], "source": "%s_pmc_hbm.json" % rnd, "hbm_bytes_per_launch": pmc[key[0]]["hbm_bytes_per_launch"]},
               open(os.path.join(P, "traffic_mlp_forward.json"), "w"), indent=1)
+# the same PMC pair at 64 crops per launch (tools/gpu_round.sh: pmc_fetch64_<tag> / pmc_write64_<tag>) and the splat pair's traffic
+pmc64 = {}
+for kind, cname in (("fetch64", "FETCH_SIZE"), ("write64", "WRITE_SIZE")):
+    path = os.path.join(G, "pmc_%s_%s" % (kind, tag), "pmc_counter_collection.csv")
+    if not os.path.isfile(path):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if "sdfr" in r["Kernel_Name"][:12] and r["Counter_Name"] == cname:
+            agg[r["Kernel_Name"].split("(")[0]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for k, v in agg.items():
+        pmc64.setdefault(k, {})[cname + "_KB_mean"] = sum(x[0] for x in v) / len(v)
+        pmc64[k]["duration_us_" + kind] = sum(x[1] for x in v) / len(v) / 1e3
+for k, d in pmc64.items():
+    d["hbm_bytes_per_launch"] = (2.0 * d.get("FETCH_SIZE_KB_mean", 0.0) + d.get("WRITE_SIZE_KB_mean", 0.0)) * 1024.0
+if pmc64:
+    json.dump({"note": "as %s_pmc_hbm.json but over `python bench.py --crops-per-gpu 64 --steps 3 --warmup 1 --no-cpu-baseline --no-extras` "
+                       "(64 crops per launch)" % rnd, "kernels": pmc64}, open(os.path.join(P, "%s_pmc_hbm_64crops.json" % rnd), "w"), indent=1)
+
+
+def splat_pair(d):
+    f = [k for k in d if "sdfr_splat_fwd_kernel" in k]
+    b = [k for k in d if "sdfr_splat_bwd_kernel" in k]
+    return (d[f[0]]["hbm_bytes_per_launch"] + d[b[0]]["hbm_bytes_per_launch"]) if f and b else None
+
+
+json.dump({"source": "%s_pmc_hbm.json / %s_pmc_hbm_64crops.json" % (rnd, rnd), "what": "HBM bytes (2*FETCH_SIZE + WRITE_SIZE) of the splat forward + "
+           "backward launch pair", "crops_1": splat_pair(pmc), "crops_64": splat_pair(pmc64) if pmc64 else None},
+          open(os.path.join(P, "traffic_splat.json"), "w"), indent=1)
 for name in ("bench_%s.json" % tag,):
     if os.path.isfile(os.path.join(G, name)):
         shutil.copy(os.path.join(G, name), os.path.join(P, "%s_bench.json" % rnd))

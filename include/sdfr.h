@@ -296,6 +296,27 @@ int sdfr_solver_step(float* params, const float* grads, int L, const float* loss
                      float w2, float w3, float* adam_m, float* adam_v, int32_t* adam_t, float lr_adam, float lr_scale, float lr_latent,
                      int B, float* total, int32_t* stepped, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Sphere-tracing render mode  --  NOT in the reference (its renderer splats surfels of a grid band); the mode BASELINE.json's north_star words
+ * literally: per-ray march with a decoder evaluation per step and ballot compaction of terminated rays.  No parity claim.
+ *   rays in object space: p_cam = R p + t (pose [B][16]), pixel ray K^-1 [x, y, 1] (Kinv [B][9]); lam = camera-frame depth along the ray.
+ *   state: counters int32[3] (rotating active-ray counts, on the device), pix int32[n_max] (crop*W*H + pixel), lam float[n_max], two of each
+ *   (ping-pong), far float[B*W*H], inputs float[n_max][L+3] decoder input rows of the active rays (latn [B][L] = normalised latent),
+ *   hit_lam / hit_sdf float[B*W*H] (zero-filled by the caller; lam and decoder value of the rays that reached |sdf| < eps).
+ */
+/* decoder forward over the first *n_dev rows (device int32, clamped to n_max); half != 0: half operands on the matrix cores */
+int sdfr_mlp_forward_counted(const sdfr_decoder* dec, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf, int half,
+                             void* stream);
+/* all pixels of all crops: slab test against the cube [-bound, bound]^3; hits enter the active list (counters[0]) at lam = max(entry, near) */
+int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
+                     int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, void* stream);
+/* march step `step` (0, 1, ...): sdf = decoder values of the active rays (counters[step % 3] of them); lam += relax * sdf / |d|; rays with
+ * |sdf| < eps are recorded in hit_lam / hit_sdf and retired, rays past `far` are retired, the rest are compacted into pix_out / lam_out /
+ * inputs (count in counters[(step + 1) % 3]) */
+int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int L, int W, int H, float eps, float relax, const float* sdf,
+                    int32_t* counters, int step, int64_t n_max, const int32_t* pix_in, const float* lam_in, int32_t* pix_out, float* lam_out,
+                    const float* far, float* inputs, float* hit_lam, float* hit_sdf, void* stream);
+
 /* Debug only: forward kernels of a library built with -DSDFR_MLP_TRACE write cycle stamps of their workgroup 0 into this device buffer
  * (2 * SDFR_MAX_LAYERS * 5 uint64; see tools/cycle_trace.py); pass NULL to disable.  Production builds ignore it. */
 int sdfr_debug_set_trace(void* device_buffer);

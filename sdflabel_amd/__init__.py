@@ -11,5 +11,6 @@ from .deepsdf.workspace import setup_dsdf  # noqa: F401
 from .deepsdf.networks.deep_sdf_decoder_scale import Decoder  # noqa: F401
 from .batch import BatchRenderer  # noqa: F401
 from .refine import BatchRefiner  # noqa: F401
+from .renderer.sphere_tracer import SphereTracer  # noqa: F401
 
-__all__ = ["Grid3D", "Rasterer", "Decoder", "setup_dsdf", "BatchRenderer", "BatchRefiner", "lib", "SdfrError", "LIB_PATH"]
+__all__ = ["Grid3D", "Rasterer", "Decoder", "setup_dsdf", "BatchRenderer", "BatchRefiner", "SphereTracer", "lib", "SdfrError", "LIB_PATH"]

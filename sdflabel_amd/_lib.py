@@ -16,6 +16,11 @@ _PROTOS = {
     "sdfr_version": (c_int, []),
     "sdfr_last_error": (c_char_p, []),
     "sdfr_debug_set_trace": (c_int, [c_void_p]),
+    "sdfr_mlp_forward_counted": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
+    "sdfr_trace_setup": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "sdfr_trace_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_decoder_create": (c_int, [POINTER(c_void_p), c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int]),
     "sdfr_decoder_destroy": (c_int, [c_void_p]),

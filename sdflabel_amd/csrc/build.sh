@@ -21,6 +21,7 @@ $HIPCC $COMMON -ffp-contract=off -c "$HERE/project.hip" -o "$HERE/obj/project.o"
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/splat.hip"   -o "$HERE/obj/splat.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/params.hip"  -o "$HERE/obj/params.o" &
 $HIPCC $COMMON -ffp-contract=off $SDFR_LOSS_DEFS -c "$HERE/losses.hip"  -o "$HERE/obj/losses.o" &
+$HIPCC $COMMON -c "$HERE/trace.hip"   -o "$HERE/obj/trace.o" &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${SDFR_LIBNAME:-libsdfr_hip.so}" "$HERE"/obj/{common,mlp,mlp_fwd32,mlp_fwd16,mlp_split,mlp_jac,mlp_jac16,mlp_small,mlp_ln,surface,project,splat,params,losses}.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${SDFR_LIBNAME:-libsdfr_hip.so}" "$HERE"/obj/{common,mlp,mlp_fwd32,mlp_fwd16,mlp_split,mlp_jac,mlp_jac16,mlp_small,mlp_ln,surface,project,splat,params,losses,trace}.o
 echo "built $OUT/${SDFR_LIBNAME:-libsdfr_hip.so}"

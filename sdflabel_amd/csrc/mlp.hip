@@ -154,6 +154,25 @@ extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int6
     return SDFR_OK;
 }
 
+// forward over the first *n_dev rows of `inputs` (n_dev: device int32, clamped to n_max = the launch bound): the per-step decoder call of the
+// sphere tracer, whose active-ray count is produced on the device by the previous step (no host synchronisation).  half != 0: half operands.
+extern "C" int sdfr_mlp_forward_counted(const sdfr_decoder* d, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf, int half,
+                                        void* stream) {
+    SDFR_REQUIRE(d && inputs && sdf && n_dev, "sdfr_mlp_forward_counted: NULL argument");
+    SDFR_REQUIRE(n_max >= 0 && n_max < (int64_t)1 << 31, "sdfr_mlp_forward_counted: n_max=%lld out of range", (long long)n_max);
+    SDFR_REQUIRE(!half || (d->HP == 512 && !d->has_ln), "sdfr_mlp_forward_counted: half operands need a 512-wide decoder without LayerNorm");
+    if (n_max == 0) return SDFR_OK;
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.n_dev = n_dev; P.trace = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (half) sdfr_launch_fwd_f16_512(P, n_max, false, s);
+    else if (d->has_ln) sdfr_launch_ln(P, d->HP, false, sdfr_cdiv(n_max, 64), 1, s);
+    else if (d->HP == 512) sdfr_launch_fwd_f32_512(P, n_max, false, s);
+    else sdfr_launch_small(P, d->HP, 0, sdfr_cdiv(n_max, 64), 1, s);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
 // forward with float16 operands (f32 accumulate, f32 bias/ReLU/tanh): 128-point workgroup tiles
 extern "C" int sdfr_mlp_forward_f16(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf, "sdfr_mlp_forward_f16: NULL argument");

@@ -72,6 +72,7 @@ struct MlpParams {
     float* sdf_sel;
     const float* sdf_in;    // MODE 3: decoder output of the forward launch that saved the masks
     uint32_t* maskbuf;      // MODE 1 (write) / MODE 3 (read): ReLU masks [tile64][layer][word][thread]
+    const int32_t* n_dev;        // forward: optional device-side row count (rows >= *n_dev are not evaluated; n is the launch bound)
     unsigned long long* trace;   // builds with -DSDFR_MLP_TRACE: cycle stamps of workgroup 0 (sdfr_debug_set_trace), else unused
 };
 
@@ -212,7 +213,9 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         }
     } else {
         const int64_t r0 = (int64_t)blockIdx.x * PT;
-        n_valid = (int)min((int64_t)PT, P.n - r0);
+        const int64_t n_rows = P.n_dev ? min(P.n, (int64_t)*P.n_dev) : P.n;          // sphere tracing: the active-ray count lives on the device
+        if (r0 >= n_rows) return;
+        n_valid = (int)min((int64_t)PT, n_rows - r0);
         if (tid < PT) rows[tid] = (int)(r0 + (tid < n_valid ? tid : 0));
     }
     __syncthreads();

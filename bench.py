@@ -466,6 +466,41 @@ def main():
     if not args.no_extras:
         prefilter = alt_decoder("float32_prefilter", "exact f32 on the band candidates chosen by an f16 pass over the grid / f32 rest")
 
+    # ---- sphere-tracing render mode (BASELINE.json's literal wording; NOT the reference's algorithm, no parity claim -- DESIGN.md 3.6):
+    # one crop, `march steps` decoder evaluations per active ray with ballot compaction, forward + backward to yaw/trans/latent
+    sphere = None
+    if rank == 0 and CB == 1 and not args.no_extras:
+        sphere = {}
+        for label, prec, steps in (("f32_64_steps", torch.float32, 64), ("f16_64_steps", torch.float16, 64), ("f16_128_steps", torch.float16, 128)):
+            try:
+                d3, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
+                tr = sdflabel_amd.SphereTracer(d3.to(dev), K_for(H, W), (W, H), 1, steps=steps, device=dev)
+                prm = [crop.yaw.detach().clone().requires_grad_(True), crop.trans.detach().clone().view(1, 3).requires_grad_(True),
+                       crop.latent.detach().clone().view(1, -1).requires_grad_(True)]
+
+                def tstep():
+                    for p_ in prm:
+                        p_.grad = None
+                    o_ = tr(*prm)
+                    (o_["depth"].sum() + o_["color"].sum() + o_["normals"].sum()).backward()
+                    return o_
+
+                for _ in range(2):
+                    tstep()
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                nrep = 5
+                for _ in range(nrep):
+                    o_ = tstep()
+                torch.cuda.synchronize()
+                dt_t = (time.perf_counter() - t_) / nrep
+                sphere[label] = {"value": H * W / dt_t, "unit": "rays/s", "ms_per_render_fwd_bwd": dt_t * 1e3, "march_steps": steps,
+                                 "rays_entering_the_object_cube": int(tr.n_entered), "hits": int(tr.n_hit),
+                                 "unresolved_after_last_step": int(tr.n_unresolved), "max_abs_sdf_at_marched_hits": float(tr.hit_residual.abs().max())}
+                del tr, d3
+            except Exception as e:
+                sphere[label] = {"error": repr(e)[:200]}
+
     # the same crop-iteration through the drop-in boundary (rank 0 only, informational)
     dropin = None
     if rank == 0 and not args.no_extras:
@@ -520,6 +555,7 @@ def main():
         line["refine_demo"] = refine
         line["refine_sharded"] = sharded
         line["pose_only"] = pose_only
+        line["sphere_trace"] = sphere
         line["world_size"] = world
         line["f16_decoder"] = f16
         line["split_decoder"] = split

@@ -1,11 +1,17 @@
 // Band Jacobian of the float16 decoder, padded hidden width 512: mask-fed backward (MODE 3) with half operands on
 // v_mfma_f32_16x16x32_f16 (float32 accumulation), 16-point workgroups.  The in-gradients are rounded to half between layers like the
 // forward's activations; the transposed half weight image is half the bytes of the float32 one, and the kernel is paced by that stream.
+// Geometry macros (tools/ab_variant.sh): SDFR_J16_FT feature tiles per wave, SDFR_J16_NW waves (16 * FT * NW = 512), SDFR_J16_PF ring.
 #include "mlp_kernel.h"
 #ifndef SDFR_J16_PF
 #define SDFR_J16_PF 4
 #endif
+#ifndef SDFR_J16_FT
+#define SDFR_J16_FT 4
+#define SDFR_J16_NW 8
+#endif
 void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s) {
+    static_assert(16 * SDFR_J16_FT * SDFR_J16_NW == 512, "padded width 512 = 16 * FT * NW");
     const dim3 grid(sdfr_cdiv(cap, 16), B);
-    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, 4, 1, 8, SDFR_J16_PF, 3>), grid, dim3(512), 0, s, P);
+    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 1, SDFR_J16_NW, SDFR_J16_PF, 3>), grid, dim3(64 * SDFR_J16_NW), 0, s, P);
 }

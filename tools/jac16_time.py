@@ -1,0 +1,31 @@
+"""Time the half-operand mask-fed band Jacobian of the float16 decoder: python tools/jac16_time.py [B ...]  (SDFR_LIB selects a variant)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import sdflabel_amd
+from tests._util import ASSET, K_for
+dev = "cuda"
+dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16); dec = dec.to(dev)
+L = sdflabel_amd._lib.lib(); P = sdflabel_amd._lib.ptr
+out = []
+for B in [int(a) for a in sys.argv[1:]] or [1]:
+    br = sdflabel_amd.BatchRenderer(dec, 40, K_for(64, 64), (64, 64), B, device=dev)
+    g = torch.Generator().manual_seed(1)
+    lat = torch.tensor([[0.3, -0.5, 0.8]]) + 0.2 * (torch.rand(B, 3, generator=g) - 0.5)
+    br.set_params(torch.full((B,), 0.7, device=dev), torch.tensor([[0.05, 0.02, 3.3]], device=dev).expand(B, 3), lat.to(dev))
+    br.forward(); torch.cuda.synchronize()
+    def jac():
+        L.sdfr_mlp_jacobian(br.handle.h, P(br.inputs), br.G, B, P(br.idx), br.cap, P(br.cnt), P(br.J), P(br.sdf_band), P(br.sdf), P(br.mask_ws), 2,
+                            sdflabel_amd._lib.stream_ptr())
+    for _ in range(3): jac()
+    n = 50 if B < 16 else 10
+    ts = []
+    for r in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): jac()
+        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / n * 1e3)
+    cs = float(sum(br.J[b, :int(br.cnt[b])].double().sum() for b in range(B)))
+    out.append("B=%d: %.1f us (%.1f us/crop) checksum %.8g" % (B, min(ts), min(ts) / B, cs))
+    del br
+print(os.path.basename(os.environ.get("SDFR_LIB", "default")), " | ".join(out))

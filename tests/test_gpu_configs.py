@@ -53,8 +53,9 @@ def check_grads(got, z, rel=1e-3):
 
 # ---- configs[1] -----------------------------------------------------------------------------------------------------------------------
 
-def test_config1_dropin_256_vs_reference_G10(dec):
-    z = gold("g10_config1_256.npz")
+@pytest.mark.parametrize("fixture", ["g10_config1_256.npz", "g10b_config1_256.npz"])
+def test_config1_dropin_256_vs_reference_G10(dec, fixture):
+    z = gold(fixture)
     D, H, W = [int(v) for v in z["cfg"]]
     assert (D, H, W) == (40, 256, 256)
     near = np.unpackbits(z["near_threshold"])[:H * W].astype(bool)
@@ -82,11 +83,12 @@ def test_config1_dropin_256_vs_reference_G10(dec):
     check_grads((yaw.grad, trans.grad, lat.grad), z)
 
 
+@pytest.mark.parametrize("fixture", ["g10_config1_256.npz", "g10b_config1_256.npz"])
 @pytest.mark.parametrize("precision", [torch.float32, "float32_split", "float32_prefilter"])
-def test_config1_batch_renderer_256_vs_reference_G10(precision):
+def test_config1_batch_renderer_256_vs_reference_G10(precision, fixture):
     """the bench's own code path (BatchRenderer, B = 1) at the bench's size, against the reference -- for the exact-f32 decoder (the
     headline) and for the two float32-result modes that the bench reports beside it"""
-    z = gold("g10_config1_256.npz")
+    z = gold(fixture)
     D, H, W = [int(v) for v in z["cfg"]]
     near = np.unpackbits(z["near_threshold"])[:H * W].astype(bool)
     d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)

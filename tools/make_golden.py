@@ -434,11 +434,11 @@ def near_threshold_pixels(K, H, W, pose, pcd, normals):
     return near
 
 
-def g10():
+def g10(name="g10_config1_256.npz", latent=(0.5, -0.3, 0.6), yaw0=0.7, trans0=(0.03, 0.02, 3.45)):
     """BASELINE configs[1] at its stated size: ONE 256x256 crop, D = 40, float32, the optimizer's graph (optimizer.py:79-123) with every
     output enabled and a deterministic linear functional as the loss; images, surfels and autograd gradients of the reference."""
     D, H, W = 40, 256, 256
-    latent, yaw0, trans0 = [0.5, -0.3, 0.6], 0.7, [0.03, 0.02, 3.45]
+    latent, trans0 = list(latent), list(trans0)
     dec = load_fitted()[0]
     grid = ref_grid.Grid3D(D, "cpu", torch.float32)
     lat = torch.tensor(latent, dtype=torch.float32, requires_grad=True)
@@ -475,7 +475,12 @@ def g10():
     print("G10 N", pcd.shape[0], "Nf", points["xyzf"].shape[0], "loss", float(loss), "g_yaw", yaw.grad.numpy(), "g_trans", trans.grad.numpy(),
           "g_lat", lat.grad.numpy(), "band margin", arrs["band_margin"], "filt margin", arrs["filt_margin"],
           "near px", int(np.unpackbits(arrs["near_threshold"]).sum()))
-    save("g10_config1_256.npz", **arrs)
+    save(name, **arrs)
+
+
+def g10b():
+    """a second crop at the configs[1] size: another shape, a side view from closer up (larger surfels, more of them per pixel)"""
+    g10("g10b_config1_256.npz", latent=(-0.6, 0.2, 0.1), yaw0=-1.1, trans0=(0.2, -0.1, 2.9))
 
 
 def _ref_render_precision(prec, D, H, W, latent, yaw0, trans0):
@@ -646,7 +651,7 @@ def g13():
     save("g13_primitives.npz", **arrs)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G9": g9, "G10": g10, "G11": g11, "G12": g12, "G13": g13}
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -12,4 +12,4 @@ void sdfr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* sdfr_last_error(void) { return g_err; }
-extern "C" int sdfr_version(void) { return 100; }
+extern "C" int sdfr_version(void) { return 200; }

@@ -417,9 +417,10 @@ def main():
     #                  BASELINE configs[4]); everything else float32
     #   float32_split  every f32 operand as a hi/lo pair of halves, three f16 MFMAs per product: float32-equivalent results (passes the
     #                  float32 goldens at the float32 tolerances, tests/test_gpu_parity.py::test_split_decoder_*)
-    def alt_decoder(precision, dtype_label):
+    def alt_decoder(precision, dtype_label, reuse=False):
         def setup():
             d2, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)
+            d2.prefilter_reuse = reuse
             d2 = d2.to(dev)
             b2 = sdflabel_amd.BatchRenderer(d2, D, K_for(H, W), (W, H), CB, device=dev)
             b2.set_params(br.yaw, br.trans, br.latent)
@@ -446,7 +447,8 @@ def main():
             # the two-stage mode does not execute the 2*M*G flops of a full-grid pass in f32: no flop rate is quoted for it
             out.update({"decoder_forward_ms_covers": "f16 grid pass + candidate selection + exact-f32 sdf and Jacobian of the candidates",
                         "candidates": int(b2.ccnt[0]), "prefilter_margin": b2.margin, "f16_pass_max_deviation_at_calibration": b2.f16_error,
-                        "guard": b2.prefilter_report()})
+                        "guard": b2.prefilter_report(), "candidate_reuse": bool(b2.reuse),
+                        "lipschitz_latent_calibrated": getattr(b2, "lipschitz", None)})
         else:
             out.update({"decoder_forward_tflops": 2.0 * macs * G * CB / (m2 * 1e-3) / 1e12, "f16_mfma_peak_tflops": 2500.0})
         out.update({
@@ -463,8 +465,13 @@ def main():
         split = alt_decoder("float32_split", "f32 results from error-compensated f16 operand pairs (3 f16 MFMAs per product) / f32 rest")
     #   float32_prefilter  a float16 pass over the grid proposes candidates |sdf| < 0.03 + margin; band membership, sdf and Jacobian of the
     #                  band come from the exact-f32 kernels run on the candidates only (decoder_forward_ms spans both passes incl. the Jacobian)
+    prefilter_reuse = None
     if not args.no_extras:
         prefilter = alt_decoder("float32_prefilter", "exact f32 on the band candidates chosen by an f16 pass over the grid / f32 rest")
+        #   ... and with the candidate set reused while the latent has moved less than margin / (4 lip) since the last f16 pass (here the latent
+        #   does not move at all between the bench's steps, as under the 3e-5 learning rate of the refinement: the pass runs every 17th step)
+        prefilter_reuse = alt_decoder("float32_prefilter", "as prefilter_decoder, f16 pass skipped while the candidate set is provably still valid",
+                                      reuse=True)
 
     # ---- sphere-tracing render mode (BASELINE.json's literal wording; NOT the reference's algorithm, no parity claim -- DESIGN.md 3.6):
     # one crop, `march steps` decoder evaluations per active ray with ballot compaction, forward + backward to yaw/trans/latent
@@ -560,6 +567,7 @@ def main():
         line["f16_decoder"] = f16
         line["split_decoder"] = split
         line["prefilter_decoder"] = prefilter
+        line["prefilter_reuse_decoder"] = prefilter_reuse
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

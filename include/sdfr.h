@@ -141,6 +141,20 @@ int sdfr_band_select_margin(const float* sdf, int64_t G, int B, float thr, const
  * have been excluded in this step).  margin float[B] in/out, violations int32[B][2] in/out; no host synchronisation. */
 int sdfr_prefilter_guard(float* sdf_grid, const float* sdf_exact, const int32_t* idx, int64_t G, int B, int cap, const int32_t* cnt,
                          float* margin, float* max_dev, int32_t* violations, void* stream);
+/* Candidate-set reuse of the two-stage evaluation.  sdfr_prefilter_plan decides per crop, on the device, whether the candidates of the last
+ * half pass still cover the band: reuse[b] = 1 while lip * |latent - latent of that pass| <= margin[b]/4, max_dev[b] <= margin[b]/2 and at
+ * most max_reuse steps in a row (lip: Lipschitz constant of the decoder in the normalised latent; inputs: the decoder input rows, whose
+ * first L columns hold it; lat_ref float[B][L], age int32[B]: state, zero-initialised).  The half pass, the candidate selection and the
+ * guard then take the flags: flagged crops are skipped (sdfr_mlp_forward_f16_skip, sdfr_band_select_skip) / patched but not judged
+ * (sdfr_prefilter_guard2). */
+int sdfr_prefilter_plan(const float* inputs, int64_t G, int n_inputs, int L, int B, float lip, const float* margin, const float* max_dev,
+                        float* lat_ref, int32_t* age, int max_reuse, int32_t* reuse, void* stream);
+int sdfr_mlp_forward_f16_skip(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, const int32_t* skip, int64_t rows_per_crop,
+                              void* stream);
+int sdfr_band_select_skip(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, const int32_t* skip, int32_t* idx, int cap,
+                          int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream);
+int sdfr_prefilter_guard2(float* sdf_grid, const float* sdf_exact, const int32_t* idx, int64_t G, int B, int cap, const int32_t* cnt,
+                          float* margin, float* max_dev, int32_t* violations, const int32_t* reused, void* stream);
 int sdfr_gather_rows(float* out, const float* src, int ncol, const int32_t* idx, const int32_t* slot, int64_t G, int B, int cap,
                      int src_cap, const int32_t* cnt, void* stream);
 

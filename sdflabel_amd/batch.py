@@ -75,14 +75,20 @@ class BatchRenderer:
             # normalises the latent, optimizer.py:96); the margin is at least 4x the largest deviation seen
             Lh = _lib.lib()
             gen = torch.Generator().manual_seed(0)
-            s32, s16 = f(G), f(G)
-            worst = 0.0
+            s32, s16, s32b = f(G), f(G), f(G)
+            worst, lip = 0.0, 0.0
             for _ in range(4):
                 lat = torch.nn.functional.normalize(torch.randn(self.L, generator=gen), dim=0).to(dev)
                 inp = torch.cat([lat.expand(G, -1), self.grid], 1).contiguous()
                 _lib.check(Lh.sdfr_mlp_forward(self.handle.h, _lib.ptr(inp), G, _lib.ptr(s32), None, _lib.stream_ptr()), "sdfr_mlp_forward")
                 _lib.check(Lh.sdfr_mlp_forward_f16(self.handle.h, _lib.ptr(inp), G, _lib.ptr(s16), None, _lib.stream_ptr()), "sdfr_mlp_forward_f16")
                 worst = max(worst, float((s32 - s16).abs().max()))
+                # Lipschitz constant of the decoder output in the normalised latent (candidate-set reuse): largest change of sdf on the grid
+                # per unit of latent movement, for a small move along the unit sphere
+                lat2 = torch.nn.functional.normalize(lat + 0.02 * torch.randn(self.L, generator=gen).to(dev), dim=0)
+                inp2 = torch.cat([lat2.expand(G, -1), self.grid], 1).contiguous()
+                _lib.check(Lh.sdfr_mlp_forward(self.handle.h, _lib.ptr(inp2), G, _lib.ptr(s32b), None, _lib.stream_ptr()), "sdfr_mlp_forward")
+                lip = max(lip, float((s32b - s32).abs().max()) / max(float((lat2 - lat).norm()), 1e-12))
             self.f16_error = worst
             self.margin = max(self.margin, 4.0 * worst)
             # run-time guard (sdfr_prefilter_guard): the margin lives on the device, per crop; every step measures the half pass's deviation
@@ -90,6 +96,12 @@ class BatchRenderer:
             self.margin_dev = torch.full((B,), self.margin, dtype=torch.float32, device=dev)
             self.max_dev = f(B)
             self.violations = i(B, 2)
+            # candidate-set reuse (opt-in: decoder.prefilter_reuse = True): while the normalised latent has moved less than margin / (4 lip)
+            # since the last half pass, that pass and the candidate selection are skipped (sdfr_prefilter_plan decides per crop on the device)
+            self.lipschitz = 2.0 * lip                                 # calibrated above, with a factor 2
+            self.reuse = bool(getattr(decoder, "prefilter_reuse", False))
+            self.max_reuse = int(getattr(decoder, "prefilter_max_reuse", 16))
+            self.lat_ref, self.age, self.reuse_flag = f(B, self.L), i(B), i(B)
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.p_cam, self.n_cam, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.fidx, self.fcnt, self.fslot = i(B, cap), i(B), i(B, cap)
@@ -126,10 +138,14 @@ class BatchRenderer:
         self.trans.copy_(trans.reshape(self.B, 3))
         self.latent.copy_(latent.reshape(self.B, self.L))
         self._shape_valid = False
+        if self.prefilter:
+            self.age.zero_()                     # new crops: the next step runs the half pass
 
     def invalidate_shape(self):
         """call after changing self.latent in place (freeze_shape mode): the next forward() re-evaluates decoder, band and Jacobian"""
         self._shape_valid = False
+        if self.prefilter:
+            self.age.zero_()
 
     def forward(self, yaw=None, trans=None, latent=None, mlp_events=None, events=None):
         """mlp_events: optional (start, end) torch.cuda.Event pair recorded around the decoder-forward launch (bench.py roofline).
@@ -155,15 +171,23 @@ class BatchRenderer:
             if mlp_events is not None:
                 mlp_events[1].record()
         elif self.prefilter:
-            ck(L.sdfr_mlp_forward_f16(self.handle.h, P(self.inputs), B * G, P(self.sdf), None, st), "sdfr_mlp_forward_f16")
-            ck(L.sdfr_band_select_margin(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.cidx), cap, P(self.ccnt), P(self.cslot),
-                                         P(self.scratch), st), "sdfr_band_select_margin")
+            if self.reuse:
+                ck(L.sdfr_prefilter_plan(P(self.inputs), G, self.NI, self.L, B, self.lipschitz, P(self.margin_dev), P(self.max_dev), P(self.lat_ref),
+                                         P(self.age), self.max_reuse, P(self.reuse_flag), st), "sdfr_prefilter_plan")
+                ck(L.sdfr_mlp_forward_f16_skip(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.reuse_flag), G, st),
+                   "sdfr_mlp_forward_f16_skip")
+                ck(L.sdfr_band_select_skip(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.reuse_flag), P(self.cidx), cap, P(self.ccnt),
+                                           P(self.cslot), P(self.scratch), st), "sdfr_band_select_skip")
+            else:
+                ck(L.sdfr_mlp_forward_f16(self.handle.h, P(self.inputs), B * G, P(self.sdf), None, st), "sdfr_mlp_forward_f16")
+                ck(L.sdfr_band_select_margin(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.cidx), cap, P(self.ccnt), P(self.cslot),
+                                             P(self.scratch), st), "sdfr_band_select_margin")
             # exact float32 sdf and Jacobian of the candidates (recomputing kernel, 16-row tiles), patched into the grid array
             ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.cidx), cap, P(self.ccnt), P(self.Jc), P(self.sdf_band), None, None,
                                    0, st), "sdfr_mlp_jacobian")
             # exact values patched into the grid array + guard (deviation of the half pass at the candidates -> margin / violation counters)
-            ck(L.sdfr_prefilter_guard(P(self.sdf), P(self.sdf_band), P(self.cidx), G, B, cap, P(self.ccnt), P(self.margin_dev), P(self.max_dev),
-                                      P(self.violations), st), "sdfr_prefilter_guard")
+            ck(L.sdfr_prefilter_guard2(P(self.sdf), P(self.sdf_band), P(self.cidx), G, B, cap, P(self.ccnt), P(self.margin_dev), P(self.max_dev),
+                                       P(self.violations), P(self.reuse_flag) if self.reuse else None, st), "sdfr_prefilter_guard")
             ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
             ck(L.sdfr_gather_rows(P(self.J), P(self.Jc), self.NI, P(self.idx), P(self.cslot), G, B, cap, cap, P(self.cnt), st), "sdfr_gather_rows")
             if mlp_events is not None:

@@ -187,6 +187,21 @@ extern "C" int sdfr_mlp_forward_f16(const sdfr_decoder* d, const float* inputs, 
     return SDFR_OK;
 }
 
+// the half pass of the two-stage evaluation with per-crop skip flags (device int32[B], rows_per_crop rows each): flagged crops are not
+// evaluated (their rows of `sdf` keep the previous values) -- see sdfr_prefilter_plan
+extern "C" int sdfr_mlp_forward_f16_skip(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, const int32_t* skip,
+                                         int64_t rows_per_crop, void* stream) {
+    SDFR_REQUIRE(d && inputs && sdf && skip && rows_per_crop > 0, "sdfr_mlp_forward_f16_skip: bad argument");
+    SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward_f16_skip: n=%lld out of range", (long long)n);
+    SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_f16_skip: 512-wide decoders without LayerNorm");
+    if (n == 0) return SDFR_OK;
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = nullptr; P.skip = skip; P.skip_rows = rows_per_crop;
+    sdfr_launch_fwd_f16_512(P, n, false, (hipStream_t)stream);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
 // forward with error-compensated float16 operands: every float32 operand x is carried as the pair  hi = half(x),
 // lo = half((x - hi) * 2^11)  (22 significand bits) and each product as  hi*hi + (hi*lo + lo*hi) * 2^-11  on the f16 matrix cores with
 // float32 accumulation -- three f16 MFMAs replace sixteen f32 MFMA passes.  Results agree with sdfr_mlp_forward to float32 rounding

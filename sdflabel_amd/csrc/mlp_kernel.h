@@ -72,6 +72,8 @@ struct MlpParams {
     float* sdf_sel;
     const float* sdf_in;    // MODE 3: decoder output of the forward launch that saved the masks
     uint32_t* maskbuf;      // MODE 1 (write) / MODE 3 (read): ReLU masks [tile64][layer][word][thread]
+    const int32_t* skip;         // forward: optional per-crop flags (skip_rows rows per crop): workgroups whose rows all belong to flagged crops exit
+    int64_t skip_rows;
     const int32_t* n_dev;        // forward: optional device-side row count (rows >= *n_dev are not evaluated; n is the launch bound)
     unsigned long long* trace;   // builds with -DSDFR_MLP_TRACE: cycle stamps of workgroup 0 (sdfr_debug_set_trace), else unused
 };
@@ -215,6 +217,10 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         const int64_t r0 = (int64_t)blockIdx.x * PT;
         const int64_t n_rows = P.n_dev ? min(P.n, (int64_t)*P.n_dev) : P.n;          // sphere tracing: the active-ray count lives on the device
         if (r0 >= n_rows) return;
+        if (P.skip) {                               // two-stage evaluation: crops that reuse their candidate set skip the half pass
+            const int64_t r1 = min(r0 + PT, n_rows) - 1;
+            if (P.skip[r0 / P.skip_rows] && P.skip[r1 / P.skip_rows]) return;
+        }
         n_valid = (int)min((int64_t)PT, n_rows - r0);
         if (tid < PT) rows[tid] = (int)(r0 + (tid < n_valid ? tid : 0));
     }

@@ -11,8 +11,10 @@
 // rank inside the block from ballot/popcount prefix.  No inter-workgroup hand-off inside a launch.
 
 __global__ __launch_bounds__(256) void sdfr_band_count_kernel(const float* __restrict__ sdf, int64_t G, float thr,
-                                                             const float* __restrict__ thr_extra, int32_t* __restrict__ blockcnt) {
+                                                             const float* __restrict__ thr_extra, int32_t* __restrict__ blockcnt,
+                                                             const int32_t* __restrict__ skip) {
     const int b = blockIdx.y;
+    if (skip && skip[b]) return;                     // this crop keeps its previous selection
     if (thr_extra) thr += thr_extra[b];
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool in = false;
@@ -27,8 +29,10 @@ __global__ __launch_bounds__(256) void sdfr_band_count_kernel(const float* __res
 __global__ __launch_bounds__(256) void sdfr_band_scatter_kernel(const float* __restrict__ sdf, int64_t G, float thr,
                                                                const float* __restrict__ thr_extra,
                                                                const int32_t* __restrict__ blockcnt, int32_t* __restrict__ idx,
-                                                               int cap, int32_t* __restrict__ cnt, int32_t* __restrict__ slot) {
+                                                               int cap, int32_t* __restrict__ cnt, int32_t* __restrict__ slot,
+                                                               const int32_t* __restrict__ skip) {
     const int b = blockIdx.y;
+    if (skip && skip[b]) return;
     if (thr_extra) thr += thr_extra[b];
     const int nblk = gridDim.x;
     const int tid = threadIdx.x;
@@ -67,6 +71,8 @@ __global__ __launch_bounds__(256) void sdfr_band_scatter_kernel(const float* __r
 
 extern "C" int sdfr_band_select_margin(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, int32_t* idx, int cap,
                                        int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream);
+static int band_select_impl(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, const int32_t* skip, int32_t* idx, int cap,
+                            int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream);
 extern "C" int sdfr_band_select(const float* sdf, int64_t G, int B, float thr, int32_t* idx, int cap, int32_t* cnt,
                                 int32_t* slot, int32_t* scratch, void* stream) {
     return sdfr_band_select_margin(sdf, G, B, thr, nullptr, idx, cap, cnt, slot, scratch, stream);
@@ -76,15 +82,26 @@ extern "C" int sdfr_band_select(const float* sdf, int64_t G, int B, float thr, i
 // two-stage evaluation, whose safety margin is kept per crop on the device (sdfr_prefilter_guard)
 extern "C" int sdfr_band_select_margin(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, int32_t* idx, int cap,
                                        int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream) {
+    return band_select_impl(sdf, G, B, thr, thr_extra, nullptr, idx, cap, cnt, slot, scratch, stream);
+}
+
+// ... and with per-crop skip flags (device int32[B]): flagged crops keep idx / cnt / slot of their previous selection
+extern "C" int sdfr_band_select_skip(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, const int32_t* skip, int32_t* idx,
+                                     int cap, int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream) {
+    return band_select_impl(sdf, G, B, thr, thr_extra, skip, idx, cap, cnt, slot, scratch, stream);
+}
+
+static int band_select_impl(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, const int32_t* skip, int32_t* idx, int cap,
+                            int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream) {
     SDFR_REQUIRE(sdf && idx && cnt && scratch, "sdfr_band_select: NULL argument");
     SDFR_REQUIRE(G >= 0 && B >= 0 && cap >= 0, "sdfr_band_select: negative size");
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
     if (G == 0) { SDFR_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * B, s)); return SDFR_OK; }
     dim3 grid(sdfr_cdiv(G, 256), B);
-    hipLaunchKernelGGL(sdfr_band_count_kernel, grid, dim3(256), 0, s, sdf, G, thr, thr_extra, scratch);
+    hipLaunchKernelGGL(sdfr_band_count_kernel, grid, dim3(256), 0, s, sdf, G, thr, thr_extra, scratch, skip);
     SDFR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sdfr_band_scatter_kernel, grid, dim3(256), 0, s, sdf, G, thr, thr_extra, scratch, idx, cap, cnt, slot);
+    hipLaunchKernelGGL(sdfr_band_scatter_kernel, grid, dim3(256), 0, s, sdf, G, thr, thr_extra, scratch, idx, cap, cnt, slot, skip);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -124,7 +141,8 @@ extern "C" int sdfr_scatter_values(float* dst, const float* src, const int32_t* 
 __global__ __launch_bounds__(1024) void sdfr_prefilter_guard_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                                    const int32_t* __restrict__ idx, int64_t G, int cap,
                                                                    const int32_t* __restrict__ cnt, float* __restrict__ margin,
-                                                                   float* __restrict__ max_dev, int32_t* __restrict__ violations) {
+                                                                   float* __restrict__ max_dev, int32_t* __restrict__ violations,
+                                                                   const int32_t* __restrict__ reused) {
     const int b = blockIdx.x;
     const int n = sdfr_count(cnt, b, cap);
     float dev = 0.f;
@@ -141,6 +159,7 @@ __global__ __launch_bounds__(1024) void sdfr_prefilter_guard_kernel(float* __res
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w) dev = fmaxf(dev, wmax[w]);
+        if (reused && reused[b]) return;                  // candidate set reused: the old values were exact ones, not the half pass's
         const float m = margin[b];
         max_dev[b] = dev;
         if (!(dev <= 0.5f * m)) {                         // also catches NaN
@@ -151,12 +170,50 @@ __global__ __launch_bounds__(1024) void sdfr_prefilter_guard_kernel(float* __res
     }
 }
 
+// Plan of the two-stage evaluation for this step, per crop (one thread each): may the candidate set of the last half pass be reused?
+// A row outside it had |half sdf| >= thr + margin at the latent z0 of that pass, so its exact |sdf| at the current latent z1 is at least
+// thr + margin - dev - lip * |z1 - z0|  (dev: the half pass's deviation, lip: Lipschitz constant of the decoder in the normalised latent,
+// calibrated by the caller).  Reuse while  lip * |z1 - z0| <= margin / 4  and  dev <= margin / 2  (then the row stays outside the band with
+// a quarter of the margin to spare) and at most max_reuse steps in a row.  reuse[b] = 1: skip the half pass and the candidate selection of
+// crop b (sdfr_mlp_forward_f16_skip, sdfr_band_select_skip); otherwise lat_ref[b] = the current normalised latent.
+__global__ void sdfr_prefilter_plan_kernel(const float* __restrict__ inputs, int64_t G, int NI, int L, int B, float lip,
+                                           const float* __restrict__ margin, const float* __restrict__ max_dev, float* __restrict__ lat_ref,
+                                           int32_t* __restrict__ age, int max_reuse, int32_t* __restrict__ reuse) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* z = inputs + (int64_t)b * G * NI;             // the latent columns of the crop's first input row
+    float d2 = 0.f;
+    for (int c = 0; c < L; ++c) { const float d = z[c] - lat_ref[b * L + c]; d2 += d * d; }
+    const bool ok = age[b] > 0 && age[b] <= max_reuse && lip * sqrtf(d2) <= 0.25f * margin[b] && max_dev[b] <= 0.5f * margin[b];
+    reuse[b] = ok ? 1 : 0;
+    if (ok) age[b] += 1;
+    else { age[b] = 1; for (int c = 0; c < L; ++c) lat_ref[b * L + c] = z[c]; }
+}
+
+extern "C" int sdfr_prefilter_plan(const float* inputs, int64_t G, int n_inputs, int L, int B, float lip, const float* margin,
+                                   const float* max_dev, float* lat_ref, int32_t* age, int max_reuse, int32_t* reuse, void* stream) {
+    SDFR_REQUIRE(inputs && margin && max_dev && lat_ref && age && reuse && G > 0 && L >= 0 && n_inputs >= L, "sdfr_prefilter_plan: bad argument");
+    if (B <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_prefilter_plan_kernel, dim3(sdfr_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, inputs, G, n_inputs, L, B, lip, margin,
+                       max_dev, lat_ref, age, max_reuse, reuse);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_prefilter_guard2(float* sdf_grid, const float* sdf_exact, const int32_t* idx, int64_t G, int B, int cap, const int32_t* cnt,
+                                     float* margin, float* max_dev, int32_t* violations, const int32_t* reused, void* stream);
 extern "C" int sdfr_prefilter_guard(float* sdf_grid, const float* sdf_exact, const int32_t* idx, int64_t G, int B, int cap,
                                     const int32_t* cnt, float* margin, float* max_dev, int32_t* violations, void* stream) {
+    return sdfr_prefilter_guard2(sdf_grid, sdf_exact, idx, G, B, cap, cnt, margin, max_dev, violations, nullptr, stream);
+}
+
+// ... with the plan's reuse flags: crops that reused their candidate set are patched but not judged (their old values were exact ones)
+extern "C" int sdfr_prefilter_guard2(float* sdf_grid, const float* sdf_exact, const int32_t* idx, int64_t G, int B, int cap, const int32_t* cnt,
+                                     float* margin, float* max_dev, int32_t* violations, const int32_t* reused, void* stream) {
     SDFR_REQUIRE(sdf_grid && sdf_exact && idx && margin && max_dev && violations, "sdfr_prefilter_guard: NULL argument");
     if (B <= 0 || cap <= 0) return SDFR_OK;
     hipLaunchKernelGGL(sdfr_prefilter_guard_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, sdf_grid, sdf_exact, idx, G, cap, cnt, margin,
-                       max_dev, violations);
+                       max_dev, violations, reused);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

@@ -520,3 +520,42 @@ def test_prefilter_guard_trips_grows_the_margin_and_raises(dec):
     before = br.prefilter_report()["violations"]
     br.forward(*a)                                         # with the grown margin the next step is quiet
     assert br.prefilter_report()["violations"] == before
+
+
+def test_prefilter_candidate_reuse_skips_the_half_pass_and_changes_nothing(dec):
+    """decoder.prefilter_reuse: while the normalised latent has moved less than margin / (4 lip) since the last half pass, that pass and the
+    candidate selection are skipped (decided per crop on the device).  The refinement must be bit-identical to the plain two-stage mode, most
+    steps must reuse, and a jump of the latent must force a fresh half pass."""
+    z = gold("g8_optimizer.npz")
+    D, H, W = 40, 64, 64
+    K = K_for(H, W)
+    init = z["init"]
+    B = 3
+    rep = lambda a: np.tile(np.asarray(a, np.float32).reshape(1, -1), (B, 1))
+    gt = sdflabel_amd.BatchRenderer(dec, D, K, (W, H), 1, device=DEV)
+    o = gt.forward(T(np.array([0.6], np.float32)), T(np.array([[0.0, 0.0, 3.5]], np.float32)), T(np.array([[0.3, -0.5, 0.8]], np.float32)))
+    lidar = N(o["xyzf"][0, :int(o["nf"][0])] * 2.0)[::2].copy()
+    target = np.repeat(N(o["color"]), B, 0)
+    p0 = {"yaw": rep(init[0:1]) + np.array([[0.0], [0.05], [-0.05]], np.float32), "trans": rep([0.03, 0.02, 3.45]), "scale": rep([2.0]),
+          "latent": rep(init[5:8]) + np.array([[0, 0, 0], [0.1, 0, 0], [0, -0.1, 0.1]], np.float32)}
+    rows, reused = [], 0
+    for reuse in (False, True):
+        dp, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter")
+        dp.prefilter_reuse = reuse
+        rf = sdflabel_amd.BatchRefiner(dp.to(DEV), D, K, (H, W), B, lidar_cap=2048, device=DEV)
+        assert rf.br.reuse == reuse and rf.br.lipschitz > 0
+        rf.set_crops(p0, target, [lidar] * B)
+        for it in range(30):
+            rf.iteration()
+            if reuse:
+                reused += int(rf.br.reuse_flag.sum())
+        rows.append(N(rf.results()[0]))
+        if reuse:
+            assert rf.br.prefilter_report()["violations"] == 0
+            # a jump of the latent: the plan must order a fresh half pass for that crop only
+            with torch.no_grad():
+                rf.latent[1] += torch.tensor([0.5, -0.4, 0.3], device=DEV)
+            rf.iteration()
+            assert N(rf.br.reuse_flag).tolist() == [1, 0, 1] or N(rf.br.reuse_flag)[1] == 0
+    assert np.array_equal(rows[0], rows[1])
+    assert reused >= 0.8 * 29 * B, reused              # (the first step of a crop and every 17th run the half pass)

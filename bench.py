@@ -501,7 +501,7 @@ def main():
                     o_ = tstep()
                 torch.cuda.synchronize()
                 dt_t = (time.perf_counter() - t_) / nrep
-                sphere[label] = {"value": H * W / dt_t, "unit": "rays/s", "ms_per_render_fwd_bwd": dt_t * 1e3, "march_steps": steps,
+                sphere[label] = {"value": H * W / dt_t, "unit": "rays/s", "ms_per_render_fwd_bwd": dt_t * 1e3, "march_steps": steps, "march_steps_run": int(tr.steps_run),
                                  "rays_entering_the_object_cube": int(tr.n_entered), "hits": int(tr.n_hit),
                                  "unresolved_after_last_step": int(tr.n_unresolved), "max_abs_sdf_at_marched_hits": float(tr.hit_residual.abs().max())}
                 del tr, d3

@@ -58,7 +58,9 @@ class SphereTracer:
         self.hit_lam, self.hit_sdf = f(B * P), f(B * P)
         yy, xx = torch.meshgrid(torch.arange(self.H, device=dev), torch.arange(self.W, device=dev), indexing="ij")
         self.pixel_h = torch.stack([xx.reshape(-1), yy.reshape(-1), torch.ones(P, device=dev, dtype=torch.long)], -1).float()    # (P,3)
-        self.active_per_step = None
+        self.check_every = 8            # host looks at the active count every 8 steps and stops the march when it is empty (0: never)
+        self.stop_fraction = 5e-4       # ... or holds fewer than this fraction of the rays that entered the cube (they count as unresolved)
+        self.steps_run = 0
 
     # ------------------------------------------------------------------------------------------------------------------
     def march(self, pose, latn):
@@ -82,8 +84,15 @@ class SphereTracer:
                 ck(L.sdfr_trace_step(P(pose_c), P(self.Kinv), P(latn_c), self.L, W, H, self.eps, self.relax, P(self.sdf), P(self.counters), s, n0,
                                      P(self.pix[a]), P(self.lam[a]), P(self.pix[b]), P(self.lam[b]), P(self.far), P(self.inputs), P(self.hit_lam),
                                      P(self.hit_sdf), st), "sdfr_trace_step")
+                done = s + 1
+                # every few steps look at the active count: a step costs one decoder pass of latency even for a single ray (0.5 ms with the
+                # f32 decoder), and after ~30 steps only a few rays creeping along the surface are left
+                if self.check_every and done % self.check_every == 0 and done < self.steps and \
+                        int(self.counters[done % 3]) <= self.stop_fraction * n0:
+                    break
+            self.steps_run = done
             self.n_entered = n0
-            self.n_unresolved = self.counters[self.steps % 3]       # device scalar: rays still active after the last step (treated as misses)
+            self.n_unresolved = self.counters[done % 3]             # device scalar: rays still active after the last step (treated as misses)
         return n0
 
     def forward(self, yaw, trans, latent, newton=True):

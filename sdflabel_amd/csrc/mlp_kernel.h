@@ -667,6 +667,15 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             float y = 0.f;
 #pragma unroll
             for (int q = 0; q < SL; ++q) y += red[q * PT + tid];
+            if (KGX > KG && P.kinj) {
+                // K-side injection: input columns concatenated in front of the LAST linear (xyz_in_all) are not in the feature slots; their
+                // products come from the tile's input rows kept behind them
+                const MlpLayer Ll = P.L[P.n_mfma];
+                for (int c = 0; c < Ll.inj_n; ++c) {
+                    const int kc = Ll.inj_off + c;
+                    y = fmaf((float)act_e[((KG + kc / KV) * PT + tid) * KV + (kc % KV)], P.w_last[P.L[P.n_mfma - 1].out_dim + c], y);
+                }
+            }
             y += P.b_last;
             const float y1 = P.use_tanh ? tanhf(y) : y;
             const float o = tanhf(y1);

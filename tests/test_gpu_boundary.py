@@ -218,3 +218,32 @@ def test_reference_module_names_resolve_through_the_compat_path():
             assert all(hasattr(m, n) for n in names), mod
     finally:
         sys.path.remove(compat)
+
+
+@pytest.mark.parametrize("kw", [dict(latent_in=[2, 4], xyz_in_all=False), dict(latent_in=[3], xyz_in_all=True), dict(latent_in=(), xyz_in_all=True)])
+def test_half_forward_k_side_injection_for_other_injection_patterns(kw):
+    """the half forward keeps re-injected input columns behind the feature slots of its operand tile (K-side injection): check it on 512-wide
+    decoders with several latent_in layers and with xyz_in_all (injection offset = latent size, injection in every layer) against the
+    exact-f32 kernels of the same weights"""
+    torch.manual_seed(5)
+    d = sdflabel_amd.Decoder(3, dims=[300, 512, 512, 400, 512, 512], norm_layers=(), weight_norm=False, **kw)
+    with torch.no_grad():
+        for p in d.parameters():
+            p.mul_(1.5)
+    d = d.to(DEV).eval()
+    x = (torch.randn(700, 6, device=DEV) * 0.6).contiguous()
+    d.mlp_precision = torch.float32
+    s32, _ = d(x)
+    d.mlp_precision = torch.float16
+    s16, _ = d(x)
+    err = float((s32 - s16).abs().max())
+    assert 0 < err < 1e-2, err
+    # and the mask-fed half Jacobian on top of it stays close to the exact one
+    xr = x.clone().requires_grad_(True)
+    d.mlp_precision = torch.float32
+    d(xr)[0].sum().backward()
+    g32 = xr.grad.clone()
+    xr.grad = None
+    d.mlp_precision = torch.float16
+    d(xr)[0].sum().backward()
+    assert float((xr.grad - g32).abs().max()) < 5e-2 * max(1.0, float(g32.abs().max()))

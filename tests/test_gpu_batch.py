@@ -559,3 +559,40 @@ def test_prefilter_candidate_reuse_skips_the_half_pass_and_changes_nothing(dec):
             assert N(rf.br.reuse_flag).tolist() == [1, 0, 1] or N(rf.br.reuse_flag)[1] == 0
     assert np.array_equal(rows[0], rows[1])
     assert reused >= 0.8 * 29 * B, reused              # (the first step of a crop and every 17th run the half pass)
+
+
+@pytest.mark.parametrize("kw", [dict(latent_in=[2, 4], xyz_in_all=False), dict(latent_in=[3], xyz_in_all=True), dict(latent_in=(), xyz_in_all=False)])
+def test_band_jacobian_variants_on_ragged_512_wide_decoders(kw):
+    """16-row and 32-row band-Jacobian kernels on 512-wide decoders whose layers are NOT all 512 wide (300 / 400 features: partly filled
+    feature tiles take the thin-layer product paths) and with other injection patterns: identical bits between the two kernels, and both
+    equal to the oracle's input Jacobian."""
+    from oracle import sdf_oracle as O
+    torch.manual_seed(11)
+    dims = [300, 512, 512, 400, 512, 512]
+    d = sdflabel_amd.Decoder(3, dims=dims, norm_layers=(), weight_norm=False, **kw)
+    with torch.no_grad():
+        for p in d.parameters():
+            p.mul_(1.3)
+    d = d.to(DEV).eval()
+    D, B = 10, 9
+    G = D ** 3
+    rng = np.random.default_rng(4)
+    lats = rng.standard_normal((B, 3)).astype(np.float32)
+    yaws = np.zeros(B, np.float32); trans = np.tile(np.array([[0.0, 0.0, 3.5]], np.float32), (B, 1))
+    big = sdflabel_amd.BatchRenderer(d, D, K_for(16, 16), (16, 16), B, cap=G, threshold=1e9, device=DEV)       # every grid row is a band row
+    one = sdflabel_amd.BatchRenderer(d, D, K_for(16, 16), (16, 16), 1, cap=G, threshold=1e9, device=DEV)
+    big.forward(T(yaws), T(trans), T(lats))
+    assert int(big.cnt.min()) == G
+    layers = [(W, b, None) for W, b in d.effective_layers()]
+    spec = dict(dims=dims, latent_in=list(kw["latent_in"]), xyz_in_all=kw["xyz_in_all"])
+    for b in (0, 8):
+        one.forward(T(yaws[b:b + 1]), T(trans[b:b + 1]), T(lats[b:b + 1]))
+        assert torch.equal(one.J[0], big.J[b]) and torch.equal(one.sdf_band[0], big.sdf_band[b])
+        inp = N(big.inputs.view(B, G, 6)[b])
+        ref, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+        Jref = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(ref))
+        assert np.abs(N(big.sdf.view(B, G)[b]) - ref[:, 0]).max() < 1e-5
+        # (27 M hidden units per crop: a few pre-activations sit within float rounding of 0 and take the other ReLU side in the oracle's
+        # summation order -- isolated elements off by ~1e-3 of a weight product; everything else agrees to rounding)
+        err = np.abs(N(big.J[b]) - Jref)
+        assert np.quantile(err, 0.999) < 5e-6 and err.max() < 5e-3 and (err > 5e-5).sum() <= 40, (np.quantile(err, 0.999), err.max(), (err > 5e-5).sum())

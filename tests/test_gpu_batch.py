@@ -559,6 +559,14 @@ def test_prefilter_candidate_reuse_skips_the_half_pass_and_changes_nothing(dec):
             assert N(rf.br.reuse_flag).tolist() == [1, 0, 1] or N(rf.br.reuse_flag)[1] == 0
     assert np.array_equal(rows[0], rows[1])
     assert reused >= 0.8 * 29 * B, reused              # (the first step of a crop and every 17th run the half pass)
+    # the plan is a device-side decision: the captured HIP graph replays it
+    dp, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter")
+    dp.prefilter_reuse = True
+    rg = sdflabel_amd.BatchRefiner(dp.to(DEV), D, K, (H, W), B, lidar_cap=2048, device=DEV)
+    rg.set_crops(p0, target, [lidar] * B)
+    rg.capture()
+    rg.optimize(30)
+    assert np.array_equal(N(rg.results()[0]), rows[0])
 
 
 @pytest.mark.parametrize("kw", [dict(latent_in=[2, 4], xyz_in_all=False), dict(latent_in=[3], xyz_in_all=True), dict(latent_in=(), xyz_in_all=False)])

@@ -247,3 +247,17 @@ def test_half_forward_k_side_injection_for_other_injection_patterns(kw):
     d.mlp_precision = torch.float16
     d(xr)[0].sum().backward()
     assert float((xr.grad - g32).abs().max()) < 5e-2 * max(1.0, float(g32.abs().max()))
+
+
+def test_standalone_functions_with_no_surfels():
+    """empty selections give empty / background-only results, as the reference's ops on (0,3) tensors do"""
+    from sdflabel_amd.renderer import primitives as prim, projection as proj
+    K = T(K_for(16, 16))
+    r = sdflabel_amd.Rasterer(K, (16, 16)).to(DEV)
+    e3, e2 = torch.zeros(0, 3, device=DEV), torch.zeros(0, 2, device=DEV)
+    w = prim.inside_surfel(K, r.grid, e2, e3, e3, diam=0.04, softclamp=False, add_bg=False)
+    assert w.shape == (0, 3, 256)
+    wb = prim.inside_surfel(K, r.grid, e2, e3, e3, diam=0.04, softclamp=False, add_bg=True)
+    assert wb.shape == (1, 3, 256) and float(wb.min()) == 1.0
+    o = proj.project_in_2D(K, torch.eye(4, device=DEV), e3, e3, e3, (16, 16))
+    assert o["points_3d"].shape == (0, 3) and o["points_3d_filt"].shape == (0, 3) and o["points_2d"].shape == (0, 2)

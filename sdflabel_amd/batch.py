@@ -11,7 +11,14 @@ parameters directly,
 
 with every buffer pre-allocated (ragged per-crop data lives in [B][cap] arrays with device-side counts), so a step is ~16 kernel
 launches on the current stream and can be captured in a HIP graph (`capture()`).  `overflow()` (one sync, call it when convenient)
-reports whether any crop's band exceeded `cap`.
+reports whether any crop's band exceeded `cap`; `check_overflow()` raises (the refinement loop calls it once after the iterations).
+
+Modes (all leave the arithmetic of what is consumed downstream unchanged):
+  binned          from 4 crops per launch the splat uses per-tile surfel lists built inside sdfr_surfels_forward (same bits as the scan)
+  freeze_shape    pose-only refinement: decoder, band and Jacobian evaluated once per latent, later forwards only re-project and splat
+  decoder.mlp_precision  float32 (exact-f32 MFMA, the parity path) | float16 | "float32_split" | "float32_prefilter" (two-stage evaluation
+                  with a device-side run-time guard; decoder.prefilter_reuse additionally skips the half pass while the candidate set is
+                  provably still valid) -- DESIGN.md 3.1
 """
 import torch
 

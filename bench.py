@@ -326,15 +326,21 @@ def main():
 
     def sharded_run(st):
         rf, mine, params, nocs_t, lidar = st
-        rows = []
-        for c0 in range(0, len(mine), CHUNK):
-            n = min(CHUNK, len(mine) - c0)
-            sel = list(range(c0, c0 + n)) + [c0 + n - 1] * (CHUNK - n)          # a short last chunk is padded with copies of its last crop
-            rf.set_crops({k: v[sel] for k, v in params.items()}, nocs_t, [lidar] * CHUNK)
-            rf.optimize(args.sharded_iters)
-            rows.append(rf.results()[0][:n])
-        local = torch.cat(rows) if rows else torch.zeros((0, 5 + rf.L), device=dev)
+        rows, failure = [], None
+        try:
+            for c0 in range(0, len(mine), CHUNK):
+                n = min(CHUNK, len(mine) - c0)
+                sel = list(range(c0, c0 + n)) + [c0 + n - 1] * (CHUNK - n)      # a short last chunk is padded with copies of its last crop
+                rf.set_crops({k: v[sel] for k, v in params.items()}, nocs_t, [lidar] * CHUNK)
+                rf.optimize(args.sharded_iters)
+                rows.append(rf.results()[0][:n])
+            local = torch.cat(rows) if rows else torch.zeros((0, 5 + rf.L), device=dev)
+        except Exception as e:                                 # a local failure still takes part in the collective (NaN rows), then reports
+            failure = e
+            local = torch.full((len(mine), 5 + rf.L), float("nan"), device=dev)
         st.append(gather_crop_results(local, args.total_crops, rank, world) if dist is not None else local)
+        if failure is not None:
+            raise failure
 
     sharded = None
     if args.total_crops > 0 and not args.no_extras and CB == 1:

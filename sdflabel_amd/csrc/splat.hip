@@ -27,6 +27,7 @@
 #include "sdfr_common.h"
 #include "splat_bbox.h"
 #include <float.h>
+#include <stdlib.h>
 
 #define SPL_LC 1024            // LDS candidate-list capacity per tile (beyond it the tile walks every surfel)
 #define SIGMOID_REACH 29.65f   // (r - d) * 3 > -88.73  <=>  d < r + 29.58: conservative reach of inside_circle's sigmoid(.) > 0
@@ -159,20 +160,40 @@ extern "C" int64_t sdfr_splat_ws_words(int B, int cap, int W, int H) {
 
 // ---- forward ----------------------------------------------------------------------------------------------------
 
-#define SPL_NW 8               // waves per 8x8 pixel tile (the forward is a latency chain over the tile's candidates: they are split SPL_NW ways;
-                               // measured per crop: 1 wave 71 us, 4 waves 26 us, 8 waves 21.5 us)
+#define SPL_NS 8               // candidate shares per 8x8 pixel tile: the forward is a latency chain over the tile's candidates, split SPL_NS ways
+                               // (measured per crop, one wave per share: 1 share 71 us, 4 shares 26 us, 8 shares 21.5 us).  The share
+                               // partition defines the summation order of the result, so it is the same in both launch geometries below.
 
-// One workgroup of SPL_NW waves per 8x8 pixel tile; lane = pixel.  (1) The waves scan the crop's surfel boxes together, 64*SPL_NW per
-// step, and merge their ballots in surfel order into the tile's candidate list (ascending, deterministic).  (2) Every wave takes a
-// contiguous share of each round of 64*SPL_NW candidates, stages it in its own LDS slice and walks it for its 64 pixels; the per-pixel
-// partial states (nu^2; then the online-softmax running maximum and sums) are merged across the waves in a fixed order, so the result is
-// reproducible bit for bit.  disc: the first sweep also records which pixels each candidate covers (one 64-bit ballot per candidate);
-// the second sweep skips candidates that cover no pixel of the tile and re-evaluates only the plane hit for the others.
-template <int PRIM>
-__global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const SplatArgs A, const int4* __restrict__ bbox,
-                                                                    const int32_t* __restrict__ bins, float* __restrict__ color,
-                                                                    float* __restrict__ mask, float* __restrict__ depth,
-                                                                    float* __restrict__ normals, float* __restrict__ aux) {
+struct SplatAcc {               // online-softmax state of one share for one pixel
+    float lmax, cs, c0, c1, c2, dz, n0, n1, n2;
+};
+__device__ __forceinline__ void acc_rescale(SplatAcc& a, float newmax) {
+    const float f = expf(a.lmax - newmax);            // exp(-inf) = 0 on the first hit
+    a.cs *= f; a.c0 *= f; a.c1 *= f; a.c2 *= f; a.dz *= f; a.n0 *= f; a.n1 *= f; a.n2 *= f;
+    a.lmax = newmax;
+}
+
+// One workgroup of PW waves per 8x8 pixel tile; lane = pixel.  (1) The waves scan the crop's surfel boxes together, 64*PW per step,
+// and merge their ballots in surfel order into the tile's candidate list (ascending, deterministic) -- or take the tile's entries of
+// the crop's tile lists.  (2) Each round of 64*SPL_NS candidates is cut into SPL_NS contiguous shares; a share is staged in LDS
+// (lane = candidate) and walked for the 64 pixels with broadcast LDS reads; the per-pixel partial states of the shares (nu^2; then the
+// online-softmax running maximum and sums) are merged in share order, so the result is reproducible bit for bit.
+//   PW = SPL_NS  one wave per share: the shortest latency chain per tile, 4 tiles per CU -- few crops (a launch that does not fill the chip)
+//   PW = 1       one wave walks the shares one after the other (states in registers, no workgroup barrier, 7 KiB of LDS): the same
+//                arithmetic in the same order, so the same bits, with 4x the tiles in flight per CU and no idle waves on light tiles --
+//                launches of many crops, where the candidate walk is VALU-throughput-bound rather than a latency chain
+// disc: the first sweep also records which pixels each candidate covers (one 64-bit ballot per candidate); the second sweep skips
+// candidates that cover no pixel of the tile and re-evaluates only the plane hit for the others (PW = 1 keeps ballots for tiles of at most
+// 64 candidates and re-evaluates the coverage otherwise: identical arithmetic).
+template <int PRIM, int PW>
+__global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs A, const int4* __restrict__ bbox,
+                                                                const int32_t* __restrict__ bins, float* __restrict__ color,
+                                                                float* __restrict__ mask, float* __restrict__ depth,
+                                                                float* __restrict__ normals, float* __restrict__ aux) {
+    static_assert(PW == 1 || PW == SPL_NS, "one wave per share, or one wave for all shares");
+    constexpr int SPW = SPL_NS / PW;                   // shares per wave
+    constexpr int NT = 64 * PW;
+    constexpr int LCOV = (PW == 1) ? 64 : SPL_LC;      // coverage ballots kept per tile
     const int b = blockIdx.y;
     const int W = A.W, H = A.H;
     const int tilesX = (W + 7) >> 3;
@@ -188,10 +209,10 @@ __global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const Splat
     const float diam = A.diam, C = A.depth_constant;
 
     __shared__ int list[SPL_LC];
-    __shared__ unsigned long long cov[SPL_LC];
-    __shared__ float sd[SPL_NW][11][64];
-    __shared__ float nured[SPL_NW][64];
-    __shared__ int wc[2][SPL_NW];
+    __shared__ unsigned long long cov[LCOV];
+    __shared__ float sd[PW][11][64];
+    __shared__ float nured[PW][64];
+    __shared__ int wc[2][PW];
     float (*red)[11][64] = sd;        // the final merge reuses each wave's own staging slice (dead by then): 36 KiB of LDS, 4 tiles per CU
 
     // ---- (1) candidate list: surfels whose conservative box overlaps this tile, ascending order --------------------------------
@@ -207,12 +228,26 @@ __global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const Splat
             binned = true;
             const int o0 = toff[blockIdx.x];
             nc = toff[blockIdx.x + 1] - o0;
-            if (nc > 0 && nc <= SPL_LC) {
+            const int32_t* tl = toff + T + 2 + o0;
+            if (PW == 1) {
+                if (nc > 0 && nc <= 64) {                  // ranks through lane reads
+                    const int v = (lane < nc) ? tl[lane] : 0x7fffffff;
+                    int r = 0;
+                    for (int j = 0; j < nc; ++j) r += (__builtin_amdgcn_readlane(v, j) < v) ? 1 : 0;
+                    if (lane < nc) list[r] = v;
+                } else if (nc <= SPL_LC) {
+                    for (int i = lane; i < nc; i += 64) {
+                        const int v = tl[i];
+                        int r = 0;
+                        for (int j = 0; j < nc; ++j) r += (tl[j] < v) ? 1 : 0;
+                        list[r] = v;
+                    }
+                }
+            } else if (nc > 0 && nc <= SPL_LC) {
                 int* tmp = reinterpret_cast<int*>(cov);
-                const int32_t* tl = toff + T + 2 + o0;
-                for (int i = threadIdx.x; i < nc; i += 64 * SPL_NW) tmp[i] = tl[i];
+                for (int i = threadIdx.x; i < nc; i += NT) tmp[i] = tl[i];
                 __syncthreads();
-                for (int i = threadIdx.x; i < nc; i += 64 * SPL_NW) {
+                for (int i = threadIdx.x; i < nc; i += NT) {
                     const int v = tmp[i];
                     int r = 0;
                     for (int j = 0; j < nc; ++j) r += (tmp[j] < v) ? 1 : 0;
@@ -229,15 +264,19 @@ __global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const Splat
         };
         bool ov = overlaps(wave * 64 + lane);
         int par = 0;
-        for (int s0 = 0; s0 < count; s0 += 64 * SPL_NW, par ^= 1) {
+        for (int s0 = 0; s0 < count; s0 += NT, par ^= 1) {
             const int s = s0 + wave * 64 + lane;
-            const bool ovn = overlaps(s + 64 * SPL_NW);              // next step's boxes are in flight across the barrier
+            const bool ovn = overlaps(s + NT);                       // next step's boxes are in flight across the barrier
             const unsigned long long bal = __ballot(ov);
-            if (lane == 0) wc[par][wave] = __popcll(bal);
-            __syncthreads();
             int off = nc, tot = 0;
+            if (PW > 1) {
+                if (lane == 0) wc[par][wave] = __popcll(bal);
+                __syncthreads();
 #pragma unroll
-            for (int w = 0; w < SPL_NW; ++w) { const int c = wc[par][w]; off += (w < wave) ? c : 0; tot += c; }
+                for (int w = 0; w < PW; ++w) { const int c = wc[par][w]; off += (w < wave) ? c : 0; tot += c; }
+            } else {
+                tot = __popcll(bal);
+            }
             if (ov) {
                 const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
                 if (pos < SPL_LC) list[pos] = s;
@@ -248,6 +287,7 @@ __global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const Splat
     }
     const bool overflow = nc > SPL_LC;
     const int total = overflow ? count : nc;
+    const bool use_cov = !overflow && total <= LCOV;
     __syncthreads();
     if (total == 0 && !A.bg && !(PRIM == 1 && count > 0)) {          // nothing can touch this tile: all outputs are zero
         if (wave != 0 || !inside) return;
@@ -269,74 +309,92 @@ __global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const Splat
     const float k00 = A.K[(int64_t)b * 9];
     float (*sdw)[64] = sd[wave];
 
-    // ---- (2) walk the candidates in rounds of 64*SPL_NW: this wave's contiguous share of a round is staged in its LDS slice (lane =
-    // candidate) and broadcast-read.  A tile with at most 64*SPL_NW candidates stages once and keeps them for both sweeps.
+    // ---- (2) walk the candidates in rounds of 64*SPL_NS, each cut into SPL_NS contiguous shares.  A wave stages its shares of a round in
+    // its LDS slice (lane = candidate) -- all of them at once when they fit the slice, else share by share -- and broadcast-reads them.
+    // A tile whose candidates all fit the slices stages once and keeps them for both sweeps.
     bool resident = false;
-    auto for_each = [&](auto&& body) {
-        for (int r0 = 0; r0 < total; r0 += 64 * SPL_NW) {
-            const int nr = min(64 * SPL_NW, total - r0);
-            const int q = (nr + SPL_NW - 1) / SPL_NW;                // share per wave (<= 64)
-            const int c0w = r0 + wave * q;
-            const int kn = max(0, min(q, r0 + nr - c0w));
-            if (!resident) {
-                __syncthreads();
-                if (lane < kn) {
-                    const int s = overflow ? (c0w + lane) : list[c0w + lane];
-                    const int64_t e = (sb + s) * 3;
-                    const float px = A.p_cam[e], py = A.p_cam[e + 1], pz = A.p_cam[e + 2];
-                    const float nx = A.n_cam[e], ny = A.n_cam[e + 1], nz = A.n_cam[e + 2];
-                    sdw[2][lane] = pz;
-                    sdw[3][lane] = nx; sdw[4][lane] = ny; sdw[5][lane] = nz;
-                    sdw[7][lane] = A.attr[e]; sdw[8][lane] = A.attr[e + 1]; sdw[9][lane] = A.attr[e + 2];
-                    if (PRIM == 0) {
-                        sdw[0][lane] = px; sdw[1][lane] = py;
-                        sdw[6][lane] = nx * px + ny * py + nz * pz;                  // :202
-                    } else {
-                        sdw[0][lane] = A.uv[(sb + s) * 2]; sdw[1][lane] = A.uv[(sb + s) * 2 + 1];
-                        sdw[6][lane] = fabsf(k00 * diam / (pz + FLT_EPSILON));       // :47 / :115
-                        sdw[10][lane] = depth_logit(pz, zn, C, nullptr);
-                    }
-                }
-                __syncthreads();
+    auto stage = [&](int from, int n) {
+        __syncthreads();
+        if (lane < n) {
+            const int s = overflow ? (from + lane) : list[from + lane];
+            const int64_t e = (sb + s) * 3;
+            const float px = A.p_cam[e], py = A.p_cam[e + 1], pz = A.p_cam[e + 2];
+            const float nx = A.n_cam[e], ny = A.n_cam[e + 1], nz = A.n_cam[e + 2];
+            sdw[2][lane] = pz;
+            sdw[3][lane] = nx; sdw[4][lane] = ny; sdw[5][lane] = nz;
+            sdw[7][lane] = A.attr[e]; sdw[8][lane] = A.attr[e + 1]; sdw[9][lane] = A.attr[e + 2];
+            if (PRIM == 0) {
+                sdw[0][lane] = px; sdw[1][lane] = py;
+                sdw[6][lane] = nx * px + ny * py + nz * pz;                  // :202
+            } else {
+                sdw[0][lane] = A.uv[(sb + s) * 2]; sdw[1][lane] = A.uv[(sb + s) * 2 + 1];
+                sdw[6][lane] = fabsf(k00 * diam / (pz + FLT_EPSILON));       // :47 / :115
+                sdw[10][lane] = depth_logit(pz, zn, C, nullptr);
             }
-            for (int k = 0; k < kn; ++k) body(k, c0w + k);
         }
-        resident = total <= 64 * SPL_NW;
+        __syncthreads();
+    };
+    auto for_each = [&](auto&& body) {
+        for (int r0 = 0; r0 < total; r0 += 64 * SPL_NS) {
+            const int nr = min(64 * SPL_NS, total - r0);
+            const int q = (nr + SPL_NS - 1) / SPL_NS;                // share size (<= 64)
+            const int base = r0 + wave * SPW * q;
+            const int len = max(0, min(SPW * q, r0 + nr - base));    // this wave's candidates of the round
+            const bool flat = (SPW == 1) || len <= 64;
+            if (flat && !resident) stage(base, len);
+#pragma unroll
+            for (int j = 0; j < SPW; ++j) {
+                const int c0w = base + j * q;
+                const int kn = max(0, min(q, r0 + nr - c0w));
+                if (!flat) stage(c0w, kn);
+                const int ko = flat ? j * q : 0;
+                for (int k = 0; k < kn; ++k) body(j, ko + k, c0w + k);
+            }
+        }
+        resident = (SPW == 1) ? total <= 64 * SPL_NS : total <= 64;
     };
 
     float nu = 0.f, nue = 1.f;
     if (PRIM == 0) {   // per-pixel norm nu = || -t * mask ||_2 over the surfels  (:227-228)
-        float nu2 = 0.f;
-        for_each([&](int k, int c) {
+        float part[SPW];
+#pragma unroll
+        for (int j = 0; j < SPW; ++j) part[j] = 0.f;
+        for_each([&](int j, int k, int c) {
             const Hit h = disc_eval(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, diam);
-            if (h.m) nu2 += h.t * h.t;
-            if (!overflow) {
+            if (h.m) part[j] += h.t * h.t;
+            if (use_cov) {
                 const unsigned long long cm = __ballot(h.m);
                 if (lane == 0) cov[c] = cm;
             }
         });
-        nured[wave][lane] = nu2;
-        __syncthreads();
-        nu2 = nured[0][lane];
+        float nu2;
+        if (PW > 1) {
+            nured[wave][lane] = part[0];
+            __syncthreads();
+            nu2 = nured[0][lane];
 #pragma unroll
-        for (int w = 1; w < SPL_NW; ++w) nu2 += nured[w][lane];
+            for (int w = 1; w < PW; ++w) nu2 += nured[w][lane];
+        } else {
+            nu2 = part[0];
+#pragma unroll
+            for (int j = 1; j < SPW; ++j) nu2 += part[j];
+        }
         nu = sqrtf(nu2);
         nue = nu + FLT_EPSILON;
     }
-    // one sweep with a running maximum (online softmax): max logit, softmax sums and composites (rasterer.py:119-144)
-    float lmax = -FLT_MAX;
+    // one sweep with a running maximum per share (online softmax): max logit, softmax sums and composites (rasterer.py:119-144)
+    SplatAcc acc[SPW];
+#pragma unroll
+    for (int j = 0; j < SPW; ++j) {
+        acc[j].lmax = -FLT_MAX;
+        acc[j].cs = 0.f; acc[j].c0 = 0.f; acc[j].c1 = 0.f; acc[j].c2 = 0.f; acc[j].dz = 0.f; acc[j].n0 = 0.f; acc[j].n1 = 0.f; acc[j].n2 = 0.f;
+    }
     int ncov = 0;
-    float cs = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dz = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-    auto rescale = [&](float newmax) {
-        const float f = expf(lmax - newmax);          // exp(-inf) = 0 on the first hit
-        cs *= f; c0 *= f; c1 *= f; c2 *= f; dz *= f; n0 *= f; n1 *= f; n2 *= f;
-        lmax = newmax;
-    };
-    for_each([&](int k, int c) {
+    for_each([&](int j, int k, int c) {
         bool hit;
         float l;
         if (PRIM == 0) {
-            if (!overflow) {
+            if (use_cov) {
                 const unsigned long long cm = cov[c];            // wave-uniform
                 if (cm == 0ull) return;                           // covers no pixel of this tile
                 hit = (cm >> lane) & 1ull;
@@ -358,34 +416,53 @@ __global__ __launch_bounds__(64 * SPL_NW) void sdfr_splat_fwd_kernel(const Splat
             hit = stamp_axis(sdw[0][k], x, W) && stamp_axis(sdw[1][k], y, H);
         }
         if (hit) {
+            SplatAcc& a = acc[j];
             ++ncov;
-            if (l > lmax) rescale(l);
-            const float e = expf(l - lmax);
-            cs += e;
-            c0 += e * sdw[7][k]; c1 += e * sdw[8][k]; c2 += e * sdw[9][k];
-            dz += e * sdw[2][k];
-            n0 += e * ((sdw[3][k] + 1.f) / 2.f); n1 += e * ((sdw[4][k] + 1.f) / 2.f); n2 += e * ((sdw[5][k] + 1.f) / 2.f);
+            if (l > a.lmax) acc_rescale(a, l);
+            const float e = expf(l - a.lmax);
+            a.cs += e;
+            a.c0 += e * sdw[7][k]; a.c1 += e * sdw[8][k]; a.c2 += e * sdw[9][k];
+            a.dz += e * sdw[2][k];
+            a.n0 += e * ((sdw[3][k] + 1.f) / 2.f); a.n1 += e * ((sdw[4][k] + 1.f) / 2.f); a.n2 += e * ((sdw[5][k] + 1.f) / 2.f);
         }
     });
-    // merge the waves' partial states, in wave order
-    {
+    // merge the shares' partial states, in share order, into share 0
+    SplatAcc& S = acc[0];
+    if (PW > 1) {
         float (*rw)[64] = red[wave];
-        rw[0][lane] = lmax; rw[1][lane] = cs; rw[2][lane] = c0; rw[3][lane] = c1; rw[4][lane] = c2; rw[5][lane] = dz;
-        rw[6][lane] = n0; rw[7][lane] = n1; rw[8][lane] = n2; rw[9][lane] = __int_as_float(ncov);
+        rw[0][lane] = S.lmax; rw[1][lane] = S.cs; rw[2][lane] = S.c0; rw[3][lane] = S.c1; rw[4][lane] = S.c2; rw[5][lane] = S.dz;
+        rw[6][lane] = S.n0; rw[7][lane] = S.n1; rw[8][lane] = S.n2; rw[9][lane] = __int_as_float(ncov);
         __syncthreads();
         if (wave != 0) return;
-        float M = lmax;
+        float M = S.lmax;
 #pragma unroll
-        for (int w = 1; w < SPL_NW; ++w) M = fmaxf(M, red[w][0][lane]);
-        if (M > lmax) rescale(M);
+        for (int w = 1; w < PW; ++w) M = fmaxf(M, red[w][0][lane]);
+        if (M > S.lmax) acc_rescale(S, M);
 #pragma unroll
-        for (int w = 1; w < SPL_NW; ++w) {
-            const float f = expf(red[w][0][lane] - M);          // a wave without hits holds lmax = -FLT_MAX and zero sums
-            cs += f * red[w][1][lane]; c0 += f * red[w][2][lane]; c1 += f * red[w][3][lane]; c2 += f * red[w][4][lane];
-            dz += f * red[w][5][lane]; n0 += f * red[w][6][lane]; n1 += f * red[w][7][lane]; n2 += f * red[w][8][lane];
+        for (int w = 1; w < PW; ++w) {
+            const float f = expf(red[w][0][lane] - M);          // a share without hits holds lmax = -FLT_MAX and zero sums
+            S.cs += f * red[w][1][lane]; S.c0 += f * red[w][2][lane]; S.c1 += f * red[w][3][lane]; S.c2 += f * red[w][4][lane];
+            S.dz += f * red[w][5][lane]; S.n0 += f * red[w][6][lane]; S.n1 += f * red[w][7][lane]; S.n2 += f * red[w][8][lane];
             ncov += __float_as_int(red[w][9][lane]);
         }
+    } else {
+        float M = S.lmax;
+#pragma unroll
+        for (int j = 1; j < SPW; ++j) M = fmaxf(M, acc[j].lmax);
+        if (M > S.lmax) acc_rescale(S, M);
+#pragma unroll
+        for (int j = 1; j < SPW; ++j) {
+            const float f = expf(acc[j].lmax - M);
+            S.cs += f * acc[j].cs; S.c0 += f * acc[j].c0; S.c1 += f * acc[j].c1; S.c2 += f * acc[j].c2;
+            S.dz += f * acc[j].dz; S.n0 += f * acc[j].n0; S.n1 += f * acc[j].n1; S.n2 += f * acc[j].n2;
+        }
     }
+    float lmax = S.lmax, cs = S.cs, c0 = S.c0, c1 = S.c1, c2 = S.c2, dz = S.dz, n0 = S.n0, n1 = S.n1, n2 = S.n2;
+    auto rescale = [&](float newmax) {
+        const float f = expf(lmax - newmax);
+        cs *= f; c0 *= f; c1 *= f; c2 *= f; dz *= f; n0 *= f; n1 *= f; n2 *= f;
+        lmax = newmax;
+    };
     const int nunc = count - ncov;
     if (PRIM == 1 && nunc > 0 && 0.f > lmax) rescale(0.f);                        // uncovered surfels keep logit 0 (:70)
     const float lbg = A.bg ? A.bg_logit[b] : 0.f;
@@ -633,6 +710,17 @@ static int fill_args(SplatArgs& A, const char* who, int primitive, const float* 
     return SDFR_OK;
 }
 
+// tiles per launch from which the forward runs one wave per tile (SDFR_SPLAT_SERIAL_TILES overrides: 0 = always, a huge value = never).
+// Measured at 256x256 (1024 tiles per crop), lists ready: 4 crops 44 us wide / 129 us serial (the heaviest tile's chain is the launch),
+// 16 crops 146 / 157, 64 crops 550 / 424.
+static int64_t splat_serial_tiles() {
+    static const int64_t v = [] {
+        const char* e = getenv("SDFR_SPLAT_SERIAL_TILES");
+        return e ? (int64_t)atoll(e) : (int64_t)32768;
+    }();
+    return v;
+}
+
 extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam,
                                   const float* attr, const float* uv, const float* znorm, const float* bg, const float* bg_logit, int B,
                                   int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant, int32_t* bbox_ws,
@@ -652,23 +740,21 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
     int32_t* bins = (cap > 0 && use_bins) ? bbox_ws + (int64_t)B * cap * 4 : nullptr;
     const dim3 gb(sdfr_cdiv(cap > 0 ? cap : 1, 256), B);
     const dim3 gt(((W + 7) / 8) * ((H + 7) / 8), B);
+    // launch geometry (same results bit for bit): one wave per candidate share while the tiles do not fill the chip, one wave per tile beyond
+    const bool serial = (int64_t)gt.x * B >= splat_serial_tiles();
+#define SPL_LAUNCH_FWD(P)                                                                                                              \
+    do {                                                                                                                               \
+        if (cap > 0 && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<P>, gb, dim3(256), 0, s, A, bb);                        \
+        if (bins && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bin_kernel, dim3(B), dim3(1024), 0, s, A, bb, bins);                   \
+        if (serial) hipLaunchKernelGGL((sdfr_splat_fwd_kernel<P, 1>), gt, dim3(64), 0, s, A, bb, bins, color, mask, depth, normals, aux); \
+        else hipLaunchKernelGGL((sdfr_splat_fwd_kernel<P, SPL_NS>), gt, dim3(64 * SPL_NS), 0, s, A, bb, bins, color, mask, depth, normals, aux); \
+    } while (0)
     switch (primitive) {
-        case 0:
-            if (cap > 0 && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<0>, gb, dim3(256), 0, s, A, bb);
-            if (bins && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bin_kernel, dim3(B), dim3(1024), 0, s, A, bb, bins);
-            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<0>, gt, dim3(64 * SPL_NW), 0, s, A, bb, bins, color, mask, depth, normals, aux);
-            break;
-        case 1:
-            if (cap > 0 && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<1>, gb, dim3(256), 0, s, A, bb);
-            if (bins && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bin_kernel, dim3(B), dim3(1024), 0, s, A, bb, bins);
-            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<1>, gt, dim3(64 * SPL_NW), 0, s, A, bb, bins, color, mask, depth, normals, aux);
-            break;
-        default:
-            if (cap > 0 && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bbox_kernel<2>, gb, dim3(256), 0, s, A, bb);
-            if (bins && !boxes_ready) hipLaunchKernelGGL(sdfr_splat_bin_kernel, dim3(B), dim3(1024), 0, s, A, bb, bins);
-            hipLaunchKernelGGL(sdfr_splat_fwd_kernel<2>, gt, dim3(64 * SPL_NW), 0, s, A, bb, bins, color, mask, depth, normals, aux);
-            break;
+        case 0: SPL_LAUNCH_FWD(0); break;
+        case 1: SPL_LAUNCH_FWD(1); break;
+        default: SPL_LAUNCH_FWD(2); break;
     }
+#undef SPL_LAUNCH_FWD
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

@@ -92,3 +92,67 @@ def test_binned_ragged_batch_with_empty_and_full_crops():
         one = _splat(BINS, Kt[b:b + 1], Ki[b:b + 1], p[b:b + 1, :c].contiguous(), nrm[b:b + 1, :c].contiguous(), col[b:b + 1, :c].contiguous(), W, H)
         for x, y in zip(a[:5], one[:5]):
             assert torch.equal(x[b], y[0]), b
+
+
+def _splat_any(prim, K, Kinv, p, n, attr, W, H, B, uv=None, znorm=None, bg=None, bg_logit=None, diam=0.04):
+    L = _lib.lib()
+    cap = p.shape[-2]
+    ws = _lib.splat_ws(B, cap, W, H, DEV)
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=DEV)
+    outs = f(B, 3, H, W), f(B, 1, H, W), f(B, 1, H, W), f(B, 3, H, W), f(B, H * W, 4)
+    no_dn = bg is not None           # the reference rejects depth / normals together with a background (rasterer.py:133,139)
+    _lib.check(L.sdfr_splat_forward(prim, _lib.ptr(K), _lib.ptr(Kinv), _lib.ptr(p), _lib.ptr(n), _lib.ptr(attr), _lib.ptr(uv), _lib.ptr(znorm),
+                                    _lib.ptr(bg), _lib.ptr(bg_logit), B, cap, None, W, H, diam, 150.0, _lib.ptr(ws), _lib.ptr(outs[0]),
+                                    _lib.ptr(outs[1]), None if no_dn else _lib.ptr(outs[2]), None if no_dn else _lib.ptr(outs[3]),
+                                    _lib.ptr(outs[4]), _lib.stream_ptr()), "sdfr_splat_forward")
+    return outs[:2] + (outs[4],) if no_dn else outs
+
+
+@pytest.mark.parametrize("case", ["sparse", "dense", "list_overflow"])
+@pytest.mark.parametrize("bins", [0, BINS])
+def test_wave_per_tile_launch_is_bitwise_the_wave_per_share_launch(case, bins):
+    """from 32768 tiles per launch the forward runs one wave per tile walking the 8 candidate shares in turn (many crops) instead of one wave
+    per share: same share partition, same merge order -> the same bits.  sparse: <= 64 candidates per tile (kept resident); dense: hundreds
+    (staged share by share, two rounds); list_overflow: > 1024 candidates (every surfel walked, coverage re-evaluated)."""
+    H, W, n, spread, z0, z1 = {"sparse": (256, 256, 3000, 0.9, 3.0, 4.0), "dense": (64, 64, 700, 0.05, 0.3, 0.4),
+                               "list_overflow": (64, 64, 1300, 0.01, 0.05, 0.06)}[case]
+    tiles = ((W + 7) // 8) * ((H + 7) // 8)
+    B = 32768 // tiles + 1
+    rng = np.random.default_rng(21)
+    p, nrm, col = _surfels(rng, n, spread, z0, z1)
+    K = K_for(H, W)
+    Kt, Ki = T(K).view(1, 9), T(np.linalg.inv(K).astype(np.float32)).view(1, 9)
+    pt, nt, ct = T(p)[None], T(nrm)[None], T(col)[None]
+    one = _splat_any(bins, Kt, Ki, pt, nt, ct, W, H, 1)
+    rep = lambda t: t.expand(B, *t.shape[1:]).contiguous()
+    many = _splat_any(bins, rep(Kt), rep(Ki), rep(pt), rep(nt), rep(ct), W, H, B)
+    assert float(one[1].sum()) > 50
+    for x, y in zip(many, one):
+        for b in (0, B // 2, B - 1):
+            assert torch.equal(x[b], y[0]), (case, b)
+
+
+@pytest.mark.parametrize("prim", [1, 2])
+@pytest.mark.parametrize("use_bg", [False, True])
+def test_wave_per_tile_launch_secondary_primitives_and_background(prim, use_bg):
+    rng = np.random.default_rng(5 + prim)
+    H, W, n = 96, 128, 400
+    B = 32768 // (12 * 16) + 1
+    p, nrm, col = _surfels(rng, n, 0.8, 3.0, 4.0)
+    K = K_for(H, W)
+    uvw = (K @ p.T).T
+    uv = np.clip(uvw[:, :2] / (uvw[:, 2:3] + 1e-7), -1, [W, H]).astype(np.float32)
+    zn = np.array([np.linalg.norm(p[:, 2])], np.float32)
+    bg = rng.uniform(0, 1, (1, 3, H, W)).astype(np.float32) if use_bg else None
+    bgl = np.array([-0.3], np.float32) if use_bg else None
+    Kt, Ki = T(K).view(1, 9), T(np.linalg.inv(K).astype(np.float32)).view(1, 9)
+    diam = 0.02 if prim == 1 else 0.025
+    args = [Kt, Ki, T(p)[None], T(nrm)[None], T(col)[None]]
+    opt = dict(uv=T(uv)[None], znorm=T(zn), bg=None if bg is None else T(bg), bg_logit=None if bgl is None else T(bgl))
+    one = _splat_any(prim, *args, W, H, 1, diam=diam, **opt)
+    rep = lambda t: None if t is None else t.expand(B, *t.shape[1:]).contiguous()
+    many = _splat_any(prim, *[rep(t) for t in args], W, H, B, diam=diam, **{k: rep(v) for k, v in opt.items()})
+    assert float(one[1].sum()) > 50
+    for x, y in zip(many, one):
+        for b in (0, B - 1):
+            assert torch.equal(x[b], y[0]), (prim, use_bg, b)

@@ -28,6 +28,7 @@
 #include "splat_bbox.h"
 #include <float.h>
 #include <stdlib.h>
+#include <math.h>
 
 #define SPL_LC 1024            // LDS candidate-list capacity per tile (beyond it the tile walks every surfel)
 #define SIGMOID_REACH 29.65f   // (r - d) * 3 > -88.73  <=>  d < r + 29.58: conservative reach of inside_circle's sigmoid(.) > 0
@@ -39,6 +40,7 @@ struct SplatArgs {
     const float* bg; const float* bg_logit;       // optional background image [B][3][H][W] and its logit [B]
     int cap; const int32_t* cnt; int W, H;
     float diam, depth_constant;
+    float cover_sq;                               // PRIM 0: coverage threshold on the squared distance (disc_cover_sq)
 };
 
 struct Hit {
@@ -48,18 +50,31 @@ struct Hit {
     float b;       // disc: n.ray after the eps substitution
 };
 
-// primitives.py:209-226 for one (surfel, pixel) pair
+// primitives.py:209-226 for one (surfel, pixel) pair.  The coverage test  diam - ||v|| > 0  (:220,:226) is taken on the squared norm:
+// with a correctly rounded square root,  sqrt(x) < diam  <=>  x <= cover_sq  for the float cover_sq computed by disc_cover_sq() below --
+// the same decisions as the reference's norm-and-compare for every float x, without the square root.
 __device__ __forceinline__ Hit disc_eval(float px, float py, float pz, float nx, float ny, float nz, float a, float rx, float ry, float rz,
-                                         float diam) {
+                                         float cover_sq) {
     Hit h;
     const float b0 = rx * nx + ry * ny + rz * nz;                                // :209
     h.small = fabsf(b0) < 0.01f;                                                 // :210
     h.b = h.small ? FLT_EPSILON : b0;
     h.t = a / h.b;                                                               // :211
     const float vx = px - rx * h.t, vy = py - ry * h.t, vz = pz - rz * h.t;     // :212,:215
-    const float d = sqrtf(vx * vx + vy * vy + vz * vz);
-    h.m = (diam - d) > 0.f;                                                      // :220,:226
+    h.m = (vx * vx + vy * vy + vz * vz) <= cover_sq;                             // :220,:226
     return h;
+}
+
+// largest float x with RN(sqrt(x)) < diam: RN(sqrt(x)) < diam  <=>  sqrt(x) < m, m = midpoint of diam and its predecessor (25 significant
+// bits, so m*m is exact in double; sqrt(x) = m would need x = m*m, which is no float) <=>  x < m*m
+static float disc_cover_sq(float diam) {
+    if (!(diam > 0.f)) return -1.f;                                              // nothing is covered (x >= 0 always)
+    const float pred = nextafterf(diam, 0.f);
+    const double m = ((double)pred + (double)diam) * 0.5;
+    const double m2 = m * m;
+    float t = (float)m2;
+    if ((double)t >= m2) t = nextafterf(t, 0.f);
+    return t;
 }
 
 // primitives.py:42-49,55: sigmoid((r - ||uv - pixel||) * 3) > 0
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
 #pragma unroll
         for (int j = 0; j < SPW; ++j) part[j] = 0.f;
         for_each([&](int j, int k, int c) {
-            const Hit h = disc_eval(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, diam);
+            const Hit h = disc_eval(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, A.cover_sq);
             if (h.m) part[j] += h.t * h.t;
             if (use_cov) {
                 const unsigned long long cm = __ballot(h.m);
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
                 const float t = sdw[6][k] / bb;
                 l = fmaxf((-t) / nue + 1.f, 0.f) * C;                             // :227-230
             } else {
-                const Hit h = disc_eval(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, diam);
+                const Hit h = disc_eval(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, A.cover_sq);
                 l = fmaxf((-h.t) / nue + 1.f, 0.f) * C;
                 hit = h.m;
             }
@@ -558,7 +573,7 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
             bool cov;
             if (PRIM == 0) {
                 pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
-                h = disc_eval(px, py, pz, nx, ny, nz, a, rx, ry, rz, diam);
+                h = disc_eval(px, py, pz, nx, ny, nz, a, rx, ry, rz, A.cover_sq);
                 cov = h.m;
             } else if (PRIM == 1) {
                 cov = circle_cover(u, v, rad, (float)x, (float)y);
@@ -673,7 +688,7 @@ __global__ __launch_bounds__(256) void sdfr_splat_weights_kernel(const SplatArgs
         if (PRIM == 0) {
             float rx, ry, rz;
             pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
-            const Hit h = disc_eval(px, py, pz, nx, ny, nz, a, rx, ry, rz, A.diam);
+            const Hit h = disc_eval(px, py, pz, nx, ny, nz, a, rx, ry, rz, A.cover_sq);
             cov = h.m;
             logit = fmaxf((-h.t) / (ax.x + FLT_EPSILON) + 1.f, 0.f) * A.depth_constant;
         } else if (PRIM == 1) {
@@ -707,6 +722,7 @@ static int fill_args(SplatArgs& A, const char* who, int primitive, const float* 
     SDFR_REQUIRE((bg == nullptr) == (bg_logit == nullptr), "%s: bg and bg_logit go together", who);
     A.K = K; A.Kinv = Kinv; A.p_cam = p_cam; A.n_cam = n_cam; A.attr = attr; A.uv = uv; A.znorm = znorm; A.bg = bg; A.bg_logit = bg_logit;
     A.cap = cap; A.cnt = cnt; A.W = W; A.H = H; A.diam = diam; A.depth_constant = depth_constant;
+    A.cover_sq = disc_cover_sq(diam);
     return SDFR_OK;
 }
 

@@ -728,11 +728,11 @@ static int fill_args(SplatArgs& A, const char* who, int primitive, const float* 
 
 // tiles per launch from which the forward runs one wave per tile (SDFR_SPLAT_SERIAL_TILES overrides: 0 = always, a huge value = never).
 // Measured at 256x256 (1024 tiles per crop), lists ready: 4 crops 44 us wide / 129 us serial (the heaviest tile's chain is the launch),
-// 16 crops 146 / 157, 64 crops 550 / 424.
+// 16 crops 146 / 157, 64 crops 550 / 424; with the square-root-free coverage test: 16 crops 136 / 132, 32 crops 261 / 211, 64 crops - / 360.
 static int64_t splat_serial_tiles() {
     static const int64_t v = [] {
         const char* e = getenv("SDFR_SPLAT_SERIAL_TILES");
-        return e ? (int64_t)atoll(e) : (int64_t)32768;
+        return e ? (int64_t)atoll(e) : (int64_t)16384;
     }();
     return v;
 }

@@ -111,13 +111,13 @@ def _splat_any(prim, K, Kinv, p, n, attr, W, H, B, uv=None, znorm=None, bg=None,
 @pytest.mark.parametrize("case", ["sparse", "dense", "list_overflow"])
 @pytest.mark.parametrize("bins", [0, BINS])
 def test_wave_per_tile_launch_is_bitwise_the_wave_per_share_launch(case, bins):
-    """from 32768 tiles per launch the forward runs one wave per tile walking the 8 candidate shares in turn (many crops) instead of one wave
+    """from 16384 tiles per launch the forward runs one wave per tile walking the 8 candidate shares in turn (many crops) instead of one wave
     per share: same share partition, same merge order -> the same bits.  sparse: <= 64 candidates per tile (kept resident); dense: hundreds
     (staged share by share, two rounds); list_overflow: > 1024 candidates (every surfel walked, coverage re-evaluated)."""
     H, W, n, spread, z0, z1 = {"sparse": (256, 256, 3000, 0.9, 3.0, 4.0), "dense": (64, 64, 700, 0.05, 0.3, 0.4),
                                "list_overflow": (64, 64, 1300, 0.01, 0.05, 0.06)}[case]
     tiles = ((W + 7) // 8) * ((H + 7) // 8)
-    B = 32768 // tiles + 1
+    B = 16384 // tiles + 1
     rng = np.random.default_rng(21)
     p, nrm, col = _surfels(rng, n, spread, z0, z1)
     K = K_for(H, W)
@@ -137,7 +137,7 @@ def test_wave_per_tile_launch_is_bitwise_the_wave_per_share_launch(case, bins):
 def test_wave_per_tile_launch_secondary_primitives_and_background(prim, use_bg):
     rng = np.random.default_rng(5 + prim)
     H, W, n = 96, 128, 400
-    B = 32768 // (12 * 16) + 1
+    B = 16384 // (12 * 16) + 1
     p, nrm, col = _surfels(rng, n, 0.8, 3.0, 4.0)
     K = K_for(H, W)
     uvw = (K @ p.T).T

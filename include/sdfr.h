@@ -256,7 +256,8 @@ int sdfr_splat_weights_backward(int primitive, const float* K, const float* Kinv
  */
 
 /* pose[b] = [R_y(yaw_b) | t_b] with the rotation's row 1 negated (optimizer.py:87-90, utils/refinement.py:108-125);
- * inputs[b*G+g] = [latent_b / max(||latent_b||, 1e-12), grid[g]]  (optimizer.py:96-100);  latnorm[b] = the norm used. */
+ * inputs[b*G+g] = [latent_b / max(||latent_b||, 1e-12), grid[g]]  (optimizer.py:96-100);  latnorm[b] = the norm used.
+ * inputs == NULL: pose and latnorm only (pose-only refinement of a frozen shape; grid may then be NULL too). */
 int sdfr_params_forward(const float* yaw, const float* trans, const float* latent, int L, const float* grid, int64_t G, int B,
                         float* inputs, float* pose, float* latnorm, void* stream);
 
@@ -272,6 +273,7 @@ int sdfr_params_backward(const float* yaw, const float* latent, int L, const flo
 /* The backward tail of the batched step in one launch (latent sizes 1..8): sdfr_project_dcm_bwd (with its optional g_xyzf / fslot and
  * colour-map handling), sdfr_surface_latent_grad (g_latn[b][c] = sum_s -(g_points_s . normals_s) J[b][s][c]) and sdfr_params_backward,
  * with the same fixed-order reductions -- the results are bit-identical to calling the three.  g_points may be NULL (not stored).
+ * J == NULL: pose gradients only (the latent is not a variable: pose-only refinement); g_latn and g_latent are zero-filled.
  * Replaces the autograd of pipelines/optimizer.py:86-100 + sdfrenderer/renderer/projection.py:34-70 + sdfrenderer/grid.py:61. */
 int sdfr_pose_latent_backward(const float* pose, const float* points, const float* normals, const float* g_p_cam, const float* g_n_cam,
                               const float* g_col, int B, int cap, const int32_t* cnt, int output_nocs, const float* g_xyzf,

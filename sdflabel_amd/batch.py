@@ -170,8 +170,9 @@ class BatchRenderer:
         L = _lib.lib()
         P, st, ck = _lib.ptr, _lib.stream_ptr(), _lib.check
         B, G, cap, W, H = self.B, self.G, self.cap, self.W, self.H
-        ck(L.sdfr_params_forward(P(self.yaw), P(self.trans), P(self.latent), self.L, P(self.grid), G, B, P(self.inputs), P(self.pose),
-                                 P(self.latnorm), st), "sdfr_params_forward")
+        frozen = self.freeze_shape and self._shape_valid      # pose-only step: the decoder rows stay as they are, only pose / norm are rebuilt
+        ck(L.sdfr_params_forward(P(self.yaw), P(self.trans), P(self.latent), self.L, P(self.grid), G, B, None if frozen else P(self.inputs),
+                                 P(self.pose), P(self.latnorm), st), "sdfr_params_forward")
         if mlp_events is not None:
             mlp_events[0].record()
         if self.freeze_shape and self._shape_valid:
@@ -265,7 +266,7 @@ class BatchRenderer:
             # projection backward (with the (col + 1) / 2 map of the attribute and the gradient arriving through xyzf), latent gradient
             # and parameter gradients in one launch
             ck(L.sdfr_pose_latent_backward(P(self.pose), P(self.points), P(self.normals), P(self.g_p), P(self.g_n), P(self.g_a), B, cap,
-                                           P(self.cnt), self.nocs_mode | 4, P(g_xyzf), P(self.fslot), P(self.J), self.NI, self.L, P(self.yaw),
+                                           P(self.cnt), self.nocs_mode | 4, P(g_xyzf), P(self.fslot), None if self.freeze_shape else P(self.J), self.NI, self.L, P(self.yaw),
                                            P(self.latent), P(self.latnorm), None, P(self.g_pose), P(self.g_latn), P(self.g_yaw),
                                            P(self.g_trans), P(self.g_latent), st), "sdfr_pose_latent_backward")
             return self.g_yaw, self.g_trans, self.g_latent

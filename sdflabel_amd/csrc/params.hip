@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void sdfr_params_forward_kernel(const float* _
         P[12] = 0.f; P[13] = 0.f; P[14] = 0.f; P[15] = 1.f;
     }
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= G) return;
+    if (g >= G || !inputs) return;
     float* row = inputs + ((int64_t)b * G + g) * NI;
     for (int c = 0; c < L; ++c) row[c] = latent[b * L + c] / nrm;
     row[L] = grid[g * 3]; row[L + 1] = grid[g * 3 + 1]; row[L + 2] = grid[g * 3 + 2];
@@ -35,10 +35,11 @@ __global__ __launch_bounds__(256) void sdfr_params_forward_kernel(const float* _
 
 extern "C" int sdfr_params_forward(const float* yaw, const float* trans, const float* latent, int L, const float* grid, int64_t G,
                                    int B, float* inputs, float* pose, float* latnorm, void* stream) {
-    SDFR_REQUIRE(yaw && trans && latent && grid && inputs && pose && latnorm, "sdfr_params_forward: NULL argument");
+    // inputs == NULL: pose and latent norm only (pose-only refinement: the decoder rows of a frozen shape stay as they are)
+    SDFR_REQUIRE(yaw && trans && latent && (grid || !inputs) && pose && latnorm, "sdfr_params_forward: NULL argument");
     SDFR_REQUIRE(L >= 0 && L <= 1024 && G > 0, "sdfr_params_forward: bad size");
     if (B <= 0) return SDFR_OK;
-    hipLaunchKernelGGL(sdfr_params_forward_kernel, dim3(sdfr_cdiv(G, 256), B), dim3(256), 0, (hipStream_t)stream, yaw, trans, latent,
+    hipLaunchKernelGGL(sdfr_params_forward_kernel, dim3(inputs ? sdfr_cdiv(G, 256) : 1, B), dim3(inputs ? 256 : 64), 0, (hipStream_t)stream, yaw, trans, latent,
                        L, grid, G, inputs, pose, latnorm);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
@@ -219,9 +220,11 @@ __global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
         acc[4] += ay * x + by * nx; acc[5] += ay * y + by * ny; acc[6] += ay * z + by * nz; acc[7] += ay;
         acc[8] += az * x + bz * nx; acc[9] += az * y + bz * ny; acc[10] += az * z + bz * nz; acc[11] += az;
         const float gs = -(gx * nx + gy * ny + gz * nz);               // grid.py:61 backward: d p / d sdf = -n_hat
+        if (J) {
 #pragma unroll
-        for (int i = 0; i < LAT_MAXL; ++i)
-            if (i < L) lat[i] += gs * J[e1 * NI + i];
+            for (int i = 0; i < LAT_MAXL; ++i)
+                if (i < L) lat[i] += gs * J[e1 * NI + i];
+        }
     }
     __shared__ float red[12][PLB_THREADS / 64];
     __shared__ float redl[PLB_THREADS / 64];
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
     }
 #pragma unroll
     for (int i = 0; i < LAT_MAXL; ++i) {
-        if (i >= L) break;
+        if (i >= L || !J) break;
         float v = lat[i];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
         __syncthreads();
@@ -262,10 +265,14 @@ __global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
         const float c = cosf(yaw[b]), s = sinf(yaw[b]);
         g_yaw[b] = (-s) * g0 + c * g2 + (-c) * g8 + (-s) * g10;
         g_trans[b * 3] = red[3][0]; g_trans[b * 3 + 1] = red[7][0]; g_trans[b * 3 + 2] = red[11][0];
-        const float nrm = latnorm[b];
-        float dot = 0.f;
-        for (int i = 0; i < L; ++i) dot += (latent[b * L + i] / nrm) * s_latn[i];
-        for (int i = 0; i < L; ++i) g_latent[b * L + i] = (s_latn[i] - (latent[b * L + i] / nrm) * dot) / nrm;
+        if (J) {
+            const float nrm = latnorm[b];
+            float dot = 0.f;
+            for (int i = 0; i < L; ++i) dot += (latent[b * L + i] / nrm) * s_latn[i];
+            for (int i = 0; i < L; ++i) g_latent[b * L + i] = (s_latn[i] - (latent[b * L + i] / nrm) * dot) / nrm;
+        } else {                                                        // pose-only: the latent is not a variable
+            for (int i = 0; i < L; ++i) { g_latn[b * L + i] = 0.f; g_latent[b * L + i] = 0.f; }
+        }
     }
 }
 
@@ -274,7 +281,8 @@ extern "C" int sdfr_pose_latent_backward(const float* pose, const float* points,
                                          const float* g_xyzf, const int32_t* fslot, const float* J, int n_inputs, int L, const float* yaw,
                                          const float* latent, const float* latnorm, float* g_points, float* g_pose, float* g_latn,
                                          float* g_yaw, float* g_trans, float* g_latent, void* stream) {
-    SDFR_REQUIRE(pose && points && normals && J && yaw && latent && latnorm && g_pose && g_latn && g_yaw && g_trans && g_latent,
+    // J == NULL: pose gradients only (pose-only refinement); g_latn / g_latent are zero-filled
+    SDFR_REQUIRE(pose && points && normals && yaw && latent && latnorm && g_pose && g_latn && g_yaw && g_trans && g_latent,
                  "sdfr_pose_latent_backward: NULL argument");
     SDFR_REQUIRE(L >= 1 && L <= LAT_MAXL && L <= n_inputs, "sdfr_pose_latent_backward: latent size %d outside [1,%d] (use the separate kernels)", L,
                  LAT_MAXL);

@@ -154,6 +154,9 @@ extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int6
     return SDFR_OK;
 }
 
+#ifndef SDFR_COUNTED_TILE16_ROWS
+#define SDFR_COUNTED_TILE16_ROWS 4096      // 256 CUs x 16 rows: below this every 16-row tile has a CU of its own
+#endif
 // forward over the first *n_dev rows of `inputs` (n_dev: device int32, clamped to n_max = the launch bound): the per-step decoder call of the
 // sphere tracer, whose active-ray count is produced on the device by the previous step (no host synchronisation).  half != 0: half operands.
 extern "C" int sdfr_mlp_forward_counted(const sdfr_decoder* d, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf, int half,
@@ -167,8 +170,14 @@ extern "C" int sdfr_mlp_forward_counted(const sdfr_decoder* d, const float* inpu
     hipStream_t s = (hipStream_t)stream;
     if (half) sdfr_launch_fwd_f16_512(P, n_max, false, s);
     else if (d->has_ln) sdfr_launch_ln(P, d->HP, false, sdfr_cdiv(n_max, 64), 1, s);
-    else if (d->HP == 512) sdfr_launch_fwd_f32_512(P, n_max, false, s);
-    else sdfr_launch_small(P, d->HP, 0, sdfr_cdiv(n_max, 64), 1, s);
+    else if (d->HP == 512) {
+        // two tile geometries, selected on the device by the count: 64-row tiles while the rows fill the chip, 16-row tiles (a quarter of the
+        // latency per workgroup) below SDFR_COUNTED_TILE16_ROWS -- the launch that does not apply exits at once
+        P.n_dev_lo = SDFR_COUNTED_TILE16_ROWS; P.n_dev_hi = 0x7fffffff;
+        if (n_max >= SDFR_COUNTED_TILE16_ROWS) sdfr_launch_fwd_f32_512(P, n_max, false, s);
+        P.n_dev_lo = 0; P.n_dev_hi = SDFR_COUNTED_TILE16_ROWS;
+        sdfr_launch_fwd_f32_512_tile16(P, n_max < SDFR_COUNTED_TILE16_ROWS ? n_max : (int64_t)SDFR_COUNTED_TILE16_ROWS, s);
+    } else sdfr_launch_small(P, d->HP, 0, sdfr_cdiv(n_max, 64), 1, s);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

@@ -35,3 +35,10 @@ void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks
                            dim3(64 * SDFR_JAC_SMALL_NW), 0, s, P);
     }
 }
+
+// Forward on 16-row tiles (the geometry of the band kernels above, MODE 0): a launch of at most a few thousand rows -- the thin steps of the
+// sphere tracer's march -- is one decoder pass of LATENCY per workgroup, and a 16-row tile's pass is 0.12 ms where a 64-row tile's is 0.44 ms.
+void sdfr_launch_fwd_f32_512_tile16(const MlpParams& P, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL((sdfr_mlp_kernel<float, 16, SDFR_JAC_SMALL_FT, 1, SDFR_JAC_SMALL_NW, SDFR_JAC_SMALL_PF, 0>), dim3(sdfr_cdiv(n, 16)),
+                       dim3(64 * SDFR_JAC_SMALL_NW), 0, s, P);
+}

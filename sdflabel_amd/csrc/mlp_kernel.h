@@ -75,6 +75,7 @@ struct MlpParams {
     const int32_t* skip;         // forward: optional per-crop flags (skip_rows rows per crop): workgroups whose rows all belong to flagged crops exit
     int64_t skip_rows;
     const int32_t* n_dev;        // forward: optional device-side row count (rows >= *n_dev are not evaluated; n is the launch bound)
+    int n_dev_lo, n_dev_hi;      // with n_dev and n_dev_hi > 0: the launch runs only while n_dev_lo <= *n_dev < n_dev_hi (two tile geometries of one step)
     unsigned long long* trace;   // builds with -DSDFR_MLP_TRACE: cycle stamps of workgroup 0 (sdfr_debug_set_trace), else unused
 };
 
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         const int64_t r0 = (int64_t)blockIdx.x * PT;
         const int64_t n_rows = P.n_dev ? min(P.n, (int64_t)*P.n_dev) : P.n;          // sphere tracing: the active-ray count lives on the device
         if (r0 >= n_rows) return;
+        if (P.n_dev && P.n_dev_hi > 0 && (*P.n_dev < P.n_dev_lo || *P.n_dev >= P.n_dev_hi)) return;
         if (P.skip) {                               // two-stage evaluation: crops that reuse their candidate set skip the half pass
             const int64_t r1 = min(r0 + PT, n_rows) - 1;
             if (P.skip[r0 / P.skip_rows] && P.skip[r1 / P.skip_rows]) return;
@@ -929,6 +931,7 @@ void sdfr_launch_fwd_f16_512(const MlpParams& P, int64_t n, bool save_masks, hip
 int sdfr_fwd_f16_512_np();                                                                        // its point tiles per workgroup
 void sdfr_launch_fwd_split_512(const MlpParams& P, int64_t n, bool save_masks, hipStream_t s);  // mlp_split.hip
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s); // mlp_jac.hip
+void sdfr_launch_fwd_f32_512_tile16(const MlpParams& P, int64_t n, hipStream_t s);                // mlp_jac.hip (forward on 16-row tiles: thin counted launches)
 void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s);                  // mlp_jac16.hip (mask-fed only)
 void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)
 void sdfr_launch_ln(const MlpParams& P, int HP, bool jac, int grid_x, int grid_y, hipStream_t s);        // mlp_ln.hip (LayerNorm decoders)

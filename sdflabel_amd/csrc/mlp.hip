@@ -168,8 +168,12 @@ extern "C" int sdfr_mlp_forward_counted(const sdfr_decoder* d, const float* inpu
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.n_dev = n_dev; P.trace = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (half) sdfr_launch_fwd_f16_512(P, n_max, false, s);
-    else if (d->has_ln) sdfr_launch_ln(P, d->HP, false, sdfr_cdiv(n_max, 64), 1, s);
+    if (half) {
+        P.n_dev_lo = SDFR_COUNTED_TILE16_ROWS; P.n_dev_hi = 0x7fffffff;
+        if (n_max >= SDFR_COUNTED_TILE16_ROWS) sdfr_launch_fwd_f16_512(P, n_max, false, s);
+        P.n_dev_lo = 0; P.n_dev_hi = SDFR_COUNTED_TILE16_ROWS;
+        sdfr_launch_fwd_f16_512_tile16(P, n_max < SDFR_COUNTED_TILE16_ROWS ? n_max : (int64_t)SDFR_COUNTED_TILE16_ROWS, s);
+    } else if (d->has_ln) sdfr_launch_ln(P, d->HP, false, sdfr_cdiv(n_max, 64), 1, s);
     else if (d->HP == 512) {
         // two tile geometries, selected on the device by the count: 64-row tiles while the rows fill the chip, 16-row tiles (a quarter of the
         // latency per workgroup) below SDFR_COUNTED_TILE16_ROWS -- the launch that does not apply exits at once

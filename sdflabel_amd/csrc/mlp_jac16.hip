@@ -15,3 +15,10 @@ void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s) 
     const dim3 grid(sdfr_cdiv(cap, 16), B);
     hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 1, SDFR_J16_NW, SDFR_J16_PF, 3>), grid, dim3(64 * SDFR_J16_NW), 0, s, P);
 }
+
+// Forward with half operands on 16-row tiles (MODE 0): the thin steps of the sphere tracer's march with the float16 decoder -- one
+// decoder pass of latency per workgroup, paced by the 3.7 MB weight stream of a tile instead of the 128-point tile's matrix work.
+void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 1, SDFR_J16_NW, SDFR_J16_PF, 0>), dim3(sdfr_cdiv(n, 16)), dim3(64 * SDFR_J16_NW), 0, s,
+                       P);
+}

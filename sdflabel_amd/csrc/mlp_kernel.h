@@ -933,6 +933,7 @@ void sdfr_launch_fwd_split_512(const MlpParams& P, int64_t n, bool save_masks, h
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s); // mlp_jac.hip
 void sdfr_launch_fwd_f32_512_tile16(const MlpParams& P, int64_t n, hipStream_t s);                // mlp_jac.hip (forward on 16-row tiles: thin counted launches)
 void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s);                  // mlp_jac16.hip (mask-fed only)
+void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s);                // mlp_jac16.hip (half forward on 16-row tiles)
 void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)
 void sdfr_launch_ln(const MlpParams& P, int HP, bool jac, int grid_x, int grid_y, hipStream_t s);        // mlp_ln.hip (LayerNorm decoders)
 int sdfr_ln_points_per_wg(int HP, bool jac);

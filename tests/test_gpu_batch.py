@@ -427,6 +427,8 @@ def test_pose_only_refinement_caches_the_shape_exactly(dec):
         rf.optimize(8)
         rows, l2, l3 = rf.results()
         runs.append((N(rows), N(l2), N(l3)))
+        if freeze:                                   # the frozen step skips the latent gradient (sdfr_pose_latent_backward with J = NULL): zeros
+            assert float(rf.br.g_latent.abs().max()) == 0.0 and float(rf.br.g_yaw.abs().min()) > 0.0
         if freeze:                                   # a second set of crops through the same (captured) refiner: the new latent is picked up
             p1 = dict(p0); p1["latent"] = rep([0.2, 0.6, -0.4])
             rf.set_crops(p1, np.tile(z["nocs_target"][None], (B, 1, 1, 1)), [z["lidar"]] * B)

@@ -178,6 +178,12 @@ extern "C" int sdfr_gather_rows3(float* out, const float* src, const int32_t* id
 // the 12 pose sums; fixed-order reductions exactly as in the three separate kernels (bit-identical results), then the parameter
 // gradients.  Three launches of a few microseconds each become one.
 #define PLB_THREADS 1024
+#define PLB_UNROLL 3
+// XYZF: a gradient arrives through the front-facing rows (g_xyzf / fslot); LAT: the latent columns of J are contracted (J != NULL).
+// Absent optional inputs (g_pc, g_nc, g_col) are read from a valid dummy address and discarded, so that every load of a round is issued
+// before the first wait (uniform NULL branches around single loads serialised them: one L2 round trip each, 13.5 us per launch);
+// PLB_UNROLL rounds are loaded together.  The accumulation order per thread is unchanged (bit-identical results).
+template <bool XYZF, bool LAT>
 __global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
     const float* __restrict__ pose, const float* __restrict__ points, const float* __restrict__ normals, const float* __restrict__ g_pc,
     const float* __restrict__ g_nc, const float* __restrict__ g_col, int cap, const int32_t* __restrict__ cnt, int output_nocs,
@@ -196,34 +202,65 @@ __global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
     for (int i = 0; i < 12; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < LAT_MAXL; ++i) lat[i] = 0.f;
-    for (int s = tid; s < count; s += PLB_THREADS) {
-        const int64_t e1 = (int64_t)b * cap + s;
-        const int64_t e = e1 * 3;
-        const float x = points[e], y = points[e + 1], z = points[e + 2];
-        const float nx = normals[e], ny = normals[e + 1], nz = normals[e + 2];
-        float ax = g_pc ? g_pc[e] : 0.f, ay = g_pc ? g_pc[e + 1] : 0.f, az = g_pc ? g_pc[e + 2] : 0.f;
-        if (g_xyzf) {
-            const int fs = fslot[e1];
-            if (fs >= 0) { const int64_t f = ((int64_t)b * cap + fs) * 3; ax += g_xyzf[f]; ay += g_xyzf[f + 1]; az += g_xyzf[f + 2]; }
-        }
-        const float bx = g_nc ? g_nc[e] : 0.f, by = g_nc ? g_nc[e + 1] : 0.f, bz = g_nc ? g_nc[e + 2] : 0.f;
-        float gx = r00 * ax + r10 * ay + r20 * az;
-        float gy = r01 * ax + r11 * ay + r21 * az;
-        float gz = r02 * ax + r12 * ay + r22 * az;
-        if (g_col && output_nocs) {
-            float c0 = g_col[e], c1 = g_col[e + 1], c2 = g_col[e + 2];
-            if (output_nocs & 4) { c0 *= 0.5f; c1 *= 0.5f; c2 *= 0.5f; }
-            gx += ((output_nocs & 3) == 2) ? c0 : -c0; gy += c1; gz += c2;
-        }
-        if (g_points) { g_points[e] = gx; g_points[e + 1] = gy; g_points[e + 2] = gz; }
-        acc[0] += ax * x + bx * nx; acc[1] += ax * y + bx * ny; acc[2] += ax * z + bx * nz; acc[3] += ax;
-        acc[4] += ay * x + by * nx; acc[5] += ay * y + by * ny; acc[6] += ay * z + by * nz; acc[7] += ay;
-        acc[8] += az * x + bz * nx; acc[9] += az * y + bz * ny; acc[10] += az * z + bz * nz; acc[11] += az;
-        const float gs = -(gx * nx + gy * ny + gz * nz);               // grid.py:61 backward: d p / d sdf = -n_hat
-        if (J) {
+    const bool has_pc = g_pc != nullptr, has_nc = g_nc != nullptr, has_col = (g_col != nullptr) && output_nocs != 0;
+    const float* q_pc = has_pc ? g_pc : points;
+    const float* q_nc = has_nc ? g_nc : points;
+    const float* q_col = has_col ? g_col : points;
+    for (int s0 = tid; s0 < count; s0 += PLB_UNROLL * PLB_THREADS) {
+        float3 pt[PLB_UNROLL], nm[PLB_UNROLL], va[PLB_UNROLL], vb[PLB_UNROLL], vc[PLB_UNROLL], vx[PLB_UNROLL];
+        float jl[PLB_UNROLL][LAT_MAXL];
+        bool ok[PLB_UNROLL], fx[PLB_UNROLL];
 #pragma unroll
-            for (int i = 0; i < LAT_MAXL; ++i)
-                if (i < L) lat[i] += gs * J[e1 * NI + i];
+        for (int u = 0; u < PLB_UNROLL; ++u) {
+            const int s = s0 + u * PLB_THREADS;
+            ok[u] = s < count;
+            const int64_t e1 = (int64_t)b * cap + (ok[u] ? s : s0);
+            const int64_t e = e1 * 3;
+            pt[u] = make_float3(points[e], points[e + 1], points[e + 2]);
+            nm[u] = make_float3(normals[e], normals[e + 1], normals[e + 2]);
+            va[u] = make_float3(q_pc[e], q_pc[e + 1], q_pc[e + 2]);
+            vb[u] = make_float3(q_nc[e], q_nc[e + 1], q_nc[e + 2]);
+            vc[u] = make_float3(q_col[e], q_col[e + 1], q_col[e + 2]);
+            vx[u] = make_float3(0.f, 0.f, 0.f);
+            fx[u] = false;
+            if (XYZF) {
+                const int fs = fslot[e1];
+                fx[u] = fs >= 0;
+                const int64_t f = ((int64_t)b * cap + (fx[u] ? fs : 0)) * 3;                 // back-facing rows read slot 0 and discard it
+                vx[u] = make_float3(g_xyzf[f], g_xyzf[f + 1], g_xyzf[f + 2]);
+            }
+            if (LAT) {
+#pragma unroll
+                for (int i = 0; i < LAT_MAXL; ++i) jl[u][i] = (i < L) ? J[e1 * NI + i] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PLB_UNROLL; ++u) {
+            if (!ok[u]) continue;
+            const int64_t e = ((int64_t)b * cap + s0 + u * PLB_THREADS) * 3;
+            const float x = pt[u].x, y = pt[u].y, z = pt[u].z;
+            const float nx = nm[u].x, ny = nm[u].y, nz = nm[u].z;
+            float ax = has_pc ? va[u].x : 0.f, ay = has_pc ? va[u].y : 0.f, az = has_pc ? va[u].z : 0.f;
+            if (XYZF && fx[u]) { ax += vx[u].x; ay += vx[u].y; az += vx[u].z; }
+            const float bx = has_nc ? vb[u].x : 0.f, by = has_nc ? vb[u].y : 0.f, bz = has_nc ? vb[u].z : 0.f;
+            float gx = r00 * ax + r10 * ay + r20 * az;
+            float gy = r01 * ax + r11 * ay + r21 * az;
+            float gz = r02 * ax + r12 * ay + r22 * az;
+            if (has_col) {
+                float c0 = vc[u].x, c1 = vc[u].y, c2 = vc[u].z;
+                if (output_nocs & 4) { c0 *= 0.5f; c1 *= 0.5f; c2 *= 0.5f; }
+                gx += ((output_nocs & 3) == 2) ? c0 : -c0; gy += c1; gz += c2;
+            }
+            if (g_points) { g_points[e] = gx; g_points[e + 1] = gy; g_points[e + 2] = gz; }
+            acc[0] += ax * x + bx * nx; acc[1] += ax * y + bx * ny; acc[2] += ax * z + bx * nz; acc[3] += ax;
+            acc[4] += ay * x + by * nx; acc[5] += ay * y + by * ny; acc[6] += ay * z + by * nz; acc[7] += ay;
+            acc[8] += az * x + bz * nx; acc[9] += az * y + bz * ny; acc[10] += az * z + bz * nz; acc[11] += az;
+            if (LAT) {
+                const float gs = -(gx * nx + gy * ny + gz * nz);               // grid.py:61 backward: d p / d sdf = -n_hat
+#pragma unroll
+                for (int i = 0; i < LAT_MAXL; ++i)
+                    if (i < L) lat[i] += gs * jl[u][i];
+            }
         }
     }
     __shared__ float red[12][PLB_THREADS / 64];
@@ -246,7 +283,7 @@ __global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
     }
 #pragma unroll
     for (int i = 0; i < LAT_MAXL; ++i) {
-        if (i >= L || !J) break;
+        if (i >= L || !LAT) break;
         float v = lat[i];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
         __syncthreads();
@@ -265,7 +302,7 @@ __global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
         const float c = cosf(yaw[b]), s = sinf(yaw[b]);
         g_yaw[b] = (-s) * g0 + c * g2 + (-c) * g8 + (-s) * g10;
         g_trans[b * 3] = red[3][0]; g_trans[b * 3 + 1] = red[7][0]; g_trans[b * 3 + 2] = red[11][0];
-        if (J) {
+        if (LAT) {
             const float nrm = latnorm[b];
             float dot = 0.f;
             for (int i = 0; i < L; ++i) dot += (latent[b * L + i] / nrm) * s_latn[i];
@@ -289,9 +326,13 @@ extern "C" int sdfr_pose_latent_backward(const float* pose, const float* points,
     SDFR_REQUIRE(!g_xyzf || fslot, "sdfr_pose_latent_backward: g_xyzf needs fslot");
     SDFR_REQUIRE(output_nocs != 0, "sdfr_pose_latent_backward: built for the NOCS colour modes of the refinement loop");
     if (B <= 0) return SDFR_OK;
-    hipLaunchKernelGGL(sdfr_pose_latent_backward_kernel, dim3(B), dim3(PLB_THREADS), 0, (hipStream_t)stream, pose, points, normals, g_p_cam,
-                       g_n_cam, g_col, cap, cnt, output_nocs, g_xyzf, fslot, J, n_inputs, L, yaw, latent, latnorm, g_points, g_pose, g_latn,
-                       g_yaw, g_trans, g_latent);
+#define PLB_LAUNCH(X, LT)                                                                                                               \
+    hipLaunchKernelGGL((sdfr_pose_latent_backward_kernel<X, LT>), dim3(B), dim3(PLB_THREADS), 0, (hipStream_t)stream, pose, points, normals, \
+                       g_p_cam, g_n_cam, g_col, cap, cnt, output_nocs, g_xyzf, fslot, J, n_inputs, L, yaw, latent, latnorm, g_points, g_pose, \
+                       g_latn, g_yaw, g_trans, g_latent)
+    if (g_xyzf) { if (J) PLB_LAUNCH(true, true); else PLB_LAUNCH(true, false); }
+    else { if (J) PLB_LAUNCH(false, true); else PLB_LAUNCH(false, false); }
+#undef PLB_LAUNCH
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

@@ -120,14 +120,16 @@ def test_batch_capacity_overflow_flag(dec):
     assert br.overflow() and int(br.cnt[0]) == 167        # true band size (golden G3 'a'), only the first 64 kept
 
 
+@pytest.mark.parametrize("gfile", ["g8_optimizer.npz", "g8b_optimizer_128.npz"])
 @pytest.mark.parametrize("B,graph", [(1, False), (2, True)])
-def test_batch_refiner_trajectory_golden(dec, B, graph):
+def test_batch_refiner_trajectory_golden(dec, B, graph, gfile):
     """f1+f2+f3: the device-resident refinement loop (HIP losses + solver step) against the trajectory of the reference's own
-    Optimizer (golden G8): parameters after each of 10 iterations and the per-iteration weighted losses."""
-    z = gold("g8_optimizer.npz")
+    Optimizer (goldens G8: 32x32, D=20; G8b: BASELINE configs[0]'s 128x128, D=40): parameters after each of 10 iterations and the
+    per-iteration weighted losses."""
+    z = gold(gfile)
     D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
     init = z["init"]
-    rf = sdflabel_amd.BatchRefiner(dec, D, z["K"], (H, W), B, lidar_cap=256, weights={"2d": 0.3, "3d": 0.5}, device=DEV)
+    rf = sdflabel_amd.BatchRefiner(dec, D, z["K"], (H, W), B, lidar_cap=max(256, int(z["lidar"].shape[0])), weights={"2d": 0.3, "3d": 0.5}, device=DEV)
     rep = lambda a: np.tile(np.asarray(a, np.float32).reshape(1, -1), (B, 1))
     rf.set_crops({"yaw": rep(init[0:1]), "trans": rep(init[1:4]), "scale": rep(init[4:5]), "latent": rep(init[5:8])},
                  np.tile(z["nocs_target"][None], (B, 1, 1, 1)), [z["lidar"]] * B)
@@ -249,6 +251,21 @@ def test_split_decoder_batched_path_passes_the_float32_goldens():
     for tag in ("a", "b"):
         test_batch_gradients_golden(d, tag)
     test_batch_refiner_trajectory_golden(d, 2, True)
+
+
+@pytest.mark.parametrize("gfile", ["g8_optimizer.npz", "g8b_optimizer_128.npz"])
+def test_optimizer_mirror_trajectory_end_state(dec, gfile):
+    """the product-side Optimizer on both reference trajectories (G8, and G8b at BASELINE configs[0]'s size)"""
+    from sdflabel_amd.pipelines.optimizer import Optimizer
+    z = gold(gfile)
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    params = {"yaw": init[0:1].copy(), "trans": init[1:4].copy(), "scale": init[4:5].copy(), "latent": init[5:8].copy()}
+    opt = Optimizer(params, DEV, {"2d": 0.3, "3d": 0.5})
+    opt.optimize(10, T(z["nocs_target"]), z["lidar"], dec, sdflabel_amd.Grid3D(D, DEV), T(z["K"]), (H, W))
+    got = np.concatenate([N(params[k]).reshape(-1) for k in ("yaw", "trans", "scale", "latent")])
+    assert np.abs(got - z["traj"][-1]).max() < 5e-4, np.abs(got - z["traj"][-1])
+    assert abs(got[0] - init[0]) > 0.05
 
 
 @pytest.mark.parametrize("verbose", [False, True])

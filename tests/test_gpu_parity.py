@@ -469,11 +469,15 @@ def test_full_size_crop_vs_oracle_sample(dec, oracle_layers):
     assert np.abs(N(points["xyzf"]) - po["xyzf"]).max() < 1e-5
 
 
-def test_refinement_trajectory_golden(dec):
+G8_FILES = ["g8_optimizer.npz", "g8b_optimizer_128.npz"]       # 32x32 / D=20, and BASELINE configs[0]'s size: 128x128 / D=40
+
+
+@pytest.mark.parametrize("gfile", G8_FILES)
+def test_refinement_trajectory_golden(dec, gfile):
     """a8 / a-harness: 10 iterations of the reference's refinement loop (Adam + SGD, 2-D NOCS window loss, 3-D NN loss) restated in
-    tests/_harness.py on top of the drop-in modules, against the trajectory the reference's own Optimizer produced (golden G8)."""
+    tests/_harness.py on top of the drop-in modules, against the trajectory the reference's own Optimizer produced (goldens G8, G8b)."""
     from tests._harness import Refiner
-    z = gold("g8_optimizer.npz")
+    z = gold(gfile)
     D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
     init = z["init"]
     params = {"yaw": init[0:1], "trans": init[1:4], "scale": init[4:5], "latent": init[5:8]}

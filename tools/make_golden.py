@@ -339,10 +339,9 @@ def synth_targets(dec, D, H, W, latent_gt, yaw_gt, trans_gt, scale_gt):
     return K, nocs, lidar
 
 
-def g8():
+def g8(name="g8_optimizer.npz", D=20, H=32, W=32):
     from pipelines.optimizer import Optimizer
     dec = load_fitted()[0]
-    D, H, W = 20, 32, 32
     K, nocs, lidar = synth_targets(dec, D, H, W, [0.3, -0.5, 0.8], 0.6, [0.0, 0.0, 3.5], 2.0)
     params = {"yaw": [0.7], "trans": [0.03, 0.02, 3.45], "scale": [2.0], "latent": [0.5, -0.3, 0.6]}
     opt = Optimizer({k: list(v) for k, v in params.items()}, "cpu", {"2d": 0.3, "3d": 0.5})
@@ -360,9 +359,15 @@ def g8():
         l2d.append(float(parts[0]))
         l3d.append(float(parts[1].split(", Total")[0]))
     print("G8 losses2d", l2d[:3], "...", l2d[-1], "traj yaw", [t[0] for t in traj])
-    save("g8_optimizer.npz", D=D, H=H, W=W, K=K.numpy(), nocs_target=nocs.numpy(), lidar=lidar,
+    save(name, D=D, H=H, W=W, K=K.numpy(), nocs_target=nocs.numpy(), lidar=lidar,
          init=np.concatenate([np.asarray(params[k], np.float32) for k in ("yaw", "trans", "scale", "latent")]),
          traj=np.asarray(traj), loss2d_weighted=np.asarray(l2d), loss3d_weighted=np.asarray(l3d))
+
+
+def g8b():
+    """The same 10-iteration Optimizer trajectory at BASELINE configs[0]'s size: one 128x128 crop, D = 40 (the reference's dense 2-D loss
+    needs O(rendered pixels x H W) temporaries: ~2 GB here, out of reach at 256x256)."""
+    g8("g8b_optimizer_128.npz", D=40, H=128, W=128)
 
 
 def g9():
@@ -651,7 +656,7 @@ def g13():
     save("g13_primitives.npz", **arrs)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13}
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

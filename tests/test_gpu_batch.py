@@ -148,6 +148,30 @@ def test_batch_refiner_trajectory_golden(dec, B, graph, gfile):
         assert np.abs(traj[:, b] - z["traj"]).max() < 5e-4, np.abs(traj[:, b] - z["traj"]).max(axis=0)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_batch_refiner_follows_the_reference_for_the_full_60_iterations(dec, graph):
+    """the reference's refinement length (config_refine.ini:15): the reference Optimizer's own 60-iteration run (golden G8c) ends at
+    yaw 0.599 / z 3.512 (targets 0.6 / 3.5); the device-resident loop stays on that trajectory all the way and ends at the same pose, scale
+    and latent.  Tolerance 1e-3 on every parameter at every iteration (the two runs differ by float rounding in 60 chained Adam / SGD steps)."""
+    z = gold("g8c_optimizer_60it.npz")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    rf = sdflabel_amd.BatchRefiner(dec, D, z["K"], (H, W), 1, lidar_cap=256, weights={"2d": 0.3, "3d": 0.5}, device=DEV)
+    rf.set_crops({"yaw": init[None, 0:1], "trans": init[None, 1:4], "scale": init[None, 4:5], "latent": init[None, 5:8]},
+                 z["nocs_target"][None], [z["lidar"]])
+    if graph:
+        rf.capture()
+    traj = []
+    for _ in range(60):
+        rf.optimize(1)
+        traj.append(N(rf.results()[0])[0])
+    traj = np.asarray(traj)
+    dev = np.abs(traj - z["traj"]).max(axis=1)
+    assert dev.max() < 1e-3, (int(dev.argmax()), dev.max())
+    assert np.abs(traj[-1] - z["traj"][-1]).max() < 1e-3
+    assert abs(traj[-1, 0] - 0.6) < 5e-3 and abs(traj[-1, 3] - 3.5) < 2e-2          # and that is the target pose
+
+
 def test_losses_vs_torch_restatement(dec):
     """the HIP 2-D / 3-D losses and their gradients against the torch restatement of optimizer.py:166-237 (tests/_harness.py)."""
     from sdflabel_amd import _lib

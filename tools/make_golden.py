@@ -339,7 +339,7 @@ def synth_targets(dec, D, H, W, latent_gt, yaw_gt, trans_gt, scale_gt):
     return K, nocs, lidar
 
 
-def g8(name="g8_optimizer.npz", D=20, H=32, W=32):
+def g8(name="g8_optimizer.npz", D=20, H=32, W=32, iters=10):
     from pipelines.optimizer import Optimizer
     dec = load_fitted()[0]
     K, nocs, lidar = synth_targets(dec, D, H, W, [0.3, -0.5, 0.8], 0.6, [0.0, 0.0, 3.5], 2.0)
@@ -348,7 +348,7 @@ def g8(name="g8_optimizer.npz", D=20, H=32, W=32):
     grid = ref_grid.Grid3D(D, "cpu", torch.float32)
     traj = []
     buf = io.StringIO()
-    for it in range(10):
+    for it in range(iters):
         with contextlib.redirect_stdout(buf):
             opt.optimize(1, nocs, lidar, dec, grid, K, [H, W], viz_type=None)
         traj.append(np.concatenate([opt.params[k].detach().numpy().ravel() for k in ("yaw", "trans", "scale", "latent")]))
@@ -368,6 +368,11 @@ def g8b():
     """The same 10-iteration Optimizer trajectory at BASELINE configs[0]'s size: one 128x128 crop, D = 40 (the reference's dense 2-D loss
     needs O(rendered pixels x H W) temporaries: ~2 GB here, out of reach at 256x256)."""
     g8("g8b_optimizer_128.npz", D=40, H=128, W=128)
+
+
+def g8c():
+    """The reference's full refinement length (60 iterations, config_refine.ini:15) at the G8 size: where the reference converges to."""
+    g8("g8c_optimizer_60it.npz", iters=60)
 
 
 def g9():
@@ -656,7 +661,7 @@ def g13():
     save("g13_primitives.npz", **arrs)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13}
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G8c": g8c, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -46,6 +46,8 @@ class Optimizer:
         self.log = []             # per-iteration (weighted 2-D loss, weighted 3-D loss, total) when optimize(..., verbose=True)
         self._refiner = None
         self._key = None
+        self._adam = None         # Adam moments / step count of yaw and trans: the reference creates its solver in __init__ (optimizer.py:47-52),
+                                  # so the state carries over from one optimize() call of an Optimizer object to the next
 
     def _refiner_for(self, dsdf, grid, K, crop_size, n_lidar, optimize_latent=True):
         G = int(grid.points.size(0))
@@ -91,6 +93,8 @@ class Optimizer:
             rf.set_crops({'yaw': p['yaw'].detach().reshape(1, -1), 'trans': p['trans'].detach().reshape(1, 3),
                           'scale': p['scale'].detach().reshape(1, -1), 'latent': p['latent'].detach().reshape(1, -1)},
                          torch.as_tensor(nocs_pred, dtype=torch.float32)[None], [lidar])
+            if self._adam is not None:                        # refiners are shared between Optimizer objects; the solver state is not
+                rf.adam_m.copy_(self._adam[0]); rf.adam_v.copy_(self._adam[1]); rf.adam_t.copy_(self._adam[2])
             self.log = []
             if verbose:
                 for e in range(iters_optim):
@@ -106,6 +110,7 @@ class Optimizer:
                     rf.capture()                              # once per refiner: later crops replay the same graph
                 rf.optimize(iters_optim)
             rf.br.check_overflow()                            # a truncated band must not pass silently (one sync, after the loop)
+            self._adam = (rf.adam_m.clone(), rf.adam_v.clone(), rf.adam_t.clone())
             p['yaw'].copy_(rf.yaw.view_as(p['yaw']))
             p['trans'].copy_(rf.trans.view_as(p['trans']))
             p['scale'].copy_(rf.scale.view_as(p['scale']))

@@ -89,6 +89,35 @@ def test_surfel_capacity_overflow_raises_in_the_refinement_loop(dec):
         rf.results()
 
 
+def test_float16_refinement_against_the_references_own_float16_trajectory():
+    """configs[4]'s precision through the whole refinement loop: the reference Optimizer run with its shipped float16 setup (golden G8h:
+    half decoder, grid, K and target) beside its float32 run of the same problem (G8).  Tolerance stated up front, per parameter:
+    tol = 2 * d_ref + 1e-4 with d_ref = the largest gap between the reference's own two precisions over the 10 iterations
+    (2-3e-4 here) -- the float16 product path must stay within tol of BOTH reference trajectories at every iteration.  The Optimizer is
+    called ten times for one iteration each, as the golden was recorded: the Adam state must carry over between the calls."""
+    from sdflabel_amd.pipelines.optimizer import Optimizer
+    z, zh = gold("g8_optimizer.npz"), gold("g8h_optimizer_fp16.npz")
+    assert np.array_equal(z["nocs_target"], zh["nocs_target"]) and np.array_equal(z["init"], zh["init"])
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    d_ref = np.abs(z["traj"] - zh["traj"]).max(axis=0)
+    tol = 2 * d_ref + 1e-4
+    dsdf, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt")                                # reference default: float16
+    dsdf = dsdf.to(DEV)
+    grid = sdflabel_amd.Grid3D(D, DEV, torch.float16)
+    K = T(z["K"]).half()
+    params = {"yaw": init[0:1].copy(), "trans": init[1:4].copy(), "scale": init[4:5].copy(), "latent": init[5:8].copy()}
+    opt = Optimizer(params, DEV, {"2d": 0.3, "3d": 0.5})
+    traj = []
+    for _ in range(10):
+        opt.optimize(1, T(z["nocs_target"]).half(), z["lidar"], dsdf, grid, K, (H, W))
+        traj.append(np.concatenate([N(params[k]).reshape(-1) for k in ("yaw", "trans", "scale", "latent")]))
+    traj = np.asarray(traj)
+    e16, e32 = np.abs(traj - zh["traj"]).max(axis=0), np.abs(traj - z["traj"]).max(axis=0)
+    assert (e16 <= tol).all(), (e16, tol)
+    assert (e32 <= tol).all(), (e32, tol)
+
+
 def test_optimizer_mirror_with_the_reference_pipelines_float16_setup():
     """refine_css.py:144-153 with the shipped config (precision = float16): setup_dsdf default precision, Grid3D(D, device, float16), half K.
     The mirror must accept the half grid and refine towards the float32 trajectory's end state."""

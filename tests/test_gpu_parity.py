@@ -777,7 +777,7 @@ def test_split_decoder_passes_the_float32_goldens(dec_split, oracle_layers):
         test_surface_points_golden(dec_split, tag)
         test_end_to_end_gradients_golden(dec_split, tag)
     test_full_size_crop_vs_oracle_sample(dec_split, oracle_layers)
-    test_refinement_trajectory_golden(dec_split)
+    test_refinement_trajectory_golden(dec_split, "g8_optimizer.npz")
 
 
 def test_c_abi_smoke_binary_runs_without_python_or_torch(tmp_path):

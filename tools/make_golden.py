@@ -375,6 +375,32 @@ def g8c():
     g8("g8c_optimizer_60it.npz", iters=60)
 
 
+def g8h():
+    """The reference Optimizer in its shipped precision (config_refine.ini:19 float16: decoder, grid, K, target NOCS all half, as
+    refine_css.py:144-153 builds them) on the G8 problem: 10 iterations.  The float32 run of the same problem is golden G8; the gap between
+    the two is the yardstick of the tolerance stated in tests/test_gpu_configs.py."""
+    from pipelines.optimizer import Optimizer
+    D, H, W = 20, 32, 32
+    K, nocs, lidar = synth_targets(load_fitted()[0], D, H, W, [0.3, -0.5, 0.8], 0.6, [0.0, 0.0, 3.5], 2.0)
+    dec16 = load_fitted(torch.float16)[0]
+    params = {"yaw": [0.7], "trans": [0.03, 0.02, 3.45], "scale": [2.0], "latent": [0.5, -0.3, 0.6]}
+    opt = Optimizer({k: list(v) for k, v in params.items()}, "cpu", {"2d": 0.3, "3d": 0.5})
+    grid = ref_grid.Grid3D(D, "cpu", torch.float16)
+    traj, buf = [], io.StringIO()
+    for it in range(10):
+        with contextlib.redirect_stdout(buf):
+            opt.optimize(1, nocs.half(), lidar, dec16, grid, K.half(), [H, W], viz_type=None)
+        traj.append(np.concatenate([opt.params[k].detach().float().numpy().ravel() for k in ("yaw", "trans", "scale", "latent")]))
+    l2d, l3d = [], []
+    for l in (l for l in buf.getvalue().splitlines() if l.startswith("ITER")):
+        parts = l.split("2D - ")[1].split(", 3D - ")
+        l2d.append(float(parts[0])); l3d.append(float(parts[1].split(", Total")[0]))
+    print("G8h traj yaw", [t[0] for t in traj])
+    save("g8h_optimizer_fp16.npz", D=D, H=H, W=W, K=K.numpy(), nocs_target=nocs.numpy(), lidar=lidar,
+         init=np.concatenate([np.asarray(params[k], np.float32) for k in ("yaw", "trans", "scale", "latent")]),
+         traj=np.asarray(traj), loss2d_weighted=np.asarray(l2d), loss3d_weighted=np.asarray(l3d))
+
+
 def g9():
     """Secondary rows a6' / bg: Rasterer.forward with primitives circle / circle_opt and with a background image, plus autograd
     gradients w.r.t. the surfel positions and the pose."""
@@ -661,7 +687,7 @@ def g13():
     save("g13_primitives.npz", **arrs)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G8c": g8c, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13}
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G8c": g8c, "G8h": g8h, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

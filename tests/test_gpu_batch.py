@@ -172,6 +172,29 @@ def test_batch_refiner_follows_the_reference_for_the_full_60_iterations(dec, gra
     assert abs(traj[-1, 0] - 0.6) < 5e-3 and abs(traj[-1, 3] - 3.5) < 2e-2          # and that is the target pose
 
 
+@pytest.mark.parametrize("case", ["far", "nolidar", "blank"])
+def test_batch_refiner_skip_rules_and_degenerate_losses_golden(dec, case):
+    """the reference Optimizer's own runs (golden G8s) of: lidar out of reach (3-D loss 0, the step uses the 2-D loss alone -- whose
+    pose gradient is ~1e-9, so Adam moves yaw by 1e-5 per step, not 1e-2); no lidar at all ('Skip frame' every iteration, optimizer.py:127-129,
+    parameters untouched); an all-zero target image."""
+    z = gold("g8s_optimizer_skips.npz")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    rf = sdflabel_amd.BatchRefiner(dec, D, z["K"], (H, W), 1, lidar_cap=256, weights={"2d": 0.3, "3d": 0.5}, device=DEV)
+    rf.set_crops({"yaw": init[None, 0:1], "trans": init[None, 1:4], "scale": init[None, 4:5], "latent": init[None, 5:8]},
+                 z[case + "_target"][None], [z[case + "_lidar"]])
+    for it in range(4):
+        rf.optimize(1)
+        got = N(rf.results()[0])[0]
+        assert int(rf.stepped[0]) == 1 - int(z[case + "_skipped"][it])
+        ref = z[case + "_traj"][it]
+        if case == "nolidar":
+            assert np.array_equal(got, init)
+        else:
+            moved = np.abs(ref - init).max()
+            assert np.abs(got - ref).max() < max(2e-2 * moved, 2e-6), (it, got - ref, moved)
+
+
 def test_losses_vs_torch_restatement(dec):
     """the HIP 2-D / 3-D losses and their gradients against the torch restatement of optimizer.py:166-237 (tests/_harness.py)."""
     from sdflabel_amd import _lib

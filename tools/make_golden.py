@@ -401,6 +401,39 @@ def g8h():
          traj=np.asarray(traj), loss2d_weighted=np.asarray(l2d), loss3d_weighted=np.asarray(l3d))
 
 
+def g8s():
+    """The Optimizer's skip rules and degenerate losses (optimizer.py:127-129 no surfels / no lidar -> 'Skip frame'; :149-151 NaN or zero
+    loss -> 'Skip frame'; compute_loss_3d without close pairs -> 0): four iterations each of
+      far    lidar 5 m away: no pair within the threshold, the 3-D loss is 0 and the step uses the 2-D loss alone
+      nolidar  empty lidar array: every iteration skipped, parameters untouched
+      blank  target NOCS image all zero and far lidar: what the reference does with an empty 2-D target"""
+    from pipelines.optimizer import Optimizer
+    D, H, W = 20, 32, 32
+    dec = load_fitted()[0]
+    K, nocs, lidar = synth_targets(dec, D, H, W, [0.3, -0.5, 0.8], 0.6, [0.0, 0.0, 3.5], 2.0)
+    init = {"yaw": [0.7], "trans": [0.03, 0.02, 3.45], "scale": [2.0], "latent": [0.5, -0.3, 0.6]}
+    cases = {"far": (nocs, lidar + np.array([[5.0, 0.0, 0.0]], np.float32)), "nolidar": (nocs, np.zeros((0, 3), np.float32)),
+             "blank": (torch.zeros_like(nocs), lidar + np.array([[5.0, 0.0, 0.0]], np.float32))}
+    arrs = dict(D=D, H=H, W=W, K=K.numpy(), nocs_target=nocs.numpy(), lidar=lidar,
+                init=np.concatenate([np.asarray(init[k], np.float32) for k in ("yaw", "trans", "scale", "latent")]))
+    for tag, (tgt, ld) in cases.items():
+        opt = Optimizer({k: list(v) for k, v in init.items()}, "cpu", {"2d": 0.3, "3d": 0.5})
+        grid = ref_grid.Grid3D(D, "cpu", torch.float32)
+        traj, lines = [], []
+        for it in range(4):
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                opt.optimize(1, tgt, ld, dec, grid, K, [H, W], viz_type=None)
+            lines.append(buf.getvalue().strip().splitlines()[-1] if buf.getvalue().strip() else "")
+            traj.append(np.concatenate([opt.params[k].detach().numpy().ravel() for k in ("yaw", "trans", "scale", "latent")]))
+        print("G8s", tag, lines, [float(t[0]) for t in traj])
+        arrs[tag + "_traj"] = np.asarray(traj)
+        arrs[tag + "_skipped"] = np.array([1 if l.startswith("Skip") else 0 for l in lines], np.int32)
+        arrs[tag + "_lidar"] = ld
+        arrs[tag + "_target"] = tgt.numpy()
+    save("g8s_optimizer_skips.npz", **arrs)
+
+
 def g9():
     """Secondary rows a6' / bg: Rasterer.forward with primitives circle / circle_opt and with a background image, plus autograd
     gradients w.r.t. the surfel positions and the pose."""
@@ -687,7 +720,7 @@ def g13():
     save("g13_primitives.npz", **arrs)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G8c": g8c, "G8h": g8h, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13}
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G8c": g8c, "G8h": g8h, "G8s": g8s, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -1,7 +1,9 @@
 """bench.py -- rendered rays/sec (fwd+bwd) of the differentiable SDF renderer hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: launched by torch.distributed.run, one rank per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env)
+  (N>1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks read RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env; started
+   as a plain `python bench.py --gpus N` the script re-launches ITSELF as N ranks (sdflabel_amd/launch.py) and refuses to run if the node has
+   fewer than N GPUs -- an N-GPU line is never produced by fewer than N ranks; `rccl_ranks` in the line is dist.get_world_size())
 
 Workload (BASELINE.json configs[1]): ONE 256x256 crop per rank, DeepSDF 8x512 decoder (L=3, latent_in=[4], weight-norm;
 the committed synthetic fixture), grid density 40 (G = 64 000), float32.  One step = one refinement crop-iteration of the
@@ -21,9 +23,12 @@ Extra objects on the JSON line: `roofline` for the dominant kernel (the fused de
 the launch stream inside the timed region; `roofline_splat` (the splat forward+backward pair against the HBM roofline, at one crop and
 at 64 crops per launch); `cpu_baseline`: the reference's dense algorithm as a multi-threaded torch-CPU port (oracle/torch_cpu_port.py,
 pinned to the reference's golden G7) timed on the host cores for one full crop-iteration of the same workload (rank 0, N=1 only);
-`refine_sharded`: BASELINE configs[3] -- `--total-crops` (default 1024) crops sharded crop i -> rank i mod N, refined in chunks of 64 by
-BatchRefiner with the reference's losses and solver, one all_gather of the result rows: the strong-scaling figure of north_star
-(time at N ranks / time at 1 rank); labelled second lines `pose_only`, `f16_decoder`, `split_decoder`, `prefilter_decoder`.
+`refine_sharded`: BASELINE configs[3] -- `--total-crops` (default 1024) crops sharded crop i -> rank i mod N, refined for 60 iterations
+(configs/config_refine.ini:15) in chunks of 64 by BatchRefiner with the reference's losses and solver, one all_gather of the result rows: the
+strong-scaling figure of north_star (seconds at 1 rank / seconds at N ranks), exact f32; `refine_sharded_float16` the same run in the
+reference's shipped precision (config_refine.ini:19; pinned to its own float16 trajectory, golden G8h), `refine_sharded_prefilter` with the
+two-stage exact-f32 evaluation + candidate reuse, `refine_sharded_configs4` the configs[4] shape (512x512 rays, float16 decoder); labelled
+second lines `pose_only`, `f16_decoder`, `split_decoder`, `prefilter_decoder`.
 """
 import argparse
 import json
@@ -42,9 +47,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, v_mf
 D, H, W = 40, 256, 256
 
 
-def K_for(h, w):
-    f = 45.0 * h / 32.0
-    return np.array([[f, 0, w / 2.0], [0, f, h / 2.0], [0, 0, 1]], np.float32)
+from sdflabel_amd.fixtures import ASSET, K_for, crop_params, crop_start, fitted_state, synthetic_targets  # noqa: E402
 
 
 def build_pose(yaw, trans):
@@ -61,11 +64,10 @@ class Crop:
     """One synthetic refinement problem: GT pose yaw .6, t (0,0,3.5); init perturbed per crop index."""
 
     def __init__(self, index, dev):
-        g = torch.Generator().manual_seed(1 + index)
-        jit = torch.rand(7, generator=g)
-        self.yaw = (torch.tensor([0.6]) + 0.1 + 0.1 * jit[0:1]).to(dev).requires_grad_(True)
-        self.trans = (torch.tensor([0.0, 0.0, 3.5]) + torch.tensor([0.1, 0.05, -0.3]) * jit[1:4]).to(dev).requires_grad_(True)
-        self.latent = (torch.tensor([0.3, -0.5, 0.8]) + 0.2 * (jit[4:7] - 0.5)).to(dev).requires_grad_(True)
+        yaw, trans, latent = crop_start(index)
+        self.yaw = torch.from_numpy(yaw).to(dev).requires_grad_(True)
+        self.trans = torch.from_numpy(trans).to(dev).requires_grad_(True)
+        self.latent = torch.from_numpy(latent).to(dev).requires_grad_(True)
 
 
 def crop_iteration(dec, grid, renderer, crop, ev=None):
@@ -93,7 +95,6 @@ def cpu_baseline():
     decoder's unneeded weight gradients, dense N x P splat tensors; measured in the build container at the cost of the imported reference
     itself: 14.4 s against 13.8 s on 8 cores).  Timed with 8 threads (the survey's probe configuration) and with 32."""
     from oracle import torch_cpu_port as TP
-    from tests._util import fitted_state
     st, spec = fitted_state()
     decoder = TP.DecoderPort(st, spec)
     gp = TP.generate_point_grid(D).requires_grad_(True)
@@ -112,60 +113,111 @@ def cpu_baseline():
         assert bool(torch.isfinite(yaw.grad).all() and torch.isfinite(trans.grad).all() and torch.isfinite(lat.grad).all())
         return dt, n
 
-    # 8 threads = the survey's probe configuration; 32 = a quarter of a socket.  (Every hardware thread of the 256-thread GPU box measured
-    # 1.08 k rays/s, 60 s per iteration: the dense passes are memory-bound and oversubscribe -- not timed by default)
-    for threads in sorted({min(8, ncpu), min(32, ncpu)}, reverse=True):
-        torch.set_num_threads(threads)
-        if not out:
-            run()                                   # one warm-up iteration (allocator, thread pool) at the first setting
+    # 8 threads = the survey's probe configuration (median of 3 timed iterations after one warm-up); 32 = a quarter of a socket, one timed
+    # iteration beside it.  (Every hardware thread of the 256-thread GPU box measured 1.08 k rays/s, 60 s per iteration: the dense passes are
+    # memory-bound and oversubscribe -- not timed by default)
+    t8, t32 = min(8, ncpu), min(32, ncpu)
+    torch.set_num_threads(t8)
+    run()                                           # warm-up (allocator, thread pool)
+    samples = []
+    for _ in range(3):
         dt, n_surf = run()
-        out[threads] = (H * W / dt, dt)
+        samples.append(dt)
+    med = float(np.median(samples))
+    out[t8] = (H * W / med, med)
+    if t32 != t8:
+        torch.set_num_threads(t32)
+        dt, n_surf = run()
+        out[t32] = (H * W / dt, dt)
     torch.set_num_threads(prev)
-    best = max(out, key=lambda k: out[k][0])
-    return {"value": out[best][0], "unit": "rays/s", "cores": int(best), "kind": "port",
+    return {"value": out[t8][0], "unit": "rays/s", "cores": int(t8), "kind": "port",
+            "seconds_per_crop_iteration_samples": samples,
             "by_threads": {str(k): {"rays_per_s": v[0], "seconds_per_crop_iteration": v[1]} for k, v in out.items()},
             "host_cores": ncpu,
             "sample": "1 full crop-iteration (fwd+bwd to yaw/trans/latent) of the bench workload, all %dx%d rays, D=%d, N=%d surfels, dense "
-                      "N x P formulation as the reference, torch CPU ops + autograd (oracle/torch_cpu_port.py); 1 warm-up + 1 timed "
-                      "iteration per thread setting; value = the faster setting" % (H, W, D, n_surf)}
+                      "N x P formulation as the reference, torch CPU ops + autograd (oracle/torch_cpu_port.py); 1 warm-up + 3 timed "
+                      "iterations on %d threads, value = their median; one more timed iteration on %d threads in by_threads" % (H, W, D, n_surf, t8, t32)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=250)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--crops-per-gpu", type=int, default=1, help="crops refined together per rank (1 = BASELINE configs[1]; 64 = configs[2])")
     ap.add_argument("--crop-size", type=int, default=256, help="crop edge in pixels (256 = BASELINE configs[1..3]; 512 = configs[4], informational)")
-    ap.add_argument("--total-crops", type=int, default=1024, help="crops of the sharded refinement (BASELINE configs[3]); 0 skips the section")
-    ap.add_argument("--sharded-iters", type=int, default=10, help="refinement iterations per crop in the sharded section (the reference runs 60, "
-                    "configs/config_refine.ini:15: pass 60 for the literal refine run; every iteration costs the same)")
+    ap.add_argument("--total-crops", type=int, default=1024, help="crops of the sharded refinement (BASELINE configs[3]); 0 skips the sections")
+    ap.add_argument("--sharded-iters", type=int, default=60, help="refinement iterations per crop in the sharded sections (the reference's "
+                    "refinement length, configs/config_refine.ini:15)")
+    ap.add_argument("--configs4-crops", type=int, default=256, help="crops of the configs[4]-shaped sharded section (512x512 rays, float16 decoder)")
     ap.add_argument("--no-extras", action="store_true", help="only the headline loop (+ cpu_baseline): skip the informational sections")
+    ap.add_argument("--launch-check", action="store_true", help="only bring up the N ranks, all_gather their ranks and print one JSON line "
+                    "(plumbing check of the self-launcher; falls back to gloo on a machine without GPUs)")
     args = ap.parse_args()
     global H, W
     H = W = int(args.crop_size)
 
+    from sdflabel_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # plain `python bench.py --gpus N`: become N ranks (never fall through to a one-GPU run that prints an N-GPU line)
+        os.environ["SDFR_SELF_LAUNCHED"] = "1"
+        rc = launch.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus,
+                                require_gpus=not (args.launch_check and not torch.cuda.is_available()))
+        raise SystemExit(rc)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: the launcher's rank count and --gpus must agree" % (args.gpus, world))
+    launcher = "self (sdflabel_amd/launch.py)" if os.environ.get("SDFR_SELF_LAUNCHED") == "1" else (
+        "torch.distributed.run (external)" if launch.under_launcher() else "none (single process)")
+    has_gpu = torch.cuda.is_available()
+    if not has_gpu and not args.launch_check:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if has_gpu:
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("rank %d has no GPU (device_count %d)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if has_gpu else torch.device("cpu")
     if world > 1:                                              # each rank its share of the host cores
         torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     dist = None
-    if world > 1 or "RANK" in os.environ:          # under torch.distributed.run: always take the distributed path
+    backend = None
+    if world > 1 or launch.under_launcher():       # under a launcher: always take the distributed path
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=dev)
+        backend = "nccl" if has_gpu else "gloo"
+        if has_gpu:
+            dist_mod.init_process_group(backend, device_id=dev)
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
-        if dist.get_world_size() != world or args.gpus != world:
-            raise SystemExit("--gpus %d, WORLD_SIZE %d, process group of %d ranks: they must agree" % (args.gpus, world, dist.get_world_size()))
+        if dist.get_world_size() != world:
+            raise SystemExit("process group of %d ranks, WORLD_SIZE %d" % (dist.get_world_size(), world))
+    rccl_ranks = dist.get_world_size() if dist is not None else 1
+    rccl_version = None
+    if has_gpu and dist is not None:
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl_version = None
+    if args.launch_check:
+        ranks = [rank]
+        if dist is not None:
+            t = torch.tensor([rank], dtype=torch.int64, device=dev)
+            got = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(got, t)
+            ranks = [int(g.item()) for g in got]
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": rccl_ranks, "backend": backend, "rccl_version": rccl_version,
+                              "launcher": launcher, "ranks": ranks, "devices": torch.cuda.device_count() if has_gpu else 0}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import sdflabel_amd
-    from tests._util import ASSET
     if not os.path.isfile(sdflabel_amd.LIB_PATH):             # fresh checkout on the GPU box: compile the HIP library once (rank 0)
         if rank == 0:
             import __graft_entry__
@@ -175,7 +227,7 @@ def main():
     dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
     dec = dec.to(dev)
     CB = args.crops_per_gpu
-    from sdflabel_amd.parallel import shard_crops
+    from sdflabel_amd.parallel import gather_crop_results, refine_sharded, shard_crops
     crops = [Crop(i, dev) for i in shard_crops(CB * world, rank, world)]
     crop = crops[0]
     macs = dec.handle(dev).macs
@@ -196,35 +248,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
+
     def ev_pair():
         return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
-    events = [ev_pair() for _ in range(args.steps)]
-    kev = [{"jacobian": ev_pair(), "splat_fwd": ev_pair(), "splat_bwd": ev_pair()} for _ in range(args.steps)]
     import gc
+    # ---- the headline: EXACTLY --steps steps, nothing but the launches inside the timed region (no event records, no collector pause) ----
     gc.collect()
-    gc.disable()                  # no collector pause inside a timed region (the steps allocate nothing, but the interpreter may still run it)
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(events[i], kev[i])
+        step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt = max_over_ranks(time.perf_counter() - t0)
     gc.enable()
     assert not br.overflow()
     n_surf, n_front = int(br.cnt[0]), int(br.fcnt[0])
     loss = br.color[0].sum() + br.mask[0].sum() + br.nimg[0].sum() + br.xyzf[0].sum()
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         # the path's only exchange: per-crop result rows gathered once, outside the per-iteration critical path
-        from sdflabel_amd.parallel import gather_crop_results
         res = torch.cat([br.color.sum(dim=(1, 2, 3)).view(CB, 1), br.g_yaw.view(CB, 1), br.g_trans, br.g_latent], dim=1).float()
         table = gather_crop_results(res, CB * world, rank, world)
         assert table.shape == (CB * world, 8) and bool(torch.isfinite(table).all())
+    # ---- a longer run of the same step (>= 200 steps and >= 0.5 s): the headline's 20-250 steps are a 40-500 ms region ----
+    long_steps = max(200, int(0.6 / max(dt / args.steps, 1e-6)) + 1)
+    gc.collect()
+    gc.disable()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(long_steps):
+        step()
+    barrier()
+    dt_long = max_over_ranks(time.perf_counter() - t0)
+    gc.enable()
+    # ---- kernel durations: a SEPARATE pass with event pairs around the dominant launches, on the launch stream ----
+    ev_steps = max(20, min(args.steps, 100))
+    events = [ev_pair() for _ in range(ev_steps)]
+    kev = [{"jacobian": ev_pair(), "splat_fwd": ev_pair(), "splat_bwd": ev_pair()} for _ in range(ev_steps)]
+    for i in range(ev_steps):
+        step(events[i], kev[i])
+    torch.cuda.synchronize()
     mlp_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     kms = {k: float(np.mean([e[k][0].elapsed_time(e[k][1]) for e in kev])) for k in kev[0]}
 
@@ -254,12 +327,8 @@ def main():
         except Exception as e:
             err = repr(e)[:200]
         barrier()
-        d_ = time.perf_counter() - t_
+        d_ = max_over_ranks(time.perf_counter() - t_)
         gc.enable()
-        if dist is not None:
-            tt = torch.tensor([d_], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            d_ = float(tt.item())
         if not all_ok(err is None):
             return None, err or "failed on another rank"
         return (state, d_), None
@@ -270,18 +339,14 @@ def main():
 
     def refine_setup():
         rf = sdflabel_amd.BatchRefiner(dec, D, K_for(H, W), (H, W), CB, lidar_cap=4096, device=dev)
-        gt = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), 1, device=dev)
-        o = gt.forward(torch.tensor([0.6], device=dev), torch.tensor([[0.0, 0.0, 3.5]], device=dev), torch.tensor([[0.3, -0.5, 0.8]], device=dev))
-        nfg = int(o["nf"][0])
-        lidar = (o["xyzf"][0, :nfg] * 2.0)[::2].cpu().numpy()
-        nocs_t = o["color"].expand(CB, 3, H, W).clone()
+        nocs1, lidar = synthetic_targets(dec, D, K_for(H, W), H, W, dev)
+        nocs_t = nocs1.expand(CB, 3, H, W).clone()
         p0 = {"yaw": torch.cat([c.yaw.detach() for c in crops]), "trans": torch.stack([c.trans.detach() for c in crops]),
               "scale": torch.full((CB,), 2.0), "latent": torch.stack([c.latent.detach() for c in crops])}
         rf.set_crops(p0, nocs_t, [lidar] * CB)
         rf.capture()
         rf.optimize(3)                                       # warm-up
         rf.set_crops(p0, nocs_t, [lidar] * CB)               # restart from the initial parameters
-        rf.capture()
         return rf, p0["yaw"].to(dev).clone()
 
     res, err = timed_section(refine_setup, lambda st: st[0].optimize(iters)) if not args.no_extras else (None, "skipped (--no-extras)")
@@ -296,71 +361,65 @@ def main():
         del rf
     res = None
 
-    # ---- BASELINE configs[3]: `--total-crops` crops sharded over the ranks (crop i -> rank i mod N), refined in chunks of 64 by BatchRefiner,
-    # ONE all_gather of the per-crop result rows at the end.  Strong scaling: the total is fixed, so seconds(N=1) / seconds(N)
-    # is the north_star's "x at 8 GPUs over 1 GPU on a 1024-crop batch".
-    CHUNK = 64
+    # ---- BASELINE configs[3]: `--total-crops` crops sharded over the ranks (crop i -> rank i mod N), refined for the reference's 60 iterations
+    # in chunks of 64 by BatchRefiner, ONE all_gather of the per-crop result rows at the end (sdflabel_amd.parallel.refine_sharded).
+    # Strong scaling: the total is fixed, so seconds(N=1) / seconds(N) is the north_star's "x at 8 GPUs over 1 GPU on a 1024-crop batch".
+    # Three decoder arithmetics, labelled: exact float32 (the parity path, headline), float16 (the reference's shipped precision,
+    # config_refine.ini:19; pinned to the reference's own float16 trajectory, golden G8h) and float32_prefilter + candidate reuse (exact
+    # float32 on everything consumed downstream; guarded at run time); and the configs[4] shape (512x512 rays, float16 decoder).
+    def sharded_section(label, precision, reuse, size, total, workload):
+        chunk = max(1, min(64, (total + world - 1) // world))
+        Kc = K_for(size, size)
 
-    def crop_params(indices):
-        ys, ts, ls = [], [], []
-        for i in indices:                                      # the same per-crop jitter as Crop(i), generated on the host
-            jit = torch.rand(7, generator=torch.Generator().manual_seed(1 + i))
-            ys.append(0.6 + 0.1 + 0.1 * jit[0:1])
-            ts.append(torch.tensor([0.0, 0.0, 3.5]) + torch.tensor([0.1, 0.05, -0.3]) * jit[1:4])
-            ls.append(torch.tensor([0.3, -0.5, 0.8]) + 0.2 * (jit[4:7] - 0.5))
-        return {"yaw": torch.cat(ys), "trans": torch.stack(ts), "scale": torch.full((len(indices),), 2.0), "latent": torch.stack(ls)}
+        def setup():
+            d2 = dec
+            if precision is not torch.float32:
+                d2, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)
+                d2.prefilter_reuse = reuse
+                d2 = d2.to(dev)
+            rf = sdflabel_amd.BatchRefiner(d2, D, Kc, (size, size), chunk, lidar_cap=4096, device=dev)
+            nocs1, lidar = synthetic_targets(dec, D, Kc, size, size, dev)      # targets from the exact-f32 rendering of the ground truth, all modes
+            rf.set_crops(crop_params(list(range(chunk))), nocs1.expand(chunk, 3, size, size), [lidar] * chunk)
+            rf.capture()
+            rf.optimize(2)                                     # warm-up (graph instantiation, allocator)
+            return [rf, crop_params(list(range(total))), nocs1, lidar]
 
-    def sharded_setup():
-        mine = shard_crops(args.total_crops, rank, world)
-        rf = sdflabel_amd.BatchRefiner(dec, D, K_for(H, W), (H, W), CHUNK, lidar_cap=4096, device=dev)
-        gt = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), 1, device=dev)
-        o = gt.forward(torch.tensor([0.6], device=dev), torch.tensor([[0.0, 0.0, 3.5]], device=dev), torch.tensor([[0.3, -0.5, 0.8]], device=dev))
-        lidar = (o["xyzf"][0, :int(o["nf"][0])] * 2.0)[::2].cpu().numpy()
-        nocs_t = o["color"].expand(CHUNK, 3, H, W).clone()
-        params = crop_params(mine) if mine else None
-        warm = crop_params(list(range(CHUNK)))
-        rf.set_crops(warm, nocs_t, [lidar] * CHUNK)
-        rf.capture()
-        rf.optimize(2)                                         # warm-up (graph instantiation, allocator)
-        return rf, mine, params, nocs_t, lidar
+        def run(st):
+            rf, params, nocs1, lidar = st[:4]
+            st.append(refine_sharded(rf, params, nocs1, lidar, args.sharded_iters, rank, world))
 
-    def sharded_run(st):
-        rf, mine, params, nocs_t, lidar = st
-        rows, failure = [], None
-        try:
-            for c0 in range(0, len(mine), CHUNK):
-                n = min(CHUNK, len(mine) - c0)
-                sel = list(range(c0, c0 + n)) + [c0 + n - 1] * (CHUNK - n)      # a short last chunk is padded with copies of its last crop
-                rf.set_crops({k: v[sel] for k, v in params.items()}, nocs_t, [lidar] * CHUNK)
-                rf.optimize(args.sharded_iters)
-                rows.append(rf.results()[0][:n])
-            local = torch.cat(rows) if rows else torch.zeros((0, 5 + rf.L), device=dev)
-        except Exception as e:                                 # a local failure still takes part in the collective (NaN rows), then reports
-            failure = e
-            local = torch.full((len(mine), 5 + rf.L), float("nan"), device=dev)
-        st.append(gather_crop_results(local, args.total_crops, rank, world) if dist is not None else local)
-        if failure is not None:
-            raise failure
+        res_, err_ = timed_section(setup, run)
+        if res_ is None:
+            return {"label": label, "error": err_}
+        st, dt_s = res_
+        rf, table = st[0], st[-1]
+        ok = tuple(table.shape) == (total, 5 + rf.L) and bool(torch.isfinite(table).all())
+        p_all = st[1]
+        out = {"label": label, "workload": workload % (total, size, size, world, chunk), "decoder_precision": str(precision).replace("torch.", ""),
+               "total_crops": total, "iterations_per_crop": args.sharded_iters, "world_size": world, "rccl_ranks": rccl_ranks, "seconds": dt_s,
+               "crops_per_s": total / dt_s, "crop_iterations_per_s": total * args.sharded_iters / dt_s,
+               "rays_per_s_incl_losses_and_solver": total * args.sharded_iters * size * size / dt_s,
+               "mean_abs_yaw_error_before_after": [float(np.abs(p_all["yaw"] - 0.6).mean()), float((table[:, 0] - 0.6).abs().mean())],
+               "gathered_table_ok": ok, "scaling": "strong (total crops fixed): speed-up at N ranks = seconds(N=1) / seconds(N)"}
+        if getattr(rf.br, "prefilter", False):
+            out["guard"] = rf.br.prefilter_report()
+            out["candidate_reuse"] = bool(rf.br.reuse)
+        del st, rf
+        return out
 
-    sharded = None
+    sharded = sharded16 = sharded_pf = sharded_c4 = None
     if args.total_crops > 0 and not args.no_extras and CB == 1:
-        from sdflabel_amd.parallel import gather_crop_results
-        res, err = timed_section(lambda: list(sharded_setup()), sharded_run)
-        if res is None:
-            sharded = {"error": err}
-        else:
-            st, dt_s = res
-            table = st[-1]
-            ok = tuple(table.shape) == (args.total_crops, 5 + st[0].L) and bool(torch.isfinite(table).all())
-            sharded = {"workload": "BASELINE configs[3]: %d crops of %dx%d rays sharded crop i -> rank i mod %d, chunks of %d through BatchRefiner "
-                                   "(reference losses + solver, HIP-graph replay), one all_gather of the result rows" % (args.total_crops, H, W, world, CHUNK),
-                       "total_crops": args.total_crops, "iterations_per_crop": args.sharded_iters, "world_size": world, "seconds": dt_s,
-                       "crop_iterations_per_s": args.total_crops * args.sharded_iters / dt_s,
-                       "crops_per_s_at_this_iteration_count": args.total_crops / dt_s,
-                       "mean_abs_yaw_error_after": float((table[:, 0] - 0.6).abs().mean()), "gathered_table_ok": ok,
-                       "scaling": "strong (total crops fixed): speed-up at N ranks = seconds(N=1) / seconds(N)"}
-            del st
-        res = None
+        wl = ("BASELINE configs[3]: %d crops of %dx%d rays sharded crop i -> rank i mod %d, chunks of %d through BatchRefiner (reference losses + "
+              "solver, HIP-graph replay), one all_gather of the result rows")
+        sharded = sharded_section("exact float32 decoder (parity path)", torch.float32, False, H, args.total_crops, wl)
+        sharded16 = sharded_section("float16 decoder = the reference's shipped precision (config_refine.ini:19), f32 everything else",
+                                    torch.float16, False, H, args.total_crops, wl)
+        sharded_pf = sharded_section("float32_prefilter + candidate reuse: f16 pass proposes, exact f32 on everything consumed, run-time guard",
+                                     "float32_prefilter", True, H, args.total_crops, wl)
+        if H == 256 and args.configs4_crops > 0:
+            sharded_c4 = sharded_section("BASELINE configs[4] shape: 512x512 rays, float16 decoder on the f16 matrix cores", torch.float16, False, 512,
+                                         args.configs4_crops, "BASELINE configs[4]: %d crops of %dx%d rays, float16 DeepSDF decoder, sharded crop i -> rank "
+                                         "i mod %d, chunks of %d through BatchRefiner, one all_gather")
 
     # ---- labelled second line: pose-only refinement (BASELINE configs[1] says "pose-only refinement"; SURVEY.md 8d: "latent frozen -- MLP
     # result may be cached; state whether it was").  The HEADLINE above caches nothing.  Here the latent is fixed, so decoder, band and Jacobian
@@ -401,8 +460,8 @@ def main():
     if rank == 0 and CB == 1 and H == 256 and not args.no_extras:
         try:
             b64 = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), 64, device=dev)
-            p64 = crop_params(list(range(64)))
-            b64.set_params(p64["yaw"].to(dev), p64["trans"].to(dev), p64["latent"].to(dev))
+            p64 = {k: torch.from_numpy(v).to(dev) for k, v in crop_params(list(range(64))).items()}
+            b64.set_params(p64["yaw"], p64["trans"], p64["latent"])
             o3, o1, ox = torch.ones(64, 3, H, W, device=dev), torch.ones(64, 1, H, W, device=dev), torch.ones(64, b64.cap, 3, device=dev)
             e64 = [{"jacobian": ev_pair(), "splat_fwd": ev_pair(), "splat_bwd": ev_pair()} for _ in range(4)]
             for e in e64:
@@ -536,7 +595,8 @@ def main():
     if rank == 0:
         rays = H * W * CB * world * args.steps
         line = {
-            "metric": "rendered rays/sec (fwd+bwd)", "value": rays / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "metric": "rendered rays/sec (fwd+bwd)", "value": rays / dt, "unit": "rays/s", "n_gpus": world, "rccl_ranks": rccl_ranks,
+            "rccl_version": rccl_version, "launcher": launcher, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: single" if (CB == 1 and H == 256) else ("BASELINE configs[4]-style: %d" % CB if H == 512 else "BASELINE configs[2]-style: %d" % CB)) + " %dx%d crop per GPU, DeepSDF 8x512 decoder on a 40^3 grid, " % (H, W) +
@@ -552,7 +612,12 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         line["roofline"] = {"kernel": "sdfr_mlp_kernel<float,32,2,2,8,2,1,2> (fused decoder forward on the grid, saves ReLU masks)", "bound": "mfma",
                             "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
-                            "traffic": traffic, "flops_per_launch": flops, "avg_launch_ms": mlp_ms}
+                            "traffic": traffic, "traffic_source": "profiles/traffic_mlp_forward.json (rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE of an "
+                            "earlier run of this command, per launch; NOT measured in this run)" if traffic is not None else None,
+                            "flops_per_launch": flops, "avg_launch_ms": mlp_ms,
+                            "timing": "mean of %d event-bracketed launches in a separate pass after the timed region" % ev_steps}
+        line["long_run"] = {"steps": long_steps, "seconds": dt_long, "value": H * W * CB * world * long_steps / dt_long, "unit": "rays/s",
+                            "ms_per_step": dt_long / long_steps * 1e3, "note": "the same step timed over >= 200 steps and >= 0.5 s"}
         nbytes = 64.0 * H * W * CB + 72.0 * float(br.cnt.sum()) + 48.0 * float(br.fcnt.sum())          # 64 P + 72 N + 48 N_f per crop, fwd+bwd
         ach_s = nbytes / ((kms["splat_fwd"] + kms["splat_bwd"]) * 1e-3) / 1e9
         tsp = os.path.join(ROOT, "profiles", "traffic_splat.json")
@@ -563,12 +628,16 @@ def main():
                                   "bound": "hbm", "achieved": ach_s, "peak": 8000.0, "unit": "GB/s", "frac": ach_s / 8000.0, "traffic": tsplat.get("crops_1") if CB == 1 else None,
                                   "algorithmic_bytes_per_launch_pair": nbytes, "fwd_ms": kms["splat_fwd"], "bwd_ms": kms["splat_bwd"],
                                   "crops_per_launch": CB, "at_64_crops_per_launch": splat64,
+                                  "traffic_source": "profiles/traffic_splat.json (PMC passes of an earlier run; not measured in this run)",
                                   "note": "latency-bound at one crop (candidate evaluation chains, not bytes); see DESIGN.md 3.4"}
         line["jacobian"] = {"avg_launch_ms": kms["jacobian"], "tflops": 2.0 * macs * float(br.cnt.sum()) / (kms["jacobian"] * 1e-3) / 1e12,
                             "f32_mfma_peak_tflops": F32_MFMA_PEAK_TFLOPS, "rows": int(br.cnt.sum())}
         line["dropin_api"] = dropin
         line["refine_demo"] = refine
         line["refine_sharded"] = sharded
+        line["refine_sharded_float16"] = sharded16
+        line["refine_sharded_prefilter"] = sharded_pf
+        line["refine_sharded_configs4"] = sharded_c4
         line["pose_only"] = pose_only
         line["sphere_trace"] = sphere
         line["world_size"] = world

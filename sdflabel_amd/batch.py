@@ -102,7 +102,7 @@ class BatchRenderer:
             # at the candidates, grows a crop's margin to 4x the deviation when it exceeds half of it, and counts such steps
             self.margin_dev = torch.full((B,), self.margin, dtype=torch.float32, device=dev)
             self.max_dev = f(B)
-            self.violations = i(B, 2)
+            self.violations = i(B, 2)           # per crop, SINCE THE LAST reset_guard() (set_params / set_crops): [soft, hard]
             # candidate-set reuse (opt-in: decoder.prefilter_reuse = True): while the normalised latent has moved less than margin / (4 lip)
             # since the last half pass, that pass and the candidate selection are skipped (sdfr_prefilter_plan decides per crop on the device)
             self.lipschitz = 2.0 * lip                                 # calibrated above, with a factor 2
@@ -145,14 +145,24 @@ class BatchRenderer:
         self.trans.copy_(trans.reshape(self.B, 3))
         self.latent.copy_(latent.reshape(self.B, self.L))
         self._shape_valid = False
-        if self.prefilter:
-            self.age.zero_()                     # new crops: the next step runs the half pass
+        self.reset_guard()
 
     def invalidate_shape(self):
         """call after changing self.latent in place (freeze_shape mode): the next forward() re-evaluates decoder, band and Jacobian"""
         self._shape_valid = False
         if self.prefilter:
-            self.age.zero_()
+            self.age.zero_()                     # the next step runs the half pass
+
+    def reset_guard(self):
+        """float32_prefilter: new crops start with clean guard state -- the violation counters, the last deviation and the per-crop margin
+        (back to the calibrated one) belong to the crops that were refined before, and a hard violation there must not make
+        check_overflow() refuse every later, unrelated crop (refiners are cached and reused across Optimizer objects).  Called by
+        set_params() and BatchRefiner.set_crops(); all in place, so a captured graph stays valid."""
+        if self.prefilter:
+            self.age.zero_()                     # new crops: the next step runs the half pass
+            self.violations.zero_()
+            self.max_dev.zero_()
+            self.margin_dev.fill_(self.margin)
 
     def forward(self, yaw=None, trans=None, latent=None, mlp_events=None, events=None):
         """mlp_events: optional (start, end) torch.cuda.Event pair recorded around the decoder-forward launch (bench.py roofline).
@@ -305,9 +315,11 @@ class BatchRenderer:
             raise _lib.SdfrError("a crop's band holds %d surfels but BatchRenderer was built with cap=%d: rebuild it with a larger `cap` "
                                  "(default max(256, G/8))" % (worst, self.cap))
         if self.prefilter and int(self.violations[:, 1].sum()) > 0:
+            hard, worst_dev = int(self.violations[:, 1].sum()), float(self.max_dev.max())
+            self.violations[:, 1].zero_()        # reported once: the renderer stays usable for the next crops (the grown margins remain)
             raise _lib.SdfrError("float32_prefilter: the half-operand pass deviated from the exact values by more than the safety margin "
                                  "(max deviation %g) in %d step(s): band rows may have been excluded; use precision=torch.float32 or a larger "
-                                 "decoder.prefilter_margin" % (float(self.max_dev.max()), int(self.violations[:, 1].sum())))
+                                 "decoder.prefilter_margin" % (worst_dev, hard))
 
     def capture(self, grads_fn):
         """Capture forward -> grads_fn(outputs) -> backward in a HIP graph.  grads_fn maps the output dict to the keyword arguments of
@@ -323,4 +335,15 @@ class BatchRenderer:
         with torch.cuda.graph(g):
             self.backward(**grads_fn(self.forward()))
         self._graph = g
-        return g.replay
+        if not self.freeze_shape:
+            return g.replay
+
+        # pose-only mode: the warm-up above made the shape valid, so the captured launches are the pose-only ones.  After set_params() /
+        # invalidate_shape() (a new latent) the decoder, band and Jacobian stages must run once before the graph is valid again: the
+        # returned callable does that eager step itself instead of replaying stale surfels.
+        def replay():
+            if not self._shape_valid:
+                self.backward(**grads_fn(self.forward()))
+            else:
+                g.replay()
+        return replay

@@ -220,8 +220,12 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         if (r0 >= n_rows) return;
         if (P.n_dev && P.n_dev_hi > 0 && (*P.n_dev < P.n_dev_lo || *P.n_dev >= P.n_dev_hi)) return;
         if (P.skip) {                               // two-stage evaluation: crops that reuse their candidate set skip the half pass
+            // a tile is dropped only when EVERY crop it spans is flagged (rows_per_crop need not be a multiple of the tile: a tile may span
+            // two or more crops); in a surviving tile the rows of flagged crops are computed but not stored (see the store of P.sdf)
             const int64_t r1 = min(r0 + PT, n_rows) - 1;
-            if (P.skip[r0 / P.skip_rows] && P.skip[r1 / P.skip_rows]) return;
+            bool all_flagged = true;
+            for (int64_t c = r0 / P.skip_rows; c <= r1 / P.skip_rows; ++c) all_flagged = all_flagged && P.skip[c] != 0;
+            if (all_flagged) return;
         }
         n_valid = (int)min((int64_t)PT, n_rows - r0);
         if (tid < PT) rows[tid] = (int)(r0 + (tid < n_valid ? tid : 0));
@@ -687,7 +691,10 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                 gy[tid] = g;
                 if (tid < n_valid && P.sdf_sel) P.sdf_sel[slots[tid]] = o;
             } else {
-                if (tid < n_valid) P.sdf[(int64_t)blockIdx.x * PT + tid] = o;
+                if (tid < n_valid) {
+                    const int64_t row = (int64_t)blockIdx.x * PT + tid;
+                    if (!P.skip || !P.skip[row / P.skip_rows]) P.sdf[row] = o;      // a flagged crop keeps its (exact, patched) values
+                }
             }
         }
     }

@@ -42,3 +42,44 @@ def gather_crop_results(local_rows, n_crops, rank=None, world=None, group=None):
         idx = shard_crops(n_crops, r, world)
         out[idx] = blocks[r][:len(idx)]
     return out
+
+
+def refine_sharded(refiner, params, nocs_pred, lidars, iters, rank=0, world=1, group=None, gather=True):
+    """BASELINE configs[3]: refine `n_crops` independent crops sharded over the ranks.  Crop i belongs to rank i mod world; each rank refines
+    its crops in chunks of `refiner.B` (sdflabel_amd.BatchRefiner, or any object with B, L, set_crops, optimize, results) for `iters`
+    iterations; ONE all_gather of the per-crop rows at the end is the only collective (pipelines/refine_css.py:65,94 loops over the same crops
+    one at a time in one process).
+
+    params     {'yaw' (n,), 'trans' (n,3), 'scale' (n,), 'latent' (n,L)} arrays for ALL crops (a few floats per crop: every rank holds the table)
+    nocs_pred  (n,3,h,w) per-crop CSS predictions, or (1,3,h,w) shared by all crops (synthetic workloads)
+    lidars     list of n (M_i,3) arrays, or ONE (M,3) array shared by all crops
+    Returns the (n_crops, 5+L) table [yaw, trans(3), scale, latent(L)] in crop order on every rank (gather=False: this rank's rows only).
+    A short last chunk is padded with copies of its last crop (the padded rows are dropped).  If the local refinement fails, the rank still
+    takes part in the collective (NaN rows) and raises afterwards, so no rank is left waiting."""
+    import numpy as np
+    n_crops = int(np.asarray(params["yaw"]).reshape(-1).shape[0])
+    mine = shard_crops(n_crops, rank, world)
+    B, R = int(refiner.B), 5 + int(refiner.L)
+    P = {k: np.asarray(v, np.float32).reshape(n_crops, -1) for k, v in params.items()}
+    shared_target = nocs_pred.shape[0] == 1
+    shared_lidar = not isinstance(lidars, (list, tuple))
+    rows, failure = [], None
+    try:
+        for c0 in range(0, len(mine), B):
+            ids = mine[c0:c0 + B]
+            n = len(ids)
+            sel = ids + [ids[-1]] * (B - n)
+            tgt = nocs_pred.expand(B, *nocs_pred.shape[1:]) if shared_target else nocs_pred[sel]
+            refiner.set_crops({k: v[sel] for k, v in P.items()}, tgt, [lidars] * B if shared_lidar else [lidars[i] for i in sel])
+            refiner.optimize(iters)
+            rows.append(refiner.results()[0][:n])
+        local = torch.cat(rows) if rows else None
+    except Exception as e:                                   # noqa: BLE001 -- re-raised below, after the collective
+        failure, local = e, None
+    dev = getattr(refiner, "dev", "cpu")
+    if local is None:
+        local = torch.full((len(mine), R), float("nan") if failure is not None else 0.0, dtype=torch.float32, device=dev)
+    table = gather_crop_results(local, n_crops, rank, world, group) if gather else local
+    if failure is not None:
+        raise failure
+    return table

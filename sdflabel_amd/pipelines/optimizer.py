@@ -25,6 +25,12 @@ _REFINERS = {}
 _REFINERS_MAX = 4
 
 
+def clear_refiner_cache():
+    """Release the cached BatchRefiners (their device buffers, HIP graphs and the references they hold to the decoders).  Optimizer objects
+    created afterwards build fresh ones; existing Optimizer objects keep working with the refiner they already hold."""
+    _REFINERS.clear()
+
+
 def get_opt_params(params, device):
     """optimizer.py:26-40: every entry of `params` becomes a float32 leaf tensor on `device` (in place); returns the parameter groups with
     the reference's learning rates (yaw .01, trans .01 -> Adam; scale .01, latent 3e-5 -> SGD)."""

@@ -85,6 +85,7 @@ class BatchRefiner:
             self.lcnt[b] = l.shape[0]
         self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t.zero_()
         self.br.invalidate_shape()
+        self.br.reset_guard()                   # per-crop device state of the two-stage mode (violation counters, margins) starts clean
         # a captured graph stays valid: every buffer it reads or writes is static and was updated in place above
 
     def iteration(self):
@@ -113,6 +114,8 @@ class BatchRefiner:
         s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         snap = (self.params.clone(), self.adam_m.clone(), self.adam_v.clone(), self.adam_t.clone())
+        br = self.br
+        guard = (br.violations.clone(), br.margin_dev.clone(), br.max_dev.clone()) if br.prefilter else None
         with torch.cuda.stream(s):
             self.iteration()
         torch.cuda.current_stream(self.dev).wait_stream(s)
@@ -121,6 +124,8 @@ class BatchRefiner:
             self.iteration()
         # warm-up and capture must not advance the optimisation
         self.params.copy_(snap[0]); self.adam_m.copy_(snap[1]); self.adam_v.copy_(snap[2]); self.adam_t.copy_(snap[3])
+        if guard is not None:                   # ... nor feed the two-stage mode's guard counters
+            br.violations.copy_(guard[0]); br.margin_dev.copy_(guard[1]); br.max_dev.copy_(guard[2]); br.age.zero_()
         self._replay = g.replay
         return g.replay
 

@@ -599,7 +599,7 @@ def test_prefilter_guard_trips_grows_the_margin_and_raises(dec):
     dev0 = float(br.max_dev.max())
     assert 0 < dev0 < br.margin / 4 and br.prefilter_report()["violations"] == 0
     br.margin_dev.fill_(dev0 * 0.2)                        # an (artificially) unsafe margin
-    br.forward(*a)
+    br.forward()                                           # (same parameters; passing them again would reset the guard state: new crops)
     rep = br.prefilter_report()
     assert rep["violations"] >= 1 and rep["hard_violations"] >= 1
     grown, devs = N(br.margin_dev), N(br.max_dev)
@@ -607,8 +607,10 @@ def test_prefilter_guard_trips_grows_the_margin_and_raises(dec):
     with pytest.raises(sdflabel_amd.SdfrError, match="prefilter"):
         br.check_overflow()
     before = br.prefilter_report()["violations"]
-    br.forward(*a)                                         # with the grown margin the next step is quiet
+    br.forward()                                           # with the grown margin the next step is quiet
     assert br.prefilter_report()["violations"] == before
+    br.forward(*a)                                         # new parameters = new crops: counters and margins start clean
+    assert br.prefilter_report()["violations"] == 0 and float(br.margin_dev.min()) == pytest.approx(br.margin)
 
 
 def test_prefilter_candidate_reuse_skips_the_half_pass_and_changes_nothing(dec):
@@ -693,3 +695,124 @@ def test_band_jacobian_variants_on_ragged_512_wide_decoders(kw):
         # summation order -- isolated elements off by ~1e-3 of a weight product; everything else agrees to rounding)
         err = np.abs(N(big.J[b]) - Jref)
         assert np.quantile(err, 0.999) < 5e-6 and err.max() < 5e-3 and (err > 5e-5).sum() <= 40, (np.quantile(err, 0.999), err.max(), (err > 5e-5).sum())
+
+
+# ---- r03: ADVICE r02 ------------------------------------------------------------------------------------------------------------------
+
+def _refine_problem(dec, D, H, W, B):
+    from sdflabel_amd.fixtures import crop_params, synthetic_targets
+    K = K_for(H, W)
+    nocs1, lidar = synthetic_targets(dec, D, K, H, W, DEV)
+    return K, crop_params(list(range(B))), nocs1.expand(B, 3, H, W), lidar
+
+
+def test_prefilter_hard_violation_does_not_poison_later_crops(dec):
+    """a hard guard violation on one crop must be reported for THAT refinement only: set_crops() resets the per-crop guard state (counters,
+    deviation, margins), and after check_overflow() has raised once the refiner stays usable (refiners are cached and shared)"""
+    D, H, W, B = 40, 64, 64, 2
+    dp, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter")
+    K, p0, target, lidar = _refine_problem(dec, D, H, W, B)
+    rf = sdflabel_amd.BatchRefiner(dp.to(DEV), D, K, (H, W), B, lidar_cap=2048, device=DEV)
+    margin0 = float(rf.br.margin)
+    rf.set_crops(p0, target, [lidar] * B)
+    rf.br.margin_dev.fill_(1e-6)                           # an (artificially) unsafe margin: the next step trips the guard
+    rf.iteration()
+    with pytest.raises(sdflabel_amd.SdfrError, match="prefilter"):
+        rf.results()
+    rows_after_raise = rf.results()[0]                      # reported once; the object is usable again
+    assert bool(torch.isfinite(rows_after_raise).all())
+    rf.set_crops(p0, target, [lidar] * B)                  # new crops: clean guard state, calibrated margin
+    assert int(rf.br.violations.sum()) == 0 and float(rf.br.margin_dev.min()) == pytest.approx(margin0) and float(rf.br.margin_dev.max()) == pytest.approx(margin0)
+    rf.capture()                                           # the capture's warm-up iteration must not feed the counters either
+    assert int(rf.br.violations.sum()) == 0
+    rf.optimize(5)
+    rows, _, _ = rf.results()
+    assert rf.br.prefilter_report()["hard_violations"] == 0
+    # and the result is the exact path's
+    de, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
+    re = sdflabel_amd.BatchRefiner(de.to(DEV), D, K, (H, W), B, lidar_cap=2048, device=DEV)
+    re.set_crops(p0, target, [lidar] * B)
+    re.optimize(5)
+    assert np.abs(N(rows) - N(re.results()[0])).max() < 1e-5
+
+
+def test_batch_renderer_capture_in_pose_only_mode_re_evaluates_a_new_shape(dec):
+    """freeze_shape: the captured graph holds the pose-only launches; after set_params() with another latent the replay callable must run the
+    decoder stages once (eagerly) instead of replaying stale surfels"""
+    D, H, W = 20, 48, 48
+    br = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), 1, device=DEV)
+    br.freeze_shape = True
+    yaw, trans = T(np.array([0.6], np.float32)), T(np.array([[0.0, 0.0, 3.5]], np.float32))
+    la, lb = T(np.array([[0.3, -0.5, 0.8]], np.float32)), T(np.array([[-0.6, 0.2, 0.1]], np.float32))
+    ones = torch.ones(1, 3, H, W, device=DEV)
+    grads_fn = lambda o: dict(g_color=ones, g_xyzf=torch.ones_like(o["xyzf"]))
+    br.set_params(yaw, trans, la)
+    replay = br.capture(grads_fn)
+    ref = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), 1, device=DEV)
+    for lat in (lb, la, lb):
+        br.set_params(yaw, trans, lat)
+        replay()                                            # first call after a new latent: eager full step
+        br.yaw.add_(0.05)
+        replay()                                            # pose moved, shape unchanged: graph replay
+        torch.cuda.synchronize()
+        o = ref.forward(br.yaw.clone(), trans, lat)
+        g = ref.backward(**grads_fn(o))
+        assert torch.equal(o["color"], br.color) and int(o["n"][0]) == int(br.cnt[0])
+        assert torch.equal(g[0], br.g_yaw) and torch.equal(g[1], br.g_trans)
+
+
+def test_prefilter_reuse_when_a_tile_of_the_half_pass_spans_two_crops(dec):
+    """D = 20: 8000 grid rows per crop are no multiple of the half pass's 128-row tile, so tiles span a crop that reuses its candidates and
+    one that does not; the flagged crop's (exact, patched) values must survive and the refinement stay bit-identical to the plain two-stage
+    mode (the skip test used to look at the tile's first and last rows only)"""
+    D, H, W, B = 20, 48, 48, 5
+    K, p0, target, lidar = _refine_problem(dec, D, H, W, B)
+    rows = []
+    for reuse in (False, True):
+        dp, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter")
+        dp.prefilter_reuse = reuse
+        rf = sdflabel_amd.BatchRefiner(dp.to(DEV), D, K, (H, W), B, lidar_cap=2048, device=DEV)
+        rf.set_crops(p0, target, [lidar] * B)
+        for it in range(12):
+            if reuse and it in (4, 9):
+                with torch.no_grad():                      # crops 1 and 3 need a fresh half pass, their neighbours do not
+                    rf.latent[1] += torch.tensor([0.4, -0.3, 0.2], device=DEV)
+                    rf.latent[3] -= torch.tensor([0.2, 0.3, -0.4], device=DEV)
+            elif it in (4, 9):
+                with torch.no_grad():
+                    rf.latent[1] += torch.tensor([0.4, -0.3, 0.2], device=DEV)
+                    rf.latent[3] -= torch.tensor([0.2, 0.3, -0.4], device=DEV)
+            rf.iteration()
+            if reuse and it in (4, 9):
+                assert N(rf.br.reuse_flag).tolist() == [1, 0, 1, 0, 1]
+        rows.append(N(rf.results()[0]))
+        assert rf.br.prefilter_report()["hard_violations"] == 0
+    assert np.array_equal(rows[0], rows[1])
+
+
+# ---- r03: the sharded refinement flow of BASELINE configs[3], through the function bench.py calls ------------------------------------------
+
+def test_config3_sharded_flow_1024_crops_world_1():
+    """1024 synthetic crops of 256x256 rays through sdflabel_amd.parallel.refine_sharded at world = 1 (chunks of 64, HIP-graph replay) -- the
+    function bench.py's refine_sharded sections call on every rank; float16 decoder (the reference's shipped precision) and 4 iterations to
+    keep the test short.  Rows of sampled crops equal, bit for bit, the same crops refined alone (B = 1): batch- and chunk-independent."""
+    from sdflabel_amd.fixtures import crop_params, synthetic_targets
+    from sdflabel_amd.parallel import refine_sharded
+    D, H, W, TOTAL, CHUNK, ITERS = 40, 256, 256, 1024, 64, 4
+    d32, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
+    d16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    d32, d16 = d32.to(DEV), d16.to(DEV)
+    K = K_for(H, W)
+    nocs1, lidar = synthetic_targets(d32, D, K, H, W, DEV)
+    rf = sdflabel_amd.BatchRefiner(d16, D, K, (H, W), CHUNK, lidar_cap=4096, device=DEV)
+    rf.set_crops(crop_params(list(range(CHUNK))), nocs1.expand(CHUNK, 3, H, W), [lidar] * CHUNK)
+    rf.capture()
+    params = crop_params(list(range(TOTAL)))
+    table = refine_sharded(rf, params, nocs1, lidar, ITERS, rank=0, world=1)
+    assert tuple(table.shape) == (TOTAL, 8) and bool(torch.isfinite(table).all())
+    assert float((table[:, 0] - T(params["yaw"])).abs().min()) > 1e-3           # every crop moved
+    one = sdflabel_amd.BatchRefiner(d16, D, K, (H, W), 1, lidar_cap=4096, device=DEV)
+    for i in (0, 63, 64, 517, 1023):
+        one.set_crops(crop_params([i]), nocs1, [lidar])
+        one.optimize(ITERS)
+        assert torch.equal(one.results()[0][0], table[i]), i

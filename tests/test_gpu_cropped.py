@@ -1,0 +1,243 @@
+"""GPU parity in the camera regime of the reference PIPELINE (goldens G14 / G14o / G14e, tools/make_golden.py).
+
+Every other golden uses K_for(): fx = fy, principal point at the crop centre, object on the optical axis.  The pipeline never renders like
+that: pipelines/refine_css_demo.py:85-95 cuts the detection's 2-D box out of the KITTI frame and utils/refinement.py:586-609
+(adjust_intrinsics_crop) moves the principal point by the box corner and rescales the focal lengths to the rendering area -- principal points
+hundreds of pixels outside the crop, objects metres off the optical axis, crop edges that are no multiples of the 8x8 splat tiles.  The K in
+these goldens was produced by the reference's own adjust_intrinsics_crop for KITTI-like boxes:
+
+  G14   a  12 m away, 4 m to the right   160x306 rays, cx = -128     b  25 m, 4 m left, fx != fy, 155x316, cx = 462
+        c   8 m, 4 m right, 156x313, cx = -102                          -- Rasterer.forward images + autograd gradients (yaw, trans, latent)
+  G14o  the reference Optimizer's 10-iteration trajectory at rendering_area = 32 (config_refine.ini:12: 23x44 / 22x45 rays) with such a K
+  G14e  a SECOND decoder at full size: the ellipsoid fit (weight-norm, and the LayerNorm variant), centred and cropped intrinsics
+
+Tolerances are those of the centred-K tests: images 1e-4 (pixels attributable to a selection threshold within 1e-5 bounded at 0.1 %), gradients
+1e-3 relative, trajectories 5e-4 / losses 2e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import sdflabel_amd
+from tests._util import ASSET, gold, pattern_weights
+from tests.test_gpu_parity import N, T, build_pose
+from tests.test_gpu_configs import SALT, check_grads, check_images
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class Sub:
+    """view of the arrays of one case of a multi-case golden file: Sub(z, 'a_')['K'] == z['a_K']"""
+
+    def __init__(self, z, prefix):
+        self.z, self.p = z, prefix
+
+    def __getitem__(self, k):
+        return self.z[self.p + k]
+
+
+@pytest.fixture(scope="module")
+def dec():
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
+    return d.to(DEV)
+
+
+def _dropin_case(dec, z):
+    D, H, W = [int(v) for v in z["cfg"]]
+    near = np.unpackbits(z["near_threshold"])[:H * W].astype(bool)
+    grid = sdflabel_amd.Grid3D(D, DEV)
+    lat = T(z["latent"]).requires_grad_(True)
+    yaw = T(z["yaw"]).requires_grad_(True)
+    trans = T(z["trans"]).requires_grad_(True)
+    renderer = sdflabel_amd.Rasterer(T(z["K"]), (W, H)).to(DEV)
+    lat_ = F.normalize(lat, p=2, dim=0)
+    inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1)
+    sdf, _ = dec(inputs)
+    assert np.abs(N(sdf)[::7, 0] - z["sdf_stride7"]).max() < 5e-6
+    pcd, _, normals = grid.get_surface_points(sdf)
+    assert pcd.shape[0] == z["pcd"].shape[0], "band differs from the reference's (its margin to the threshold: %g)" % float(z["band_margin"])
+    dn = np.abs(N(normals) - z["normals"])
+    assert np.abs(N(pcd) - z["pcd"]).max() < 2e-5 and np.median(dn) < 1e-6 and (dn.max(1) > 1e-4).sum() <= 3
+    pose = build_pose(yaw, trans)
+    rendering, points = renderer(pcd, normals, normals, pose, primitives="disc", rot="dcm", bg=None, output_depth=True,
+                                 output_normals=True, output_nocs=True, output_points=True, output_mask=True)
+    check_images(rendering, z, near=near)
+    assert points["xyzf"].shape == z["xyzf"].shape and np.abs(N(points["xyzf"]) - z["xyzf"]).max() < 1e-5
+    loss = sum((rendering[k] * T(pattern_weights(tuple(rendering[k].shape), SALT[k]))).sum() for k in ("color", "mask", "depth", "normals"))
+    loss = loss + (points["xyzf"] * T(pattern_weights(tuple(points["xyzf"].shape), SALT["xyzf"]))).sum()
+    assert abs(float(loss) - float(z["loss"])) < 2e-3 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    check_grads((yaw.grad, trans.grad, lat.grad), z)
+    assert float(rendering["mask"].sum()) > 2000
+
+
+def _batch_case(decoder, z, B, binned=None):
+    D, H, W = [int(v) for v in z["cfg"]]
+    near = np.unpackbits(z["near_threshold"])[:H * W].astype(bool)
+    br = sdflabel_amd.BatchRenderer(decoder, D, z["K"], (W, H), B, device=DEV)
+    if binned is not None:
+        br.binned = binned
+    rep = lambda a: T(np.tile(np.asarray(a, np.float32).reshape(1, -1), (B, 1)))
+    out = br.forward(rep(z["yaw"]).view(B), rep(z["trans"]), rep(z["latent"]))
+    nf = z["xyzf"].shape[0]
+    gx = torch.zeros(B, br.cap, 3, device=DEV)
+    gx[:, :nf] = T(pattern_weights((nf, 3), SALT["xyzf"]))
+    w = {k: T(pattern_weights(tuple(out[k][0].shape), SALT[k]))[None].expand(B, *out[k][0].shape).contiguous() for k in ("color", "mask", "depth", "normals")}
+    g = br.backward(g_color=w["color"], g_mask=w["mask"], g_depth=w["depth"], g_normals=w["normals"], g_xyzf=gx)
+    assert not br.overflow()
+    for b in sorted({0, B // 2, B - 1}):
+        assert int(out["n"][b]) == z["pcd"].shape[0] and int(out["nf"][b]) == nf
+        assert torch.equal(br.idx[b, :int(out["n"][b])].cpu(), torch.from_numpy(z["band_idx"]))
+        check_images({k: out[k][b] for k in ("color", "mask", "depth", "normals")}, z, near=near)
+        assert np.abs(N(out["xyzf"][b, :nf]) - z["xyzf"]).max() < 1e-5
+        check_grads([t[b] for t in g], z)
+    return br, out
+
+
+# ---- G14: Rasterer.forward + gradients ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g14_dropin_modules_with_cropped_offcentre_intrinsics(dec, tag):
+    z = Sub(gold("g14_cropped_intrinsics.npz"), tag + "_")
+    H, W = int(z["cfg"][1]), int(z["cfg"][2])
+    assert not (0 <= float(z["K"][0, 2]) < W) and (H % 8 or W % 8)
+    _dropin_case(dec, z)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("B", [1, 4, 22])
+def test_g14_batch_renderer_scan_binned_and_wave_per_tile_paths(dec, tag, B):
+    """B = 1: every tile scans all screen boxes, eight waves per tile; B = 4: per-tile surfel lists (binned), eight waves per tile; B = 22:
+    binned, >= 16384 tiles per launch -> one wave per tile.  Every crop of the batch carries the golden's parameters and must match it."""
+    z = Sub(gold("g14_cropped_intrinsics.npz"), tag + "_")
+    H, W = int(z["cfg"][1]), int(z["cfg"][2])
+    br, _ = _batch_case(dec, z, B)
+    assert br.binned == (B >= 4)
+    if B == 22:
+        assert B * ((H + 7) // 8) * ((W + 7) // 8) >= 16384
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_g14_unbinned_and_binned_are_the_same_bits_with_offcentre_intrinsics(dec, B):
+    z = Sub(gold("g14_cropped_intrinsics.npz"), "c_")
+    a, oa = _batch_case(dec, z, B, binned=False)
+    imgs = {k: oa[k].clone() for k in ("color", "mask", "depth", "normals")}
+    grads = [t.clone() for t in (a.g_yaw, a.g_trans, a.g_latent)]
+    b, ob = _batch_case(dec, z, B, binned=True)
+    for k in imgs:
+        assert torch.equal(imgs[k], ob[k]), k
+    for x, y in zip(grads, (b.g_yaw, b.g_trans, b.g_latent)):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("precision", ["float32_split", "float32_prefilter", torch.float16])
+def test_g14_alternative_decoder_arithmetics_with_cropped_intrinsics(precision):
+    """the float32-result modes at the float32 tolerances; the float16 decoder within the pixel counts its own error allows (the reference's
+    float16 run is pinned at the centred K, golden G11: here only closeness to float32 is asserted)"""
+    z = Sub(gold("g14_cropped_intrinsics.npz"), "a_")
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)
+    d = d.to(DEV)
+    if precision is not torch.float16:
+        _batch_case(d, z, 1)
+        return
+    D, H, W = [int(v) for v in z["cfg"]]
+    br = sdflabel_amd.BatchRenderer(d, D, z["K"], (W, H), 1, device=DEV)
+    out = br.forward(T(z["yaw"]), T(z["trans"])[None], T(z["latent"])[None])
+    assert abs(int(out["n"][0]) - z["pcd"].shape[0]) <= 0.02 * z["pcd"].shape[0]
+    for k in ("color", "mask", "depth", "normals"):
+        d_ = np.abs(N(out[k][0]) - z["out_" + k]).reshape(-1, H * W).max(0)
+        assert (d_ > 1e-2).mean() < 0.02, (k, (d_ > 1e-2).mean())
+
+
+# ---- G14o: the Optimizer's trajectory at rendering_area = 32 ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_g14o_refinement_loop_on_the_dropin_modules(dec, tag):
+    from tests._harness import Refiner
+    z = Sub(gold("g14o_optimizer_cropped.npz"), tag + "_")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    ref = Refiner({"yaw": init[0:1], "trans": init[1:4], "scale": init[4:5], "latent": init[5:8]}, DEV, {"2d": 0.3, "3d": 0.5})
+    grid = sdflabel_amd.Grid3D(D, DEV)
+    renderer = sdflabel_amd.Rasterer(T(z["K"]), (W, H)).to(DEV)
+    traj = []
+    for _ in range(10):
+        ref.optimize(1, T(z["nocs_target"]), z["lidar"], dec, grid, renderer)
+        traj.append(ref.vector())
+    traj = np.asarray(traj)
+    assert len(ref.log) == 10
+    l2 = np.array([a for a, _ in ref.log]); l3 = np.array([b for _, b in ref.log])
+    assert np.abs(l2 - z["loss2d_weighted"]).max() < 2e-4, (l2, z["loss2d_weighted"])
+    assert np.abs(l3 - z["loss3d_weighted"]).max() < 2e-4
+    assert np.abs(traj - z["traj"]).max() < 5e-4, np.abs(traj - z["traj"]).max(axis=0)
+    assert abs(traj[-1, 0] - init[0]) > 0.04
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+@pytest.mark.parametrize("B,graph", [(1, False), (2, True)])
+def test_g14o_batch_refiner_trajectory(dec, tag, B, graph):
+    z = Sub(gold("g14o_optimizer_cropped.npz"), tag + "_")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    rf = sdflabel_amd.BatchRefiner(dec, D, z["K"], (H, W), B, lidar_cap=max(256, int(z["lidar"].shape[0])), weights={"2d": 0.3, "3d": 0.5}, device=DEV)
+    rep = lambda a: np.tile(np.asarray(a, np.float32).reshape(1, -1), (B, 1))
+    rf.set_crops({"yaw": rep(init[0:1]), "trans": rep(init[1:4]), "scale": rep(init[4:5]), "latent": rep(init[5:8])},
+                 np.tile(z["nocs_target"][None], (B, 1, 1, 1)), [z["lidar"]] * B)
+    if graph:
+        rf.capture()
+    traj, l2, l3 = [], [], []
+    for _ in range(10):
+        rf.optimize(1)
+        rows, a, b = rf.results()
+        traj.append(N(rows)); l2.append(N(a)); l3.append(N(b))
+        assert int(rf.stepped.min()) == 1
+    traj, l2, l3 = np.asarray(traj), np.asarray(l2), np.asarray(l3)
+    for b in range(B):
+        assert np.abs(l2[:, b] - z["loss2d_weighted"]).max() < 2e-4
+        assert np.abs(l3[:, b] - z["loss3d_weighted"]).max() < 2e-4
+        assert np.abs(traj[:, b] - z["traj"]).max() < 5e-4, np.abs(traj[:, b] - z["traj"]).max(axis=0)
+
+
+def test_g14o_optimizer_mirror_with_cropped_intrinsics(dec):
+    """sdflabel_amd.pipelines.optimizer.Optimizer called as pipelines/refine_css_demo.py:168-191 calls the reference's, K = the crop's
+    adjusted intrinsics, crop_size = [H, W]"""
+    from sdflabel_amd.pipelines.optimizer import Optimizer
+    z = Sub(gold("g14o_optimizer_cropped.npz"), "a_")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    params = {"yaw": init[0:1].copy(), "trans": init[1:4].copy(), "scale": init[4:5].copy(), "latent": init[5:8].copy()}
+    opt = Optimizer(params, DEV, {"2d": 0.3, "3d": 0.5})
+    opt.optimize(10, T(z["nocs_target"]), z["lidar"], dec, sdflabel_amd.Grid3D(D, DEV), T(z["K"]), [H, W])
+    got = np.concatenate([N(params[k]).reshape(-1) for k in ("yaw", "trans", "scale", "latent")])
+    assert np.abs(got - z["traj"][-1]).max() < 5e-4, got - z["traj"][-1]
+
+
+# ---- G14e: a second decoder ---------------------------------------------------------------------------------------------------------------
+
+E_ASSETS = {"wn_centre": "deepsdf_synth_ellipsoid", "wn_crop": "deepsdf_synth_ellipsoid", "ln_centre": "deepsdf_synth_ellipsoid_ln"}
+
+
+def _second_decoder(tag):
+    z = gold("g14e_second_decoder.npz")
+    if tag + "_cfg" not in z.files:
+        pytest.skip("golden G14e has no case " + tag)
+    path = os.path.join(os.path.dirname(ASSET), E_ASSETS[tag] + ".pt")
+    d, _ = sdflabel_amd.setup_dsdf(path, precision=torch.float32)
+    return d.to(DEV), Sub(z, tag + "_")
+
+
+@pytest.mark.parametrize("tag", ["wn_centre", "wn_crop", "ln_centre"])
+def test_g14e_second_decoder_dropin_modules_full_size(tag):
+    d, z = _second_decoder(tag)
+    _dropin_case(d, z)
+
+
+@pytest.mark.parametrize("tag", ["wn_centre", "wn_crop", "ln_centre"])
+@pytest.mark.parametrize("B", [1, 4])
+def test_g14e_second_decoder_batch_renderer_full_size(tag, B):
+    d, z = _second_decoder(tag)
+    _batch_case(d, z, B)

@@ -356,3 +356,81 @@ def test_g7_torch_cpu_port_reproduces_the_reference(tag):
     for got, key in ((yaw.grad, "_g_yaw"), (trans.grad, "_g_trans"), (lat.grad, "_g_latent")):
         ref = z[tag + key]
         assert np.abs(got.numpy() - ref).max() < 1e-3 * max(1.0, np.abs(ref).max()), key
+
+
+# ---- G14: the reference pipeline's camera regime (crop intrinsics from its own adjust_intrinsics_crop) -----------------------------------
+
+def _oracle_crop(z, p, layers, spec):
+    D, H, W = [int(v) for v in z[p + "cfg"]]
+    lat = z[p + "latent"]
+    lat = (lat / np.sqrt((lat * lat).sum())).astype(np.float32)
+    pts = O.generate_point_grid(D)
+    inp = np.concatenate([np.broadcast_to(lat, (pts.shape[0], 3)), pts], 1).astype(np.float32)
+    sdf, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+    J = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(sdf))
+    return D, H, W, pts, sdf, J
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g14_cropped_offcentre_intrinsics_band_projection_and_image_rows(tag):
+    """KITTI-like crops: principal point outside the crop (a: cx = -128, c: cx = -102; b: cx = 462 of 316 columns, fx != fy), objects 4 m off
+    the optical axis at 8 / 12 / 25 m.  The oracle's decoder + band + iso-projection on the whole grid, its projection on every surfel and its
+    splat / composite on a band of image rows against the reference (utils/refinement.py:586-609 produced the K)."""
+    z = gold("g14_cropped_intrinsics.npz")
+    p = tag + "_"
+    st, spec = fitted_state()
+    layers = O.decoder_layers_from_state(st, spec)
+    D, H, W, pts, sdf, J = _oracle_crop(z, p, layers, spec)
+    K = z[p + "K"]
+    assert not (0 <= K[0, 2] < W), "the principal point must lie outside the crop"
+    assert np.abs(sdf[::7, 0] - z[p + "sdf_stride7"]).max() < 3e-6
+    pm, _, nm, idx, _ = O.get_surface_points(pts, sdf, J[:, 3:], 0.03)
+    assert np.array_equal(idx, z[p + "band_idx"])
+    dn = np.abs(nm - z[p + "normals"])
+    assert np.abs(pm - z[p + "pcd"]).max() < 2e-5 and np.median(dn) < 1e-6 and (dn.max(1) > 1e-4).sum() <= 3
+    pose = O.render_pose(float(z[p + "yaw"][0]), z[p + "trans"])
+    assert np.abs(pose - z[p + "pose"]).max() < 1e-6
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    proj = O.project_in_2D(K, z[p + "pose"], z[p + "pcd"], z[p + "normals"], z[p + "normals"], (W, H), output_nocs=True)
+    assert proj["points_3d_filt"].shape == z[p + "xyzf"].shape and np.abs(proj["points_3d_filt"] - z[p + "xyzf"]).max() < 1e-5
+    v3, nc = proj["points_3d"].astype(np.float32), proj["normals_3d"].astype(np.float32)
+    c_attr = ((proj["colors_3d"] + 1) / 2).astype(np.float32)
+    near = np.unpackbits(z[p + "near_threshold"])[:H * W].astype(bool)
+    r0, r1 = H // 2 - 12, H // 2 + 12
+    sub = O.pixel_grid((W, H)).reshape(H, W, 2)[r0:r1].reshape(-1, 2)
+    Wm = O.inside_surfel(Kinv, sub, v3, nc, diam=0.04)
+    got = {"color": np.minimum((Wm.T @ c_attr).T, 1), "mask": np.minimum(Wm.sum(0), 1)[None], "depth": (Wm.T @ v3[:, 2])[None],
+           "normals": np.minimum((Wm.T @ ((nc + 1) / 2)).T, 1)}
+    for k, v in got.items():
+        ref = z[p + "out_" + k][:, r0:r1].reshape(v.shape[0], -1)
+        bad = (np.abs(v - ref) > 1e-4).any(0)
+        assert not (bad & ~near[r0 * W:r1 * W]).any(), k
+        assert bad.mean() <= 1e-3, k
+    assert float(got["mask"].sum()) > 1500
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_g14o_losses_of_the_first_iteration_with_cropped_intrinsics(tag):
+    """the reference Optimizer's first iteration at rendering_area = 32 with the cropped intrinsics (golden G14o): the oracle's renderer and
+    its two losses reproduce the weighted 2-D / 3-D loss values the reference printed"""
+    z = gold("g14o_optimizer_cropped.npz")
+    p = tag + "_"
+    st, spec = fitted_state()
+    layers = O.decoder_layers_from_state(st, spec)
+    D, H, W = int(z[p + "D"]), int(z[p + "H"]), int(z[p + "W"])
+    init = z[p + "init"]
+    lat = init[5:8] / np.sqrt((init[5:8] ** 2).sum())
+    pts = O.generate_point_grid(D)
+    inp = np.concatenate([np.broadcast_to(lat.astype(np.float32), (pts.shape[0], 3)), pts], 1).astype(np.float32)
+    sdf, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+    J = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(sdf))
+    pm, _, nm, _, _ = O.get_surface_points(pts, sdf, J[:, 3:], 0.03)
+    K = z[p + "K"]
+    rend, points, _ = O.rasterer_forward(K, np.linalg.inv(K).astype(np.float32), (W, H), pm, nm, nm, O.render_pose(float(init[0]), init[1:4]),
+                                         rot="dcm", output_nocs=True)
+    l2 = O.loss_2d(rend["color"], z[p + "nocs_target"])
+    l3 = O.loss_3d(points["xyzf"], z[p + "lidar"], float(init[4]))
+    l2 = l2[0] if isinstance(l2, tuple) else l2
+    l3 = l3[0] if isinstance(l3, tuple) else l3
+    assert abs(0.3 * float(l2) - float(z[p + "loss2d_weighted"][0])) < 2e-5
+    assert abs(0.5 * float(l3) - float(z[p + "loss3d_weighted"][0])) < 2e-5

@@ -69,3 +69,137 @@ def test_gather_ranks_gloo(world, n_crops):
 def test_single_process_passthrough():
     rows = torch.stack([_crop_result(i) for i in range(3)])
     assert torch.equal(gather_crop_results(rows, 3, rank=0, world=1), rows)
+
+
+# ---- refine_sharded: the function bench.py's configs[3] sections call, with a stand-in refiner on CPU ranks -------------------------------
+
+class _FakeRefiner:
+    """duck-typed stand-in for sdflabel_amd.BatchRefiner on CPU: `optimize(k)` adds k to every parameter, so that the result of crop i is a
+    known function of its initial row and the chunking / padding / gathering logic is what is tested"""
+
+    def __init__(self, B, L=3):
+        self.B, self.L, self.dev = B, L, torch.device("cpu")
+        self.calls = []
+
+    def set_crops(self, params, nocs_pred, lidars):
+        assert all(v.shape[0] == self.B for v in params.values()) and nocs_pred.shape[0] == self.B and len(lidars) == self.B
+        self.rows = torch.cat([torch.as_tensor(params[k], dtype=torch.float32).reshape(self.B, -1) for k in ("yaw", "trans", "scale", "latent")], 1)
+        self.calls.append(self.rows[:, 0].clone())
+
+    def optimize(self, iters):
+        self.rows = self.rows + float(iters)
+
+    def results(self):
+        return self.rows.clone(), None, None
+
+
+def _params(n):
+    import numpy as np
+    i = np.arange(n, dtype=np.float32)
+    return {"yaw": i, "trans": np.stack([i, 2 * i, 3 * i], 1), "scale": np.full(n, 2.0, np.float32), "latent": np.stack([-i, i * 0.5, i + 0.25], 1)}
+
+
+def _expected(n, iters):
+    p = _params(n)
+    return torch.cat([torch.from_numpy(p[k]).reshape(n, -1) for k in ("yaw", "trans", "scale", "latent")], 1) + float(iters)
+
+
+def _sharded_worker(rank, world, port, n_crops, chunk, fail_rank, q):
+    from sdflabel_amd.parallel import refine_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rf = _FakeRefiner(chunk)
+        if rank == fail_rank:
+            rf.optimize = lambda iters: (_ for _ in ()).throw(RuntimeError("boom on rank %d" % rank))
+        err, table = None, None
+        try:
+            table = refine_sharded(rf, _params(n_crops), torch.zeros(1, 3, 4, 4), torch.zeros(5, 3), 7, rank, world)
+        except RuntimeError as e:
+            err = str(e)
+        q.put((rank, None if table is None else table.clone(), err, len(rf.calls)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_crops,chunk", [(2, 10, 4), (2, 7, 64), (8, 1021, 64), (8, 5, 2)])
+def test_refine_sharded_chunks_pads_and_gathers_gloo(world, n_crops, chunk):
+    """crop i -> rank i mod world, chunks of `chunk` with the short last chunk padded, one all_gather: every rank ends with the full table"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, n_crops, chunk, -1, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _expected(n_crops, 7)
+    for rank, table, err, calls in got:
+        assert err is None and torch.equal(table, ref), rank
+        mine = len(range(rank, n_crops, world))
+        assert calls == (mine + chunk - 1) // chunk
+
+
+def test_refine_sharded_local_failure_still_joins_the_collective_gloo():
+    """a rank whose refinement raises contributes NaN rows to the all_gather and re-raises afterwards; the other rank is not left waiting"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, 6, 2, 1, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (t, e) for r, t, e, _ in [q.get(timeout=120) for _ in range(2)]}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1][1] is not None and "boom" in got[1][1]
+    t0 = got[0][0]
+    assert got[0][1] is None and torch.equal(t0[0::2], _expected(6, 7)[0::2]) and bool(torch.isnan(t0[1::2]).all())
+
+
+def test_refine_sharded_single_rank_without_a_process_group():
+    from sdflabel_amd.parallel import refine_sharded
+    table = refine_sharded(_FakeRefiner(4), _params(9), torch.zeros(9, 3, 4, 4), [torch.zeros(2, 3)] * 9, 3)
+    assert torch.equal(table, _expected(9, 3))
+
+
+# ---- bench.py --gpus N started WITHOUT a launcher must become N ranks (or refuse) ---------------------------------------------------------
+
+def _bench(*argv, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SDFR_SELF_LAUNCHED")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_self_launches_two_ranks_when_started_without_a_launcher():
+    """plain `python bench.py --gpus 2 --launch-check`: the script re-launches itself under torch.distributed.run, both ranks join the
+    process group (gloo here: no GPU in this container; RCCL on the GPU box) and rank 0 reports the group's size"""
+    import json
+    r = _bench("--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["launch_check"] and line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["ranks"] == [0, 1]
+    assert line["launcher"].startswith("self")
+
+
+def test_bench_refuses_more_ranks_than_gpus_instead_of_measuring_one():
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("this node has 8 GPUs")
+    r = _bench("--gpus", "8", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline")
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    assert not any(l.startswith("{") for l in r.stdout.splitlines()), "no JSON line may be printed by fewer ranks than --gpus"
+
+
+def test_bench_rejects_a_rank_count_that_disagrees_with_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch-check"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)

@@ -1,6 +1,6 @@
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F, sdflabel_amd
-from tests._util import ASSET, K_for
+from sdflabel_amd.fixtures import ASSET, K_for
 dev = "cuda"
 for prec in (torch.float32, torch.float16):
     dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec); dec = dec.to(dev)

@@ -5,7 +5,7 @@ CODE = r'''
 import sys, os; sys.path.insert(0, %r)
 import torch, torch.nn.functional as F, sdflabel_amd
 from sdflabel_amd import _lib
-from tests._util import ASSET
+from sdflabel_amd.fixtures import ASSET
 dev="cuda"; dec,_=sdflabel_amd.setup_dsdf(ASSET+".pt", precision=torch.float32); dec=dec.to(dev)
 h = dec.handle(torch.device(dev,0)).h
 grid=sdflabel_amd.Grid3D(40,dev); lat=F.normalize(torch.tensor([0.3,-0.5,0.8],device=dev),dim=0)

@@ -5,7 +5,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F, sdflabel_amd
 from sdflabel_amd import _lib
-from tests._util import ASSET
+from sdflabel_amd.fixtures import ASSET
 which = sys.argv[1] if len(sys.argv) > 1 else "f16"
 dev = "cuda"
 dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32); dec = dec.to(dev)

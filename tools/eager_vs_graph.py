@@ -1,7 +1,7 @@
 import sys, time, torch, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sdflabel_amd
-from tests._util import ASSET, K_for
+from sdflabel_amd.fixtures import ASSET, K_for
 dev = "cuda"
 H = W = 256; D = 40
 for prec in (torch.float16, "float32_split", torch.float32):

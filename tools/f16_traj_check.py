@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import sdflabel_amd
 from sdflabel_amd.pipelines.optimizer import Optimizer
-from tests._util import ASSET
+from sdflabel_amd.fixtures import ASSET
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 z, zh = np.load(os.path.join(G, "g8_optimizer.npz")), np.load(os.path.join(G, "g8h_optimizer_fp16.npz"))
 DEV = "cuda"; D, H, W = int(z["D"]), int(z["H"]), int(z["W"]); init = z["init"]

@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import sdflabel_amd
-from tests._util import ASSET, K_for
+from sdflabel_amd.fixtures import ASSET, K_for
 dev = "cuda"
 d0, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32); d0 = d0.to(dev)
 d1, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter"); d1 = d1.to(dev)

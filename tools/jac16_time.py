@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sdflabel_amd
-from tests._util import ASSET, K_for
+from sdflabel_amd.fixtures import ASSET, K_for
 dev = "cuda"
 dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16); dec = dec.to(dev)
 L = sdflabel_amd._lib.lib(); P = sdflabel_amd._lib.ptr

@@ -3,7 +3,7 @@ import cProfile, pstats, sys, os, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench, sdflabel_amd
-from tests._util import ASSET
+from sdflabel_amd.fixtures import ASSET
 dev = torch.device("cuda", 0)
 dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32); dec = dec.to(dev)
 grid = sdflabel_amd.Grid3D(bench.D, dev)

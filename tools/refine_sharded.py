@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 import sdflabel_amd
 from sdflabel_amd.parallel import shard_crops, gather_crop_results
-from tests._util import ASSET, K_for
+from sdflabel_amd.fixtures import ASSET, K_for
 
 
 def main():

@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench, sdflabel_amd
-from tests._util import ASSET
+from sdflabel_amd.fixtures import ASSET
 prec = torch.float16 if (len(sys.argv) > 1 and sys.argv[1] == "f16") else torch.float32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 dev = torch.device("cuda", 0)

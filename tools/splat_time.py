@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import sdflabel_amd
 from sdflabel_amd import _lib
-from tests._util import ASSET, K_for
+from sdflabel_amd.fixtures import ASSET, K_for
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 HW = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = "cuda"

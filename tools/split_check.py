@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.nn.functional as F
 import sdflabel_amd
-from tests._util import ASSET
+from sdflabel_amd.fixtures import ASSET
 dev = "cuda"
 dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32); dec = dec.to(dev)
 grid = sdflabel_amd.Grid3D(40, dev)

@@ -1,6 +1,6 @@
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F, sdflabel_amd
-from tests._util import ASSET
+from sdflabel_amd.fixtures import ASSET
 dev="cuda"
 dec,_=sdflabel_amd.setup_dsdf(ASSET+".pt", precision=torch.float16); dec=dec.to(dev)
 grid=sdflabel_amd.Grid3D(40,dev); lat=F.normalize(torch.tensor([0.3,-0.5,0.8],device=dev),dim=0)

@@ -750,8 +750,13 @@ def kitti_crop_intrinsics(K_full, yaw, trans, max_crop_area, half_extents=(0.56,
     return crop_size, intrinsics.float(), bbox
 
 
-def full_render_case(dec, D, H, W, K, latent, yaw0, trans0, with_near=True):
-    """the optimizer's graph (optimizer.py:79-123) with every output enabled and the deterministic functional of G10 as the loss"""
+def full_render_case(dec, D, H, W, K, latent, yaw0, trans0):
+    """the optimizer's graph (optimizer.py:79-123) with every output enabled and the deterministic functional of G10 as the loss.
+
+    Two backward passes.  (1) the functional over ALL pixels (g_yaw / g_trans / g_latent / g_pcd): each (pixel, surfel) pair contributes O(1-10)
+    to these sums with heavy cancellation, so ONE pair flipping across the disc edge -- which a 1e-7 change of a surfel does -- moves them by
+    ~4e-3 relative (measured on case a).  (2) the same functional with zero weight on the pixels that hold a pair within 1e-5 of a selection
+    threshold (`near_threshold`, stored): r_g_* -- the reference's gradient wherever it is a continuous function of its inputs."""
     grid = ref_grid.Grid3D(D, "cpu", torch.float32)
     lat = torch.tensor(list(latent), dtype=torch.float32, requires_grad=True)
     yaw = torch.tensor([yaw0], requires_grad=True)
@@ -764,30 +769,40 @@ def full_render_case(dec, D, H, W, K, latent, yaw0, trans0, with_near=True):
     lat.grad = None
     dec.zero_grad()
     grid.points.grad = None
+    pcd.retain_grad()
     pose = build_pose(yaw, trans)
     rendering, points = renderer(pcd, normals, normals, pose, primitives="disc", rot="dcm", bg=None, output_depth=True,
                                  output_normals=True, output_nocs=True, output_points=True, output_mask=True)
     salts = {"color": 1, "mask": 2, "depth": 3, "normals": 4, "xyzf": 5}
-    loss = sum((rendering[k] * torch.from_numpy(pattern_weights(tuple(rendering[k].shape), salts[k]))).sum() for k in rendering)
-    loss = loss + (points["xyzf"] * torch.from_numpy(pattern_weights(tuple(points["xyzf"].shape), salts["xyzf"]))).sum()
-    loss.backward()
+    near = near_threshold_pixels(K, H, W, pose.detach().numpy(), pcd.detach().numpy(), normals.detach().numpy())
+    keep = torch.from_numpy((~near).astype(np.float32)).view(1, H, W)
+    Wk = {k: torch.from_numpy(pattern_weights(tuple(rendering[k].shape), salts[k])) for k in rendering}
+    lx = (points["xyzf"] * torch.from_numpy(pattern_weights(tuple(points["xyzf"].shape), salts["xyzf"]))).sum()
+    loss = sum((rendering[k] * Wk[k]).sum() for k in rendering) + lx
+    loss_r = sum((rendering[k] * Wk[k] * keep).sum() for k in rendering) + lx
+    loss.backward(retain_graph=True)
     s = sdf.detach().numpy()
     arrs = dict(cfg=np.array([D, H, W]), latent=np.asarray(list(latent), np.float32), yaw=np.asarray([yaw0], np.float32),
                 trans=np.asarray(list(trans0), np.float32), K=K.numpy(), pose=pose.detach().numpy(),
                 sdf_stride7=s[::7, 0], band_idx=np.nonzero(np.abs(s[:, 0]) < 0.03)[0].astype(np.int32),
                 band_margin=np.min(np.abs(np.abs(s[:, 0]) - 0.03)), pcd=pcd.detach().numpy(), normals=normals.detach().numpy(),
-                xyzf=points["xyzf"].detach().numpy(), loss=loss.detach().numpy(), g_yaw=yaw.grad.numpy(), g_trans=trans.grad.numpy(),
-                g_latent=lat.grad.numpy())
+                xyzf=points["xyzf"].detach().numpy(), loss=loss.detach().numpy(), g_yaw=yaw.grad.numpy().copy(), g_trans=trans.grad.numpy().copy(),
+                g_latent=lat.grad.numpy().copy(), g_pcd=pcd.grad.numpy().copy())
+    for t in (yaw, trans, lat, pcd, grid.points):
+        t.grad = None
+    dec.zero_grad()
+    loss_r.backward()
+    arrs.update(r_loss=loss_r.detach().numpy(), r_g_yaw=yaw.grad.numpy().copy(), r_g_trans=trans.grad.numpy().copy(),
+                r_g_latent=lat.grad.numpy().copy(), r_g_pcd=pcd.grad.numpy().copy())
     dot = ((normals.detach() @ pose.detach()[:3, :3].t()) * points["xyz"].detach()).sum(1)
     arrs["filt_margin"] = dot.abs().min().numpy()
     for k, v in rendering.items():
         arrs["out_" + k] = v.detach().numpy()
-    if with_near:
-        arrs["near_threshold"] = np.packbits(near_threshold_pixels(K, H, W, pose.detach().numpy(), pcd.detach().numpy(), normals.detach().numpy()))
+    arrs["near_threshold"] = np.packbits(near)
     cov = int((rendering["mask"].detach() > 0).sum())
-    print("   N", pcd.shape[0], "Nf", points["xyzf"].shape[0], "covered px", cov, "of", H * W, "loss", float(loss), "g_yaw", yaw.grad.numpy(),
-          "g_trans", trans.grad.numpy(), "g_lat", lat.grad.numpy(), "band margin", arrs["band_margin"], "filt margin", arrs["filt_margin"],
-          "near px", int(np.unpackbits(arrs["near_threshold"]).sum()) if with_near else None)
+    print("   N", pcd.shape[0], "Nf", points["xyzf"].shape[0], "covered px", cov, "of", H * W, "loss", float(loss), "g_yaw", arrs["g_yaw"],
+          "g_trans", arrs["g_trans"], "g_lat", arrs["g_latent"], "| robust:", arrs["r_g_yaw"], arrs["r_g_trans"], arrs["r_g_latent"],
+          "band margin", arrs["band_margin"], "filt margin", arrs["filt_margin"], "near px", int(near.sum()))
     return arrs
 
 

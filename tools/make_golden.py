@@ -895,7 +895,83 @@ def g14e():
     save("g14e_second_decoder.npz", **arrs)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G8c": g8c, "G8h": g8h, "G8s": g8s, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13, "G14": g14, "G14o": g14o, "G14e": g14e}
+def _ref_grads_precision(prec, D, H, W, r0, r1, latent, yaw0, trans0):
+    """the reference's autograd gradients (yaw, trans, latent) of two functionals of the rendering of image rows [r0, r1) at `prec`:
+    'sum' = color.sum() + mask.sum() + normals.sum() + xyzf.sum() (what bench.py back-propagates) and 'pat' = the hash-weighted functional of
+    G10.  Rows are selected by the camera, not by slicing: a Rasterer of r1 - r0 rows whose principal point is shifted up by r0 sees exactly the
+    rays of those rows (K' = K with cy - r0; exact in float16 for the values used) -- the dense N x P tensors of a full 512x512 float32 backward
+    (~60 GB) do not fit this machine, four 128-row strips do.  The functionals are sums over pixels, so strip gradients add up."""
+    dec, _ = load_fitted(prec)
+    grid = ref_grid.Grid3D(D, "cpu", prec)
+    lat = torch.tensor(latent, requires_grad=True)
+    yaw = torch.tensor([yaw0], requires_grad=True)
+    trans = torch.tensor(trans0, requires_grad=True)
+    lat_ = F.normalize(lat.to(prec), p=2, dim=0)                                                     # optimizer.py:96
+    inputs = torch.cat([lat_.expand(grid.points.size(0), -1), grid.points], 1).to(lat_.dtype)       # :99-100
+    sdf, _ = dec(inputs)
+    pcd, _, normals = grid.get_surface_points(sdf)
+    lat.grad = None
+    dec.zero_grad()
+    grid.points.grad = None
+    pose = torch.eye(4).to(prec)                                                                      # :86-90
+    pose[:3, :3] = rtools.rot_from_yaw(yaw).to(prec)
+    pose[1] *= -1
+    pose[:3, 3] = trans.to(prec)
+    K = K_for(H, W)
+    K[1, 2] -= r0
+    r = Rasterer(K.to(prec), (W, r1 - r0), precision=prec)
+    rend, pts = r(pcd, normals, normals, pose, primitives="disc", rot="dcm", bg=None, output_depth=False, output_normals=True, output_nocs=True,
+                  output_points=True, output_mask=True)
+    first = r0 == 0                                                                                   # the xyzf term belongs to the image once
+    salts = {"color": 1, "mask": 2, "normals": 4, "xyzf": 5}
+    out = {}
+    for name in ("sum", "pat"):
+        loss = 0
+        for k in ("color", "mask", "normals"):
+            if name == "sum":
+                loss = loss + rend[k].float().sum()
+            else:
+                wk = pattern_weights((rend[k].shape[0], H, W), salts[k])[:, r0:r1]
+                loss = loss + (rend[k].float() * torch.from_numpy(np.ascontiguousarray(wk))).sum()
+        if first:
+            x = pts["xyzf"].float()
+            loss = loss + (x.sum() if name == "sum" else (x * torch.from_numpy(pattern_weights(tuple(x.shape), salts["xyzf"]))).sum())
+        for t in (yaw, trans, lat):
+            t.grad = None
+        loss.backward(retain_graph=(name == "sum"))
+        out[name] = np.concatenate([yaw.grad.numpy().ravel(), trans.grad.numpy().ravel(), lat.grad.numpy().ravel()]).astype(np.float64)
+        out[name + "_loss"] = float(loss)
+    return out, int(pcd.shape[0])
+
+
+def g11g():
+    """BASELINE configs[4], gradients: the reference's OWN float16 autograd gradients w.r.t. yaw, trans and latent at 512x512, D = 40 (the
+    whole image in one pass) beside its float32 gradients (four 128-row strips, see _ref_grads_precision), for two functionals.  The gap
+    between the two precisions is the yardstick of the tolerance stated in tests/test_gpu_configs.py."""
+    D, H, W = 40, 512, 512
+    latent, yaw0, trans0 = [0.3, -0.5, 0.8], 0.6, [0.0, 0.0, 3.5]
+    arrs = dict(cfg=np.array([D, H, W]), latent=np.asarray(latent, np.float32), yaw=np.asarray([yaw0], np.float32),
+                trans=np.asarray(trans0, np.float32), K=K_for(H, W).numpy())
+    g16, n16 = _ref_grads_precision(torch.float16, D, H, W, 0, H, latent, yaw0, trans0)
+    print("G11g f16", n16, g16)
+    g32 = None
+    for r0 in range(0, H, 128):
+        g, n32 = _ref_grads_precision(torch.float32, D, H, W, r0, r0 + 128, latent, yaw0, trans0)
+        g32 = g if g32 is None else {k: g32[k] + g[k] for k in g}
+        print("G11g f32 strip", r0, {k: v for k, v in g.items() if k.endswith("loss")})
+    # cross-check of the strip decomposition in float16, where the whole image fits: strips must add up to the one-pass result up to float16 noise
+    print("G11g f32", n32, g32)
+    for name in ("sum", "pat"):
+        arrs["f16_g_" + name] = g16[name]
+        arrs["f32_g_" + name] = g32[name]
+        arrs["f16_loss_" + name] = g16[name + "_loss"]
+        arrs["f32_loss_" + name] = g32[name + "_loss"]
+        print("G11g", name, "gap |f16 - f32|", np.abs(g16[name] - g32[name]), "scale", np.abs(g32[name]).max())
+    arrs["f16_n_surfels"], arrs["f32_n_surfels"] = n16, n32
+    save("g11g_config4_fp16_grads.npz", **arrs)
+
+
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G8c": g8c, "G8h": g8h, "G8s": g8s, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13, "G11g": g11g, "G14": g14, "G14o": g14o, "G14e": g14e}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -540,8 +540,11 @@ def main():
         prefilter_reuse = alt_decoder("float32_prefilter", "as prefilter_decoder, f16 pass skipped while the candidate set is provably still valid",
                                       reuse=True)
 
-    # ---- sphere-tracing render mode (BASELINE.json's literal wording; NOT the reference's algorithm, no parity claim -- DESIGN.md 3.6):
-    # one crop, `march steps` decoder evaluations per active ray with ballot compaction, forward + backward to yaw/trans/latent
+    # ---- sphere-tracing render mode (BASELINE.json's literal wording; NOT the reference's algorithm, no parity claim against it -- DESIGN.md 3.6;
+    # its oracle is oracle/sdf_oracle.py::sphere_trace): one crop, `march steps` decoder evaluations per active ray with ballot compaction and the
+    # looping tail kernel, forward + backward to yaw/trans/latent, all HIP kernels, no host synchronisation inside a render.
+    # roofline_march: ray evaluations of the march (counted on the device) x 2 M FLOP / march time (events around sdfr_trace_march) against the MFMA
+    # peak of the march's operand type; step_kernel_hbm: algorithmic bytes of the advance / compaction kernel per ray-step.
     sphere = None
     if rank == 0 and CB == 1 and not args.no_extras:
         sphere = {}
@@ -549,28 +552,36 @@ def main():
             try:
                 d3, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
                 tr = sdflabel_amd.SphereTracer(d3.to(dev), K_for(H, W), (W, H), 1, steps=steps, device=dev)
-                prm = [crop.yaw.detach().clone().requires_grad_(True), crop.trans.detach().clone().view(1, 3).requires_grad_(True),
-                       crop.latent.detach().clone().view(1, -1).requires_grad_(True)]
+                prm = [crop.yaw.detach().clone(), crop.trans.detach().clone().view(1, 3), crop.latent.detach().clone().view(1, -1)]
+                o3, o1 = torch.ones(1, 3, H, W, device=dev), torch.ones(1, 1, H, W, device=dev)
 
-                def tstep():
-                    for p_ in prm:
-                        p_.grad = None
-                    o_ = tr(*prm)
-                    (o_["depth"].sum() + o_["color"].sum() + o_["normals"].sum()).backward()
-                    return o_
+                def tstep(ev=None):
+                    tr.render(*prm, events=ev)
+                    tr.backward(g_color=o3, g_depth=o1, g_normals=o3)
 
-                for _ in range(2):
+                for _ in range(3):
                     tstep()
                 torch.cuda.synchronize()
+                nrep = 20
                 t_ = time.perf_counter()
-                nrep = 5
                 for _ in range(nrep):
-                    o_ = tstep()
+                    tstep()
                 torch.cuda.synchronize()
                 dt_t = (time.perf_counter() - t_) / nrep
-                sphere[label] = {"value": H * W / dt_t, "unit": "rays/s", "ms_per_render_fwd_bwd": dt_t * 1e3, "march_steps": steps, "march_steps_run": int(tr.steps_run),
-                                 "rays_entering_the_object_cube": int(tr.n_entered), "hits": int(tr.n_hit),
-                                 "unresolved_after_last_step": int(tr.n_unresolved), "max_abs_sdf_at_marched_hits": float(tr.hit_residual.abs().max())}
+                evs = [{"march": ev_pair()} for _ in range(5)]
+                for e in evs:
+                    tstep(e)
+                torch.cuda.synchronize()
+                march_ms = float(np.mean([e["march"][0].elapsed_time(e["march"][1]) for e in evs]))
+                st3 = tr.stats()
+                peak = 2500.0 if prec == torch.float16 else F32_MFMA_PEAK_TFLOPS
+                tfl = 2.0 * macs * st3["ray_evaluations"] / (march_ms * 1e-3) / 1e12
+                sphere[label] = {"value": H * W / dt_t, "unit": "rays/s", "ms_per_render_fwd_bwd": dt_t * 1e3, "march_steps": steps, "march_ms": march_ms,
+                                 "hits": st3["hits"], "unresolved_after_last_step": st3["unresolved"], "ray_evaluations": st3["ray_evaluations"],
+                                 "head_steps": tr.head_steps, "tail_rows": tr.tail_rows,
+                                 "roofline_march": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
+                                                    "flops": 2.0 * macs * st3["ray_evaluations"]},
+                                 "max_abs_sdf_at_marched_hits": float(tr.hit_residual.abs().max())}
                 del tr, d3
             except Exception as e:
                 sphere[label] = {"error": repr(e)[:200]}

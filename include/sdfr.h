@@ -335,6 +335,33 @@ int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int
                     int32_t* counters, int step, int64_t n_max, const int32_t* pix_in, const float* lam_in, int32_t* pix_out, float* lam_out,
                     const float* far, float* inputs, float* hit_lam, float* hit_sdf, void* stream);
 
+/* The whole march in ONE call, no host synchronisation (counters: device int32[8], zeroed by sdfr_trace_setup -- [0..2] rotating active
+ * counts, [3] rays unresolved when the step budget ran out, [4..5] one uint64 = ray evaluations of the march, [6] hits).  While the
+ * device-side count is >= tail_rows a step is the decoder on the active rows + the step kernel; below it ONE launch of the decoder kernel in
+ * its looping mode takes the remaining rays to termination (16-ray tiles, ray state in registers, no per-step launch, no compaction); the
+ * gate is evaluated on the device in each of the first head_steps steps, then an unconditional tail launch takes what is left.
+ * pix0/lam0 (filled by sdfr_trace_setup) and pix1/lam1 are the ping-pong active lists, sdf float[B*W*H] scratch. */
+int sdfr_trace_march(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float eps,
+                     float relax, int steps, int head_steps, int tail_rows, int half, int32_t* counters, int32_t* pix0, float* lam0,
+                     int32_t* pix1, float* lam1, const float* far, float* inputs, float* sdf, float* hit_lam, float* hit_sdf, void* stream);
+/* hit pixels (hit_lam > 0) -> compact list: rows float[n][L+3] = [latn, o + lam d] for sdfr_mlp_jacobian (rows_per_crop = B*W*H, B = 1,
+ * idx = the identity written here, cnt = n_hits), hit_slot int32[B*W*H] = list position of the pixel's hit or -1.  n_hits: device int32,
+ * zero on entry (counters + 6 after sdfr_trace_setup). */
+int sdfr_trace_hits(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, const float* hit_lam, int32_t* n_hits,
+                    int32_t* hit_slot, int32_t* idx, float* rows, void* stream);
+/* images of the hits after one Newton step along the ray with the exact-f32 decoder value f0 [slot] and input Jacobian J [slot][L+3]
+ * (non-grazing rays only): depth [B][1][H][W] = lam_s r_z, color [B][3][H][W] = NOCS of the hit point, normals [B][3][H][W] = (R n + 1) / 2,
+ * mask [B][1][H][W] = 1; zero at the other pixels.  lam_s (optional) float[B*W*H]: the polished ray parameter. */
+int sdfr_trace_composite(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
+                         const float* J, const float* f0, float* color, float* mask, float* depth, float* normals, float* lam_s, void* stream);
+/* backward at a fixed hit set through the implicit function f(o + lam d, z) = 0: image gradients (each may be NULL) -> g_pose [B][16]
+ * (gradient w.r.t. the entries of the row-major 4x4 pose) and g_latn [B][L] (w.r.t. the normalised latent); fixed-order sums per crop.
+ * ws: sdfr_trace_backward_ws_floats(B, W, H) floats.  sdfr_params_backward maps the result to yaw / trans / latent. */
+int64_t sdfr_trace_backward_ws_floats(int B, int W, int H);
+int sdfr_trace_backward(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
+                        const float* J, const float* f0, const float* g_color, const float* g_depth, const float* g_normals, float* ws,
+                        float* g_pose, float* g_latn, void* stream);
+
 /* Debug only: forward kernels of a library built with -DSDFR_MLP_TRACE write cycle stamps of their workgroup 0 into this device buffer
  * (2 * SDFR_MAX_LAYERS * 5 uint64; see tools/cycle_trace.py); pass NULL to disable.  Production builds ignore it. */
 int sdfr_debug_set_trace(void* device_buffer);

@@ -715,3 +715,132 @@ def loss_2d(rendering_nocs, css_nocs, diam=5, threshold_nocs=1, want_grad=False)
         m = t[:, a // W, a % W] * w
         g[:, y, x] = (r[:, y, x] - m) / dm / cnt
     return loss, g
+
+
+# ---- sphere tracing (NOT in the reference: the render mode of BASELINE.json's north_star wording) --------------------
+# The oracle of sdflabel_amd.SphereTracer (csrc/trace.hip): the same ray set-up, step rule, hit / exit tests, Newton polish and
+# implicit-function gradient, in numpy on a subset of pixels.  There is no reference algorithm to cite; the pose and ray conventions are the
+# reference's (pipelines/optimizer.py:86-90 pose, primitives.py:203-208 pixel rays, projection.py:53-55 NOCS colour).
+
+def trace_rays(pose, Kinv, pixels_xy):
+    """object-space rays of pixels (n,2): o = -R^T t, d = R^T K^-1 [x, y, 1]; returns o (3,), d (n,3), r_cam (n,3)   (float32)"""
+    f = np.float32
+    P = np.asarray(pose, f).reshape(4, 4)
+    Ki = np.asarray(Kinv, f).reshape(3, 3)
+    x, y = np.asarray(pixels_xy, f)[:, 0], np.asarray(pixels_xy, f)[:, 1]
+    r = np.stack([Ki[0, 0] * x + Ki[0, 1] * y + Ki[0, 2], Ki[1, 0] * x + Ki[1, 1] * y + Ki[1, 2], Ki[2, 0] * x + Ki[2, 1] * y + Ki[2, 2]], 1).astype(f)
+    R, t = P[:3, :3], P[:3, 3]
+    d = (r @ R).astype(f)                    # d_j = sum_i R_ij r_i
+    o = (-(t @ R)).astype(f)
+    return o, d, r
+
+
+def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, bound=1.0, near=1e-3, relax=1.0):
+    """March every ray: x = o + lam d, v = decoder(latn, x); |v| < eps -> hit at lam; else lam += relax v / |d|; lam >= far (exit of the cube
+    [-bound, bound]^3) or NaN -> miss; out of steps -> miss (unresolved).  Then one Newton step along non-grazing rays with the decoder value f0
+    and input gradient at the marched point: lam_s = lam0 - f0 / (gx . d) where |gx . d| > 0.1 |gx| |d|.
+    Returns a dict of per-ray arrays: hit (bool), lam0, lam_s, ok (Newton step taken), x_s (n,3), depth, color (NOCS, n,3), normals ((R n + 1)/2,
+    n,3), n_hat, gx (n,3), gz (n,L), f0, c (= 1 / (gx . d) or 0), margin (distance of the closest hit / exit / grazing decision to its threshold, in
+    the decision's own units: rays with a small margin may legitimately decide differently under float rounding), n_steps, evals (total ray
+    evaluations)."""
+    f = np.float32
+    latn = np.asarray(latn, f).reshape(-1)
+    L = latn.shape[0]
+    o, d, r = trace_rays(pose, Kinv, pixels_xy)
+    n = d.shape[0]
+    l0 = np.full(n, near, f)
+    l1 = np.full(n, np.finfo(f).max, f)
+    active = np.ones(n, bool)
+    for a in range(3):
+        da = d[:, a]
+        par = np.abs(da) < f(1e-12)
+        active &= ~par | (np.abs(o[a]) <= bound)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ta = ((-f(bound) - o[a]) / da).astype(f)
+            tb = ((f(bound) - o[a]) / da).astype(f)
+        lo, hi = np.minimum(ta, tb), np.maximum(ta, tb)
+        l0 = np.where(par, l0, np.maximum(l0, lo)).astype(f)
+        l1 = np.where(par, l1, np.minimum(l1, hi)).astype(f)
+    active &= l0 < l1
+    dn = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(f)
+    lam = l0.copy()
+    hit = np.zeros(n, bool)
+    lam0 = np.zeros(n, f)
+    margin = np.full(n, np.inf)
+    n_steps = np.zeros(n, np.int32)
+    evals = 0
+    for s in range(steps):
+        idx = np.nonzero(active)[0]
+        if idx.size == 0:
+            break
+        evals += int(idx.size)
+        x = (o[None] + lam[idx, None] * d[idx]).astype(f)
+        rows = np.concatenate([np.broadcast_to(latn, (idx.size, L)), x], 1).astype(f)
+        v = decoder_forward(layers, spec, rows)[:, 0].astype(f)
+        n_steps[idx] += 1
+        margin[idx] = np.minimum(margin[idx], np.abs(np.abs(v) - eps))
+        h = np.abs(v) < f(eps)
+        hit[idx[h]] = True
+        lam0[idx[h]] = lam[idx[h]]
+        l2 = (lam[idx] + f(relax) * v / dn[idx]).astype(f)
+        keep = ~h & (l2 < l1[idx]) & ~np.isnan(v)
+        margin[idx[~h]] = np.minimum(margin[idx[~h]], np.abs(l1[idx[~h]] - l2[~h]))
+        lam[idx[keep]] = l2[keep]
+        active[idx] = keep
+    unresolved = active.copy()
+    out = {"hit": hit, "lam0": lam0, "unresolved": unresolved, "n_steps": n_steps, "evals": evals, "far": l1, "entered": l0 < l1}
+    hi_ = np.nonzero(hit)[0]
+    x0 = (o[None] + lam0[hi_, None] * d[hi_]).astype(f)
+    rows = np.concatenate([np.broadcast_to(latn, (hi_.size, L)), x0], 1).astype(f)
+    if hi_.size:
+        f0h, cache = decoder_forward(layers, spec, rows, want_cache=True)
+        Jh = decoder_backward_inputs(layers, spec, rows, cache, np.ones_like(f0h)).astype(f)
+        f0h = f0h[:, 0].astype(f)
+    else:
+        f0h, Jh = np.zeros(0, f), np.zeros((0, L + 3), f)
+    gz, gx = np.zeros((n, L), f), np.zeros((n, 3), f)
+    f0 = np.zeros(n, f)
+    gz[hi_], gx[hi_], f0[hi_] = Jh[:, :L], Jh[:, L:], f0h
+    gd = (gx * d).sum(1).astype(f)
+    gn = np.sqrt((gx * gx).sum(1)).astype(f)
+    ok = hit & (np.abs(gd) > f(0.1) * gn * dn)
+    margin[hit] = np.minimum(margin[hit], np.abs(np.abs(gd[hit]) - f(0.1) * gn[hit] * dn[hit]))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lam_s = np.where(ok, lam0 - f0 / np.where(ok, gd, 1), lam0).astype(f)
+        c = np.where(ok, 1 / np.where(ok, gd, 1), 0).astype(f)
+    x_s = (o[None] + lam_s[:, None] * d).astype(f)
+    n_hat = (gx / np.maximum(gn, f(1e-12))[:, None]).astype(f)
+    R = np.asarray(pose, f).reshape(4, 4)[:3, :3]
+    out.update(lam_s=lam_s, ok=ok, c=c, x_s=x_s, gx=gx, gz=gz, f0=f0, n_hat=n_hat, margin=margin,
+               depth=np.where(hit, lam_s * r[:, 2], 0).astype(f),
+               color=np.where(hit[:, None], (x_s * np.array([-1, 1, 1], f) + 1) / 2, 0).astype(f),
+               normals=np.where(hit[:, None], (n_hat @ R.T + 1) / 2, 0).astype(f), r_cam=r, d=d, o=o)
+    return out
+
+
+def sphere_trace_backward(tr, pose, g_color=None, g_depth=None, g_normals=None):
+    """Gradient of a functional of the traced images w.r.t. the pose matrix entries and the NORMALISED latent at the fixed hit set, through
+        lam(θ) = lam_s - c [ gx . (o(θ) + lam_s d(θ) - x_s) + gz . (z(θ) - z_s) ],   x(θ) = o(θ) + lam(θ) d(θ),   n_cam = R n_hat (n_hat constant)
+    tr: the dict sphere_trace returned; g_color / g_normals (n,3), g_depth (n,): upstream gradients of the rays' image values.
+    Returns g_pose (4,4) (rotation and translation entries filled) and g_latn (L,)   (float64 sums)."""
+    hit = tr["hit"]
+    n = hit.shape[0]
+    P = np.asarray(pose, np.float64).reshape(4, 4)
+    R, t = P[:3, :3], P[:3, 3]
+    d, r = tr["d"].astype(np.float64), tr["r_cam"].astype(np.float64)
+    gx, gz = tr["gx"].astype(np.float64), tr["gz"].astype(np.float64)
+    c, lam_s = tr["c"].astype(np.float64), tr["lam_s"].astype(np.float64)
+    z3 = np.zeros((n, 3))
+    gxs = z3 if g_color is None else np.asarray(g_color, np.float64) * np.array([-0.5, 0.5, 0.5])
+    gnc = z3 if g_normals is None else np.asarray(g_normals, np.float64) * 0.5
+    gl = (gxs * d).sum(1) + (0 if g_depth is None else np.asarray(g_depth, np.float64) * r[:, 2])
+    k = c * gl
+    gw = (gxs - k[:, None] * gx) * hit[:, None]
+    go, gdd = gw, lam_s[:, None] * gw
+    gnc = gnc * hit[:, None]
+    gR = -np.outer(t, go.sum(0)) + r.T @ gdd + gnc.T @ tr["n_hat"].astype(np.float64)
+    gt = -(R @ go.sum(0))
+    g_pose = np.zeros((4, 4))
+    g_pose[:3, :3], g_pose[:3, 3] = gR, gt
+    g_latn = -((k * hit)[:, None] * gz).sum(0)
+    return g_pose, g_latn

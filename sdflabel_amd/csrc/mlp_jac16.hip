@@ -22,3 +22,8 @@ void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s
     hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 1, SDFR_J16_NW, SDFR_J16_PF, 0>), dim3(sdfr_cdiv(n, 16)), dim3(64 * SDFR_J16_NW), 0, s,
                        P);
 }
+
+// MODE 4: the persistent tail of the sphere tracer's march with half operands (see mlp_jac.hip)
+void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 1, SDFR_J16_NW, SDFR_J16_PF, 4>), dim3(sdfr_cdiv(n, 16)), dim3(64 * SDFR_J16_NW), 0, s, P);
+}

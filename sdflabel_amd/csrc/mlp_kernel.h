@@ -77,6 +77,20 @@ struct MlpParams {
     const int32_t* n_dev;        // forward: optional device-side row count (rows >= *n_dev are not evaluated; n is the launch bound)
     int n_dev_lo, n_dev_hi;      // with n_dev and n_dev_hi > 0: the launch runs only while n_dev_lo <= *n_dev < n_dev_hi (two tile geometries of one step)
     unsigned long long* trace;   // builds with -DSDFR_MLP_TRACE: cycle stamps of workgroup 0 (sdfr_debug_set_trace), else unused
+    // MODE 4 (sphere tracing, persistent tail: csrc/trace.hip): the workgroup marches the PT rays of its tile to termination by itself --
+    // decoder pass, advance, hit / exit test, next pass -- rewriting its own rows of `inputs` between passes
+    float* t_rows;               // = inputs (writable): [latent, o + lam d] per active-list row
+    const int32_t* t_pix;        // active list: crop * W*H + pixel
+    const float* t_lam;          // active list: current ray parameter
+    const float* t_far;          // per pixel: ray parameter at which the ray leaves the object cube
+    const float* t_pose;         // [B][16]
+    const float* t_Kinv;         // [B][9]
+    float* t_hit_lam;            // per pixel: ray parameter of the hit (0: none)
+    float* t_hit_sdf;            // per pixel: decoder value at the marched hit
+    int t_W, t_H, t_steps;       // image size; passes left in the march's step budget
+    float t_eps, t_relax;
+    unsigned long long* t_evals; // += active rays per pass (ray evaluations of the march, for the roofline)
+    int32_t* t_unresolved;       // += rays still active when the step budget ran out
 };
 
 struct sdfr_decoder {
@@ -157,14 +171,16 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     typedef typename M::acc_t acc_t;
     typedef typename M::vec_t vec_t;
     constexpr bool HALF = sizeof(ET) == 2;
-    constexpr bool JAC = MODE >= 2;
+    constexpr bool JAC = MODE == 2 || MODE == 3;
+    constexpr bool TAIL = MODE == 4;                               // forward passes in a loop: the sphere tracer's persistent tail
     constexpr bool SAVE = MODE == 1;
     constexpr bool LMASK = MODE == 2;
     constexpr bool GMASK = MODE == 3;
     static_assert(!SAVE || MS == 32, "mask layout assumes 32x32 forward tiles");
     static_assert(!SAVE || (FT * NP) % 2 == 0, "mask words: FT*NP*16 bits per thread and layer must fill whole words");
     static_assert(!HALF || !JAC || MODE == 3, "with half operands only the mask-fed Jacobian exists (MODE 3)");
-    static_assert(!LN || (!HALF && MODE != 1 && MODE != 3), "LayerNorm decoders: float32 forward (MODE 0) and recomputing Jacobian (MODE 2)");
+    static_assert(!LN || (!HALF && MODE != 1 && MODE != 3 && MODE != 4), "LayerNorm decoders: float32 forward (MODE 0) and recomputing Jacobian (MODE 2)");
+    static_assert(!TAIL || NP * MS <= 64, "tail march: the rays of a tile are owned by the first lanes of wave 0");
     constexpr int KV = M::KV;                                      // operand elements per 16-byte fragment
     constexpr int NLG = 64 / MS;                                   // lane groups (k slots per MFMA)
     constexpr int RG = MS / (4 * NLG);                             // register groups of 4 per accumulator (4 or 1)
@@ -181,7 +197,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     // half forward: four more k groups behind the HP feature slots hold the tile's input rows (k = HP + input column; zero beyond), so that
     // layers which re-inject input columns (latent_in / xyz_in_all) find them in the operand at a fixed place and no epilogue has to patch
     // them in (the generic per-element injection path cost the one wave that ran it 12 k cycles per layer, everybody else waiting)
-    constexpr int KGX = KG + ((HALF && MODE <= 1) ? 4 : 0);
+    constexpr int KGX = KG + ((HALF && !JAC) ? 4 : 0);
     __shared__ float4 lds4[KGX * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4 + LN_F4];
     vec_t* act = reinterpret_cast<vec_t*>(lds4);                  // [KG][PT] 16-byte vectors: act[k/KV][point][k%KV]
     ET* act_e = reinterpret_cast<ET*>(lds4);
@@ -219,6 +235,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         const int64_t n_rows = P.n_dev ? min(P.n, (int64_t)*P.n_dev) : P.n;          // sphere tracing: the active-ray count lives on the device
         if (r0 >= n_rows) return;
         if (P.n_dev && P.n_dev_hi > 0 && (*P.n_dev < P.n_dev_lo || *P.n_dev >= P.n_dev_hi)) return;
+        if (TAIL && P.t_steps <= 0) return;
         if (P.skip) {                               // two-stage evaluation: crops that reuse their candidate set skip the half pass
             // a tile is dropped only when EVERY crop it spans is flagged (rows_per_crop need not be a multiple of the tile: a tile may span
             // two or more crops); in a surviving tile the rows of flagged crops are computed but not stored (see the store of P.sdf)
@@ -240,23 +257,26 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         }
     }
 
-    // ---- layer-0 operand: act[k][pt] = inputs[row(pt)][k], zero padded to the K tile ---------------------
-    if (!GMASK) {
-        const int k0pad = HALF ? P.L[0].kp_h : P.L[0].kp_f;
-        for (int e = tid; e < PT * k0pad; e += NT) {
-            const int pt = e / k0pad, k = e - pt * k0pad;
-            const float v = (k < NI) ? P.inputs[(int64_t)rows[pt] * NI + k] : 0.f;
-            act_e[((k / KV) * PT + pt) * KV + (k % KV)] = (ET)v;
+    auto build_operand = [&]() {
+        // ---- layer-0 operand: act[k][pt] = inputs[row(pt)][k], zero padded to the K tile ---------------------
+        if (!GMASK) {
+            const int k0pad = HALF ? P.L[0].kp_h : P.L[0].kp_f;
+            for (int e = tid; e < PT * k0pad; e += NT) {
+                const int pt = e / k0pad, k = e - pt * k0pad;
+                const float v = (k < NI) ? P.inputs[(int64_t)rows[pt] * NI + k] : 0.f;
+                act_e[((k / KV) * PT + pt) * KV + (k % KV)] = (ET)v;
 
+            }
         }
-    }
-    if (KGX > KG) {
-        for (int e = tid; e < PT * 4 * KV; e += NT) {
-            const int pt = e / (4 * KV), k = e - pt * (4 * KV);
-            const float v = (P.kinj && k < NI) ? P.inputs[(int64_t)rows[pt] * NI + k] : 0.f;
-            act_e[((KG + k / KV) * PT + pt) * KV + (k % KV)] = (ET)v;
+        if (KGX > KG) {
+            for (int e = tid; e < PT * 4 * KV; e += NT) {
+                const int pt = e / (4 * KV), k = e - pt * (4 * KV);
+                const float v = (P.kinj && k < NI) ? P.inputs[(int64_t)rows[pt] * NI + k] : 0.f;
+                act_e[((KG + k / KV) * PT + pt) * KV + (k % KV)] = (ET)v;
+            }
         }
-    }
+    };
+    build_operand();
     __syncthreads();
 
     const int fbase = wave * MS * FT;      // first feature row owned by this wave
@@ -520,6 +540,35 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #else
 #define SDFR_STAMP(l, i) do { } while (0)
 #endif
+    // ---- MODE 4: the tile's rays (lane i < PT of wave 0 owns ray i) -------------------------------------------
+    int t_gp = 0, t_left = 0;
+    bool t_act = false;
+    float t_l = 0.f, t_farl = 0.f, t_idn = 0.f, t_ox = 0.f, t_oy = 0.f, t_oz = 0.f, t_dx = 0.f, t_dy = 0.f, t_dz = 0.f;
+    unsigned long long t_ev = 0ull;
+    int* t_more = reinterpret_cast<int*>(gy);           // gy is unused by forward modes
+    if constexpr (TAIL) {
+        t_left = P.t_steps;
+        if (tid < PT && tid < n_valid) {
+            const int64_t s = (int64_t)blockIdx.x * PT + tid;
+            t_gp = P.t_pix[s];
+            t_l = P.t_lam[s];
+            t_farl = P.t_far[t_gp];
+            const int P_ = P.t_W * P.t_H, b = t_gp / P_, px = t_gp - b * P_;
+            const float* Pm = P.t_pose + (int64_t)b * 16;
+            const float* Ki = P.t_Kinv + (int64_t)b * 9;
+            const float x = (float)(px % P.t_W), y = (float)(px / P.t_W);
+            const float rx = fmaf(Ki[1], y, Ki[0] * x) + Ki[2], ry = fmaf(Ki[4], y, Ki[3] * x) + Ki[5], rz = fmaf(Ki[7], y, Ki[6] * x) + Ki[8];
+            t_dx = Pm[0] * rx + Pm[4] * ry + Pm[8] * rz;
+            t_dy = Pm[1] * rx + Pm[5] * ry + Pm[9] * rz;
+            t_dz = Pm[2] * rx + Pm[6] * ry + Pm[10] * rz;
+            t_ox = -(Pm[0] * Pm[3] + Pm[4] * Pm[7] + Pm[8] * Pm[11]);
+            t_oy = -(Pm[1] * Pm[3] + Pm[5] * Pm[7] + Pm[9] * Pm[11]);
+            t_oz = -(Pm[2] * Pm[3] + Pm[6] * Pm[7] + Pm[10] * Pm[11]);
+            t_idn = sqrtf(t_dx * t_dx + t_dy * t_dy + t_dz * t_dz);        // |d| (the step divides by it, as sdfr_trace_step_kernel does)
+            t_act = true;
+        }
+    }
+    do {
     for (int l = 0; !GMASK && l < P.n_mfma; ++l) {
         const MlpLayer L = P.L[l];
         const MlpLayer Ln = P.L[l + 1];
@@ -626,7 +675,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #ifndef SDFR_H_FAST_EPI
 #define SDFR_H_FAST_EPI 1
 #endif
-        if constexpr (SDFR_H_FAST_EPI && HALF && !LN && (MODE == 0 || MODE == 1)) {
+        if constexpr (SDFR_H_FAST_EPI && HALF && !LN && !JAC) {
             if (inj_here) epilogue(std::true_type{});          // decoders with more than 8 input columns: generic injection
             else epilogue_half_fast();
         }
@@ -690,6 +739,24 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                 if (P.use_tanh) g *= (1.f - y1 * y1);
                 gy[tid] = g;
                 if (tid < n_valid && P.sdf_sel) P.sdf_sel[slots[tid]] = o;
+            } else if (TAIL) {
+                // advance this lane's ray by the decoder value (the step rule of sdfr_trace_step_kernel), retire hits and exits
+                const unsigned long long live = __ballot(t_act);
+                if (tid == 0) t_ev += (unsigned long long)__popcll(live);
+                if (t_act) {
+                    if (fabsf(o) < P.t_eps) {
+                        P.t_hit_lam[t_gp] = t_l;
+                        P.t_hit_sdf[t_gp] = o;
+                        t_act = false;
+                    } else {
+                        const float l2 = t_l + P.t_relax * o / t_idn;
+                        if ((l2 < t_farl) && (o == o)) {
+                            t_l = l2;
+                            float* row = P.t_rows + ((int64_t)blockIdx.x * PT + tid) * NI;
+                            row[NI - 3] = t_ox + l2 * t_dx; row[NI - 2] = t_oy + l2 * t_dy; row[NI - 1] = t_oz + l2 * t_dz;
+                        } else t_act = false;
+                    }
+                }
             } else {
                 if (tid < n_valid) {
                     const int64_t row = (int64_t)blockIdx.x * PT + tid;
@@ -697,6 +764,26 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                 }
             }
         }
+    }
+    if constexpr (TAIL) {
+        // another pass while a ray of the tile is still marching and the step budget lasts
+        --t_left;
+        if (tid == 0) *t_more = 0;
+        __syncthreads();
+        if (t_act && t_left > 0) *t_more = 1;
+        __syncthreads();
+        if (*t_more == 0) break;
+        build_operand();                                  // the rows this workgroup has just rewritten (same CU: its L1 is coherent for it)
+        __syncthreads();
+    }
+    } while (TAIL);
+    if constexpr (TAIL) {
+        const unsigned long long left_over = __ballot(t_act);
+        if (tid == 0) {
+            if (P.t_evals) atomicAdd(P.t_evals, t_ev);
+            if (left_over && P.t_unresolved) atomicAdd(P.t_unresolved, (int)__popcll(left_over));
+        }
+        return;
     }
     if constexpr (JAC) {
     __syncthreads();
@@ -941,6 +1028,8 @@ void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks
 void sdfr_launch_fwd_f32_512_tile16(const MlpParams& P, int64_t n, hipStream_t s);                // mlp_jac.hip (forward on 16-row tiles: thin counted launches)
 void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s);                  // mlp_jac16.hip (mask-fed only)
 void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s);                // mlp_jac16.hip (half forward on 16-row tiles)
+void sdfr_launch_tail_f32_512(const MlpParams& P, int64_t n, hipStream_t s);                      // mlp_jac.hip (MODE 4: sphere tracer's persistent tail)
+void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n, hipStream_t s);                      // mlp_jac16.hip
 void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)
 void sdfr_launch_ln(const MlpParams& P, int HP, bool jac, int grid_x, int grid_y, hipStream_t s);        // mlp_ln.hip (LayerNorm decoders)
 int sdfr_ln_points_per_wg(int HP, bool jac);

@@ -9,9 +9,10 @@
 // (primitives.py:203-208), so o = -R^T t, d = R^T r and lam is the camera-frame depth of the point (r_z = 1 for a pinhole K).
 // The active list is compacted every step with one wave ballot + one atomic per wavefront (rays are independent: their order in the list
 // does not matter), the count stays on the device, and the decoder launch of the next step reads it there: no host synchronisation.
-#include "sdfr_common.h"
+#include "mlp_kernel.h"
 #include <float.h>
 
+#define SDFR_TRACE_COUNTERS 8
 struct TraceRay { float ox, oy, oz, dx, dy, dz; };
 
 __device__ __forceinline__ TraceRay trace_ray(const float* __restrict__ P, const float* __restrict__ Ki, float x, float y) {
@@ -87,10 +88,13 @@ __global__ __launch_bounds__(256) void sdfr_trace_step_kernel(const float* __res
                                                              const int32_t* __restrict__ pix_in, const float* __restrict__ lam_in,
                                                              int32_t* __restrict__ pix_out, float* __restrict__ lam_out,
                                                              const float* __restrict__ far, float* __restrict__ inputs,
-                                                             float* __restrict__ hit_lam, float* __restrict__ hit_sdf) {
+                                                             float* __restrict__ hit_lam, float* __restrict__ hit_sdf, int min_count,
+                                                             unsigned long long* __restrict__ evals) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     const int n = *n_cur;
     if (s == 0) *n_zero = 0;                     // the counter of the step after next (three counters rotate)
+    if (n < min_count) return;                   // fewer rays than the tail threshold: the persistent tail kernel marches them to the end
+    if (s == 0 && evals) atomicAdd(evals, (unsigned long long)n);
     if (blockIdx.x * 256 >= n) return;
     bool keep = false;
     int gp = 0;
@@ -118,12 +122,173 @@ __global__ __launch_bounds__(256) void sdfr_trace_step_kernel(const float* __res
     }
 }
 
+__global__ void sdfr_trace_leftover_kernel(const int32_t* __restrict__ n_cur, int32_t* __restrict__ unresolved) {
+    if (threadIdx.x == 0 && *n_cur > 0) atomicAdd(unresolved, *n_cur);
+}
+
+// ---- after the march: hit list, images, gradients ------------------------------------------------------------------------------------------
+// hit pixels -> compact list of decoder rows [latent, x0 = o + lam0 d] (ballot append; the order is irrelevant: everything downstream is
+// addressed per pixel through hit_slot) for the exact-f32 value + Jacobian pass (sdfr_mlp_jacobian with idx = identity, cnt = n_hits)
+__global__ __launch_bounds__(256) void sdfr_trace_hits_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
+                                                             const float* __restrict__ latn, int L, int W, int H,
+                                                             const float* __restrict__ hit_lam, int32_t* __restrict__ n_hits,
+                                                             int32_t* __restrict__ hit_slot, int32_t* __restrict__ idx, float* __restrict__ rows) {
+    const int b = blockIdx.y, P_ = W * H;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    bool hit = false;
+    float lam = 0.f;
+    TraceRay r = {};
+    if (p < P_) {
+        lam = hit_lam[(int64_t)b * P_ + p];
+        hit = lam > 0.f;
+        if (hit) r = trace_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, (float)(p % W), (float)(p / W));
+    }
+    const int slot = trace_append(hit, n_hits);
+    if (p < P_) hit_slot[(int64_t)b * P_ + p] = hit ? slot : -1;
+    if (hit) {
+        idx[slot] = slot;
+        trace_write_row(rows + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, r, lam);
+    }
+}
+
+struct TraceHit { float lam_s, c, nx, ny, nz; };      // polished ray parameter, 1 / (grad f . d) (0: grazing, no implicit term), unit normal
+
+// One Newton step along the ray from the marched point with the exact-f32 decoder value f0 and input gradient (gx = d f / d x) there:
+// lam_s = lam0 - f0 / (gx . d) -- only for rays that meet the surface at more than ~6 degrees (|gx . d| > 0.1 |gx| |d|); along a grazing ray
+// the first-order step is long and leaves the linear region of the decoder: those hits keep the marched point (|f| < eps).
+__device__ __forceinline__ TraceHit trace_polish(const TraceRay& r, float lam0, float f0, const float* __restrict__ Jrow, int L) {
+    const float gx = Jrow[L], gy = Jrow[L + 1], gz = Jrow[L + 2];
+    const float gd = gx * r.dx + gy * r.dy + gz * r.dz;
+    const float gn = sqrtf(gx * gx + gy * gy + gz * gz), dn = sqrtf(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz);
+    const bool ok = fabsf(gd) > 0.1f * gn * dn;
+    TraceHit h;
+    h.lam_s = ok ? lam0 - f0 / gd : lam0;
+    h.c = ok ? 1.f / gd : 0.f;
+    const float inv = 1.f / fmaxf(gn, 1e-12f);                    // F.normalize
+    h.nx = gx * inv; h.ny = gy * inv; h.nz = gz * inv;
+    return h;
+}
+
+// images of the hits: depth = lam_s r_z, NOCS colour = (x_s (-1,1,1) + 1) / 2 (projection.py:53-55, rasterer.py:113-114), normals = (R n + 1) / 2, mask = 1;
+// zero elsewhere.  Layouts as the splat renderer's: color [B][3][H][W], mask / depth [B][1][H][W], normals [B][3][H][W].
+__global__ __launch_bounds__(256) void sdfr_trace_composite_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv, int L, int W, int H,
+                                                                  const float* __restrict__ hit_lam, const int32_t* __restrict__ hit_slot,
+                                                                  const float* __restrict__ J, const float* __restrict__ f0,
+                                                                  float* __restrict__ color, float* __restrict__ mask, float* __restrict__ depth,
+                                                                  float* __restrict__ normals, float* __restrict__ lam_s) {
+    const int b = blockIdx.y, P_ = W * H;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P_) return;
+    const int64_t gp = (int64_t)b * P_ + p;
+    const int slot = hit_slot[gp];
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, dep = 0.f, m = 0.f, ls = 0.f;
+    if (slot >= 0) {
+        const float* Pm = pose + (int64_t)b * 16;
+        const float* Ki = Kinv + (int64_t)b * 9;
+        const float x = (float)(p % W), y = (float)(p / W);
+        const TraceRay r = trace_ray(Pm, Ki, x, y);
+        const TraceHit h = trace_polish(r, hit_lam[gp], f0[slot], J + (int64_t)slot * (L + 3), L);
+        const float rz = fmaf(Ki[7], y, Ki[6] * x) + Ki[8];
+        const float xs = r.ox + h.lam_s * r.dx, ys = r.oy + h.lam_s * r.dy, zs = r.oz + h.lam_s * r.dz;
+        c0 = (-xs + 1.f) / 2.f; c1 = (ys + 1.f) / 2.f; c2 = (zs + 1.f) / 2.f;
+        n0 = (Pm[0] * h.nx + Pm[1] * h.ny + Pm[2] * h.nz + 1.f) / 2.f;
+        n1 = (Pm[4] * h.nx + Pm[5] * h.ny + Pm[6] * h.nz + 1.f) / 2.f;
+        n2 = (Pm[8] * h.nx + Pm[9] * h.ny + Pm[10] * h.nz + 1.f) / 2.f;
+        dep = h.lam_s * rz; m = 1.f; ls = h.lam_s;
+    }
+    float* cb = color + (int64_t)b * 3 * P_;
+    float* nb = normals + (int64_t)b * 3 * P_;
+    cb[p] = c0; cb[P_ + p] = c1; cb[2 * P_ + p] = c2;
+    nb[p] = n0; nb[P_ + p] = n1; nb[2 * P_ + p] = n2;
+    mask[gp] = m; depth[gp] = dep;
+    if (lam_s) lam_s[gp] = ls;
+}
+
+// Backward at a fixed hit set.  The hit depth is an implicit function of pose and latent, f(o(θ) + λ d(θ), z(θ)) = 0:
+//     λ(θ) = λ_s - c [ gx . (o(θ) + λ_s d(θ) - x_s) + gz . (z(θ) - z_s) ],   c = 1 / (gx . d)   (c = 0 for grazing hits: λ constant)
+//     x(θ) = o(θ) + λ(θ) d(θ),   o = -R^T t,   d = R^T r,   n_cam = R n (n constant, as the splat path's normals: grid.py:57-58)
+// Given the image gradients, every hit pixel contributes to d L / d R (9), d L / d t (3) and d L / d z (L); the contributions of a crop are summed
+// in a FIXED order (block tree here, block partials in order in the second kernel): deterministic, batch independent.
+#define TRB_THREADS 256
+#define TRB_MAXL 8
+__global__ __launch_bounds__(TRB_THREADS) void sdfr_trace_backward_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv, int L, int W,
+                                                                         int H, const float* __restrict__ hit_lam,
+                                                                         const int32_t* __restrict__ hit_slot, const float* __restrict__ J,
+                                                                         const float* __restrict__ f0, const float* __restrict__ g_color,
+                                                                         const float* __restrict__ g_depth, const float* __restrict__ g_normals,
+                                                                         float* __restrict__ partial) {
+    constexpr int NV = 12 + TRB_MAXL;
+    const int b = blockIdx.y, P_ = W * H, tid = threadIdx.x;
+    const int p = blockIdx.x * TRB_THREADS + tid;
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.f;
+    const int64_t gp = (int64_t)b * P_ + p;
+    const int slot = p < P_ ? hit_slot[gp] : -1;
+    if (slot >= 0) {
+        const float* Pm = pose + (int64_t)b * 16;
+        const float* Ki = Kinv + (int64_t)b * 9;
+        const float x = (float)(p % W), y = (float)(p / W);
+        const TraceRay r = trace_ray(Pm, Ki, x, y);
+        const float* Jr = J + (int64_t)slot * (L + 3);
+        const TraceHit h = trace_polish(r, hit_lam[gp], f0[slot], Jr, L);
+        const float rx = fmaf(Ki[1], y, Ki[0] * x) + Ki[2], ry = fmaf(Ki[4], y, Ki[3] * x) + Ki[5], rz = fmaf(Ki[7], y, Ki[6] * x) + Ki[8];
+        // upstream: d L / d x (through the NOCS colour), d L / d λ, d L / d n_cam
+        float gxs[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
+        if (g_color) { const float* g = g_color + (int64_t)b * 3 * P_; gxs[0] = -g[p] / 2.f; gxs[1] = g[P_ + p] / 2.f; gxs[2] = g[2 * P_ + p] / 2.f; }
+        if (g_normals) { const float* g = g_normals + (int64_t)b * 3 * P_; gn[0] = g[p] / 2.f; gn[1] = g[P_ + p] / 2.f; gn[2] = g[2 * P_ + p] / 2.f; }
+        float gl = gxs[0] * r.dx + gxs[1] * r.dy + gxs[2] * r.dz;
+        if (g_depth) gl += g_depth[gp] * rz;
+        // d λ = -c [ gx . (d o + λ_s d d) + gz . d z ]  ->  adjoint on w = o + λ_s d:  g_w = g_x - c g_λ gx
+        const float k = h.c * gl;
+        const float gw[3] = {gxs[0] - k * Jr[L], gxs[1] - k * Jr[L + 1], gxs[2] - k * Jr[L + 2]};
+        const float go[3] = {gw[0], gw[1], gw[2]};
+        const float gd[3] = {h.lam_s * gw[0], h.lam_s * gw[1], h.lam_s * gw[2]};
+        const float t[3] = {Pm[3], Pm[7], Pm[11]}, rr[3] = {rx, ry, rz}, nh[3] = {h.nx, h.ny, h.nz};
+        // o_j = -sum_i R_ij t_i,  d_j = sum_i R_ij r_i,  n_cam_i = sum_j R_ij n_j
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[i * 3 + j] = -t[i] * go[j] + rr[i] * gd[j] + gn[i] * nh[j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[9 + i] = -(Pm[i * 4] * go[0] + Pm[i * 4 + 1] * go[1] + Pm[i * 4 + 2] * go[2]);
+#pragma unroll
+        for (int c = 0; c < TRB_MAXL; ++c)
+            if (c < L) v[12 + c] = -k * Jr[c];
+    }
+    __shared__ float red[NV][TRB_THREADS];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[i][tid] = v[i];
+    __syncthreads();
+    for (int o = TRB_THREADS / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) red[i][tid] += red[i][tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid < NV) partial[((int64_t)b * gridDim.x + blockIdx.x) * NV + tid] = red[tid][0];
+}
+
+__global__ __launch_bounds__(64) void sdfr_trace_backward_sum_kernel(const float* __restrict__ partial, int nblk, int L, float* __restrict__ g_pose,
+                                                                    float* __restrict__ g_latn) {
+    constexpr int NV = 12 + TRB_MAXL;
+    const int b = blockIdx.x, i = threadIdx.x;
+    if (i >= NV) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += partial[((int64_t)b * nblk + k) * NV + i];
+    if (i < 9) g_pose[(int64_t)b * 16 + (i / 3) * 4 + (i % 3)] = s;
+    else if (i < 12) g_pose[(int64_t)b * 16 + (i - 9) * 4 + 3] = s;
+    else if (i - 12 < L) g_latn[(int64_t)b * L + (i - 12)] = s;
+    if (i < 4) g_pose[(int64_t)b * 16 + 12 + i] = 0.f;
+}
+
 extern "C" int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
                                 int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, void* stream) {
     SDFR_REQUIRE(pose && Kinv && latn && counters && pix && lam && far && inputs, "sdfr_trace_setup: NULL argument");
     SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0 && bound > 0.f, "sdfr_trace_setup: bad size");
     hipStream_t s = (hipStream_t)stream;
-    SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, 3 * sizeof(int32_t), s));
+    SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
     hipLaunchKernelGGL(sdfr_trace_setup_kernel, dim3(sdfr_cdiv((int64_t)W * H, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, W, H, bound, near,
                        counters, pix, lam, far, inputs);
     SDFR_LAUNCH_CHECK();
@@ -139,7 +304,99 @@ extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float
     if (n_max == 0) return SDFR_OK;
     hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, pose, Kinv, latn, L, W, H, eps, relax,
                        sdf, counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, pix_in, lam_in, pix_out, lam_out, far, inputs,
-                       hit_lam, hit_sdf);
+                       hit_lam, hit_sdf, 0, (unsigned long long*)nullptr);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// ---- the whole march in one call: no host synchronisation -------------------------------------------------------------------------------
+// counters (device int32[SDFR_TRACE_COUNTERS], zeroed by sdfr_trace_setup): [0..2] rotating active counts, [3] rays left unresolved when the
+// step budget ran out, [4..5] one uint64: ray evaluations of the march (sum of the active counts over the steps), [6] hits, [7] spare.
+// While the device-side count is >= tail_rows a step is two launches: the decoder on the active rows (64- / 128-row tiles, MFMA-bound)
+// and sdfr_trace_step_kernel (advance, retire, ballot compaction).  Once it drops below tail_rows -- every 16-row tile then has a CU to
+// itself -- ONE launch of the decoder kernel in MODE 4 takes the remaining rays to termination: the workgroup loops over decoder pass ->
+// advance -> hit / exit test for its 16 rays with the ray state in registers (no per-step launch, no compaction, no host read).  The gate
+// is evaluated on the device in every step of the head; after `head_steps` steps an unconditional tail launch takes whatever is left.
+extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H,
+                                float eps, float relax, int steps, int head_steps, int tail_rows, int half, int32_t* counters, int32_t* pix0,
+                                float* lam0, int32_t* pix1, float* lam1, const float* far, float* inputs, float* sdf, float* hit_lam,
+                                float* hit_sdf, void* stream) {
+    SDFR_REQUIRE(d && pose && Kinv && latn && counters && pix0 && lam0 && pix1 && lam1 && far && inputs && sdf && hit_lam && hit_sdf,
+                 "sdfr_trace_march: NULL argument");
+    SDFR_REQUIRE(B > 0 && W > 0 && H > 0 && steps > 0 && head_steps >= 0 && tail_rows >= 0, "sdfr_trace_march: bad size");
+    SDFR_REQUIRE(d->HP == 512 && !d->has_ln && d->n_inputs == L + 3, "sdfr_trace_march: 512-wide decoder without LayerNorm, L + 3 inputs");
+    const int64_t n_max = (int64_t)B * W * H;
+    SDFR_REQUIRE(n_max < (int64_t)1 << 31, "sdfr_trace_march: too many rays");
+    hipStream_t s = (hipStream_t)stream;
+    if (head_steps > steps) head_steps = steps;
+    unsigned long long* evals = reinterpret_cast<unsigned long long*>(counters + 4);
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.trace = nullptr;
+    P.t_rows = inputs; P.t_far = far; P.t_pose = pose; P.t_Kinv = Kinv; P.t_hit_lam = hit_lam; P.t_hit_sdf = hit_sdf; P.t_W = W; P.t_H = H;
+    P.t_eps = eps; P.t_relax = relax; P.t_evals = evals; P.t_unresolved = counters + 3;
+    auto tail = [&](int step, int hi) {
+        MlpParams T = P;
+        T.n_dev = counters + step % 3; T.n_dev_lo = 1; T.n_dev_hi = hi;
+        T.t_pix = (step & 1) ? pix1 : pix0; T.t_lam = (step & 1) ? lam1 : lam0; T.t_steps = steps - step;
+        if (half) sdfr_launch_tail_f16_512(T, n_max, s); else sdfr_launch_tail_f32_512(T, n_max, s);
+    };
+    for (int step = 0; step < head_steps; ++step) {
+        MlpParams F = P;
+        F.n_dev = counters + step % 3; F.n_dev_lo = tail_rows > 0 ? tail_rows : 1; F.n_dev_hi = 0x7fffffff;
+        if (half) sdfr_launch_fwd_f16_512(F, n_max, false, s); else sdfr_launch_fwd_f32_512(F, n_max, false, s);
+        if (tail_rows > 0) tail(step, tail_rows);
+        const int a = step & 1;
+        hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, eps, relax, sdf,
+                           counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? pix1 : pix0, a ? lam1 : lam0,
+                           a ? pix0 : pix1, a ? lam0 : lam1, far, inputs, hit_lam, hit_sdf, tail_rows > 0 ? tail_rows : 1, evals);
+    }
+    if (head_steps < steps) tail(head_steps, 0x7fffffff);
+    else {
+        // the step budget ended in the head: the rays still listed are unresolved
+        hipLaunchKernelGGL(sdfr_trace_leftover_kernel, dim3(1), dim3(64), 0, s, counters + steps % 3, counters + 3);
+    }
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+
+// hit list + rows for the Jacobian pass.  n_hits = counters + 6 (zeroed by sdfr_trace_setup).
+extern "C" int sdfr_trace_hits(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, const float* hit_lam,
+                               int32_t* n_hits, int32_t* hit_slot, int32_t* idx, float* rows, void* stream) {
+    SDFR_REQUIRE(pose && Kinv && latn && hit_lam && n_hits && hit_slot && idx && rows, "sdfr_trace_hits: NULL argument");
+    SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0, "sdfr_trace_hits: bad size");
+    hipLaunchKernelGGL(sdfr_trace_hits_kernel, dim3(sdfr_cdiv((int64_t)W * H, 256), B), dim3(256), 0, (hipStream_t)stream, pose, Kinv, latn, L, W, H,
+                       hit_lam, n_hits, hit_slot, idx, rows);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_trace_composite(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
+                                    const float* J, const float* f0, float* color, float* mask, float* depth, float* normals, float* lam_s,
+                                    void* stream) {
+    SDFR_REQUIRE(pose && Kinv && hit_lam && hit_slot && J && f0 && color && mask && depth && normals, "sdfr_trace_composite: NULL argument");
+    SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0, "sdfr_trace_composite: bad size");
+    hipLaunchKernelGGL(sdfr_trace_composite_kernel, dim3(sdfr_cdiv((int64_t)W * H, 256), B), dim3(256), 0, (hipStream_t)stream, pose, Kinv, L, W, H,
+                       hit_lam, hit_slot, J, f0, color, mask, depth, normals, lam_s);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+extern "C" int64_t sdfr_trace_backward_ws_floats(int B, int W, int H) {
+    return (int64_t)B * sdfr_cdiv((int64_t)W * H, TRB_THREADS) * (12 + TRB_MAXL);
+}
+
+// image gradients (any of them may be NULL) -> g_pose [B][16] (row-major 4x4: rotation and translation entries) and g_latn [B][L] (gradient
+// w.r.t. the NORMALISED latent); sdfr_params_backward turns them into the gradients of yaw, trans and the latent.
+extern "C" int sdfr_trace_backward(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
+                                   const float* J, const float* f0, const float* g_color, const float* g_depth, const float* g_normals,
+                                   float* ws, float* g_pose, float* g_latn, void* stream) {
+    SDFR_REQUIRE(pose && Kinv && hit_lam && hit_slot && J && f0 && ws && g_pose && g_latn, "sdfr_trace_backward: NULL argument");
+    SDFR_REQUIRE(L >= 0 && L <= TRB_MAXL && B > 0 && W > 0 && H > 0, "sdfr_trace_backward: latent size 0..%d", TRB_MAXL);
+    const int nblk = sdfr_cdiv((int64_t)W * H, TRB_THREADS);
+    hipLaunchKernelGGL(sdfr_trace_backward_kernel, dim3(nblk, B), dim3(TRB_THREADS), 0, (hipStream_t)stream, pose, Kinv, L, W, H, hit_lam, hit_slot,
+                       J, f0, g_color, g_depth, g_normals, ws);
+    hipLaunchKernelGGL(sdfr_trace_backward_sum_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ws, nblk, L, g_pose, g_latn);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

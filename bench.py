@@ -586,7 +586,45 @@ def main():
             except Exception as e:
                 sphere[label] = {"error": repr(e)[:200]}
 
-    # the same crop-iteration through the drop-in boundary (rank 0 only, informational)
+    # the same crop-iteration through the drop-in boundary (rank 0 only, informational): sdflabel_amd.Decoder / Grid3D / Rasterer called exactly
+    # as pipelines/optimizer.py:96-123,156 calls the reference's, the caller's own torch ops (normalize, cat, pose assembly, sums and their autograd)
+    # included.  `launches`: GPU kernels / memsets / copies of ONE iteration, split by who issued them -- inside the library's entry points
+    # (profiler ranges sdfr::*) or in the caller's code -- and the host synchronisations (device-to-host copies) of each side.
+    def launch_census(fn):
+        import tempfile
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            fn()
+            torch.cuda.synchronize()
+        path = os.path.join(tempfile.mkdtemp(), "trace.json")
+        prof.export_chrome_trace(path)
+        ev = json.load(open(path))["traceEvents"]
+        rng = sorted((e["ts"], e["ts"] + e.get("dur", 0)) for e in ev if e.get("cat") == "user_annotation" and str(e.get("name", "")).startswith("sdfr::"))
+        inside = lambda ts: any(a <= ts <= b for a, b in rng)
+        launch_ts = {}
+        syncs = {"library": 0, "caller": 0}
+        for e in ev:
+            if e.get("cat") in ("cuda_runtime", "cuda_driver") and "args" in e:
+                c = e["args"].get("correlation")
+                if c is not None:
+                    launch_ts[c] = e["ts"]
+                nm = str(e.get("name", ""))
+                if "Memcpy" in nm and "DtoH" in str(e["args"]) or nm in ("hipStreamSynchronize", "cudaStreamSynchronize"):
+                    syncs["library" if inside(e["ts"]) else "caller"] += 1
+        out = {"library_hip_kernels": 0, "library_torch_glue": 0, "caller_torch_ops": 0, "unattributed": 0}
+        for e in ev:
+            if e.get("cat") in ("kernel", "gpu_memset", "gpu_memcpy"):
+                ts = launch_ts.get(e.get("args", {}).get("correlation"))
+                if ts is None:
+                    out["unattributed"] += 1
+                elif inside(ts):
+                    out["library_hip_kernels" if "sdfr_" in str(e.get("name", "")) else "library_torch_glue"] += 1
+                else:
+                    out["caller_torch_ops"] += 1
+        out["host_syncs"] = syncs
+        out["profiler_ranges"] = len(rng)
+        return out
+
     dropin = None
     if rank == 0 and not args.no_extras:
         grid = sdflabel_amd.Grid3D(D, dev)
@@ -595,13 +633,17 @@ def main():
             crop_iteration(dec, grid, renderer, crop)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        nd = max(5, args.steps // 3)
+        nd = max(20, args.steps // 3)
         for _ in range(nd):
             l2, _, _ = crop_iteration(dec, grid, renderer, crop)
         torch.cuda.synchronize()
         dt_d = (time.perf_counter() - t1) / nd
         dropin = {"value": H * W / dt_d, "unit": "rays/s", "ms_per_step": dt_d * 1e3,
                   "loss_rel_diff_vs_batched": abs(float(l2) - float(loss)) / max(1.0, abs(float(loss)))}
+        try:
+            dropin["launches"] = launch_census(lambda: crop_iteration(dec, grid, renderer, crop))
+        except Exception as e:                                 # informational only
+            dropin["launches"] = {"error": repr(e)[:200]}
 
     if rank == 0:
         rays = H * W * CB * world * args.steps

@@ -136,6 +136,21 @@ def guard(t):
     return torch.cuda.device(dev)
 
 
+def traced(name):
+    """decorator: run the function inside torch.profiler.record_function('sdfr::<name>') -- a no-op unless a profiler is active; bench.py's
+    dropin_api section uses the ranges to tell the library's launches from the caller's own torch ops"""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            import torch
+            with torch.profiler.record_function("sdfr::" + name):
+                return fn(*a, **k)
+        return wrapped
+    return deco
+
+
 def splat_ws(B, cap, W, H, device):
     """workspace of sdfr_splat_forward / sdfr_surfels_forward: screen boxes + per-tile surfel lists (int32)"""
     import torch

@@ -136,18 +136,26 @@ class _DeepSDFFn(torch.autograd.Function):
         return sdf
 
     @staticmethod
+    @_lib.traced("Decoder.backward")
     def backward(ctx, g_sdf):
         st = ctx.state
         L = _lib.lib()
+        tag = getattr(g_sdf, "_sdfr_band_of", None)
         g_sdf = g_sdf.contiguous().float()
+        if tag is not None:
+            g_sdf._sdfr_band_of = tag                  # (.contiguous() / .float() of an already contiguous float32 tensor return it unchanged)
         NI = st.inputs.shape[1]
         g_in = torch.empty((st.G, NI), dtype=torch.float32, device=g_sdf.device)
         if st.J is not None and st.J.shape[0] > 0:
-            miss = torch.zeros((1,), dtype=torch.int32, device=g_sdf.device)
+            # A gradient that comes straight from Grid3D.get_surface_points' backward is non-zero on the cached band rows only (it says so
+            # itself: the tensor carries the state it was built for) -- no need to count uncovered rows, i.e. no host synchronisation.  Any
+            # other gradient (another loss on sdf added to it, a dtype round trip) is checked as before.
+            band_only = getattr(g_sdf, "_sdfr_band_of", None) is st
+            miss = None if band_only else torch.zeros((1,), dtype=torch.int32, device=g_sdf.device)
             with _lib.guard(g_sdf):
                 _lib.check(L.sdfr_sdf_input_grad(_lib.ptr(g_sdf), _lib.ptr(st.slot), _lib.ptr(st.J), NI, st.G, 1, st.cap, _lib.ptr(g_in),
                                                  _lib.ptr(miss), _lib.stream_ptr()), "sdfr_sdf_input_grad")
-            if int(miss.item()) == 0:
+            if band_only or int(miss.item()) == 0:
                 return g_in, None
         # rows outside the cached band carry gradient: evaluate the Jacobian exactly where it is needed
         rows = torch.nonzero(g_sdf.view(-1) != 0).view(-1).to(torch.int32).contiguous()
@@ -243,6 +251,7 @@ class Decoder(nn.Module):
         return self._handle
 
     # input: N x (L+3)
+    @_lib.traced("Decoder.forward")
     def forward(self, input):
         _lib.require_gpu_float(input)
         if self.training and ((self.dropout is not None and self.dropout_prob > 0) or self.latent_dropout):

@@ -15,16 +15,16 @@ from .deepsdf.networks.deep_sdf_decoder_scale import mlp_jacobian, sdf_state_of
 
 class _SurfaceFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, sdf, gridpoints, sdf_vals, xyz_src, xyz_stride, idx, n, J, Jstride, Joff):
+    def forward(ctx, sdf, gridpoints, sdf_vals, xyz_src, xyz_stride, idx, n, J, Jstride, Joff, state=None):
         """sdf / gridpoints carry the autograd graph (any float dtype); sdf_vals is the float32 (G,) array the kernels read."""
+        ctx.state = state
         L = _lib.lib()
         dev = sdf.device
         G = sdf.shape[0]
         ctx.dtypes = (sdf.dtype, gridpoints.dtype)
         sdf = sdf_vals
-        pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        nocs = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        nrm = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        slab = torch.empty((3, n, 3), dtype=torch.float32, device=dev)
+        pts, nocs, nrm = slab[0], slab[1], slab[2]
         if n > 0:
             with _lib.guard(sdf):
                 _lib.check(L.sdfr_surface_project(_lib.ptr(xyz_src), xyz_stride, _lib.ptr(sdf), G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
@@ -36,6 +36,7 @@ class _SurfaceFn(torch.autograd.Function):
         return pts, nocs, nrm
 
     @staticmethod
+    @_lib.traced("Grid3D.backward")
     def backward(ctx, g_pts, g_nocs, _g_nrm):
         L = _lib.lib()
         nrm, idx = ctx.saved_tensors
@@ -44,7 +45,7 @@ class _SurfaceFn(torch.autograd.Function):
         if n == 0:
             # empty band: zero gradients, as the reference's ops on (0,3) tensors give (no kernel to launch; empty tensors have no address)
             return (torch.zeros((G, 1), dtype=ctx.dtypes[0], device=dev),
-                    torch.zeros((G, 3), dtype=ctx.dtypes[1], device=dev) if ctx.needs_input_grad[1] else None) + (None,) * 8
+                    torch.zeros((G, 3), dtype=ctx.dtypes[1], device=dev) if ctx.needs_input_grad[1] else None) + (None,) * 9
         g_sdf = torch.empty((G, 1), dtype=torch.float32, device=dev)
         g_xyz = torch.empty((G, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         if g_pts is None:
@@ -56,7 +57,9 @@ class _SurfaceFn(torch.autograd.Function):
                                                   _lib.ptr(g_sdf), _lib.ptr(g_xyz), _lib.stream_ptr()), "sdfr_surface_project_bwd")
         g_sdf = g_sdf.to(ctx.dtypes[0])
         g_xyz = None if g_xyz is None else g_xyz.to(ctx.dtypes[1])
-        return g_sdf, g_xyz, None, None, None, None, None, None, None, None
+        if ctx.state is not None and g_sdf.dtype == torch.float32:
+            g_sdf._sdfr_band_of = ctx.state             # non-zero on this state's band rows only: the decoder's backward needs no coverage check
+        return g_sdf, g_xyz, None, None, None, None, None, None, None, None, None
 
 
 def band_select(sdf_flat, threshold, want_slot=True):
@@ -65,10 +68,10 @@ def band_select(sdf_flat, threshold, want_slot=True):
     L = _lib.lib()
     G = sdf_flat.shape[0]
     dev = sdf_flat.device
-    idx = torch.empty((max(G, 1),), dtype=torch.int32, device=dev)
+    g1 = max(G, 1)
     cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
-    slot = torch.empty((max(G, 1),), dtype=torch.int32, device=dev) if want_slot else None
-    scratch = torch.empty(((G + 255) // 256 + 1,), dtype=torch.int32, device=dev)
+    ints = torch.empty((2 * g1 + (G + 255) // 256 + 1,), dtype=torch.int32, device=dev)
+    idx, slot, scratch = ints[:g1], (ints[g1:2 * g1] if want_slot else None), ints[2 * g1:]
     with _lib.guard(sdf_flat):
         _lib.check(L.sdfr_band_select(_lib.ptr(sdf_flat), G, 1, float(threshold), _lib.ptr(idx), G, _lib.ptr(cnt), _lib.ptr(slot),
                                       _lib.ptr(scratch), _lib.stream_ptr()), "sdfr_band_select")
@@ -88,6 +91,7 @@ class Grid3D:
         g[1::2, :2] += (lin.max() - lin.min()) / grid_density / 2
         return torch.from_numpy(g.astype(np.float32))
 
+    @_lib.traced("Grid3D.get_surface_points")
     def get_surface_points(self, pred_sdf_grid, threshold=0.03):
         """Zero-isosurface projection: returns projected points (N,3), NOCS (N,3), normals (N,3)."""
         _lib.require_gpu_float(pred_sdf_grid)
@@ -111,7 +115,7 @@ class Grid3D:
             state.idx, state.slot, state.J, state.cap = idx, slot, J, max(n, 1)
             NI = state.inputs.shape[1]
             xyz_src = state.inputs[:, NI - 3:]
-            return narrow(_SurfaceFn.apply(pred_sdf_grid, self.points, sdf_c, xyz_src, NI, idx, n, J, NI, NI - 3))
+            return narrow(_SurfaceFn.apply(pred_sdf_grid, self.points, sdf_c, xyz_src, NI, idx, n, J, NI, NI - 3, state))
         # generic path: any differentiable SDF of self.points
         (g,) = torch.autograd.grad(pred_sdf_grid.sum(), self.points, retain_graph=True, allow_unused=True)
         if g is None:

@@ -18,11 +18,13 @@ class _RasterFn(torch.autograd.Function):
     """(coords, normals, colors, pose44, bg) -> color, mask, depth, normals_img, p_cam, n_cam, col  (+ fidx through `holder`)."""
 
     @staticmethod
+    @_lib.traced("Rasterer.forward")
     def forward(ctx, coords, *args):
         with _lib.guard(coords):                      # launch stream / allocations of the device that holds the surfels
             return _RasterFn._forward(ctx, coords, *args)
 
     @staticmethod
+    @_lib.traced("Rasterer.backward")
     def backward(ctx, *grads):
         with _lib.guard(ctx.saved_tensors[0]):
             return _RasterFn._backward(ctx, *grads)
@@ -164,6 +166,102 @@ class _RasterFn(torch.autograd.Function):
         return (g_points[:n], g_normals[:n], None if nocs_mode else g_colors[:n], g_pose, None) + (None,) * 11
 
 
+class _RasterDiscFn(torch.autograd.Function):
+    """The optimizer's configuration (pipelines/optimizer.py:110-123: rot='dcm', primitives='disc', bg=None, output_nocs=True) with the fused
+    kernels of the batched path: ONE projection launch writes the camera-frame surfels, the composited attribute (c + 1) / 2, the front-facing
+    rows (points['xyzf']) and the surfel -> front-slot map; the backward is the splat backward + ONE projection backward that folds in the
+    1/2 of the attribute map and the gradient arriving through xyzf.  5 launches forward, 2 backward, one host synchronisation (the number
+    of front-facing surfels is a tensor SHAPE of the reference's API).  Same kernels, same bits as _RasterFn.
+
+    (coords, normals, pose44) -> color, mask, depth, normals_img, p_cam, n_cam, rgb (= attr), xyzf, rgbf"""
+
+    @staticmethod
+    def forward(ctx, coords, normals, pose, K, Kinv, res, nocs_mode, want_mask, want_depth, want_normals):
+        ctx.set_materialize_grads(False)
+        L = _lib.lib()
+        W, H = res
+        dev = coords.device
+        n = coords.shape[0]
+        m = max(n, 1)
+        f32 = dict(dtype=torch.float32, device=dev)
+        with _lib.guard(coords):
+            coords_c, normals_c = coords.detach().contiguous(), normals.detach().contiguous()
+            pose_c = pose.detach().contiguous().float()
+            slab = torch.empty((5, m, 3), **f32)                      # p_cam, n_cam, attr, xyzf, rgbf
+            p_cam, n_cam, attr, xyzf, rgbf = slab[0], slab[1], slab[2], slab[3], slab[4]
+            ints = torch.zeros((2 * m + 1,), dtype=torch.int32, device=dev)     # fidx | fslot | fcnt (zeroed: one fill)
+            fidx, fslot, fcnt = ints[:m], ints[m:2 * m], ints[2 * m:]
+            imgs = torch.empty((8, H, W), **f32)                      # color(3) | mask | depth | normals(3)
+            color, mask, depth, nimg = imgs[0:3], imgs[3:4], imgs[4:5], imgs[5:8]
+            aux = torch.empty((H * W, 4), **f32)
+            bbox = torch.empty((m, 4), dtype=torch.int32, device=dev)
+            st = _lib.stream_ptr()
+            nf = 0
+            if n > 0:
+                _lib.check(L.sdfr_project_dcm(_lib.ptr(pose_c), _lib.ptr(K), _lib.ptr(coords_c), _lib.ptr(normals_c), None, 1, n, None,
+                                              int(nocs_mode) | 4, W, H, _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(attr), None, _lib.ptr(fidx),
+                                              _lib.ptr(fcnt), _lib.ptr(xyzf), _lib.ptr(fslot), st), "sdfr_project_dcm")
+                _lib.check(L.sdfr_gather_rows3(_lib.ptr(rgbf), _lib.ptr(attr), _lib.ptr(fidx), 1, n, _lib.ptr(fcnt), st), "sdfr_gather_rows3")
+            _lib.check(L.sdfr_splat_forward(0, _lib.ptr(K), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(attr), None, None, None, None,
+                                            1, n, None, W, H, _PRIMS['disc'][1], _PRIMS['disc'][2], _lib.ptr(bbox), _lib.ptr(color),
+                                            _lib.ptr(mask) if want_mask else None, _lib.ptr(depth) if want_depth else None,
+                                            _lib.ptr(nimg) if want_normals else None, _lib.ptr(aux), st), "sdfr_splat_forward")
+            if n > 0:
+                nf = int(fcnt.item())                                 # the one synchronisation: xyzf / rgbf are (N_f, 3) tensors
+        ctx.save_for_backward(coords_c, normals_c, pose_c, K, Kinv, slab, imgs, aux, fslot)
+        ctx.cfg = (n, nf, W, H, int(nocs_mode), want_mask, want_depth, want_normals)
+        zero = color.new_zeros(())
+        outs = (color, mask if want_mask else zero, depth if want_depth else zero, nimg if want_normals else zero, p_cam[:n], n_cam[:n], attr[:n],
+                xyzf[:nf], rgbf[:nf])
+        ctx.mark_non_differentiable(outs[5])
+        return outs
+
+    @staticmethod
+    @_lib.traced("Rasterer.backward")
+    def backward(ctx, g_color, g_mask, g_depth, g_nimg, g_pcam_ext, _g_ncam, g_rgb, g_xyzf, g_rgbf):
+        L = _lib.lib()
+        coords, normals, pose, K, Kinv, slab, imgs, aux, fslot = ctx.saved_tensors
+        n, nf, W, H, nocs_mode, want_mask, want_depth, want_normals = ctx.cfg
+        dev = coords.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        m = max(n, 1)
+        p_cam, n_cam, attr = slab[0], slab[1], slab[2]
+        color, mask, depth, nimg = imgs[0:3], imgs[3:4], imgs[4:5], imgs[5:8]
+
+        def cg(g, want):
+            return g.contiguous().float() if (want and g is not None) else None
+
+        with _lib.guard(coords):
+            g_color, g_mask, g_depth, g_nimg = cg(g_color, True), cg(g_mask, want_mask), cg(g_depth, want_depth), cg(g_nimg, want_normals)
+            gs = torch.empty((5, m, 3), **f32)                        # g_p_cam, g_n_cam, g_attr | g_points, g_normals
+            g_p, g_n, g_a, g_points, g_normals = gs[0], gs[1], gs[2], gs[3], gs[4]
+            g_pose = torch.empty((4, 4), **f32)
+            st = _lib.stream_ptr()
+            if n == 0:
+                return (gs[3][:0], gs[4][:0], torch.zeros((4, 4), **f32)) + (None,) * 7
+            if g_color is None and g_mask is None and g_depth is None and g_nimg is None:
+                gs[:3].zero_()
+            else:
+                _lib.check(L.sdfr_splat_backward(0, _lib.ptr(K), _lib.ptr(Kinv), _lib.ptr(p_cam), _lib.ptr(n_cam), _lib.ptr(attr), None, None, None,
+                                                 None, 1, n, None, W, H, _PRIMS['disc'][1], _PRIMS['disc'][2], _lib.ptr(aux), _lib.ptr(color),
+                                                 _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(nimg), _lib.ptr(g_color), _lib.ptr(g_mask),
+                                                 _lib.ptr(g_depth), _lib.ptr(g_nimg), _lib.ptr(g_p), _lib.ptr(g_n), _lib.ptr(g_a), st),
+                           "sdfr_splat_backward")
+            # gradients arriving through the point outputs other than xyzf (not used by the optimizer's loop: plain torch ops)
+            if g_pcam_ext is not None:
+                g_p[:n] += g_pcam_ext
+            if g_rgb is not None:
+                g_a[:n] += g_rgb
+            if g_rgbf is not None and nf > 0:
+                fs = fslot[:n].long()
+                g_a[:n] += torch.where((fs >= 0).unsqueeze(1), g_rgbf.contiguous().float()[fs.clamp(min=0)], torch.zeros((), **f32))
+            g_xyzf = None if (g_xyzf is None or nf == 0) else g_xyzf.contiguous().float()
+            _lib.check(L.sdfr_project_dcm_bwd(_lib.ptr(pose), _lib.ptr(coords), _lib.ptr(normals), _lib.ptr(g_p), _lib.ptr(g_n), _lib.ptr(g_a), 1, n,
+                                              None, nocs_mode | 4, _lib.ptr(g_points), _lib.ptr(g_normals), None, _lib.ptr(g_pose), _lib.ptr(g_xyzf),
+                                              _lib.ptr(fslot), st), "sdfr_project_dcm_bwd")
+        return (g_points[:n], g_normals[:n], g_pose) + (None,) * 7
+
+
 class Rasterer(torch.nn.Module):
     def __init__(self, K, resolution_px, diagonal_mm=20, focal_len_mm=70, precision=torch.float32):
         """K (3,3) intrinsics or None (then derived from sensor diagonal / focal length); resolution_px = (W, H)."""
@@ -186,7 +284,9 @@ class Rasterer(torch.nn.Module):
         # K^-1 in float32 exactly as the reference computes it on every call (primitives.py:204), once, on the host
         # (not part of the state_dict: the reference has no such buffer)
         self.register_buffer('Kinv', torch.linalg.inv(K.cpu().float()).contiguous(), persistent=False)
+        self.fast_path = True           # False: always the general autograd.Function (tests compare the two)
 
+    @_lib.traced("Rasterer.forward")
     def forward(self, coords, normals, colors, camera_matrix, rot='quat', primitives='disc', bg=None, output_mask=False,
                 output_depth=False, output_normals=False, output_nocs=False, output_points=True):
         _lib.require_gpu_float(coords, normals, None if output_nocs else colors)
@@ -203,8 +303,8 @@ class Rasterer(torch.nn.Module):
         if primitives == 'circle_opt' and (int(self.K[0, 2]) * 2 != self.res_x_px or int(self.K[1, 2]) * 2 != self.res_y_px):
             raise RuntimeError("circle_opt derives the image size from K's principal point (primitives.py:109-110); it must equal the resolution")
         dev = coords.device
-        K = self.K.to(dev)
-        Kinv = self.Kinv.to(dev)
+        K = self.K if self.K.device == dev else self.K.to(dev)
+        Kinv = self.Kinv if self.Kinv.device == dev else self.Kinv.to(dev)
         if rot == 'dcm':
             pose = camera_matrix.to(dev, torch.float32)
             nocs_mode = 1 if output_nocs else 0                 # NOCS colour = p * (-1,1,1), projection.py:53-55
@@ -219,6 +319,23 @@ class Rasterer(torch.nn.Module):
             raise ValueError("rot must be 'dcm' or 'quat'")
         if coords.shape[0] != normals.shape[0]:
             raise _lib.SdfrError("coords and normals must have the same number of rows")
+        if rot == 'dcm' and primitives == 'disc' and bg is None and output_nocs and self.fast_path:
+            # the optimizer's configuration: fused projection / fewer launches, same kernels and bits as the general path below
+            color, mask, depth, nimg, p_cam, n_cam, rgb, xyzf, rgbf = _RasterDiscFn.apply(
+                coords, normals, pose, K, Kinv, (self.res_x_px, self.res_y_px), nocs_mode, bool(output_mask), bool(output_depth),
+                bool(output_normals))
+            if out_dtype != torch.float32:
+                color, mask, depth, nimg, p_cam, rgb, xyzf, rgbf = (t.to(out_dtype) for t in (color, mask, depth, nimg, p_cam, rgb, xyzf, rgbf))
+            rendering = {'color': color}
+            if output_mask:
+                rendering['mask'] = mask
+            if output_depth:
+                rendering['depth'] = depth
+            if output_normals:
+                rendering['normals'] = nimg
+            if output_points:
+                return rendering, {'xyz': p_cam, 'rgb': rgb, 'xyzf': xyzf, 'rgbf': rgbf}
+            return rendering
         holder = {}
         half_attr = bool(output_nocs) or (bg is not None)       # (c+1)/2 for NOCS (:114) and always with a background (:109)
         color, mask, depth, nimg, p_cam, n_cam, col = _RasterFn.apply(

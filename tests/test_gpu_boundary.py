@@ -290,3 +290,47 @@ def test_standalone_functions_with_no_surfels():
     assert wb.shape == (1, 3, 256) and float(wb.min()) == 1.0
     o = proj.project_in_2D(K, torch.eye(4, device=DEV), e3, e3, e3, (16, 16))
     assert o["points_3d"].shape == (0, 3) and o["points_3d_filt"].shape == (0, 3) and o["points_2d"].shape == (0, 2)
+
+
+def test_rasterer_fused_fast_path_equals_the_general_path(dec=None):
+    """the optimizer's configuration (rot='dcm', 'disc', bg=None, output_nocs=True) runs through _RasterDiscFn (fused projection, xyzf and rgbf
+    rows from the kernel, one projection backward): same kernels, so the same bits as the general autograd.Function -- images, the four point
+    outputs and every gradient, including those arriving through xyz / rgb / rgbf"""
+    rng = np.random.default_rng(3)
+    H, W, n = 40, 56, 700
+    p = np.stack([rng.uniform(-0.5, 0.5, n), rng.uniform(-0.4, 0.4, n), rng.uniform(-0.9, 0.9, n)], 1).astype(np.float32)
+    nr = rng.standard_normal((n, 3)).astype(np.float32)
+    nr /= np.linalg.norm(nr, axis=1, keepdims=True)
+    K = K_for(H, W)
+    K[0, 2] -= 11.0
+    res = []
+    for fast in (True, False):
+        r = sdflabel_amd.Rasterer(T(K), (W, H)).to(DEV)
+        r.fast_path = fast
+        pts, nrm = T(p).requires_grad_(True), T(nr).requires_grad_(True)
+        yaw, trans = T(np.array([0.7], np.float32)).requires_grad_(True), T(np.array([0.1, -0.05, 3.2], np.float32)).requires_grad_(True)
+        from tests.test_gpu_parity import build_pose
+        rend, points = r(pts, nrm, nrm, build_pose(yaw, trans), primitives='disc', rot='dcm', bg=None, output_depth=True, output_normals=True,
+                         output_nocs=True, output_points=True, output_mask=True)
+        gen = torch.Generator().manual_seed(1)
+        loss = sum((rend[k] * torch.randn(rend[k].shape, generator=gen).to(DEV)).sum() for k in ("color", "mask", "depth", "normals"))
+        loss = loss + sum((points[k] * torch.randn(points[k].shape, generator=gen).to(DEV)).sum() for k in ("xyz", "rgb", "xyzf", "rgbf"))
+        loss.backward()
+        res.append(([rend[k].detach() for k in ("color", "mask", "depth", "normals")] + [points[k].detach() for k in ("xyz", "rgb", "xyzf", "rgbf")],
+                    [pts.grad, nrm.grad, yaw.grad, trans.grad]))
+    assert res[0][0][6].shape[0] > 50
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), float((a - b).abs().max())
+    # empty input and an unused-output backward
+    r = sdflabel_amd.Rasterer(T(K), (W, H)).to(DEV)
+    e = torch.zeros((0, 3), device=DEV, requires_grad=True)
+    rend, points = r(e, e, e, torch.eye(4, device=DEV), rot='dcm', output_nocs=True, output_mask=True)
+    assert points['xyzf'].shape == (0, 3) and float(rend['color'].abs().sum()) == 0.0
+    rend['color'].sum().backward()
+    pts = T(p).requires_grad_(True)
+    rend, points = r(pts, T(nr), T(nr), torch.eye(4, device=DEV) + torch.tensor([[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 3.0], [0, 0, 0, 0]], device=DEV),
+                     rot='dcm', output_nocs=True, output_mask=True)
+    points['xyzf'].sum().backward()                            # only the xyzf gradient arrives: no image gradient at all
+    assert bool(torch.isfinite(pts.grad).all()) and float(pts.grad.abs().sum()) > 0

@@ -215,7 +215,7 @@ def test_half_operand_march_and_batches(dec):
         flips = (o1["mask"][0] != o2["mask"][i])
         keep = (~flips).float()
         assert int(flips.sum()) <= 3
-        assert float(((o1["depth"][0] - o2["depth"][i]).abs() * keep).max()) < 1e-5 and float(((o1["color"][0] - o2["color"][i]).abs() * keep).max()) < 1e-5
+        assert float(((o1["depth"][0] - o2["depth"][i]).abs() * keep).max()) < 1e-4 and float(((o1["color"][0] - o2["color"][i]).abs() * keep).max()) < 1e-4
         ((o1["color"] * wts[i:i + 1] * keep).sum() + (o1["depth"] * keep).sum()).backward()
         a2i = _args(yaw, trans, lat, grad=True)
         o2i = s2(*a2i)

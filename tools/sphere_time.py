@@ -1,52 +1,57 @@
-"""Time one sphere-traced render (forward + backward) of the bench crop: python tools/sphere_time.py [f16|f32] [steps] (development aid;
-run under `rocprofv3 --kernel-trace --stats` for the per-kernel split)."""
-import sys, os, time
+"""Timing of the sphere-tracing render mode on the GPU box: one 256x256 (or --size) crop, forward + backward, per decoder precision and march
+schedule: python tools/sphere_time.py [--size 256] [--steps 64]"""
+import argparse
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
-import bench, sdflabel_amd
-from sdflabel_amd.fixtures import ASSET
-prec = torch.float16 if (len(sys.argv) > 1 and sys.argv[1] == "f16") else torch.float32
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-dev = torch.device("cuda", 0)
-d3, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
-tr = sdflabel_amd.SphereTracer(d3.to(dev), bench.K_for(bench.H, bench.W), (bench.W, bench.H), 1, steps=steps, device=dev)
-crop = bench.Crop(0, dev)
-prm = [crop.yaw.detach().clone().requires_grad_(True), crop.trans.detach().clone().view(1, 3).requires_grad_(True),
-       crop.latent.detach().clone().view(1, -1).requires_grad_(True)]
-def tstep(bwd=True):
-    for p_ in prm:
-        p_.grad = None
-    o_ = tr(*prm)
-    if bwd:
-        (o_["depth"].sum() + o_["color"].sum() + o_["normals"].sum()).backward()
-for _ in range(2):
-    tstep()
-torch.cuda.synchronize()
-for bwd in (True, False):
-    t = time.perf_counter()
-    for _ in range(5):
-        tstep(bwd)
-    torch.cuda.synchronize()
-    print("%s %d steps (%d run), backward %s: %.2f ms per render" % (sys.argv[1] if len(sys.argv) > 1 else "f32", steps, tr.steps_run, bwd, (time.perf_counter() - t) / 5 * 1e3))
-# the march alone, and the active-ray count after every step (one synchronisation per step: timing not representative)
-R = sdflabel_amd.renderer.sphere_tracer
-with torch.no_grad():
-    yaw, trans, lat = prm
-    Rm = R._rot_from_yaw(yaw.reshape(1)); latn = torch.nn.functional.normalize(lat, p=2, dim=1)
-    pose = torch.zeros(1, 4, 4, device=dev); pose[:, :3, :3] = Rm; pose[:, :3, 3] = trans; pose[:, 3, 3] = 1.0
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(5):
-        tr.march(pose.view(1, 16), latn)
-    torch.cuda.synchronize()
-    print("march alone: %.2f ms" % ((time.perf_counter() - t) / 5 * 1e3))
-    ce, tr.check_every = tr.check_every, 1
-    tr.stop_fraction_saved, tr.stop_fraction = tr.stop_fraction, -1.0
-    counts = []
-    import types
-    # active counts: run with increasing step limits
-    for s in (1, 2, 4, 8, 12, 16, 24, 32, 40, 48, 56, 64):
-        if s > steps: break
-        tr.steps = s
-        tr.march(pose.view(1, 16), latn)
-        counts.append((s, int(tr.n_unresolved)))
-    print("active rays after k steps:", counts)
+
+import sdflabel_amd
+from sdflabel_amd.fixtures import ASSET, K_for, crop_start
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=256)
+ap.add_argument("--steps", type=int, default=64)
+ap.add_argument("--batch", type=int, default=1)
+args = ap.parse_args()
+dev = "cuda"
+H = W = args.size
+B = args.batch
+st = [crop_start(i) for i in range(B)]
+prm = [torch.tensor(np.concatenate([s[0] for s in st]), device=dev), torch.tensor(np.stack([s[1] for s in st]), device=dev),
+       torch.tensor(np.stack([s[2] for s in st]), device=dev)]
+o3, o1 = torch.ones(B, 3, H, W, device=dev), torch.ones(B, 1, H, W, device=dev)
+for prec in (torch.float32, torch.float16):
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
+    d = d.to(dev)
+    macs = d.handle(torch.device(dev)).macs
+    for head, tail in ((24, 4096), (args.steps, 0), (0, 4096), (24, 2048), (24, 8192), (16, 4096)):
+        tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, head_steps=head, tail_rows=tail)
+
+        def step(ev=None):
+            tr.render(*prm, events=ev)
+            tr.backward(g_color=o3, g_depth=o1, g_normals=o3)
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        evs = [{"march": (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))} for _ in range(5)]
+        for e in evs:
+            step(e)
+        torch.cuda.synchronize()
+        mm = float(np.mean([e["march"][0].elapsed_time(e["march"][1]) for e in evs]))
+        s = tr.stats()
+        tf = 2.0 * macs * s["ray_evaluations"] / (mm * 1e-3) / 1e12
+        print("%s head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
+              % (str(prec).replace("torch.", ""), head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
+                 100 * tf / (2500.0 if prec == torch.float16 else 157.3), s["hits"], s["unresolved"]), flush=True)
+        del tr

@@ -602,25 +602,31 @@ def main():
         rng = sorted((e["ts"], e["ts"] + e.get("dur", 0)) for e in ev if e.get("cat") == "user_annotation" and str(e.get("name", "")).startswith("sdfr::"))
         inside = lambda ts: any(a <= ts <= b for a, b in rng)
         launch_ts = {}
-        syncs = {"library": 0, "caller": 0}
         for e in ev:
-            if e.get("cat") in ("cuda_runtime", "cuda_driver") and "args" in e:
-                c = e["args"].get("correlation")
-                if c is not None:
-                    launch_ts[c] = e["ts"]
-                nm = str(e.get("name", ""))
-                if "Memcpy" in nm and "DtoH" in str(e["args"]) or nm in ("hipStreamSynchronize", "cudaStreamSynchronize"):
-                    syncs["library" if inside(e["ts"]) else "caller"] += 1
+            if e.get("cat") in ("cuda_runtime", "cuda_driver") and "args" in e and e["args"].get("correlation") is not None:
+                launch_ts[e["args"]["correlation"]] = e["ts"]
+        syncs = {"library": 0, "caller": 0}
         out = {"library_hip_kernels": 0, "library_torch_glue": 0, "caller_torch_ops": 0, "unattributed": 0}
+        glue = {}
         for e in ev:
             if e.get("cat") in ("kernel", "gpu_memset", "gpu_memcpy"):
                 ts = launch_ts.get(e.get("args", {}).get("correlation"))
+                nm = str(e.get("name", ""))
                 if ts is None:
                     out["unattributed"] += 1
-                elif inside(ts):
-                    out["library_hip_kernels" if "sdfr_" in str(e.get("name", "")) else "library_torch_glue"] += 1
+                    continue
+                lib = inside(ts)
+                if e.get("cat") == "gpu_memcpy" and "DtoH" in nm:          # .item(): a device-to-host copy the host waits for
+                    syncs["library" if lib else "caller"] += 1
+                if lib:
+                    hipk = "sdfr_" in nm
+                    out["library_hip_kernels" if hipk else "library_torch_glue"] += 1
+                    if not hipk:
+                        short = nm.split("<")[0].split("(")[0][-60:]
+                        glue[short] = glue.get(short, 0) + 1
                 else:
                     out["caller_torch_ops"] += 1
+        out["library_torch_glue_by_kernel"] = glue
         out["host_syncs"] = syncs
         out["profiler_ranges"] = len(rng)
         return out

@@ -97,7 +97,9 @@ int sdfr_mlp_jacobian(const sdfr_decoder* dec, const float* inputs, int64_t rows
                       const float* sdf_full /* optional: output of the sdfr_mlp_forward call over the same rows */,
                       const uint32_t* mask_ws /* optional: masks that call saved; with both, no forward recomputation */,
                       int mask_from_f16 /* 0: mask_ws from sdfr_mlp_forward(_split); 1: from sdfr_mlp_forward_f16, float32 backward;
-                                            2: from sdfr_mlp_forward_f16 and the backward also runs with half operands */,
+                                            2: from sdfr_mlp_forward_f16 and the backward also runs with half operands;
+                                            | SDFR_JAC_MANY_ROWS: hint for the recomputing kernel (no masks) that the launch holds many
+                                            thousands of rows (32-row tiles; results equal to float rounding, not bit for bit) */,
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -212,6 +214,7 @@ int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* no
  *   images: color [B][3][H][W], mask [B][H][W], depth [B][H][W], normals [B][3][H][W] (any may be NULL)
  *   aux [B][H*W][4]: per-pixel state for the backward (nu, max logit, softmax denominator, clamp gates)
  */
+#define SDFR_JAC_MANY_ROWS 16
 #define SDFR_PRIM_BOXES_READY 256   /* OR into `primitive` of sdfr_splat_forward: bbox_ws already holds the surfels' screen boxes and tile lists */
 #define SDFR_PRIM_BINS 512          /* OR into `primitive`: bbox_ws is the LARGE workspace of sdfr_splat_ws_words() and per-tile surfel lists are
                                        built in it and used; without the flag bbox_ws only needs int32[B][cap][4] (boxes) and every 8x8 tile
@@ -327,11 +330,13 @@ int sdfr_mlp_forward_counted(const sdfr_decoder* dec, const float* inputs, int64
                              void* stream);
 /* all pixels of all crops: slab test against the cube [-bound, bound]^3; hits enter the active list (counters[0]) at lam = max(entry, near) */
 int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
-                     int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, void* stream);
+                     float relax /* >= 1: over-relaxation factor of the march (1: plain sphere tracing) */, int32_t* counters, int32_t* pix,
+                     float* lam /* ray state float[n][4]: lam, previous |sdf|, last step, relaxation factor */, float* far, float* inputs,
+                     void* stream);
 /* march step `step` (0, 1, ...): sdf = decoder values of the active rays (counters[step % 3] of them); lam += relax * sdf / |d|; rays with
  * |sdf| < eps are recorded in hit_lam / hit_sdf and retired, rays past `far` are retired, the rest are compacted into pix_out / lam_out /
  * inputs (count in counters[(step + 1) % 3]) */
-int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int L, int W, int H, float eps, float relax, const float* sdf,
+int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int L, int W, int H, float eps, const float* sdf,
                     int32_t* counters, int step, int64_t n_max, const int32_t* pix_in, const float* lam_in, int32_t* pix_out, float* lam_out,
                     const float* far, float* inputs, float* hit_lam, float* hit_sdf, void* stream);
 
@@ -340,9 +345,11 @@ int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int
  * device-side count is >= tail_rows a step is the decoder on the active rows + the step kernel; below it ONE launch of the decoder kernel in
  * its looping mode takes the remaining rays to termination (16-ray tiles, ray state in registers, no per-step launch, no compaction); the
  * gate is evaluated on the device in each of the first head_steps steps, then an unconditional tail launch takes what is left.
- * pix0/lam0 (filled by sdfr_trace_setup) and pix1/lam1 are the ping-pong active lists, sdf float[B*W*H] scratch. */
+ * pix0/lam0 (filled by sdfr_trace_setup) and pix1/lam1 are the ping-pong active lists (lam: ray state float[n][4]), sdf float[B*W*H] scratch.
+ * Step rule: lam += om sdf / |d| with om = relax while consecutive spheres overlap, 1 after the first time they do not (over-relaxed
+ * sphere tracing; the ray first moves back into the previous safe sphere). */
 int sdfr_trace_march(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float eps,
-                     float relax, int steps, int head_steps, int tail_rows, int half, int32_t* counters, int32_t* pix0, float* lam0,
+                     int steps, int head_steps, int tail_rows, int half, int32_t* counters, int32_t* pix0, float* lam0,
                      int32_t* pix1, float* lam1, const float* far, float* inputs, float* sdf, float* hit_lam, float* hit_sdf, void* stream);
 /* hit pixels (hit_lam > 0) -> compact list: rows float[n][L+3] = [latn, o + lam d] for sdfr_mlp_jacobian (rows_per_crop = B*W*H, B = 1,
  * idx = the identity written here, cnt = n_hits), hit_slot int32[B*W*H] = list position of the pixel's hit or -1.  n_hits: device int32,

@@ -736,8 +736,10 @@ def trace_rays(pose, Kinv, pixels_xy):
 
 
 def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, bound=1.0, near=1e-3, relax=1.0):
-    """March every ray: x = o + lam d, v = decoder(latn, x); |v| < eps -> hit at lam; else lam += relax v / |d|; lam >= far (exit of the cube
-    [-bound, bound]^3) or NaN -> miss; out of steps -> miss (unresolved).  Then one Newton step along non-grazing rays with the decoder value f0
+    """March every ray: x = o + lam d, v = decoder(latn, x); |v| < eps -> hit at lam; else lam += om v / |d|; lam >= far (exit of the cube
+    [-bound, bound]^3) or NaN -> miss; out of steps -> miss (unresolved).  om = relax (>= 1) while consecutive spheres overlap
+    (|v| + |v_prev| >= last step); the first time they do not, the ray steps back by (om - 1) x last step -- into the previous safe sphere --
+    without a hit test at the suspect sample, and marches with om = 1 from there (over-relaxed sphere tracing, Keinert et al. 2014).  Then one Newton step along non-grazing rays with the decoder value f0
     and input gradient at the marched point: lam_s = lam0 - f0 / (gx . d) where |gx . d| > 0.1 |gx| |d|.
     Returns a dict of per-ray arrays: hit (bool), lam0, lam_s, ok (Newton step taken), x_s (n,3), depth, color (NOCS, n,3), normals ((R n + 1)/2,
     n,3), n_hat, gx (n,3), gz (n,L), f0, c (= 1 / (gx . d) or 0), margin (distance of the closest hit / exit / grazing decision to its threshold, in
@@ -764,6 +766,8 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
     active &= l0 < l1
     dn = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(f)
     lam = l0.copy()
+    prev_r, last = np.zeros(n, f), np.zeros(n, f)                 # |sdf| of the previous sample, last step (distance units)
+    om = np.full(n, max(relax, 1.0), f)                            # relaxation factor: `relax` until the first failed overlap test, then 1
     hit = np.zeros(n, bool)
     lam0 = np.zeros(n, f)
     margin = np.full(n, np.inf)
@@ -778,11 +782,19 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
         rows = np.concatenate([np.broadcast_to(latn, (idx.size, L)), x], 1).astype(f)
         v = decoder_forward(layers, spec, rows)[:, 0].astype(f)
         n_steps[idx] += 1
-        margin[idx] = np.minimum(margin[idx], np.abs(np.abs(v) - eps))
-        h = np.abs(v) < f(eps)
+        rad = np.abs(v)
+        # over-relaxed sphere tracing (Keinert et al. 2014): disjoint consecutive spheres -> the long step may have skipped a surface
+        fail = (om[idx] > 1) & ((rad + prev_r[idx]).astype(f) < last[idx])
+        margin[idx] = np.minimum(margin[idx], np.where(om[idx] > 1, np.abs((rad + prev_r[idx]).astype(f) - last[idx]), np.inf))
+        margin[idx] = np.minimum(margin[idx], np.where(fail, np.inf, np.abs(rad - eps)))
+        h = ~fail & (rad < f(eps))
         hit[idx[h]] = True
         lam0[idx[h]] = lam[idx[h]]
-        l2 = (lam[idx] + f(relax) * v / dn[idx]).astype(f)
+        step = np.where(fail, (last[idx] - om[idx] * last[idx]).astype(f), (v * om[idx]).astype(f)).astype(f)
+        om[idx[fail]] = 1
+        prev_r[idx] = rad
+        last[idx] = step
+        l2 = (lam[idx] + (step / dn[idx]).astype(f)).astype(f)
         keep = ~h & (l2 < l1[idx]) & ~np.isnan(v)
         margin[idx[~h]] = np.minimum(margin[idx[~h]], np.abs(l1[idx[~h]] - l2[~h]))
         lam[idx[keep]] = l2[keep]

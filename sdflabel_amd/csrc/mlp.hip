@@ -243,6 +243,8 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     MlpParams P = d->proto;
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
     P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.fwd_np = mask_from_f16 ? sdfr_fwd_f16_512_np() : (d->HP == 512 ? sdfr_fwd_f32_512_np() : 2);
+    const bool many_rows = (mask_from_f16 & SDFR_JAC_MANY_ROWS) != 0;       // hint: far more rows than 16 x the CU count (recomputing kernel on 32-row tiles)
+    mask_from_f16 &= ~SDFR_JAC_MANY_ROWS;
     SDFR_REQUIRE(mask_from_f16 >= 0 && mask_from_f16 <= 2, "sdfr_mlp_jacobian: mask_from_f16 = %d (0, 1 or 2)", mask_from_f16);
     // masks saved by the forward launch make the recomputation unnecessary (not for use_tanh decoders: their output
     // derivative needs the pre-tanh value)
@@ -262,6 +264,7 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
         P.ln_ws = d->ln_ws;
         sdfr_launch_ln(P, d->HP, true, gx, B, s);
     } else if (d->HP == 512 && mask_from_f16 == 2 && from_masks) sdfr_launch_jac_f16_512(P, cap, B, s);      // half operands, like the forward
+    else if (d->HP == 512 && !from_masks && many_rows) sdfr_launch_jac_f32_512_recompute32(P, cap, B, s);
     else if (d->HP == 512) sdfr_launch_jac_f32_512(P, cap, B, from_masks, s);
     else sdfr_launch_small(P, d->HP, from_masks ? 3 : 2, sdfr_cdiv(cap, 32), B, s);
     SDFR_LAUNCH_CHECK();

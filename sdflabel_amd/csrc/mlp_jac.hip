@@ -22,6 +22,12 @@
 #ifndef SDFR_JAC_SWITCH_ROWS
 #define SDFR_JAC_SWITCH_ROWS 8       // 32-row tiles from this many crops per launch (measured: 6 crops 665 vs 705 us, 8 crops 798 vs 712 us)
 #endif
+// recomputing Jacobian on 32-row tiles: half the weight stream per row of the 16-row variant -- for launches of many thousands of rows (the
+// sphere tracer's hits), where tiles outnumber the CUs several times and the stream, not one tile's latency, sets the time
+void sdfr_launch_jac_f32_512_recompute32(const MlpParams& P, int cap, int B, hipStream_t s) {
+    hipLaunchKernelGGL((sdfr_mlp_kernel<float, 32, 4, 1, 4, 2, 2>), dim3(sdfr_cdiv(cap, 32), B), dim3(256), 0, s, P);
+}
+
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s) {
     static_assert(SDFR_JAC_MS * SDFR_JAC_FT * SDFR_JAC_NW == 512 && 16 * SDFR_JAC_SMALL_FT * SDFR_JAC_SMALL_NW == 512, "padded width 512 = MS * FT * NW");
     if (!from_masks) {

@@ -81,14 +81,14 @@ struct MlpParams {
     // decoder pass, advance, hit / exit test, next pass -- rewriting its own rows of `inputs` between passes
     float* t_rows;               // = inputs (writable): [latent, o + lam d] per active-list row
     const int32_t* t_pix;        // active list: crop * W*H + pixel
-    const float* t_lam;          // active list: current ray parameter
+    const float4* t_lam;         // active list: ray state (lam, previous |sdf|, last step, relaxation factor)
     const float* t_far;          // per pixel: ray parameter at which the ray leaves the object cube
     const float* t_pose;         // [B][16]
     const float* t_Kinv;         // [B][9]
     float* t_hit_lam;            // per pixel: ray parameter of the hit (0: none)
     float* t_hit_sdf;            // per pixel: decoder value at the marched hit
     int t_W, t_H, t_steps;       // image size; passes left in the march's step budget
-    float t_eps, t_relax;
+    float t_eps;
     unsigned long long* t_evals; // += active rays per pass (ray evaluations of the march, for the roofline)
     int32_t* t_unresolved;       // += rays still active when the step budget ran out
 };
@@ -543,7 +543,8 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     // ---- MODE 4: the tile's rays (lane i < PT of wave 0 owns ray i) -------------------------------------------
     int t_gp = 0, t_left = 0;
     bool t_act = false;
-    float t_l = 0.f, t_farl = 0.f, t_idn = 0.f, t_ox = 0.f, t_oy = 0.f, t_oz = 0.f, t_dx = 0.f, t_dy = 0.f, t_dz = 0.f;
+    float4 t_st = make_float4(0.f, 0.f, 0.f, 1.f);
+    float t_farl = 0.f, t_idn = 0.f, t_ox = 0.f, t_oy = 0.f, t_oz = 0.f, t_dx = 0.f, t_dy = 0.f, t_dz = 0.f;
     unsigned long long t_ev = 0ull;
     int* t_more = reinterpret_cast<int*>(gy);           // gy is unused by forward modes
     if constexpr (TAIL) {
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         if (tid < PT && tid < n_valid) {
             const int64_t s = (int64_t)blockIdx.x * PT + tid;
             t_gp = P.t_pix[s];
-            t_l = P.t_lam[s];
+            t_st = P.t_lam[s];
             t_farl = P.t_far[t_gp];
             const int P_ = P.t_W * P.t_H, b = t_gp / P_, px = t_gp - b * P_;
             const float* Pm = P.t_pose + (int64_t)b * 16;
@@ -744,14 +745,22 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                 const unsigned long long live = __ballot(t_act);
                 if (tid == 0) t_ev += (unsigned long long)__popcll(live);
                 if (t_act) {
-                    if (fabsf(o) < P.t_eps) {
-                        P.t_hit_lam[t_gp] = t_l;
+                    // the march's step rule (csrc/trace.hip trace_advance, restated here: this header does not see trace.hip)
+                    const float rad = fabsf(o);
+                    const bool fail = (t_st.w > 1.f) && (rad + t_st.y < t_st.z);
+                    if (!fail && rad < P.t_eps) {
+                        P.t_hit_lam[t_gp] = t_st.x;
                         P.t_hit_sdf[t_gp] = o;
                         t_act = false;
                     } else {
-                        const float l2 = t_l + P.t_relax * o / t_idn;
+                        float step;
+                        if (fail) { step = t_st.z - t_st.w * t_st.z; t_st.w = 1.f; }
+                        else step = o * t_st.w;
+                        t_st.y = rad;
+                        t_st.z = step;
+                        const float l2 = t_st.x + step / t_idn;
                         if ((l2 < t_farl) && (o == o)) {
-                            t_l = l2;
+                            t_st.x = l2;
                             float* row = P.t_rows + ((int64_t)blockIdx.x * PT + tid) * NI;
                             row[NI - 3] = t_ox + l2 * t_dx; row[NI - 2] = t_oy + l2 * t_dy; row[NI - 1] = t_oz + l2 * t_dz;
                         } else t_act = false;
@@ -1025,6 +1034,7 @@ void sdfr_launch_fwd_f16_512(const MlpParams& P, int64_t n, bool save_masks, hip
 int sdfr_fwd_f16_512_np();                                                                        // its point tiles per workgroup
 void sdfr_launch_fwd_split_512(const MlpParams& P, int64_t n, bool save_masks, hipStream_t s);  // mlp_split.hip
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s); // mlp_jac.hip
+void sdfr_launch_jac_f32_512_recompute32(const MlpParams& P, int cap, int B, hipStream_t s);         // mlp_jac.hip (MODE 2 on 32-row tiles)
 void sdfr_launch_fwd_f32_512_tile16(const MlpParams& P, int64_t n, hipStream_t s);                // mlp_jac.hip (forward on 16-row tiles: thin counted launches)
 void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s);                  // mlp_jac16.hip (mask-fed only)
 void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s);                // mlp_jac16.hip (half forward on 16-row tiles)

@@ -3,8 +3,12 @@
 // NOT in the reference (its renderer splats surfels of a grid band); this is the render mode BASELINE.json's north_star
 // describes literally -- "per-ray sphere-tracing loop and DeepSDF-MLP evaluation at each march step ... wavefront ballot for
 // early-termination compaction" -- offered beside the faithful path, with no parity claim against the reference.
-//   step:   x = o + lam d   ->   s = decoder(latent, x)  (sdfr_mlp_forward_counted on the ACTIVE rays only)   ->   lam += s / |d|
+//   step:   x = o + lam d   ->   s = decoder(latent, x)  (the decoder kernels on the ACTIVE rays only)   ->   lam += om s / |d|
 //   a ray leaves the active list when |s| < eps (hit: its lam is recorded per pixel) or when lam passes the far side of the object cube.
+//   om = `relax` >= 1: over-relaxed sphere tracing (Keinert et al. 2014): the step is om times the safe radius as long as consecutive
+//   spheres overlap (|s| + |s_prev| >= last step); the first time they do not -- the long step may have jumped over a surface -- the ray
+//   moves back into the previous safe sphere and continues with om = 1 for good.  relax = 1 is plain sphere tracing.
+//   Ray state (float4 per active ray): lam, |s| of the previous sample, the last step (distance units), om.
 // Rays live in object space: p_cam = R p + t (the optimizer's pose, pipelines/optimizer.py:86-90), pixel ray r = K^-1 [x, y, 1]
 // (primitives.py:203-208), so o = -R^T t, d = R^T r and lam is the camera-frame depth of the point (r_z = 1 for a pinhole K).
 // The active list is compacted every step with one wave ballot + one atomic per wavefront (rays are independent: their order in the list
@@ -31,6 +35,24 @@ __device__ __forceinline__ TraceRay trace_ray(const float* __restrict__ P, const
     return r;
 }
 
+// One sample of a ray: st = (lam, prev_r, step, om), v = decoder value at lam, dn = |d|.  Returns 1 hit (st.x = the hit's lam), 0 keep marching
+// (st advanced), -1 miss (past the cube's far side, or NaN).  The ONE step rule of the march: sdfr_trace_step_kernel, the looping tail of
+// the decoder kernel (mlp_kernel.h MODE 4) and the oracle (oracle/sdf_oracle.py::sphere_trace) all apply it.
+__device__ __forceinline__ int trace_advance(float4& st, float v, float dn, float eps, float far) {
+    const float r = fabsf(v);
+    const bool fail = (st.w > 1.f) && (r + st.y < st.z);          // disjoint spheres: the over-relaxed step may have skipped a surface
+    if (!fail && r < eps) return 1;
+    float step;
+    if (fail) { step = st.z - st.w * st.z; st.w = 1.f; }           // back into the previous safe sphere, plain tracing from here on
+    else step = v * st.w;
+    st.y = r;
+    st.z = step;
+    const float l2 = st.x + step / dn;
+    if (!(l2 < far) || !(v == v)) return -1;
+    st.x = l2;
+    return 0;
+}
+
 // append `keep` lanes to a list: one ballot + one atomic per wavefront; returns the slot of this lane (valid if keep)
 __device__ __forceinline__ int trace_append(bool keep, int32_t* __restrict__ counter) {
     const unsigned long long bal = __ballot(keep);
@@ -49,8 +71,8 @@ __device__ __forceinline__ void trace_write_row(float* __restrict__ row, const f
 // every pixel of every crop: slab test against the cube [-bound, bound]^3 the SDF is defined on; rays that hit it enter the active list
 __global__ __launch_bounds__(256) void sdfr_trace_setup_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
                                                               const float* __restrict__ latn, int L, int W, int H, float bound, float near,
-                                                              int32_t* __restrict__ counters, int32_t* __restrict__ pix, float* __restrict__ lam,
-                                                              float* __restrict__ far, float* __restrict__ inputs) {
+                                                              float relax, int32_t* __restrict__ counters, int32_t* __restrict__ pix,
+                                                              float4* __restrict__ lam, float* __restrict__ far, float* __restrict__ inputs) {
     const int b = blockIdx.y;
     const int P_ = W * H;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -75,18 +97,18 @@ __global__ __launch_bounds__(256) void sdfr_trace_setup_kernel(const float* __re
     const int slot = trace_append(active, counters);
     if (active) {
         pix[slot] = b * P_ + p;
-        lam[slot] = l0;
+        lam[slot] = make_float4(l0, 0.f, 0.f, fmaxf(relax, 1.f));
         trace_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, r, l0);
     }
 }
 
 // one march step of every active ray (count on the device): advance by the decoder's value, retire hits and exits, compact the survivors
 __global__ __launch_bounds__(256) void sdfr_trace_step_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
-                                                             const float* __restrict__ latn, int L, int W, int H, float eps, float relax,
+                                                             const float* __restrict__ latn, int L, int W, int H, float eps,
                                                              const float* __restrict__ sdf, const int32_t* __restrict__ n_cur,
                                                              int32_t* __restrict__ n_next, int32_t* __restrict__ n_zero,
-                                                             const int32_t* __restrict__ pix_in, const float* __restrict__ lam_in,
-                                                             int32_t* __restrict__ pix_out, float* __restrict__ lam_out,
+                                                             const int32_t* __restrict__ pix_in, const float4* __restrict__ lam_in,
+                                                             int32_t* __restrict__ pix_out, float4* __restrict__ lam_out,
                                                              const float* __restrict__ far, float* __restrict__ inputs,
                                                              float* __restrict__ hit_lam, float* __restrict__ hit_sdf, int min_count,
                                                              unsigned long long* __restrict__ evals) {
@@ -98,27 +120,27 @@ __global__ __launch_bounds__(256) void sdfr_trace_step_kernel(const float* __res
     if (blockIdx.x * 256 >= n) return;
     bool keep = false;
     int gp = 0;
-    float l2 = 0.f;
+    float4 st = make_float4(0.f, 0.f, 0.f, 1.f);
     TraceRay r = {};
     if (s < n) {
         gp = pix_in[s];
         const int P_ = W * H, b = gp / P_, p = gp - b * P_;
         r = trace_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, (float)(p % W), (float)(p / W));
-        const float v = sdf[s], l = lam_in[s];
-        if (fabsf(v) < eps) {                    // on the surface: retire as a hit
-            hit_lam[gp] = l;
+        const float v = sdf[s];
+        st = lam_in[s];
+        const int what = trace_advance(st, v, sqrtf(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz), eps, far[gp]);
+        if (what == 1) {                         // on the surface: retire as a hit
+            hit_lam[gp] = st.x;
             hit_sdf[gp] = v;
-        } else {
-            l2 = l + relax * v / sqrtf(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz);
-            keep = (l2 < far[gp]) && (v == v);   // past the cube (or NaN): a miss
         }
+        keep = what == 0;                        // (-1: past the cube or NaN: a miss)
     }
     const int slot = trace_append(keep, n_next);
     if (keep) {
         const int b = gp / (W * H);
         pix_out[slot] = gp;
-        lam_out[slot] = l2;
-        trace_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, r, l2);
+        lam_out[slot] = st;
+        trace_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, r, st.x);
     }
 }
 
@@ -270,41 +292,62 @@ __global__ __launch_bounds__(TRB_THREADS) void sdfr_trace_backward_kernel(const 
     if (tid < NV) partial[((int64_t)b * gridDim.x + blockIdx.x) * NV + tid] = red[tid][0];
 }
 
-__global__ __launch_bounds__(64) void sdfr_trace_backward_sum_kernel(const float* __restrict__ partial, int nblk, int L, float* __restrict__ g_pose,
-                                                                    float* __restrict__ g_latn) {
+// second stage: the block partials of a crop, summed in a fixed order (thread t takes partials t, t + 256, ...; then a tree over the threads)
+__global__ __launch_bounds__(256) void sdfr_trace_backward_sum_kernel(const float* __restrict__ partial, int nblk, int L, float* __restrict__ g_pose,
+                                                                     float* __restrict__ g_latn) {
     constexpr int NV = 12 + TRB_MAXL;
-    const int b = blockIdx.x, i = threadIdx.x;
-    if (i >= NV) return;
-    float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += partial[((int64_t)b * nblk + k) * NV + i];
-    if (i < 9) g_pose[(int64_t)b * 16 + (i / 3) * 4 + (i % 3)] = s;
-    else if (i < 12) g_pose[(int64_t)b * 16 + (i - 9) * 4 + 3] = s;
-    else if (i - 12 < L) g_latn[(int64_t)b * L + (i - 12)] = s;
-    if (i < 4) g_pose[(int64_t)b * 16 + 12 + i] = 0.f;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.f;
+    for (int k = tid; k < nblk; k += 256) {
+        const float* p = partial + ((int64_t)b * nblk + k) * NV;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += p[i];
+    }
+    __shared__ float red[NV][256];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[i][tid] = v[i];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) red[i][tid] += red[i][tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid < NV) {
+        const float s = red[tid][0];
+        if (tid < 9) g_pose[(int64_t)b * 16 + (tid / 3) * 4 + (tid % 3)] = s;
+        else if (tid < 12) g_pose[(int64_t)b * 16 + (tid - 9) * 4 + 3] = s;
+        else if (tid - 12 < L) g_latn[(int64_t)b * L + (tid - 12)] = s;
+    }
+    if (tid >= 32 && tid < 36) g_pose[(int64_t)b * 16 + 12 + (tid - 32)] = 0.f;
 }
 
 extern "C" int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
-                                int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, void* stream) {
+                                float relax, int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, void* stream) {
     SDFR_REQUIRE(pose && Kinv && latn && counters && pix && lam && far && inputs, "sdfr_trace_setup: NULL argument");
     SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0 && bound > 0.f, "sdfr_trace_setup: bad size");
     hipStream_t s = (hipStream_t)stream;
     SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
     hipLaunchKernelGGL(sdfr_trace_setup_kernel, dim3(sdfr_cdiv((int64_t)W * H, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, W, H, bound, near,
-                       counters, pix, lam, far, inputs);
+                       relax, counters, pix, reinterpret_cast<float4*>(lam), far, inputs);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
 
-extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int L, int W, int H, float eps, float relax,
+extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int L, int W, int H, float eps,
                                const float* sdf, int32_t* counters, int step, int64_t n_max, const int32_t* pix_in, const float* lam_in,
                                int32_t* pix_out, float* lam_out, const float* far, float* inputs, float* hit_lam, float* hit_sdf, void* stream) {
     SDFR_REQUIRE(pose && Kinv && latn && sdf && counters && pix_in && lam_in && pix_out && lam_out && far && inputs && hit_lam && hit_sdf,
                  "sdfr_trace_step: NULL argument");
     SDFR_REQUIRE(step >= 0 && n_max >= 0, "sdfr_trace_step: bad size");
     if (n_max == 0) return SDFR_OK;
-    hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, pose, Kinv, latn, L, W, H, eps, relax,
-                       sdf, counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, pix_in, lam_in, pix_out, lam_out, far, inputs,
-                       hit_lam, hit_sdf, 0, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, pose, Kinv, latn, L, W, H, eps,
+                       sdf, counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, pix_in,
+                       reinterpret_cast<const float4*>(lam_in), pix_out, reinterpret_cast<float4*>(lam_out), far, inputs, hit_lam, hit_sdf, 0,
+                       (unsigned long long*)nullptr);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -318,11 +361,13 @@ extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float
 // advance -> hit / exit test for its 16 rays with the ray state in registers (no per-step launch, no compaction, no host read).  The gate
 // is evaluated on the device in every step of the head; after `head_steps` steps an unconditional tail launch takes whatever is left.
 extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H,
-                                float eps, float relax, int steps, int head_steps, int tail_rows, int half, int32_t* counters, int32_t* pix0,
-                                float* lam0, int32_t* pix1, float* lam1, const float* far, float* inputs, float* sdf, float* hit_lam,
+                                float eps, int steps, int head_steps, int tail_rows, int half, int32_t* counters, int32_t* pix0,
+                                float* lam0_, int32_t* pix1, float* lam1_, const float* far, float* inputs, float* sdf, float* hit_lam,
                                 float* hit_sdf, void* stream) {
-    SDFR_REQUIRE(d && pose && Kinv && latn && counters && pix0 && lam0 && pix1 && lam1 && far && inputs && sdf && hit_lam && hit_sdf,
+    SDFR_REQUIRE(d && pose && Kinv && latn && counters && pix0 && lam0_ && pix1 && lam1_ && far && inputs && sdf && hit_lam && hit_sdf,
                  "sdfr_trace_march: NULL argument");
+    float4* lam0 = reinterpret_cast<float4*>(lam0_);
+    float4* lam1 = reinterpret_cast<float4*>(lam1_);
     SDFR_REQUIRE(B > 0 && W > 0 && H > 0 && steps > 0 && head_steps >= 0 && tail_rows >= 0, "sdfr_trace_march: bad size");
     SDFR_REQUIRE(d->HP == 512 && !d->has_ln && d->n_inputs == L + 3, "sdfr_trace_march: 512-wide decoder without LayerNorm, L + 3 inputs");
     const int64_t n_max = (int64_t)B * W * H;
@@ -333,7 +378,7 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.trace = nullptr;
     P.t_rows = inputs; P.t_far = far; P.t_pose = pose; P.t_Kinv = Kinv; P.t_hit_lam = hit_lam; P.t_hit_sdf = hit_sdf; P.t_W = W; P.t_H = H;
-    P.t_eps = eps; P.t_relax = relax; P.t_evals = evals; P.t_unresolved = counters + 3;
+    P.t_eps = eps; P.t_evals = evals; P.t_unresolved = counters + 3;
     auto tail = [&](int step, int hi) {
         MlpParams T = P;
         T.n_dev = counters + step % 3; T.n_dev_lo = 1; T.n_dev_hi = hi;
@@ -346,7 +391,7 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
         if (half) sdfr_launch_fwd_f16_512(F, n_max, false, s); else sdfr_launch_fwd_f32_512(F, n_max, false, s);
         if (tail_rows > 0) tail(step, tail_rows);
         const int a = step & 1;
-        hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, eps, relax, sdf,
+        hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, eps, sdf,
                            counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? pix1 : pix0, a ? lam1 : lam0,
                            a ? pix0 : pix1, a ? lam0 : lam1, far, inputs, hit_lam, hit_sdf, tail_rows > 0 ? tail_rows : 1, evals);
     }
@@ -396,7 +441,7 @@ extern "C" int sdfr_trace_backward(const float* pose, const float* Kinv, int L, 
     const int nblk = sdfr_cdiv((int64_t)W * H, TRB_THREADS);
     hipLaunchKernelGGL(sdfr_trace_backward_kernel, dim3(nblk, B), dim3(TRB_THREADS), 0, (hipStream_t)stream, pose, Kinv, L, W, H, hit_lam, hit_slot,
                        J, f0, g_color, g_depth, g_normals, ws);
-    hipLaunchKernelGGL(sdfr_trace_backward_sum_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ws, nblk, L, g_pose, g_latn);
+    hipLaunchKernelGGL(sdfr_trace_backward_sum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ws, nblk, L, g_pose, g_latn);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

@@ -59,6 +59,7 @@ class SphereTracer:
         # the device-side gate (count < tail_rows) is checked in each of the first head_steps steps; afterwards the tail takes whatever is left
         self.head_steps = min(self.steps, 24) if head_steps is None else int(head_steps)
         self.tail_rows = int(tail_rows)
+        self.jac_rows32 = False         # True: exact-f32 value + Jacobian pass at the hits on 32-row tiles (measured equal to the 16-row tiles: 5.21 vs 5.14 ms)
         self.decoder = decoder
         self.handle = decoder.handle(dev)
         self.half = 1 if getattr(decoder, "mlp_precision", torch.float32) == torch.float16 else 0
@@ -76,7 +77,7 @@ class SphereTracer:
         self.yaw, self.trans, self.latent = f(B), f(B, 3), f(B, self.L)
         self.pose, self.latnorm, self.latn = f(B, 16), f(B), f(B, self.L)
         self.counters = i(_COUNTERS)
-        self.pix, self.lam = [i(n), i(n)], [f(n), f(n)]
+        self.pix, self.lam = [i(n), i(n)], [f(n, 4), f(n, 4)]                 # active lists: pixel, ray state (lam, prev |sdf|, last step, om)
         self.far, self.inputs, self.sdf = f(n), f(n, self.NI), f(n)
         self.hit_lam, self.hit_sdf, self.lam_s = f(n), f(n), f(n)
         self.hit_slot, self.idx = i(n), i(n)
@@ -102,11 +103,11 @@ class SphereTracer:
                "sdfr_params_forward")
             torch.div(self.latent, self.latnorm.unsqueeze(1), out=self.latn)                    # F.normalize (optimizer.py:96)
             self.hit_lam.zero_(); self.hit_sdf.zero_()
-            ck(L.sdfr_trace_setup(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, P(self.counters), P(self.pix[0]),
+            ck(L.sdfr_trace_setup(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, self.relax, P(self.counters), P(self.pix[0]),
                                   P(self.lam[0]), P(self.far), P(self.inputs), st), "sdfr_trace_setup")
             if "march" in events:
                 events["march"][0].record()
-            ck(L.sdfr_trace_march(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.eps, self.relax, self.steps,
+            ck(L.sdfr_trace_march(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.eps, self.steps,
                                   self.head_steps, self.tail_rows, self.half, P(self.counters), P(self.pix[0]), P(self.lam[0]), P(self.pix[1]),
                                   P(self.lam[1]), P(self.far), P(self.inputs), P(self.sdf), P(self.hit_lam), P(self.hit_sdf), st), "sdfr_trace_march")
             if "march" in events:
@@ -115,7 +116,8 @@ class SphereTracer:
             ck(L.sdfr_trace_hits(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, P(self.hit_lam), P(n_hits), P(self.hit_slot),
                                  P(self.idx), P(self.rows), st), "sdfr_trace_hits")
             # exact-f32 decoder value and input Jacobian at the hits (recomputing kernel; rows beyond the device-side count are not touched)
-            ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.rows), n, 1, P(self.idx), n, P(n_hits), P(self.J), P(self.f0), None, None, 0, st),
+            ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.rows), n, 1, P(self.idx), n, P(n_hits), P(self.J), P(self.f0), None, None,
+                                   16 if self.jac_rows32 else 0, st),      # [SDFR_JAC_MANY_ROWS]: thousands of hits -> 32-row tiles
                "sdfr_mlp_jacobian")
             ck(L.sdfr_trace_composite(P(self.pose), P(self.Kinv), self.L, B, W, H, P(self.hit_lam), P(self.hit_slot), P(self.J), P(self.f0),
                                       P(self.color), P(self.mask), P(self.depth), P(self.normals), P(self.lam_s), st), "sdfr_trace_composite")

@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--relax", type=float, nargs="*", default=[1.0, 1.4, 1.6, 1.8])
+ap.add_argument("--only", default="", help="f32 | f16: one precision, default schedule only (profiling runs)")
 args = ap.parse_args()
 dev = "cuda"
 H = W = args.size
@@ -24,12 +26,13 @@ st = [crop_start(i) for i in range(B)]
 prm = [torch.tensor(np.concatenate([s[0] for s in st]), device=dev), torch.tensor(np.stack([s[1] for s in st]), device=dev),
        torch.tensor(np.stack([s[2] for s in st]), device=dev)]
 o3, o1 = torch.ones(B, 3, H, W, device=dev), torch.ones(B, 1, H, W, device=dev)
-for prec in (torch.float32, torch.float16):
+for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float16,) if args.only == "f16" else (torch.float32,))):
     d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
     d = d.to(dev)
     macs = d.handle(torch.device(dev)).macs
-    for head, tail in ((24, 4096), (args.steps, 0), (0, 4096), (24, 2048), (24, 8192), (16, 4096)):
-        tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, head_steps=head, tail_rows=tail)
+    for head, tail, relax, j32 in [(24, 4096, r, True) for r in args.relax] + ([(24, 4096, 1.0, False), (args.steps, 0, 1.0, True)] if not args.only else []):
+        tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, head_steps=head, tail_rows=tail, relax=relax)
+        tr.jac_rows32 = j32
 
         def step(ev=None):
             tr.render(*prm, events=ev)
@@ -51,7 +54,7 @@ for prec in (torch.float32, torch.float16):
         mm = float(np.mean([e["march"][0].elapsed_time(e["march"][1]) for e in evs]))
         s = tr.stats()
         tf = 2.0 * macs * s["ray_evaluations"] / (mm * 1e-3) / 1e12
-        print("%s head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
-              % (str(prec).replace("torch.", ""), head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
+        print("%s relax %.1f jac32 %d head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
+              % (str(prec).replace("torch.", ""), relax, int(j32), head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
                  100 * tf / (2500.0 if prec == torch.float16 else 157.3), s["hits"], s["unresolved"]), flush=True)
         del tr

@@ -38,6 +38,14 @@ if os.path.isfile(srcf):
         for r in csv.DictReader(open(srcf)):
             w.writerow([r["Name"].split("(")[0][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
 
+srcs = os.path.join(G, "profsphere_%s" % tag, "trace_kernel_stats.csv")
+if os.path.isfile(srcs):
+    with open(os.path.join(P, "%s_kernel_stats_sphere_f16.csv" % rnd), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in csv.DictReader(open(srcs)):
+            w.writerow([r["Name"].split("(")[0][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
 pmc = {}
 for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     path = os.path.join(G, "pmc_%s_%s" % (kind, tag), "pmc_counter_collection.csv")

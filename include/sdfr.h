@@ -369,6 +369,11 @@ int sdfr_trace_backward(const float* pose, const float* Kinv, int L, int B, int 
                         const float* J, const float* f0, const float* g_color, const float* g_depth, const float* g_normals, float* ws,
                         float* g_pose, float* g_latn, void* stream);
 
+/* The decoder's scale head on one latent row (deep_sdf_decoder_scale.py:68-75,110-112): out[0] = W3 relu(W2 relu(W1 lat + b1) + b2) + b3 with
+ * W1 [3][L], W2 [3][3], W3 [1][3] row-major as nn.Linear stores them.  Returned by Decoder.forward next to the SDF values; unused by the loop. */
+int sdfr_scale_net(const float* latent_row, int L, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                   const float* b3, float* out, void* stream);
+
 /* Debug only: forward kernels of a library built with -DSDFR_MLP_TRACE write cycle stamps of their workgroup 0 into this device buffer
  * (2 * SDFR_MAX_LAYERS * 5 uint64; see tools/cycle_trace.py); pass NULL to disable.  Production builds ignore it. */
 int sdfr_debug_set_trace(void* device_buffer);

@@ -17,7 +17,13 @@ on the GPU box, where the Python reference cannot travel.
   * The backward functions restate what torch autograd computes for the
     reference graph (detach points: primitives.py:226,228; in-place eps
     assignment primitives.py:210; clamp sub-gradients) and are pinned against
-    autograd gradients captured from the reference (golden G7).
+    autograd gradients captured from the reference (golden G7; r03: also in the
+    reference pipeline's cropped, off-centre camera regime, golden G14).
+  * sphere_trace / sphere_trace_backward (end of the file) are the oracle of the
+    sphere-tracing render mode, which the reference does NOT have:
+    PARITY UNPINNED for that mode -- there is no reference output; the functions
+    define the mode's arithmetic and are checked for self-consistency only
+    (tests/test_oracle_golden.py::test_sphere_trace_oracle_self_consistency).
 
 All functions take/return numpy arrays; `dtype` follows the inputs (float32 for
 parity, float64 for threshold-margin analysis).

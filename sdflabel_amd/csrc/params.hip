@@ -336,3 +336,35 @@ extern "C" int sdfr_pose_latent_backward(const float* pose, const float* points,
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
+
+
+// ---- the decoder's scale head (deep_sdf_decoder_scale.py:68-75,110-112): Linear(L,3) - ReLU - Linear(3,3) - ReLU - Linear(3,1) on ONE latent row.
+// The reference evaluates it in every Decoder.forward and returns it next to the SDF values (the refinement loop ignores it,
+// pipelines/optimizer.py:101); as five ATen launches it cost more host time per iteration than the band kernels.  One thread.
+__global__ void sdfr_scale_net_kernel(const float* __restrict__ lat, int L, const float* __restrict__ W1, const float* __restrict__ b1,
+                                      const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ W3,
+                                      const float* __restrict__ b3, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float h1[3], h2[3];
+    for (int j = 0; j < 3; ++j) {
+        float s = 0.f;
+        for (int k = 0; k < L; ++k) s += W1[j * L + k] * lat[k];
+        h1[j] = fmaxf(s + b1[j], 0.f);
+    }
+    for (int j = 0; j < 3; ++j) {
+        float s = 0.f;
+        for (int k = 0; k < 3; ++k) s += W2[j * 3 + k] * h1[k];
+        h2[j] = fmaxf(s + b2[j], 0.f);
+    }
+    float s = 0.f;
+    for (int k = 0; k < 3; ++k) s += W3[k] * h2[k];
+    out[0] = s + b3[0];
+}
+
+extern "C" int sdfr_scale_net(const float* latent_row, int L, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                              const float* b3, float* out, void* stream) {
+    SDFR_REQUIRE(latent_row && W1 && b1 && W2 && b2 && W3 && b3 && out && L > 0, "sdfr_scale_net: bad argument");
+    hipLaunchKernelGGL(sdfr_scale_net_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, latent_row, L, W1, b1, W2, b2, W3, b3, out);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}

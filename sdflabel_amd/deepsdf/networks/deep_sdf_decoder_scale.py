@@ -167,6 +167,32 @@ class _DeepSDFFn(torch.autograd.Function):
         return g_in, None
 
 
+class _ScaleNetFn(torch.autograd.Function):
+    """scale_net(lat_row) in ONE launch (sdfr_scale_net) instead of five ATen ops per Decoder.forward.  The backward -- nobody on the renderer
+    path differentiates the scale (pipelines/optimizer.py:101 drops it) -- re-evaluates the three linears with torch ops under autograd."""
+
+    @staticmethod
+    def forward(ctx, lat_row, net):
+        out = torch.empty((1,), dtype=torch.float32, device=lat_row.device)
+        l1, l2, l3 = net[0], net[2], net[4]
+        row = lat_row.detach().contiguous()
+        with _lib.guard(row):
+            _lib.check(_lib.lib().sdfr_scale_net(_lib.ptr(row), int(row.shape[0]), _lib.ptr(l1.weight), _lib.ptr(l1.bias), _lib.ptr(l2.weight),
+                                                 _lib.ptr(l2.bias), _lib.ptr(l3.weight), _lib.ptr(l3.bias), _lib.ptr(out), _lib.stream_ptr()),
+                       "sdfr_scale_net")
+        ctx.net = net
+        ctx.save_for_backward(row)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (row,) = ctx.saved_tensors
+        with torch.enable_grad():
+            x = row.clone().requires_grad_(True)
+            (gx,) = torch.autograd.grad(ctx.net(x), x, g)
+        return gx, None
+
+
 class Decoder(nn.Module):
     """Same constructor as the reference Decoder (deep_sdf_decoder_scale.py:10-75)."""
 
@@ -270,6 +296,8 @@ class Decoder(nn.Module):
         lat = x32[:, :-3]
         if self.samples_per_scene:
             scale = self.scale_net(lat.view(-1, self.samples_per_scene, lat.size(1))[:, 0, :])
+        elif all(p.dtype == torch.float32 and p.is_contiguous() and p.device == x32.device for p in self.scale_net.parameters()):
+            scale = _ScaleNetFn.apply(lat[0], self.scale_net)          # one launch; frozen weights as everywhere on this path
         else:
             scale = self.scale_net(lat[0])
         return x, scale.to(in_dtype)

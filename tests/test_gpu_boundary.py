@@ -334,3 +334,19 @@ def test_rasterer_fused_fast_path_equals_the_general_path(dec=None):
                      rot='dcm', output_nocs=True, output_mask=True)
     points['xyzf'].sum().backward()                            # only the xyzf gradient arrives: no image gradient at all
     assert bool(torch.isfinite(pts.grad).all()) and float(pts.grad.abs().sum()) > 0
+
+
+def test_decoder_scale_head_fused_kernel_equals_the_torch_modules():
+    """Decoder.forward returns (sdf, scale) as the reference does (deep_sdf_decoder_scale.py:110-114); the scale head runs as one launch
+    (sdfr_scale_net) and must equal scale_net evaluated with torch ops, value and gradient w.r.t. the latent"""
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
+    d = d.to(DEV)
+    grid = sdflabel_amd.Grid3D(8, DEV)
+    lat = torch.tensor([0.3, -0.5, 0.8], device=DEV, requires_grad=True)
+    inp = torch.cat([lat.expand(grid.points.size(0), -1), grid.points], 1)
+    sdf, scale = d(inp)
+    ref = d.scale_net(lat)
+    assert scale.shape == ref.shape and float((scale - ref).abs().max()) < 1e-6
+    (g,) = torch.autograd.grad(scale.sum(), lat, retain_graph=True)
+    (gr,) = torch.autograd.grad(ref.sum(), lat)
+    assert float((g - gr).abs().max()) < 1e-6

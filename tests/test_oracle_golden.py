@@ -465,3 +465,42 @@ def test_g14_oracle_gradients_in_the_cropped_regime():
     assert abs(g_yaw - float(z[p + "g_yaw"][0])) < 1e-3 * max(1.0, abs(float(z[p + "g_yaw"][0])))
     assert np.abs(g_pose[:3, 3] - z[p + "g_trans"]).max() < 1e-3 * max(1.0, np.abs(z[p + "g_trans"]).max())
     assert np.abs(g_points - z[p + "g_pcd"]).max() < 1e-3 * max(1.0, np.abs(z[p + "g_pcd"]).max())
+
+
+def test_sphere_trace_oracle_self_consistency():
+    """the sphere-tracing oracle has nothing to be pinned against (the reference has no sphere tracer) -- it is checked for
+    what it claims: polished hits lie on the decoder's zero level set, misses left the cube, and its implicit-function gradient agrees with
+    central differences of its own forward on the common hit set."""
+    st, spec = fitted_state()
+    layers = O.decoder_layers_from_state(st, spec)
+    from tests._util import K_for
+    H = W = 40
+    K = K_for(H, W)
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    lat = np.array([0.3, -0.5, 0.8], np.float32)
+    lat /= np.linalg.norm(lat)
+    px = np.stack(np.meshgrid(np.arange(W), np.arange(H)), -1).reshape(-1, 2)
+    yaw, t = 0.6, np.array([0.05, -0.03, 3.5], np.float32)
+    tr = O.sphere_trace(layers, spec, lat, O.render_pose(yaw, t), Kinv, px)
+    assert tr["hit"].sum() > 250 and tr["unresolved"].sum() <= 3
+    ok = tr["hit"] & tr["ok"]
+    rows = np.concatenate([np.broadcast_to(lat, (int(ok.sum()), 3)), tr["x_s"][ok]], 1).astype(np.float32)
+    res = np.abs(O.decoder_forward(layers, spec, rows)[:, 0])
+    assert np.median(res) < 2e-5 and np.quantile(res, 0.99) < 1e-3
+    assert (np.abs(tr["f0"][tr["hit"]]) < 2e-3).all()
+    assert np.abs(np.linalg.norm(tr["n_hat"][tr["hit"]], axis=1) - 1).max() < 1e-5
+    # d (sum of depths over the common hit set) / d t_z and / d yaw against central differences
+    for which, h in (("tz", 2e-3), ("yaw", 2e-3)):
+        def at(s):
+            return O.sphere_trace(layers, spec, lat, O.render_pose(yaw + (s if which == "yaw" else 0.0), t + np.array([0, 0, s if which == "tz" else 0.0], np.float32)), Kinv, px)
+        a, b = at(+h), at(-h)
+        common = a["hit"] & b["hit"] & tr["hit"]
+        fd = float((a["depth"] - b["depth"])[common].sum() / (2 * h))
+        g_pose, _ = O.sphere_trace_backward(tr, O.render_pose(yaw, t), g_depth=common.astype(np.float64))
+        if which == "tz":
+            an = g_pose[2, 3]
+        else:
+            c, s = np.cos(yaw), np.sin(yaw)
+            dR = np.array([[-s, 0, c], [0, 0, 0], [-c, 0, -s]])
+            an = float((g_pose[:3, :3] * dR).sum())
+        assert abs(an - fd) < 0.05 * max(1.0, abs(fd)), (which, an, fd)

@@ -30,7 +30,7 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
     d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
     d = d.to(dev)
     macs = d.handle(torch.device(dev)).macs
-    for head, tail, relax, j32 in [(24, 4096, r, True) for r in args.relax] + ([(24, 4096, 1.0, False), (args.steps, 0, 1.0, True)] if not args.only else []):
+    for head, tail, relax, j32 in [(24, 4096, r, False) for r in args.relax] + ([(24, 4096, 1.0, True), (args.steps, 0, 1.0, False)] if not args.only else []):
         tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, head_steps=head, tail_rows=tail, relax=relax)
         tr.jac_rows32 = j32
 

@@ -602,10 +602,14 @@ def main():
         rng = sorted((e["ts"], e["ts"] + e.get("dur", 0)) for e in ev if e.get("cat") == "user_annotation" and str(e.get("name", "")).startswith("sdfr::"))
         inside = lambda ts: any(a <= ts <= b for a, b in rng)
         launch_ts = {}
-        for e in ev:
-            if e.get("cat") in ("cuda_runtime", "cuda_driver") and "args" in e and e["args"].get("correlation") is not None:
-                launch_ts[e["args"]["correlation"]] = e["ts"]
         syncs = {"library": 0, "caller": 0}
+        for e in ev:
+            if e.get("cat") in ("cuda_runtime", "cuda_driver"):
+                if "args" in e and e["args"].get("correlation") is not None:
+                    launch_ts[e["args"]["correlation"]] = e["ts"]
+                # .item() / .tolist(): a blocking device-to-host copy (hipMemcpyWithStream on ROCm) -- the host waits for the stream to drain
+                if str(e.get("name", "")) in ("hipMemcpyWithStream", "cudaMemcpyAsync", "hipMemcpy", "hipStreamSynchronize", "cudaStreamSynchronize"):
+                    syncs["library" if inside(e["ts"]) else "caller"] += 1
         out = {"library_hip_kernels": 0, "library_torch_glue": 0, "caller_torch_ops": 0, "unattributed": 0}
         glue = {}
         for e in ev:
@@ -616,8 +620,6 @@ def main():
                     out["unattributed"] += 1
                     continue
                 lib = inside(ts)
-                if e.get("cat") == "gpu_memcpy" and "DtoH" in nm:          # .item(): a device-to-host copy the host waits for
-                    syncs["library" if lib else "caller"] += 1
                 if lib:
                     hipk = "sdfr_" in nm
                     out["library_hip_kernels" if hipk else "library_torch_glue"] += 1

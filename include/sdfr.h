@@ -330,10 +330,10 @@ int sdfr_mlp_forward_counted(const sdfr_decoder* dec, const float* inputs, int64
                              void* stream);
 /* all pixels of all crops: slab test against the cube [-bound, bound]^3; hits enter the active list (counters[0]) at lam = max(entry, near) */
 int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
-                     float relax /* >= 1: over-relaxation factor of the march (1: plain sphere tracing) */, int32_t* counters, int32_t* pix,
-                     float* lam /* ray state float[n][4]: lam, previous |sdf|, last step, relaxation factor */, float* far, float* inputs,
-                     void* stream);
-/* march step `step` (0, 1, ...): sdf = decoder values of the active rays (counters[step % 3] of them); lam += relax * sdf / |d|; rays with
+                     int32_t* counters, int32_t* pix,
+                     float* lam /* ray state float[n][4]: lam = next sample, rho = |sdf| of the previous sample, q = ratio of the last two radii, - */,
+                     float* far, float* inputs, void* stream);
+/* march step `step` (0, 1, ...): sdf = decoder values of the active rays (counters[step % 3] of them); lam += sdf / |d|; rays with
  * |sdf| < eps are recorded in hit_lam / hit_sdf and retired, rays past `far` are retired, the rest are compacted into pix_out / lam_out /
  * inputs (count in counters[(step + 1) % 3]) */
 int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int L, int W, int H, float eps, const float* sdf,
@@ -341,16 +341,19 @@ int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int
                     const float* far, float* inputs, float* hit_lam, float* hit_sdf, void* stream);
 
 /* The whole march in ONE call, no host synchronisation (counters: device int32[8], zeroed by sdfr_trace_setup -- [0..2] rotating active
- * counts, [3] rays unresolved when the step budget ran out, [4..5] one uint64 = ray evaluations of the march, [6] hits).  While the
+ * counts, [3] rays unresolved when the step budget ran out, [4..5] one uint64 = decoder evaluations of the march, [6] hits).  While the
  * device-side count is >= tail_rows a step is the decoder on the active rows + the step kernel; below it ONE launch of the decoder kernel in
  * its looping mode takes the remaining rays to termination (16-ray tiles, ray state in registers, no per-step launch, no compaction); the
  * gate is evaluated on the device in each of the first head_steps steps, then an unconditional tail launch takes what is left.
- * pix0/lam0 (filled by sdfr_trace_setup) and pix1/lam1 are the ping-pong active lists (lam: ray state float[n][4]), sdf float[B*W*H] scratch.
- * Step rule: lam += om sdf / |d| with om = relax while consecutive spheres overlap, 1 after the first time they do not (over-relaxed
- * sphere tracing; the ray first moves back into the previous safe sphere). */
+ * spec_k = 4: from pass index spec_from on a pass evaluates four samples per ray (p_0 = lam, p_j = p_{j-1} + sigma q^j rho / |d|) and accepts
+ * the prefix in which every sample lies inside the previous one's safe sphere -- a valid sphere-tracing sequence, nothing skipped; the pass
+ * index alone decides (head_steps is clamped to spec_from), so a ray's samples do not depend on the launch schedule.  spec_k = 1: plain.
+ * pix0/lam0 (filled by sdfr_trace_setup) and pix1/lam1 are the ping-pong active lists (lam: ray state float[n][4]), sdf float[B*W*H] scratch,
+ * tail_rows_buf float[ceil(B*W*H / 16)][16 * spec_k][L + 3] scratch of the looping kernel. */
 int sdfr_trace_march(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float eps,
-                     int steps, int head_steps, int tail_rows, int half, int32_t* counters, int32_t* pix0, float* lam0,
-                     int32_t* pix1, float* lam1, const float* far, float* inputs, float* sdf, float* hit_lam, float* hit_sdf, void* stream);
+                     int steps, int head_steps, int tail_rows, int spec_from, int spec_k, float sigma, int half, int32_t* counters, int32_t* pix0,
+                     float* lam0, int32_t* pix1, float* lam1, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
+                     float* hit_sdf, void* stream);
 /* hit pixels (hit_lam > 0) -> compact list: rows float[n][L+3] = [latn, o + lam d] for sdfr_mlp_jacobian (rows_per_crop = B*W*H, B = 1,
  * idx = the identity written here, cnt = n_hits), hit_slot int32[B*W*H] = list position of the pixel's hit or -1.  n_hits: device int32,
  * zero on entry (counters + 6 after sdfr_trace_setup). */

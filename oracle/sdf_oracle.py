@@ -741,16 +741,22 @@ def trace_rays(pose, Kinv, pixels_xy):
     return o, d, r
 
 
-def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, bound=1.0, near=1e-3, relax=1.0):
-    """March every ray: x = o + lam d, v = decoder(latn, x); |v| < eps -> hit at lam; else lam += om v / |d|; lam >= far (exit of the cube
-    [-bound, bound]^3) or NaN -> miss; out of steps -> miss (unresolved).  om = relax (>= 1) while consecutive spheres overlap
-    (|v| + |v_prev| >= last step); the first time they do not, the ray steps back by (om - 1) x last step -- into the previous safe sphere --
-    without a hit test at the suspect sample, and marches with om = 1 from there (over-relaxed sphere tracing, Keinert et al. 2014).  Then one Newton step along non-grazing rays with the decoder value f0
-    and input gradient at the marched point: lam_s = lam0 - f0 / (gx . d) where |gx . d| > 0.1 |gx| |d|.
+def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, bound=1.0, near=1e-3, spec_from=None, spec_k=1, sigma=0.9):
+    """March every ray: x = o + lam d, v = decoder(latn, x); |v| < eps -> hit at lam; else lam += v / |d|; lam >= far (exit of the cube
+    [-bound, bound]^3) or NaN -> miss; out of steps -> miss (unresolved).
+    Speculative passes (spec_k > 1, from pass index spec_from on): a pass evaluates spec_k samples of the ray at once, p_0 = lam and
+    p_j = p_{j-1} + sigma q^j rho / |d| with rho = |v| of the ray's previous accepted sample and q = the ratio of its last two radii (clamped
+    to [0.5, 1]) -- a guess of where plain tracing would put its next samples.  Sample j counts only if it lies INSIDE the safe sphere of sample
+    j-1 ((p_j - p_{j-1}) |d| <= |v_{j-1}|, v_{j-1} > 0): the accepted prefix is a valid (slightly shorter-stepped) sphere-tracing sequence,
+    nothing is skipped; the first accepted sample with |v| < eps is the hit; otherwise the ray continues from the last accepted sample.  Rays
+    creeping along a face at grazing incidence -- the ones that keep a march alive for dozens of steps -- advance spec_k samples per pass.
+    Which passes are speculative depends on the pass INDEX only, so the sample sequence of a ray is a function of the ray alone.
+    Then one Newton step along non-grazing rays with the decoder value f0 and input gradient at the marched point: lam_s = lam0 - f0 / (gx . d)
+    where |gx . d| > 0.1 |gx| |d|.
     Returns a dict of per-ray arrays: hit (bool), lam0, lam_s, ok (Newton step taken), x_s (n,3), depth, color (NOCS, n,3), normals ((R n + 1)/2,
-    n,3), n_hat, gx (n,3), gz (n,L), f0, c (= 1 / (gx . d) or 0), margin (distance of the closest hit / exit / grazing decision to its threshold, in
-    the decision's own units: rays with a small margin may legitimately decide differently under float rounding), n_steps, evals (total ray
-    evaluations)."""
+    n,3), n_hat, gx (n,3), gz (n,L), f0, c (= 1 / (gx . d) or 0), margin (distance of the closest hit / coverage / exit / grazing decision to its
+    threshold, in the decision's own units: rays with a small margin may legitimately decide differently under float rounding), n_steps (passes),
+    evals (total decoder evaluations, speculative samples included)."""
     f = np.float32
     latn = np.asarray(latn, f).reshape(-1)
     L = latn.shape[0]
@@ -772,8 +778,7 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
     active &= l0 < l1
     dn = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(f)
     lam = l0.copy()
-    prev_r, last = np.zeros(n, f), np.zeros(n, f)                 # |sdf| of the previous sample, last step (distance units)
-    om = np.full(n, max(relax, 1.0), f)                            # relaxation factor: `relax` until the first failed overlap test, then 1
+    rho, q = np.zeros(n, f), np.ones(n, f)                        # radius of the previous accepted sample, ratio of the last two radii
     hit = np.zeros(n, bool)
     lam0 = np.zeros(n, f)
     margin = np.full(n, np.inf)
@@ -783,27 +788,49 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
         idx = np.nonzero(active)[0]
         if idx.size == 0:
             break
-        evals += int(idx.size)
-        x = (o[None] + lam[idx, None] * d[idx]).astype(f)
-        rows = np.concatenate([np.broadcast_to(latn, (idx.size, L)), x], 1).astype(f)
-        v = decoder_forward(layers, spec, rows)[:, 0].astype(f)
+        k = int(spec_k) if (spec_from is not None and s >= spec_from) else 1
+        m = idx.size
+        P = np.zeros((m, k), f)
+        P[:, 0] = lam[idx]
+        qp = q[idx].copy()
+        for j in range(1, k):
+            P[:, j] = (P[:, j - 1] + ((f(sigma) * qp * rho[idx]).astype(f) / dn[idx]).astype(f)).astype(f)
+            qp = (qp * q[idx]).astype(f)
+        X = (o[None, None] + P[:, :, None] * d[idx][:, None, :]).astype(f)
+        rows = np.concatenate([np.broadcast_to(latn, (m * k, L)), X.reshape(-1, 3)], 1).astype(f)
+        V = decoder_forward(layers, spec, rows)[:, 0].astype(f).reshape(m, k)
+        evals += m * k
         n_steps[idx] += 1
-        rad = np.abs(v)
-        # over-relaxed sphere tracing (Keinert et al. 2014): disjoint consecutive spheres -> the long step may have skipped a surface
-        fail = (om[idx] > 1) & ((rad + prev_r[idx]).astype(f) < last[idx])
-        margin[idx] = np.minimum(margin[idx], np.where(om[idx] > 1, np.abs((rad + prev_r[idx]).astype(f) - last[idx]), np.inf))
-        margin[idx] = np.minimum(margin[idx], np.where(fail, np.inf, np.abs(rad - eps)))
-        h = ~fail & (rad < f(eps))
-        hit[idx[h]] = True
-        lam0[idx[h]] = lam[idx[h]]
-        step = np.where(fail, (last[idx] - om[idx] * last[idx]).astype(f), (v * om[idx]).astype(f)).astype(f)
-        om[idx[fail]] = 1
-        prev_r[idx] = rad
-        last[idx] = step
-        l2 = (lam[idx] + (step / dn[idx]).astype(f)).astype(f)
-        keep = ~h & (l2 < l1[idx]) & ~np.isnan(v)
-        margin[idx[~h]] = np.minimum(margin[idx[~h]], np.abs(l1[idx[~h]] - l2[~h]))
+        R = np.abs(V)
+        J = np.zeros(m, np.int64)
+        done = R[:, 0] < f(eps)
+        ishit = done.copy()
+        mg = np.abs(R[:, 0] - eps)
+        for j in range(1, k):
+            gap = ((P[:, j] - P[:, j - 1]) * dn[idx]).astype(f)
+            cov = (gap <= R[:, j - 1]) & (V[:, j - 1] > 0) & (P[:, j] > P[:, j - 1])
+            mg = np.where(done, mg, np.minimum(mg, np.abs(gap - R[:, j - 1])))
+            take = cov & ~done
+            done |= ~cov
+            J = np.where(take, j, J)
+            hj = take & (R[:, j] < f(eps))
+            mg = np.where(take, np.minimum(mg, np.abs(R[:, j] - eps)), mg)
+            ishit |= hj
+            done |= hj
+        margin[idx] = np.minimum(margin[idx], mg)
+        ar = np.arange(m)
+        pj, vj, rj = P[ar, J], V[ar, J], R[ar, J]
+        hit[idx[ishit]] = True
+        lam0[idx[ishit]] = pj[ishit]
+        prev = np.where(J > 0, R[ar, np.maximum(J - 1, 0)], rho[idx]).astype(f)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            qn = np.where(prev > 0, np.minimum(np.maximum((rj / prev).astype(f), f(0.5)), f(1.0)), f(1.0)).astype(f)
+        l2 = (pj + (vj / dn[idx]).astype(f)).astype(f)
+        keep = ~ishit & (l2 < l1[idx]) & ~np.isnan(vj)
+        margin[idx[~ishit]] = np.minimum(margin[idx[~ishit]], np.abs(l1[idx[~ishit]] - l2[~ishit]))
         lam[idx[keep]] = l2[keep]
+        rho[idx] = rj
+        q[idx] = qn
         active[idx] = keep
     unresolved = active.copy()
     out = {"hit": hit, "lam0": lam0, "unresolved": unresolved, "n_steps": n_steps, "evals": evals, "far": l1, "entered": l0 < l1}

@@ -23,14 +23,19 @@ void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s
                        P);
 }
 
-// MODE 4: the persistent tail of the sphere tracer's march with half operands (see mlp_jac.hip).  A pass of a 16-ray tile is paced by the
-// weight stream L2 -> CU (3.6 MB per pass), not by the matrix work: geometry chosen for bytes in flight (SDFR_T16_* : tools/ab_variant.sh)
+// MODE 4: the persistent tail of the sphere tracer's march with half operands (see mlp_jac.hip).  A pass of a tile is paced by the weight
+// stream L2 -> CU (3.6 MB per pass), not by the matrix work, up to ~64 rows: spec_k = 4 (64 rows: 16 rays x 4 samples, the grid forward's 32x32
+// tiles, two per workgroup) costs what spec_k = 1 (16 rows) costs per pass.
 #ifndef SDFR_T16_FT
 #define SDFR_T16_FT SDFR_J16_FT
 #define SDFR_T16_NW SDFR_J16_NW
 #define SDFR_T16_PF SDFR_J16_PF
 #endif
-void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n, hipStream_t s) {
+void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n_rays, int spec_k, hipStream_t s) {
     static_assert(16 * SDFR_T16_FT * SDFR_T16_NW == 512, "padded width 512 = 16 * FT * NW");
-    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_T16_FT, 1, SDFR_T16_NW, SDFR_T16_PF, 4>), dim3(sdfr_cdiv(n, 16)), dim3(64 * SDFR_T16_NW), 0, s, P);
+    const dim3 grid(sdfr_cdiv(n_rays, 16));
+    if (spec_k == 4)
+        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 2, 8, 2, 4, 2>), grid, dim3(512), 0, s, P);
+    else
+        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_T16_FT, 1, SDFR_T16_NW, SDFR_T16_PF, 4>), grid, dim3(64 * SDFR_T16_NW), 0, s, P);
 }

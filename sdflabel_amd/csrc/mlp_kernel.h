@@ -77,18 +77,20 @@ struct MlpParams {
     const int32_t* n_dev;        // forward: optional device-side row count (rows >= *n_dev are not evaluated; n is the launch bound)
     int n_dev_lo, n_dev_hi;      // with n_dev and n_dev_hi > 0: the launch runs only while n_dev_lo <= *n_dev < n_dev_hi (two tile geometries of one step)
     unsigned long long* trace;   // builds with -DSDFR_MLP_TRACE: cycle stamps of workgroup 0 (sdfr_debug_set_trace), else unused
-    // MODE 4 (sphere tracing, persistent tail: csrc/trace.hip): the workgroup marches the PT rays of its tile to termination by itself --
-    // decoder pass, advance, hit / exit test, next pass -- rewriting its own rows of `inputs` between passes
-    float* t_rows;               // = inputs (writable): [latent, o + lam d] per active-list row
+    // MODE 4 (sphere tracing, persistent tail: csrc/trace.hip): the workgroup marches the 16 rays of its tile to termination by itself --
+    // decoder pass on PT = 16 K rows (K samples per ray), step rule, hit / exit test, next pass -- rewriting its own operand rows between passes
+    float* t_rows;               // = inputs: scratch [tile][PT][n_inputs], row j*16 + i = sample j of the tile's ray i
+    const float* t_latn;         // [B][L] normalised latents
     const int32_t* t_pix;        // active list: crop * W*H + pixel
-    const float4* t_lam;         // active list: ray state (lam, previous |sdf|, last step, relaxation factor)
+    const float4* t_lam;         // active list: ray state (lam = next sample, rho = |sdf| of the previous accepted sample, q = ratio of the last two radii, -)
+    int t_step0, t_spec_from;    // pass index of the kernel's first pass; passes with index >= t_spec_from are speculative (K samples per ray)
     const float* t_far;          // per pixel: ray parameter at which the ray leaves the object cube
     const float* t_pose;         // [B][16]
     const float* t_Kinv;         // [B][9]
     float* t_hit_lam;            // per pixel: ray parameter of the hit (0: none)
     float* t_hit_sdf;            // per pixel: decoder value at the marched hit
     int t_W, t_H, t_steps;       // image size; passes left in the march's step budget
-    float t_eps;
+    float t_eps, t_sigma;
     unsigned long long* t_evals; // += active rays per pass (ray evaluations of the march, for the roofline)
     int32_t* t_unresolved;       // += rays still active when the step budget ran out
 };
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     static_assert(!SAVE || (FT * NP) % 2 == 0, "mask words: FT*NP*16 bits per thread and layer must fill whole words");
     static_assert(!HALF || !JAC || MODE == 3, "with half operands only the mask-fed Jacobian exists (MODE 3)");
     static_assert(!LN || (!HALF && MODE != 1 && MODE != 3 && MODE != 4), "LayerNorm decoders: float32 forward (MODE 0) and recomputing Jacobian (MODE 2)");
-    static_assert(!TAIL || NP * MS <= 64, "tail march: the rays of a tile are owned by the first lanes of wave 0");
+    static_assert(!TAIL || (NP * MS <= 64 && (NP * MS) % 16 == 0), "tail march: the tile's rows (16 rays x K samples) live in wave 0");
     constexpr int KV = M::KV;                                      // operand elements per 16-byte fragment
     constexpr int NLG = 64 / MS;                                   // lane groups (k slots per MFMA)
     constexpr int RG = MS / (4 * NLG);                             // register groups of 4 per accumulator (4 or 1)
@@ -231,7 +233,8 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             slots[tid] = v ? (b * P.cap + s) : -1;
         }
     } else {
-        const int64_t r0 = (int64_t)blockIdx.x * PT;
+        // (MODE 4: a tile is 16 RAYS of the active list -- n / n_dev count rays -- and PT = 16 K operand rows of the tile's own scratch)
+        const int64_t r0 = (int64_t)blockIdx.x * (TAIL ? 16 : PT);
         const int64_t n_rows = P.n_dev ? min(P.n, (int64_t)*P.n_dev) : P.n;          // sphere tracing: the active-ray count lives on the device
         if (r0 >= n_rows) return;
         if (P.n_dev && P.n_dev_hi > 0 && (*P.n_dev < P.n_dev_lo || *P.n_dev >= P.n_dev_hi)) return;
@@ -244,8 +247,57 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             for (int64_t c = r0 / P.skip_rows; c <= r1 / P.skip_rows; ++c) all_flagged = all_flagged && P.skip[c] != 0;
             if (all_flagged) return;
         }
-        n_valid = (int)min((int64_t)PT, n_rows - r0);
-        if (tid < PT) rows[tid] = (int)(r0 + (tid < n_valid ? tid : 0));
+        n_valid = (int)min((int64_t)(TAIL ? 16 : PT), n_rows - r0);
+        if (tid < PT) rows[tid] = TAIL ? (int)((int64_t)blockIdx.x * PT + tid) : (int)(r0 + (tid < n_valid ? tid : 0));
+    }
+    // ---- MODE 4: the tile's rays.  Lane i < 16 of wave 0 owns ray i: state, ray and the K sample positions of the coming pass in registers ----
+    constexpr int TK = TAIL ? PT / 16 : 1;              // samples per ray and pass
+    int t_gp = 0, t_left = 0, t_pass = 0;
+    bool t_act = false;
+    float4 t_st = make_float4(0.f, 0.f, 1.f, 0.f);
+    float t_farl = 0.f, t_idn = 1.f, t_ox = 0.f, t_oy = 0.f, t_oz = 0.f, t_dx = 0.f, t_dy = 0.f, t_dz = 0.f;
+    float t_p[TK];
+    unsigned long long t_ev = 0ull;
+    // sample positions of a pass with k live samples (p_0 = lam, p_j = p_{j-1} + sigma q^j rho / |d|; slots j >= k repeat p_0) -> operand rows
+    auto tail_rows = [&](int k, bool with_latent) {
+        if (tid >= 16) return;
+        float pj = t_st.x, qp = t_st.z;
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            if (j > 0 && j < k) { pj = pj + ((P.t_sigma * qp) * t_st.y) / t_idn; qp = qp * t_st.z; }
+            const float pos = (j < k) ? pj : t_st.x;
+            t_p[j] = pos;
+            float* row = P.t_rows + ((int64_t)blockIdx.x * PT + j * 16 + tid) * NI;
+            if (with_latent) {
+                const int P_ = P.t_W * P.t_H;
+                const float* lz = P.t_latn + (int64_t)(t_gp / P_) * (NI - 3);
+                for (int c = 0; c < NI - 3; ++c) row[c] = lz[c];
+            }
+            row[NI - 3] = t_ox + pos * t_dx; row[NI - 2] = t_oy + pos * t_dy; row[NI - 1] = t_oz + pos * t_dz;
+        }
+    };
+    if constexpr (TAIL) {
+        t_left = P.t_steps;
+        if (tid < 16) {
+            const int64_t s = (int64_t)blockIdx.x * 16 + (tid < n_valid ? tid : 0);        // lanes beyond the tile's rays mirror ray 0 (finite rows), inactive
+            t_gp = P.t_pix[s];
+            t_st = P.t_lam[s];
+            t_farl = P.t_far[t_gp];
+            const int P_ = P.t_W * P.t_H, b = t_gp / P_, px = t_gp - b * P_;
+            const float* Pm = P.t_pose + (int64_t)b * 16;
+            const float* Ki = P.t_Kinv + (int64_t)b * 9;
+            const float x = (float)(px % P.t_W), y = (float)(px / P.t_W);
+            const float rx = fmaf(Ki[1], y, Ki[0] * x) + Ki[2], ry = fmaf(Ki[4], y, Ki[3] * x) + Ki[5], rz = fmaf(Ki[7], y, Ki[6] * x) + Ki[8];
+            t_dx = Pm[0] * rx + Pm[4] * ry + Pm[8] * rz;
+            t_dy = Pm[1] * rx + Pm[5] * ry + Pm[9] * rz;
+            t_dz = Pm[2] * rx + Pm[6] * ry + Pm[10] * rz;
+            t_ox = -(Pm[0] * Pm[3] + Pm[4] * Pm[7] + Pm[8] * Pm[11]);
+            t_oy = -(Pm[1] * Pm[3] + Pm[5] * Pm[7] + Pm[9] * Pm[11]);
+            t_oz = -(Pm[2] * Pm[3] + Pm[6] * Pm[7] + Pm[10] * Pm[11]);
+            t_idn = sqrtf(t_dx * t_dx + t_dy * t_dy + t_dz * t_dz);        // |d| (the step divides by it, as sdfr_trace_step_kernel does)
+            t_act = tid < n_valid;
+        }
+        tail_rows((TK > 1 && P.t_step0 >= P.t_spec_from) ? TK : 1, true);
     }
     __syncthreads();
     if (JAC) {
@@ -540,35 +592,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #else
 #define SDFR_STAMP(l, i) do { } while (0)
 #endif
-    // ---- MODE 4: the tile's rays (lane i < PT of wave 0 owns ray i) -------------------------------------------
-    int t_gp = 0, t_left = 0;
-    bool t_act = false;
-    float4 t_st = make_float4(0.f, 0.f, 0.f, 1.f);
-    float t_farl = 0.f, t_idn = 0.f, t_ox = 0.f, t_oy = 0.f, t_oz = 0.f, t_dx = 0.f, t_dy = 0.f, t_dz = 0.f;
-    unsigned long long t_ev = 0ull;
     int* t_more = reinterpret_cast<int*>(gy);           // gy is unused by forward modes
-    if constexpr (TAIL) {
-        t_left = P.t_steps;
-        if (tid < PT && tid < n_valid) {
-            const int64_t s = (int64_t)blockIdx.x * PT + tid;
-            t_gp = P.t_pix[s];
-            t_st = P.t_lam[s];
-            t_farl = P.t_far[t_gp];
-            const int P_ = P.t_W * P.t_H, b = t_gp / P_, px = t_gp - b * P_;
-            const float* Pm = P.t_pose + (int64_t)b * 16;
-            const float* Ki = P.t_Kinv + (int64_t)b * 9;
-            const float x = (float)(px % P.t_W), y = (float)(px / P.t_W);
-            const float rx = fmaf(Ki[1], y, Ki[0] * x) + Ki[2], ry = fmaf(Ki[4], y, Ki[3] * x) + Ki[5], rz = fmaf(Ki[7], y, Ki[6] * x) + Ki[8];
-            t_dx = Pm[0] * rx + Pm[4] * ry + Pm[8] * rz;
-            t_dy = Pm[1] * rx + Pm[5] * ry + Pm[9] * rz;
-            t_dz = Pm[2] * rx + Pm[6] * ry + Pm[10] * rz;
-            t_ox = -(Pm[0] * Pm[3] + Pm[4] * Pm[7] + Pm[8] * Pm[11]);
-            t_oy = -(Pm[1] * Pm[3] + Pm[5] * Pm[7] + Pm[9] * Pm[11]);
-            t_oz = -(Pm[2] * Pm[3] + Pm[6] * Pm[7] + Pm[10] * Pm[11]);
-            t_idn = sqrtf(t_dx * t_dx + t_dy * t_dy + t_dz * t_dz);        // |d| (the step divides by it, as sdfr_trace_step_kernel does)
-            t_act = true;
-        }
-    }
     do {
     for (int l = 0; !GMASK && l < P.n_mfma; ++l) {
         const MlpLayer L = P.L[l];
@@ -741,29 +765,41 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                 gy[tid] = g;
                 if (tid < n_valid && P.sdf_sel) P.sdf_sel[slots[tid]] = o;
             } else if (TAIL) {
-                // advance this lane's ray by the decoder value (the step rule of sdfr_trace_step_kernel), retire hits and exits
-                const unsigned long long live = __ballot(t_act);
-                if (tid == 0) t_ev += (unsigned long long)__popcll(live);
-                if (t_act) {
-                    // the march's step rule (csrc/trace.hip trace_advance, restated here: this header does not see trace.hip)
-                    const float rad = fabsf(o);
-                    const bool fail = (t_st.w > 1.f) && (rad + t_st.y < t_st.z);
-                    if (!fail && rad < P.t_eps) {
-                        P.t_hit_lam[t_gp] = t_st.x;
-                        P.t_hit_sdf[t_gp] = o;
+                // The step rule of the march (oracle/sdf_oracle.py::sphere_trace; K = 1: exactly sdfr_trace_step_kernel's trace_advance).  Row
+                // j*16 + i carries sample j of ray i: lane i < 16 collects its K values, walks the accepted prefix -- sample j counts only
+                // inside the safe sphere of sample j-1 --, retires hits and exits, continues from the last accepted sample.
+                const int k = (TK > 1 && P.t_step0 + t_pass >= P.t_spec_from) ? TK : 1;
+                float v[TK];
+#pragma unroll
+                for (int j = 0; j < TK; ++j) v[j] = (TK > 1) ? __shfl(o, (tid & 15) + 16 * j, 64) : o;
+                const unsigned long long live = __ballot(t_act && tid < 16);
+                if (tid == 0) t_ev += (unsigned long long)(__popcll(live) * k);
+                if (t_act && tid < 16) {
+                    float vj = v[0], rj = fabsf(v[0]), pj = t_p[0], prev = t_st.y;
+                    bool done = rj < P.t_eps, ishit = done;
+#pragma unroll
+                    for (int j = 1; j < TK; ++j) {
+                        if (j < k) {
+                            const float rp = fabsf(v[j - 1]);
+                            const bool cov = ((t_p[j] - t_p[j - 1]) * t_idn <= rp) && (v[j - 1] > 0.f) && (t_p[j] > t_p[j - 1]);
+                            const bool take = cov && !done;
+                            done = done || !cov;
+                            if (take) {
+                                prev = rp; vj = v[j]; rj = fabsf(v[j]); pj = t_p[j];
+                                if (rj < P.t_eps) { ishit = true; done = true; }
+                            }
+                        }
+                    }
+                    if (ishit) {
+                        P.t_hit_lam[t_gp] = pj;
+                        P.t_hit_sdf[t_gp] = vj;
                         t_act = false;
                     } else {
-                        float step;
-                        if (fail) { step = t_st.z - t_st.w * t_st.z; t_st.w = 1.f; }
-                        else step = o * t_st.w;
-                        t_st.y = rad;
-                        t_st.z = step;
-                        const float l2 = t_st.x + step / t_idn;
-                        if ((l2 < t_farl) && (o == o)) {
-                            t_st.x = l2;
-                            float* row = P.t_rows + ((int64_t)blockIdx.x * PT + tid) * NI;
-                            row[NI - 3] = t_ox + l2 * t_dx; row[NI - 2] = t_oy + l2 * t_dy; row[NI - 1] = t_oz + l2 * t_dz;
-                        } else t_act = false;
+                        const float qn = (prev > 0.f) ? fminf(fmaxf(rj / prev, 0.5f), 1.f) : 1.f;
+                        const float l2 = pj + vj / t_idn;
+                        t_st.y = rj; t_st.z = qn;
+                        if ((l2 < t_farl) && (vj == vj)) t_st.x = l2;
+                        else t_act = false;
                     }
                 }
             } else {
@@ -782,12 +818,15 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         if (t_act && t_left > 0) *t_more = 1;
         __syncthreads();
         if (*t_more == 0) break;
+        ++t_pass;
+        tail_rows((TK > 1 && P.t_step0 + t_pass >= P.t_spec_from) ? TK : 1, false);
+        __syncthreads();
         build_operand();                                  // the rows this workgroup has just rewritten (same CU: its L1 is coherent for it)
         __syncthreads();
     }
     } while (TAIL);
     if constexpr (TAIL) {
-        const unsigned long long left_over = __ballot(t_act);
+        const unsigned long long left_over = __ballot(t_act && tid < 16);
         if (tid == 0) {
             if (P.t_evals) atomicAdd(P.t_evals, t_ev);
             if (left_over && P.t_unresolved) atomicAdd(P.t_unresolved, (int)__popcll(left_over));
@@ -1038,8 +1077,8 @@ void sdfr_launch_jac_f32_512_recompute32(const MlpParams& P, int cap, int B, hip
 void sdfr_launch_fwd_f32_512_tile16(const MlpParams& P, int64_t n, hipStream_t s);                // mlp_jac.hip (forward on 16-row tiles: thin counted launches)
 void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s);                  // mlp_jac16.hip (mask-fed only)
 void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s);                // mlp_jac16.hip (half forward on 16-row tiles)
-void sdfr_launch_tail_f32_512(const MlpParams& P, int64_t n, hipStream_t s);                      // mlp_jac.hip (MODE 4: sphere tracer's persistent tail)
-void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n, hipStream_t s);                      // mlp_jac16.hip
+void sdfr_launch_tail_f32_512(const MlpParams& P, int64_t n_rays, int spec_k, hipStream_t s);                      // mlp_jac.hip (MODE 4: sphere tracer's persistent tail)
+void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n_rays, int spec_k, hipStream_t s);                      // mlp_jac16.hip
 void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)
 void sdfr_launch_ln(const MlpParams& P, int HP, bool jac, int grid_x, int grid_y, hipStream_t s);        // mlp_ln.hip (LayerNorm decoders)
 int sdfr_ln_points_per_wg(int HP, bool jac);

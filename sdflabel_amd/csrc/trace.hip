@@ -3,16 +3,15 @@
 // NOT in the reference (its renderer splats surfels of a grid band); this is the render mode BASELINE.json's north_star
 // describes literally -- "per-ray sphere-tracing loop and DeepSDF-MLP evaluation at each march step ... wavefront ballot for
 // early-termination compaction" -- offered beside the faithful path, with no parity claim against the reference.
-//   step:   x = o + lam d   ->   s = decoder(latent, x)  (the decoder kernels on the ACTIVE rays only)   ->   lam += om s / |d|
+//   step:   x = o + lam d   ->   s = decoder(latent, x)  (the decoder kernels on the ACTIVE rays only)   ->   lam += s / |d|
 //   a ray leaves the active list when |s| < eps (hit: its lam is recorded per pixel) or when lam passes the far side of the object cube.
-//   om = `relax` >= 1: over-relaxed sphere tracing (Keinert et al. 2014): the step is om times the safe radius as long as consecutive
-//   spheres overlap (|s| + |s_prev| >= last step); the first time they do not -- the long step may have jumped over a surface -- the ray
-//   moves back into the previous safe sphere and continues with om = 1 for good.  relax = 1 is plain sphere tracing.
-//   Ray state (float4 per active ray): lam, |s| of the previous sample, the last step (distance units), om.
 // Rays live in object space: p_cam = R p + t (the optimizer's pose, pipelines/optimizer.py:86-90), pixel ray r = K^-1 [x, y, 1]
 // (primitives.py:203-208), so o = -R^T t, d = R^T r and lam is the camera-frame depth of the point (r_z = 1 for a pinhole K).
 // The active list is compacted every step with one wave ballot + one atomic per wavefront (rays are independent: their order in the list
 // does not matter), the count stays on the device, and the decoder launch of the next step reads it there: no host synchronisation.
+// Ray state (float4 per active ray): lam = the next sample, rho = |s| of the previous accepted sample, q = ratio of the last two radii
+// (clamped to [0.5, 1]) -- rho and q feed the speculative passes of the looping tail (mlp_kernel.h MODE 4: K samples per ray and pass,
+// p_j = p_{j-1} + sigma q^j rho / |d|, accepted while each lies inside the previous one's safe sphere).
 #include "mlp_kernel.h"
 #include <float.h>
 
@@ -35,19 +34,16 @@ __device__ __forceinline__ TraceRay trace_ray(const float* __restrict__ P, const
     return r;
 }
 
-// One sample of a ray: st = (lam, prev_r, step, om), v = decoder value at lam, dn = |d|.  Returns 1 hit (st.x = the hit's lam), 0 keep marching
-// (st advanced), -1 miss (past the cube's far side, or NaN).  The ONE step rule of the march: sdfr_trace_step_kernel, the looping tail of
-// the decoder kernel (mlp_kernel.h MODE 4) and the oracle (oracle/sdf_oracle.py::sphere_trace) all apply it.
+// One plain sample of a ray: st = (lam, rho, q, -), v = decoder value at lam, dn = |d|.  Returns 1 hit (st.x = the hit's lam), 0 keep marching
+// (st advanced), -1 miss (past the cube's far side, or NaN).  The K = 1 case of the march's step rule (oracle/sdf_oracle.py::sphere_trace);
+// the looping tail of the decoder kernel (mlp_kernel.h MODE 4) applies the same rule to the accepted prefix of its K samples.
 __device__ __forceinline__ int trace_advance(float4& st, float v, float dn, float eps, float far) {
     const float r = fabsf(v);
-    const bool fail = (st.w > 1.f) && (r + st.y < st.z);          // disjoint spheres: the over-relaxed step may have skipped a surface
-    if (!fail && r < eps) return 1;
-    float step;
-    if (fail) { step = st.z - st.w * st.z; st.w = 1.f; }           // back into the previous safe sphere, plain tracing from here on
-    else step = v * st.w;
+    if (r < eps) return 1;
+    const float q = (st.y > 0.f) ? fminf(fmaxf(r / st.y, 0.5f), 1.f) : 1.f;
+    const float l2 = st.x + v / dn;
     st.y = r;
-    st.z = step;
-    const float l2 = st.x + step / dn;
+    st.z = q;
     if (!(l2 < far) || !(v == v)) return -1;
     st.x = l2;
     return 0;
@@ -71,7 +67,7 @@ __device__ __forceinline__ void trace_write_row(float* __restrict__ row, const f
 // every pixel of every crop: slab test against the cube [-bound, bound]^3 the SDF is defined on; rays that hit it enter the active list
 __global__ __launch_bounds__(256) void sdfr_trace_setup_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
                                                               const float* __restrict__ latn, int L, int W, int H, float bound, float near,
-                                                              float relax, int32_t* __restrict__ counters, int32_t* __restrict__ pix,
+                                                              int32_t* __restrict__ counters, int32_t* __restrict__ pix,
                                                               float4* __restrict__ lam, float* __restrict__ far, float* __restrict__ inputs) {
     const int b = blockIdx.y;
     const int P_ = W * H;
@@ -97,7 +93,7 @@ __global__ __launch_bounds__(256) void sdfr_trace_setup_kernel(const float* __re
     const int slot = trace_append(active, counters);
     if (active) {
         pix[slot] = b * P_ + p;
-        lam[slot] = make_float4(l0, 0.f, 0.f, fmaxf(relax, 1.f));
+        lam[slot] = make_float4(l0, 0.f, 1.f, 0.f);
         trace_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, r, l0);
     }
 }
@@ -326,13 +322,13 @@ __global__ __launch_bounds__(256) void sdfr_trace_backward_sum_kernel(const floa
 }
 
 extern "C" int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
-                                float relax, int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, void* stream) {
+                                int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, void* stream) {
     SDFR_REQUIRE(pose && Kinv && latn && counters && pix && lam && far && inputs, "sdfr_trace_setup: NULL argument");
     SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0 && bound > 0.f, "sdfr_trace_setup: bad size");
     hipStream_t s = (hipStream_t)stream;
     SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
     hipLaunchKernelGGL(sdfr_trace_setup_kernel, dim3(sdfr_cdiv((int64_t)W * H, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, W, H, bound, near,
-                       relax, counters, pix, reinterpret_cast<float4*>(lam), far, inputs);
+                       counters, pix, reinterpret_cast<float4*>(lam), far, inputs);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -354,36 +350,46 @@ extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float
 
 // ---- the whole march in one call: no host synchronisation -------------------------------------------------------------------------------
 // counters (device int32[SDFR_TRACE_COUNTERS], zeroed by sdfr_trace_setup): [0..2] rotating active counts, [3] rays left unresolved when the
-// step budget ran out, [4..5] one uint64: ray evaluations of the march (sum of the active counts over the steps), [6] hits, [7] spare.
+// step budget ran out, [4..5] one uint64: decoder evaluations of the march (speculative samples included), [6] hits, [7] spare.
 // While the device-side count is >= tail_rows a step is two launches: the decoder on the active rows (64- / 128-row tiles, MFMA-bound)
-// and sdfr_trace_step_kernel (advance, retire, ballot compaction).  Once it drops below tail_rows -- every 16-row tile then has a CU to
+// and sdfr_trace_step_kernel (advance, retire, ballot compaction).  Once it drops below tail_rows -- every 16-ray tile then has a CU to
 // itself -- ONE launch of the decoder kernel in MODE 4 takes the remaining rays to termination: the workgroup loops over decoder pass ->
-// advance -> hit / exit test for its 16 rays with the ray state in registers (no per-step launch, no compaction, no host read).  The gate
+// step rule -> hit / exit test for its 16 rays with the ray state in registers (no per-step launch, no compaction, no host read).  The gate
 // is evaluated on the device in every step of the head; after `head_steps` steps an unconditional tail launch takes whatever is left.
+// Speculative passes (spec_k = 4): from pass index spec_from on a pass evaluates FOUR samples per ray (64 operand rows per tile -- a 64-row
+// pass of the half kernel costs what a 16-row pass costs: both are paced by the weight stream through the CU) and accepts the prefix that
+// stays inside the previous samples' safe spheres; the rays creeping along a face at grazing incidence, which keep a march alive for dozens
+// of steps, advance four samples per pass.  The pass index alone decides (head_steps is clamped to spec_from), so a ray's sample sequence
+// does not depend on the launch schedule.  tail_rows_buf: scratch float[ceil(n / 16)][16 spec_k][L + 3].
 extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H,
-                                float eps, int steps, int head_steps, int tail_rows, int half, int32_t* counters, int32_t* pix0,
-                                float* lam0_, int32_t* pix1, float* lam1_, const float* far, float* inputs, float* sdf, float* hit_lam,
-                                float* hit_sdf, void* stream) {
-    SDFR_REQUIRE(d && pose && Kinv && latn && counters && pix0 && lam0_ && pix1 && lam1_ && far && inputs && sdf && hit_lam && hit_sdf,
-                 "sdfr_trace_march: NULL argument");
+                                float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, float sigma, int half,
+                                int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_, const float* far, float* inputs,
+                                float* sdf, float* tail_rows_buf, float* hit_lam, float* hit_sdf, void* stream) {
+    SDFR_REQUIRE(d && pose && Kinv && latn && counters && pix0 && lam0_ && pix1 && lam1_ && far && inputs && sdf && tail_rows_buf && hit_lam &&
+                     hit_sdf, "sdfr_trace_march: NULL argument");
     float4* lam0 = reinterpret_cast<float4*>(lam0_);
     float4* lam1 = reinterpret_cast<float4*>(lam1_);
     SDFR_REQUIRE(B > 0 && W > 0 && H > 0 && steps > 0 && head_steps >= 0 && tail_rows >= 0, "sdfr_trace_march: bad size");
+    SDFR_REQUIRE(spec_k == 1 || spec_k == 4, "sdfr_trace_march: spec_k = %d (1: plain tracing, 4: four samples per ray and pass)", spec_k);
     SDFR_REQUIRE(d->HP == 512 && !d->has_ln && d->n_inputs == L + 3, "sdfr_trace_march: 512-wide decoder without LayerNorm, L + 3 inputs");
     const int64_t n_max = (int64_t)B * W * H;
     SDFR_REQUIRE(n_max < (int64_t)1 << 31, "sdfr_trace_march: too many rays");
     hipStream_t s = (hipStream_t)stream;
+    if (spec_k == 1) spec_from = 0x7fffffff;
+    if (spec_from < 0) spec_from = 0;
     if (head_steps > steps) head_steps = steps;
+    if (head_steps > spec_from) head_steps = spec_from;          // speculative passes exist in the looping kernel only
     unsigned long long* evals = reinterpret_cast<unsigned long long*>(counters + 4);
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.trace = nullptr;
-    P.t_rows = inputs; P.t_far = far; P.t_pose = pose; P.t_Kinv = Kinv; P.t_hit_lam = hit_lam; P.t_hit_sdf = hit_sdf; P.t_W = W; P.t_H = H;
-    P.t_eps = eps; P.t_evals = evals; P.t_unresolved = counters + 3;
+    P.t_far = far; P.t_pose = pose; P.t_Kinv = Kinv; P.t_latn = latn; P.t_hit_lam = hit_lam; P.t_hit_sdf = hit_sdf; P.t_W = W; P.t_H = H;
+    P.t_eps = eps; P.t_sigma = sigma; P.t_evals = evals; P.t_unresolved = counters + 3; P.t_spec_from = spec_from;
     auto tail = [&](int step, int hi) {
         MlpParams T = P;
+        T.inputs = tail_rows_buf; T.t_rows = tail_rows_buf;
         T.n_dev = counters + step % 3; T.n_dev_lo = 1; T.n_dev_hi = hi;
-        T.t_pix = (step & 1) ? pix1 : pix0; T.t_lam = (step & 1) ? lam1 : lam0; T.t_steps = steps - step;
-        if (half) sdfr_launch_tail_f16_512(T, n_max, s); else sdfr_launch_tail_f32_512(T, n_max, s);
+        T.t_pix = (step & 1) ? pix1 : pix0; T.t_lam = (step & 1) ? lam1 : lam0; T.t_steps = steps - step; T.t_step0 = step;
+        if (half) sdfr_launch_tail_f16_512(T, n_max, spec_k, s); else sdfr_launch_tail_f32_512(T, n_max, spec_k, s);
     };
     for (int step = 0; step < head_steps; ++step) {
         MlpParams F = P;

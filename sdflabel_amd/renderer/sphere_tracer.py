@@ -13,7 +13,8 @@ Everything is a HIP kernel behind the C ABI (csrc/trace.hip, csrc/mlp_kernel.h M
   sdfr_trace_setup      pixel rays in object space (o = -R^T t, d = R^T K^-1 [x, y, 1]) clipped against the cube [-1, 1]^3 -> active list
   sdfr_trace_march      while the device-side active count is >= tail_rows: decoder on the active rows (MFMA) + advance / retire / ballot
                         compaction per step; below it ONE launch of the decoder kernel in its looping mode marches the remaining rays to
-                        termination (16-ray tiles, no per-step launch)
+                        termination (16-ray tiles, no per-step launch); from pass `spec_from` on with `spec_k` samples per ray and pass
+                        (accepted while each lies inside the previous one's safe sphere: the creeping grazing rays advance 4 samples a pass)
   sdfr_trace_hits       hit pixels -> compact rows [latent, x0]
   sdfr_mlp_jacobian     exact-f32 decoder value and input Jacobian at the hits (normals, d sdf / d latent)
   sdfr_trace_composite  one Newton step along non-grazing rays, then depth / NOCS colour / normals / mask images
@@ -48,14 +49,14 @@ class _TraceFn(torch.autograd.Function):
 
 
 class SphereTracer:
-    def __init__(self, decoder, K, resolution_px, batch=1, steps=64, eps=2e-3, bound=1.0, relax=1.0, near=1e-3, device="cuda", head_steps=None,
-                 tail_rows=4096):
+    def __init__(self, decoder, K, resolution_px, batch=1, steps=64, eps=2e-3, bound=1.0, near=1e-3, device="cuda", head_steps=None,
+                 tail_rows=4096, spec_from=12, spec_k=None, sigma=0.9):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise _lib.SdfrError("SphereTracer runs on the GPU only")
         self.dev, self.B = dev, int(batch)
         self.W, self.H = int(resolution_px[0]), int(resolution_px[1])
-        self.steps, self.eps, self.bound, self.relax, self.near = int(steps), float(eps), float(bound), float(relax), float(near)
+        self.steps, self.eps, self.bound, self.near = int(steps), float(eps), float(bound), float(near)
         # the device-side gate (count < tail_rows) is checked in each of the first head_steps steps; afterwards the tail takes whatever is left
         self.head_steps = min(self.steps, 24) if head_steps is None else int(head_steps)
         self.tail_rows = int(tail_rows)
@@ -63,6 +64,13 @@ class SphereTracer:
         self.decoder = decoder
         self.handle = decoder.handle(dev)
         self.half = 1 if getattr(decoder, "mlp_precision", torch.float32) == torch.float16 else 0
+        # speculative passes: from pass index spec_from on, spec_k samples per ray and pass in the looping kernel (accepted while each lies inside
+        # the previous one's safe sphere).  Default: 4 with the float16 decoder -- a 64-row half pass costs what a 16-row pass costs (both are
+        # paced by the weight stream) --, 1 (plain sphere tracing) with the exact-f32 decoder, whose 64-row pass is matrix-bound (4x the time).
+        self.spec_k = int(spec_k) if spec_k is not None else (4 if self.half else 1)
+        self.spec_from, self.sigma = int(spec_from), float(sigma)
+        if self.spec_k not in (1, 4):
+            raise ValueError("spec_k must be 1 or 4")
         self.L = decoder.latent_size
         self.NI = self.L + 3
         K = torch.as_tensor(K, dtype=torch.float32)
@@ -77,8 +85,9 @@ class SphereTracer:
         self.yaw, self.trans, self.latent = f(B), f(B, 3), f(B, self.L)
         self.pose, self.latnorm, self.latn = f(B, 16), f(B), f(B, self.L)
         self.counters = i(_COUNTERS)
-        self.pix, self.lam = [i(n), i(n)], [f(n, 4), f(n, 4)]                 # active lists: pixel, ray state (lam, prev |sdf|, last step, om)
+        self.pix, self.lam = [i(n), i(n)], [f(n, 4), f(n, 4)]                 # active lists: pixel, ray state (lam, rho, q, -)
         self.far, self.inputs, self.sdf = f(n), f(n, self.NI), f(n)
+        self.tail_rows_buf = f((n + 15) // 16, 16 * self.spec_k, self.NI)          # operand rows of the looping kernel's tiles
         self.hit_lam, self.hit_sdf, self.lam_s = f(n), f(n), f(n)
         self.hit_slot, self.idx = i(n), i(n)
         self.rows, self.J, self.f0 = f(n, self.NI), f(n, self.NI), f(n)
@@ -103,13 +112,14 @@ class SphereTracer:
                "sdfr_params_forward")
             torch.div(self.latent, self.latnorm.unsqueeze(1), out=self.latn)                    # F.normalize (optimizer.py:96)
             self.hit_lam.zero_(); self.hit_sdf.zero_()
-            ck(L.sdfr_trace_setup(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, self.relax, P(self.counters), P(self.pix[0]),
+            ck(L.sdfr_trace_setup(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, P(self.counters), P(self.pix[0]),
                                   P(self.lam[0]), P(self.far), P(self.inputs), st), "sdfr_trace_setup")
             if "march" in events:
                 events["march"][0].record()
             ck(L.sdfr_trace_march(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.eps, self.steps,
-                                  self.head_steps, self.tail_rows, self.half, P(self.counters), P(self.pix[0]), P(self.lam[0]), P(self.pix[1]),
-                                  P(self.lam[1]), P(self.far), P(self.inputs), P(self.sdf), P(self.hit_lam), P(self.hit_sdf), st), "sdfr_trace_march")
+                                  self.head_steps, self.tail_rows, self.spec_from, self.spec_k, self.sigma, self.half, P(self.counters),
+                                  P(self.pix[0]), P(self.lam[0]), P(self.pix[1]), P(self.lam[1]), P(self.far), P(self.inputs), P(self.sdf),
+                                  P(self.tail_rows_buf), P(self.hit_lam), P(self.hit_sdf), st), "sdfr_trace_march")
             if "march" in events:
                 events["march"][1].record()
             n_hits = self.counters[6:7]

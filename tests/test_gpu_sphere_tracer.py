@@ -36,15 +36,16 @@ def _args(yaw=YAW, trans=TRANS, lat=LAT, grad=False):
     return [t.requires_grad_(True) for t in a] if grad else a
 
 
-@pytest.mark.parametrize("head_steps,tail_rows,relax", [(24, 4096, 1.0), (0, 4096, 1.0), (64, 0, 1.0), (24, 4096, 1.6), (0, 4096, 1.6), (64, 0, 1.6)])
-def test_march_polish_images_and_gradients_against_the_oracle(dec, oracle_layers, head_steps, tail_rows, relax):
+@pytest.mark.parametrize("head_steps,tail_rows,spec_k", [(24, 4096, 1), (0, 4096, 1), (64, 0, 1), (24, 4096, 4), (0, 4096, 4), (64, 0, 4)])
+def test_march_polish_images_and_gradients_against_the_oracle(dec, oracle_layers, head_steps, tail_rows, spec_k):
     """head 24 / tail 4096: the default (per-step launches while >= 4096 rays are active, then the looping tail kernel); head 0: EVERY ray is
-    marched by the looping kernel alone; tail_rows 0: per-step launches only.  All three must reproduce the oracle -- and each other."""
+    marched by the looping kernel alone; tail_rows 0: per-step launches only (until the speculative passes start, which exist in the looping
+    kernel only).  spec_k = 4: from pass 16 on four samples per ray and pass.  All schedules must reproduce the oracle -- and each other."""
     layers, spec = oracle_layers
     H, W = 96, 128
     K = K_for(H, W)
     K[0, 2] += 9.0                                             # principal point off the image centre
-    tr = sdflabel_amd.SphereTracer(dec, K, (W, H), 1, steps=64, device=DEV, head_steps=head_steps, tail_rows=tail_rows, relax=relax)
+    tr = sdflabel_amd.SphereTracer(dec, K, (W, H), 1, steps=64, device=DEV, head_steps=head_steps, tail_rows=tail_rows, spec_from=16, spec_k=spec_k)
     a = _args(grad=True)
     out = tr(*a)
     # ---- the oracle on a subset of > 2000 rays: every 2nd row and column (the object's silhouette crosses them: grazing rays included)
@@ -55,7 +56,7 @@ def test_march_polish_images_and_gradients_against_the_oracle(dec, oracle_layers
     latn = lat / np.sqrt((lat * lat).sum())
     pose = O.render_pose(YAW[0], TRANS[0])
     Kinv = np.linalg.inv(K).astype(np.float32)
-    ref = O.sphere_trace(layers, spec, latn, pose, Kinv, px, steps=64, relax=relax)
+    ref = O.sphere_trace(layers, spec, latn, pose, Kinv, px, steps=64, spec_from=16 if spec_k > 1 else None, spec_k=spec_k)
     sel = (px[:, 1], px[:, 0])
     hit = N(out["mask"][0, 0])[sel] > 0
     safe = ref["margin"] > 1e-4
@@ -100,13 +101,15 @@ def dn_all(nrm, ref):
     return np.abs(nrm - ref["normals"]).max(1)
 
 
-def test_looping_tail_per_step_launches_and_tail_only_agree(dec):
-    """the march schedules apply the same step rule per ray; the decoder values differ in the last bits between the tile geometries (64-row
-    tiles: 32x32x2 MFMA, 16-row tiles: 16x16x4, different k order), so: same hit set up to a handful of threshold rays, same depths to 2e-5"""
+@pytest.mark.parametrize("spec_k", [1, 4])
+def test_looping_tail_per_step_launches_and_tail_only_agree(dec, spec_k):
+    """the march schedules apply the same step rule per ray -- with speculative passes too: which passes are speculative depends on the pass
+    index alone; the decoder values differ in the last bits between the tile geometries (64-row tiles: 32x32x2 MFMA, 16-row tiles: 16x16x4,
+    different k order), so: same hit set up to a handful of threshold rays, same depths to 2e-5"""
     H = W = 128
     outs = []
     for head_steps, tail_rows in ((24, 4096), (0, 4096), (64, 0), (5, 1 << 30)):
-        tr = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 1, steps=64, device=DEV, head_steps=head_steps, tail_rows=tail_rows)
+        tr = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 1, steps=64, device=DEV, head_steps=head_steps, tail_rows=tail_rows, spec_k=spec_k)
         tr.render(*_args())
         outs.append((tr.hit_lam.clone(), tr.depth.clone(), tr.stats()))
     h0, d0, s0 = outs[0]
@@ -118,23 +121,28 @@ def test_looping_tail_per_step_launches_and_tail_only_agree(dec):
         assert abs(st["unresolved"] - s0["unresolved"]) <= 5
 
 
-def test_over_relaxed_march_finds_the_same_surface(dec):
-    """relax = 1.4 (steps 1.4 x the safe radius while consecutive spheres overlap, fall back to plain tracing otherwise): the same silhouette up
-    to threshold rays, the same polished depths, no more decoder evaluations than plain tracing.  (Measured at 256x256: 4 % fewer evaluations at
-    1.4, MORE at 1.6 and 1.8 -- the rays that keep the march alive are the grazing ones, which fail the overlap test and fall back to plain
-    steps; over-relaxation is kept as an option, the default stays 1.)"""
+def test_speculative_passes_find_the_same_surface_and_resolve_the_creeping_rays(dec):
+    """spec_k = 4 against plain sphere tracing: the same silhouette up to threshold rays, the same polished depths (the marched points differ
+    within eps; one Newton step takes both to the same surface point to second order), hardly more decoder evaluations (the speculative samples
+    of creeping rays are nearly all accepted), and no ray left unresolved at the step budget"""
     H = W = 128
-    a = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 1, steps=64, device=DEV, relax=1.0)
-    b = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 1, steps=64, device=DEV, relax=1.4)
+    a = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 1, steps=64, device=DEV, spec_k=1)
+    b = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 1, steps=64, device=DEV, spec_k=4)
     oa = {k: v.clone() for k, v in a.render(*_args()).items()}
     ob = b.render(*_args())
     sa, sb = a.stats(), b.stats()
-    both = (oa["mask"] > 0) & (ob["mask"] > 0)
+    both = ((oa["mask"] > 0) & (ob["mask"] > 0)).view(-1)
     assert float((oa["mask"] != ob["mask"]).float().mean()) < 2e-3
-    d = ((oa["depth"] - ob["depth"]).abs() * both).view(-1)
-    assert float(d.median()) < 1e-5 and float(torch.quantile(d[both.view(-1)], 0.99)) < 2e-3      # polished hits agree; grazing ones within eps
-    assert sb["ray_evaluations"] <= 1.0 * sa["ray_evaluations"], (sa, sb)
-    assert sb["unresolved"] <= sa["unresolved"] + 2
+    d = (oa["depth"] - ob["depth"]).abs().view(-1)[both]
+    # (the few grazing hits are not polished: their marched points differ by up to eps / sin(incidence) along the ray)
+    assert float(d.median()) < 1e-5 and float(torch.quantile(d, 0.98)) < 1e-4 and float(d.max()) < 5e-2
+    assert sb["ray_evaluations"] < 1.1 * sa["ray_evaluations"], (sa, sb)
+    assert sb["unresolved"] <= sa["unresolved"] and sb["unresolved"] <= 1, (sa, sb)
+    # the speculative march needs about half the passes: with a budget of 36 it still resolves every ray, plain tracing does not
+    a36 = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 1, steps=36, device=DEV, spec_k=1)
+    b36 = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 1, steps=36, device=DEV, spec_k=4)
+    a36.render(*_args()); b36.render(*_args())
+    assert b36.stats()["unresolved"] <= 1 < a36.stats()["unresolved"], (a36.stats(), b36.stats())
 
 
 def test_hits_lie_on_the_level_set_and_the_march_terminates(dec):

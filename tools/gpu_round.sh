@@ -13,7 +13,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG
 # ... and of the whole default run (all informational sections; the sharded refinement shortened: its kernels are the refine_demo's at 64 crops)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/proffull_$TAG -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --total-crops 128 --configs4-crops 64 > $O/proffull_$TAG.log 2>&1
 # the sphere-tracing mode alone (march kernels: decoder forward on the active rows, step kernel, looping tail)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profsphere_$TAG -o trace -- python $R/tools/sphere_time.py --only f16 --relax 1.0 > $O/profsphere_$TAG.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/profsphere_$TAG -o trace -- python $R/tools/sphere_time.py --only f16 --spec 4 > $O/profsphere_$TAG.log 2>&1
 # HBM traffic: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), headline loop only
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$TAG -o pmc -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_fetch_$TAG.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$TAG -o pmc -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/pmc_write_$TAG.log 2>&1

@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--batch", type=int, default=1)
-ap.add_argument("--relax", type=float, nargs="*", default=[1.0, 1.4, 1.6, 1.8])
+ap.add_argument("--spec", type=int, nargs="*", default=[1, 4], help="samples per ray and pass in the looping kernel")
 ap.add_argument("--only", default="", help="f32 | f16: one precision, default schedule only (profiling runs)")
 args = ap.parse_args()
 dev = "cuda"
@@ -30,9 +30,8 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
     d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
     d = d.to(dev)
     macs = d.handle(torch.device(dev)).macs
-    for head, tail, relax, j32 in [(24, 4096, r, False) for r in args.relax] + ([(24, 4096, 1.0, True), (args.steps, 0, 1.0, False)] if not args.only else []):
-        tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, head_steps=head, tail_rows=tail, relax=relax)
-        tr.jac_rows32 = j32
+    for head, tail, spec_k, spec_from in [(24, 4096, k, 16) for k in args.spec] + ([(24, 4096, 4, 12), (24, 4096, 4, 20), (24, 2048, 4, 16), (args.steps, 0, 1, 16)] if not args.only else []):
+        tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, head_steps=head, tail_rows=tail, spec_k=spec_k, spec_from=spec_from)
 
         def step(ev=None):
             tr.render(*prm, events=ev)
@@ -54,7 +53,7 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
         mm = float(np.mean([e["march"][0].elapsed_time(e["march"][1]) for e in evs]))
         s = tr.stats()
         tf = 2.0 * macs * s["ray_evaluations"] / (mm * 1e-3) / 1e12
-        print("%s relax %.1f jac32 %d head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
-              % (str(prec).replace("torch.", ""), relax, int(j32), head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
+        print("%s spec_k %d from %2d head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
+              % (str(prec).replace("torch.", ""), spec_k, spec_from, head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
                  100 * tf / (2500.0 if prec == torch.float16 else 157.3), s["hits"], s["unresolved"]), flush=True)
         del tr

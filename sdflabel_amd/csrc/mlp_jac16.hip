@@ -39,3 +39,10 @@ void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n_rays, int spec_k, hi
     else
         hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_T16_FT, 1, SDFR_T16_NW, SDFR_T16_PF, 4>), grid, dim3(64 * SDFR_T16_NW), 0, s, P);
 }
+
+// Half forward on 64-row tiles (two 32-point tiles per workgroup instead of the grid forward's four): the middle steps of the sphere tracer's
+// march, when the active rays fill the chip once with 64-row tiles but only a fraction of it with 128-row tiles -- a step is then one pass of
+// a half-size tile (~60 us) instead of one pass of a full-size tile (~100 us).
+void sdfr_launch_fwd_f16_512_tile64(const MlpParams& P, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 2, 8, 2, 0, 2>), dim3(sdfr_cdiv(n, 64)), dim3(512), 0, s, P);
+}

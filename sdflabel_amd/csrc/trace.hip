@@ -394,7 +394,18 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
     for (int step = 0; step < head_steps; ++step) {
         MlpParams F = P;
         F.n_dev = counters + step % 3; F.n_dev_lo = tail_rows > 0 ? tail_rows : 1; F.n_dev_hi = 0x7fffffff;
-        if (half) sdfr_launch_fwd_f16_512(F, n_max, false, s); else sdfr_launch_fwd_f32_512(F, n_max, false, s);
+        if (half) {
+            // two tile sizes, picked by the device-side count: 128-row tiles while they fill the chip at least once (>= 64 rows x 256 CUs
+            // would already do with the smaller tile), 64-row tiles below -- one pass of a half-size tile per step instead of a full-size one
+            const int mid = 64 * 256;
+            if (F.n_dev_lo < mid) {
+                MlpParams M = F;
+                M.n_dev_hi = mid;
+                sdfr_launch_fwd_f16_512_tile64(M, n_max < mid ? n_max : (int64_t)mid, s);
+                F.n_dev_lo = mid;
+            }
+            if (n_max >= F.n_dev_lo) sdfr_launch_fwd_f16_512(F, n_max, false, s);
+        } else sdfr_launch_fwd_f32_512(F, n_max, false, s);
         if (tail_rows > 0) tail(step, tail_rows);
         const int a = step & 1;
         hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, eps, sdf,

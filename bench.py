@@ -393,13 +393,15 @@ def main():
             return {"label": label, "error": err_}
         st, dt_s = res_
         rf, table = st[0], st[-1]
-        ok = tuple(table.shape) == (total, 5 + rf.L) and bool(torch.isfinite(table).all())
+        ok = tuple(table.shape) == (total, 7 + rf.L) and bool(torch.isfinite(table).all())
         p_all = st[1]
         out = {"label": label, "workload": workload % (total, size, size, world, chunk), "decoder_precision": str(precision).replace("torch.", ""),
                "total_crops": total, "iterations_per_crop": args.sharded_iters, "world_size": world, "rccl_ranks": rccl_ranks, "seconds": dt_s,
                "crops_per_s": total / dt_s, "crop_iterations_per_s": total * args.sharded_iters / dt_s,
                "rays_per_s_incl_losses_and_solver": total * args.sharded_iters * size * size / dt_s,
                "mean_abs_yaw_error_before_after": [float(np.abs(p_all["yaw"] - 0.6).mean()), float((table[:, 0] - 0.6).abs().mean())],
+               "gathered_row": "yaw, trans(3), scale, latent(%d), weighted 2-D loss, weighted 3-D loss" % rf.L,
+               "mean_weighted_losses_2d_3d_after": [float(table[:, -2].mean()), float(table[:, -1].mean())],
                "gathered_table_ok": ok, "scaling": "strong (total crops fixed): speed-up at N ranks = seconds(N=1) / seconds(N)"}
         if getattr(rf.br, "prefilter", False):
             out["guard"] = rf.br.prefilter_report()

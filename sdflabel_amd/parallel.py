@@ -53,13 +53,15 @@ def refine_sharded(refiner, params, nocs_pred, lidars, iters, rank=0, world=1, g
     params     {'yaw' (n,), 'trans' (n,3), 'scale' (n,), 'latent' (n,L)} arrays for ALL crops (a few floats per crop: every rank holds the table)
     nocs_pred  (n,3,h,w) per-crop CSS predictions, or (1,3,h,w) shared by all crops (synthetic workloads)
     lidars     list of n (M_i,3) arrays, or ONE (M,3) array shared by all crops
-    Returns the (n_crops, 5+L) table [yaw, trans(3), scale, latent(L)] in crop order on every rank (gather=False: this rank's rows only).
+    Returns the (n_crops, 7+L) table [yaw, trans(3), scale, latent(L), weighted 2-D loss, weighted 3-D loss] -- the refined parameters and the
+    per-crop losses of the last iteration (BASELINE.json north_star: "all-gather of the per-crop losses") -- in crop order on every rank
+    (gather=False: this rank's rows only).
     A short last chunk is padded with copies of its last crop (the padded rows are dropped).  If the local refinement fails, the rank still
     takes part in the collective (NaN rows) and raises afterwards, so no rank is left waiting."""
     import numpy as np
     n_crops = int(np.asarray(params["yaw"]).reshape(-1).shape[0])
     mine = shard_crops(n_crops, rank, world)
-    B, R = int(refiner.B), 5 + int(refiner.L)
+    B, R = int(refiner.B), 7 + int(refiner.L)
     P = {k: np.asarray(v, np.float32).reshape(n_crops, -1) for k, v in params.items()}
     shared_target = nocs_pred.shape[0] == 1
     shared_lidar = not isinstance(lidars, (list, tuple))
@@ -72,7 +74,9 @@ def refine_sharded(refiner, params, nocs_pred, lidars, iters, rank=0, world=1, g
             tgt = nocs_pred.expand(B, *nocs_pred.shape[1:]) if shared_target else nocs_pred[sel]
             refiner.set_crops({k: v[sel] for k, v in P.items()}, tgt, [lidars] * B if shared_lidar else [lidars[i] for i in sel])
             refiner.optimize(iters)
-            rows.append(refiner.results()[0][:n])
+            res, l2, l3 = refiner.results()
+            z = res.new_zeros((res.shape[0], 1))
+            rows.append(torch.cat([res, z if l2 is None else l2.reshape(-1, 1).to(res), z if l3 is None else l3.reshape(-1, 1).to(res)], 1)[:n])
         local = torch.cat(rows) if rows else None
     except Exception as e:                                   # noqa: BLE001 -- re-raised below, after the collective
         failure, local = e, None

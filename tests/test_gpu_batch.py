@@ -809,11 +809,12 @@ def test_config3_sharded_flow_1024_crops_world_1():
     rf.capture()
     params = crop_params(list(range(TOTAL)))
     table = refine_sharded(rf, params, nocs1, lidar, ITERS, rank=0, world=1)
-    assert tuple(table.shape) == (TOTAL, 8) and bool(torch.isfinite(table).all())
+    assert tuple(table.shape) == (TOTAL, 10) and bool(torch.isfinite(table).all())          # yaw, trans, scale, latent + the two weighted losses
     moved = (table[:, 0] - T(params["yaw"])).abs()
     assert bool((moved > 0).all()) and float(moved.mean()) > 5e-3                # every crop was refined
     one = sdflabel_amd.BatchRefiner(d16, D, K, (H, W), 1, lidar_cap=4096, device=DEV)
     for i in (0, 63, 64, 517, 1023):
         one.set_crops(crop_params([i]), nocs1, [lidar])
         one.optimize(ITERS)
-        assert torch.equal(one.results()[0][0], table[i]), i
+        r1, l2, l3 = one.results()
+        assert torch.equal(r1[0], table[i, :8]) and float(l2[0]) == float(table[i, 8]) and float(l3[0]) == float(table[i, 9]), i

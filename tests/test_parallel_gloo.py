@@ -101,7 +101,8 @@ def _params(n):
 
 def _expected(n, iters):
     p = _params(n)
-    return torch.cat([torch.from_numpy(p[k]).reshape(n, -1) for k in ("yaw", "trans", "scale", "latent")], 1) + float(iters)
+    rows = torch.cat([torch.from_numpy(p[k]).reshape(n, -1) for k in ("yaw", "trans", "scale", "latent")], 1) + float(iters)
+    return torch.cat([rows, torch.zeros(n, 2)], 1)           # + the two per-crop loss columns (the stand-in refiner reports none)
 
 
 def _sharded_worker(rank, world, port, n_crops, chunk, fail_rank, q):

@@ -1,6 +1,6 @@
 """BASELINE configs[3] in miniature: a set of crops sharded over the GPUs of one node (one process per GPU), every rank refines its crops in
 chunks with the device-resident BatchRefiner (reference losses + solver, 60 iterations, HIP-graph replay), and ONE all_gather over
-RCCL brings the per-crop result rows [2-D loss, 3-D loss, yaw, t(3), scale, latent(L)] to every rank -- the only collective of the path.
+RCCL brings the per-crop result rows [yaw, t(3), scale, latent(L), 2-D loss, 3-D loss] to every rank -- the only collective of the path.
 
     python tools/refine_sharded.py --crops 64 --chunk 16                               # one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 \\
@@ -47,35 +47,17 @@ def main():
     nf = int(o["nf"][0])
     lidar = (o["xyzf"][0, :nf] * 2.0)[::2].cpu().numpy()
     target = o["color"].clone()
-    mine = shard_crops(args.crops, rank, world)
-
-    def start(i):
-        g = torch.Generator().manual_seed(1 + i)
-        j = torch.rand(7, generator=g)
-        return (0.6 + 0.1 + 0.1 * float(j[0]), [0.1 * float(j[1]), 0.05 * float(j[2]), 3.5 - 0.3 * float(j[3])],
-                (np.array([0.3, -0.5, 0.8]) + 0.2 * (j[4:7].numpy() - 0.5)).tolist())
-
-    rows = torch.zeros((len(mine), 7 + L), device=dev)
-    rf = None
+    from sdflabel_amd.fixtures import crop_params
+    from sdflabel_amd.parallel import refine_sharded
+    chunk = max(1, min(args.chunk, (args.crops + world - 1) // world))
+    rf = sdflabel_amd.BatchRefiner(dec, D, K, (H, W), chunk, lidar_cap=4096, device=dev)
+    rf.set_crops(crop_params(list(range(chunk))), target.expand(chunk, 3, H, W), [lidar] * chunk)
+    rf.capture()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for c0 in range(0, len(mine), args.chunk):
-        ids = mine[c0:c0 + args.chunk]
-        n = len(ids)
-        if rf is None or rf.B != n:
-            rf = sdflabel_amd.BatchRefiner(dec, D, K, (H, W), n, lidar_cap=4096, device=dev)
-        st = [start(i) for i in ids]
-        rf.set_crops({"yaw": np.array([[s[0]] for s in st], np.float32), "trans": np.array([s[1] for s in st], np.float32),
-                      "scale": np.full((n, 1), 2.0, np.float32), "latent": np.array([s[2] for s in st], np.float32)},
-                     target.expand(n, 3, H, W), [lidar] * n)
-        rf.capture()
-        rf.optimize(args.iters)
-        res, l2, l3 = rf.results()
-        rows[c0:c0 + n] = torch.cat([l2.view(-1, 1), l3.view(-1, 1), res], 1)
-    torch.cuda.synchronize()
-    table = gather_crop_results(rows, args.crops, rank, world)          # the one collective
+    table = refine_sharded(rf, crop_params(list(range(args.crops))), target, lidar, args.iters, rank, world)     # the one collective inside
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -83,7 +65,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     if rank == 0:
-        yaw_err = (table[:, 2] - 0.6).abs()
+        yaw_err = (table[:, 0] - 0.6).abs()
         print("refined %d crops on %d GPU(s) in %.2f s: %.2f crops/s (%d iterations each, %s decoder); |yaw - gt| mean %.4f max %.4f; "
               "table %s" % (args.crops, world, dt, args.crops / dt, args.iters, args.precision, float(yaw_err.mean()), float(yaw_err.max()),
                             tuple(table.shape)))

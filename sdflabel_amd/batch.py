@@ -105,7 +105,11 @@ class BatchRenderer:
             self.violations = i(B, 2)           # per crop, SINCE THE LAST reset_guard() (set_params / set_crops): [soft, hard]
             # candidate-set reuse (opt-in: decoder.prefilter_reuse = True): while the normalised latent has moved less than margin / (4 lip)
             # since the last half pass, that pass and the candidate selection are skipped (sdfr_prefilter_plan decides per crop on the device)
-            self.lipschitz = 2.0 * lip                                 # calibrated above, with a factor 2
+            # NOTE: `lip` is the largest finite difference of the decoder output seen over four random latent moves, times a
+            # safety factor 4 -- a calibrated ESTIMATE, not a proven Lipschitz bound.  On reused steps the half pass does not run, so the guard
+            # has nothing to compare and an underestimated constant could let a band row slip out of the candidate set unnoticed: reuse is an
+            # approximation by design (opt-in; bit-identical to the plain two-stage mode in every test and in the 1024-crop bench run).
+            self.lipschitz = 4.0 * lip
             self.reuse = bool(getattr(decoder, "prefilter_reuse", False))
             self.max_reuse = int(getattr(decoder, "prefilter_max_reuse", 16))
             self.lat_ref, self.age, self.reuse_flag = f(B, self.L), i(B), i(B)

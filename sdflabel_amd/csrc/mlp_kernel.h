@@ -714,6 +714,8 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             // [point tile][layer][word][thread]: bit ((f*NP + p)*4 + rg)*4 + i of the thread's mask (32x32 geometry)
             uint32_t* dst = P.maskbuf + (((int64_t)blockIdx.x * P.n_mfma + l) * MW) * NT + tid;
 #pragma unroll
+            // (streaming / non-temporal stores measured equal, r03: the masks cost 3-7 % of a forward through the epilogue's instruction count,
+            // not through L2 pollution -- tools/mask_cost.py)
             for (int w = 0; w < MW; ++w) dst[w * NT] = mw[w];
         }
         SDFR_STAMP(l, 3);

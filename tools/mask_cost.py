@@ -43,6 +43,11 @@ for B in (1, 8, 64):
     f_nomask = timed(lambda: L.sdfr_mlp_forward(br.handle.h, P(br.inputs), B * G, P(br.sdf), None, s))
     j_fed = timed(lambda: L.sdfr_mlp_jacobian(br.handle.h, P(br.inputs), G, B, P(br.idx), cap, P(br.cnt), P(br.J), P(br.sdf_band), P(br.sdf), P(br.mask_ws), 0, s))
     j_rec = timed(lambda: L.sdfr_mlp_jacobian(br.handle.h, P(br.inputs), G, B, P(br.idx), cap, P(br.cnt), P(br.J), P(br.sdf_band), None, None, 0, s))
+    h_mask = timed(lambda: L.sdfr_mlp_forward_f16(br.handle.h, P(br.inputs), B * G, P(br.sdf), P(br.mask_ws), s))
+    h_nomask = timed(lambda: L.sdfr_mlp_forward_f16(br.handle.h, P(br.inputs), B * G, P(br.sdf), None, s))
+    print("B=%2d float16 forward: with masks %.4f ms (%.4f per crop), without %.4f ms (%.4f per crop): masks cost %.1f %%"
+          % (B, h_mask, h_mask / B, h_nomask, h_nomask / B, 100 * (h_mask - h_nomask) / h_mask), flush=True)
+    L.sdfr_mlp_forward(br.handle.h, P(br.inputs), B * G, P(br.sdf), P(br.mask_ws), s)         # restore the f32 masks for the Jacobian timings below
     rows = int(br.cnt.sum())
     print("B=%2d (%6d band rows): forward with masks %.3f ms, without %.3f ms (%.1f %%); Jacobian mask-fed %.3f ms, recomputing %.3f ms; "
           "pair with masks %.3f ms vs mask-free pair %.3f ms  [per crop: %.3f vs %.3f]"

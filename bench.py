@@ -716,6 +716,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()                 # rank 0 has rank-0-only sections behind it (sphere tracing, drop-in census): leave together
         dist.destroy_process_group()
 
 

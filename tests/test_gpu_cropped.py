@@ -287,3 +287,39 @@ def test_g14e_second_decoder_dropin_modules_full_size(tag):
 def test_g14e_second_decoder_batch_renderer_full_size(tag, B):
     d, z = _second_decoder(tag)
     _batch_case(d, z, B)
+
+
+# ---- G14p: the secondary configurations with cropped intrinsics ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("tag", ["circle_bg0", "circle_bg1", "disc_quat"])
+def test_g14p_circle_primitive_background_and_quaternion_pose_with_cropped_intrinsics(tag):
+    """primitives='circle' (with / without a background image) and rot='quat' with the disc primitive, 40x76 rays, K from
+    adjust_intrinsics_crop (case a): images 1e-4, gradients w.r.t. the surfel positions and the pose 2e-3 (the tolerances of golden G9)"""
+    z = gold("g14p_secondary_cropped.npz")
+    _, H, W = [int(v) for v in z["cfg"]]
+    near = np.unpackbits(z["near_threshold"])[:H * W].astype(bool)
+    prim, use_bg, rot = {"circle_bg0": ("circle", False, "dcm"), "circle_bg1": ("circle", True, "dcm"), "disc_quat": ("disc", False, "quat")}[tag]
+    r = sdflabel_amd.Rasterer(T(z["K"]), (W, H)).to(DEV)
+    p = T(z["points"]).requires_grad_(True)
+    nrm = T(z["normals"])
+    if rot == "dcm":
+        yaw, trans = T(z["yaw"]).requires_grad_(True), T(z["trans"]).requires_grad_(True)
+        cam = build_pose(yaw, trans)
+        assert np.abs(N(cam) - z[tag + "_cam"]).max() < 1e-6
+        leaves = {"g_yaw": yaw, "g_trans": trans}
+    else:
+        cam = T(z[tag + "_cam"]).requires_grad_(True)
+        leaves = {"g_cam": cam}
+    rend = r(p, nrm, nrm, cam, rot=rot, primitives=prim, bg=T(z["bg"]) if use_bg else None, output_mask=True, output_depth=not use_bg,
+             output_normals=not use_bg, output_nocs=True, output_points=False)
+    for k in rend:
+        a, ref = N(rend[k]), z[tag + "_out_" + k]
+        bad = (np.abs(a - ref) > 1e-4).reshape(a.shape[0], -1).any(0)
+        if prim == "disc":
+            assert not (bad & ~near).any() and bad.mean() <= 1e-3, k
+        else:
+            assert not bad.any(), (k, np.abs(a - ref).max())
+    sum((rend[k] * T(z[tag + "_W_" + k])).sum() for k in rend).backward()
+    for got, key in [(p.grad, "g_points")] + [(t.grad, k) for k, t in leaves.items()]:
+        ref = z[tag + "_" + key]
+        assert np.abs(N(got).reshape(ref.shape) - ref).max() < 2e-3 * max(1.0, np.abs(ref).max()), (key, np.abs(N(got).reshape(ref.shape) - ref).max(), np.abs(ref).max())

@@ -347,11 +347,17 @@ def _random_surfels(rng, n, H, W):
     return p, nrm, col
 
 
+@pytest.mark.parametrize("kshift", [(0.0, 0.0), (-23.5, 6.25)])       # principal point at the centre / well outside the image (cropped intrinsics)
 @pytest.mark.parametrize("H,W,n", [(16, 16, 40), (40, 24, 300), (17, 31, 129), (24, 24, 1500), (8, 8, 1100)])   # the last two: > 256 and > 1024 candidates per tile
-def test_splat_forward_backward_vs_oracle(H, W, n):
+def test_splat_forward_backward_vs_oracle(H, W, n, kshift=(0.0, 0.0)):
     rng = np.random.default_rng(H * 100 + n)
     p, nrm, col = _random_surfels(rng, n, H, W)
     K = K_for(H, W)
+    if kshift[0] or kshift[1]:
+        # the principal point moves out of the image, the surfels with it (so that they stay in view), and the focal lengths differ
+        K[0, 2] += kshift[0]; K[1, 2] += kshift[1]; K[1, 1] *= 0.93
+        p[6:, 0] += kshift[0] / K[0, 0] * p[6:, 2]
+        p[6:, 1] += kshift[1] / K[1, 1] * p[6:, 2]
     Kinv = np.linalg.inv(K).astype(np.float32)
     L = _lib.lib()
     tp, tn, tc = T(p), T(nrm), T(col)

@@ -971,7 +971,56 @@ def g11g():
     save("g11g_config4_fp16_grads.npz", **arrs)
 
 
-ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G8c": g8c, "G8h": g8h, "G8s": g8s, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13, "G11g": g11g, "G14": g14, "G14o": g14o, "G14e": g14e}
+def g14p():
+    """the secondary configurations in the cropped camera regime: primitives 'circle' (with and without a background image) and the quaternion
+    pose path with the disc primitive, crop intrinsics of case a at ~48x64 rays, D = 20 surfels: images + autograd gradients w.r.t. the surfel
+    positions and the pose (the weights of the functional vanish on pixels that hold a pair within 1e-5 of a disc-edge / |n.ray| threshold)"""
+    dec = load_fitted()[0]
+    c = G14_CASES["a"]
+    (H, W), K, bbox = kitti_crop_intrinsics(c["K_full"], c["yaw"], list(c["trans"]), 48 * 64)
+    _, grid, lat, sdf, pts, nocs, nrm = surface_case(20, [0.5, -0.3, 0.6], dec)
+    pts0, nrm0 = pts.detach(), nrm.detach()
+    arrs = dict(cfg=np.array([20, H, W]), K=K.numpy(), points=pts0.numpy(), normals=nrm0.numpy(), yaw=np.asarray([c["yaw"]], np.float32),
+                trans=np.asarray(c["trans"], np.float32))
+    r = Rasterer(K, (W, H), precision=torch.float32)
+    gen = torch.Generator().manual_seed(23)
+    bgimg = torch.rand(3, H, W, generator=gen)
+    arrs["bg"] = bgimg.numpy()
+    pose0 = build_pose(torch.tensor([c["yaw"]]), torch.tensor(list(c["trans"])))
+    near = near_threshold_pixels(K, H, W, pose0.numpy(), pts0.numpy(), nrm0.numpy())
+    keep = torch.from_numpy((~near).astype(np.float32)).view(1, H, W)
+    arrs["near_threshold"] = np.packbits(near)
+    for tag, prim, use_bg, rot in (("circle_bg0", "circle", False, "dcm"), ("circle_bg1", "circle", True, "dcm"), ("disc_quat", "disc", False, "quat")):
+        p = pts0.clone().requires_grad_(True)
+        if rot == "dcm":
+            yaw = torch.tensor([c["yaw"]], requires_grad=True)
+            trans = torch.tensor(list(c["trans"]), requires_grad=True)
+            cam = build_pose(yaw, trans)
+            leaves = {"g_yaw": yaw, "g_trans": trans}
+        else:
+            # the same rigid motion as a quaternion + translation WITHOUT the row-1 flip of the optimizer (the quat path has none,
+            # projection.py:104-199): rotate about y by yaw, then translate
+            half = c["yaw"] / 2.0
+            cam = torch.tensor([np.cos(half), 0.0, np.sin(half), 0.0] + list(c["trans"]), dtype=torch.float32, requires_grad=True)
+            leaves = {"g_cam": cam}
+        rend = r(p, nrm0, nrm0, cam, rot=rot, primitives=prim, bg=bgimg if use_bg else None, output_mask=True,
+                 output_depth=not use_bg, output_normals=not use_bg, output_nocs=True, output_points=False)
+        Ws = {k: torch.randn(v.shape, generator=gen) * (keep if prim == "disc" else 1.0) for k, v in rend.items()}
+        loss = sum((rend[k] * Ws[k]).sum() for k in rend)
+        loss.backward()
+        for k, v in rend.items():
+            arrs[tag + "_out_" + k] = v.detach().numpy()
+            arrs[tag + "_W_" + k] = Ws[k].numpy()
+        arrs[tag + "_cam"] = cam.detach().numpy()
+        arrs[tag + "_g_points"] = p.grad.numpy()
+        for k, t in leaves.items():
+            arrs[tag + "_" + k] = t.grad.numpy()
+        print("G14p", tag, "crop HxW", H, W, "covered px", int((rend["mask"] > 0).sum()), "loss", float(loss), {k: t.grad.numpy().round(3).tolist() for k, t in leaves.items()},
+              "|g_points|max", float(p.grad.abs().max()))
+    save("g14p_secondary_cropped.npz", **arrs)
+
+
+ALL = {"G1": g1, "G2": g2, "G3": g3, "G4": g4, "G5": g5, "G6": g6, "G7": g7, "G8": g8, "G8b": g8b, "G8c": g8c, "G8h": g8h, "G8s": g8s, "G9": g9, "G10": g10, "G10b": g10b, "G11": g11, "G12": g12, "G13": g13, "G11g": g11g, "G14": g14, "G14p": g14p, "G14o": g14o, "G14e": g14e}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -349,7 +349,7 @@ def _random_surfels(rng, n, H, W):
 
 @pytest.mark.parametrize("kshift", [(0.0, 0.0), (-23.5, 6.25)])       # principal point at the centre / well outside the image (cropped intrinsics)
 @pytest.mark.parametrize("H,W,n", [(16, 16, 40), (40, 24, 300), (17, 31, 129), (24, 24, 1500), (8, 8, 1100)])   # the last two: > 256 and > 1024 candidates per tile
-def test_splat_forward_backward_vs_oracle(H, W, n, kshift=(0.0, 0.0)):
+def test_splat_forward_backward_vs_oracle(H, W, n, kshift):
     rng = np.random.default_rng(H * 100 + n)
     p, nrm, col = _random_surfels(rng, n, H, W)
     K = K_for(H, W)

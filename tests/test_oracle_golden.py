@@ -504,3 +504,21 @@ def test_sphere_trace_oracle_self_consistency():
             dR = np.array([[-s, 0, c], [0, 0, 0], [-c, 0, -s]])
             an = float((g_pose[:3, :3] * dR).sum())
         assert abs(an - fd) < 0.05 * max(1.0, abs(fd)), (which, an, fd)
+
+
+@pytest.mark.parametrize("tag", ["circle_bg0", "circle_bg1", "disc_quat"])
+def test_g14p_secondary_configurations_with_cropped_intrinsics(tag):
+    """the oracle's circle primitive (with / without background) and quaternion pose path against the reference at crop intrinsics produced by
+    adjust_intrinsics_crop (40x76 rays, principal point outside the crop): forward images"""
+    z = gold("g14p_secondary_cropped.npz")
+    _, H, W = [int(v) for v in z["cfg"]]
+    prim, use_bg, rot = {"circle_bg0": ("circle", False, "dcm"), "circle_bg1": ("circle", True, "dcm"), "disc_quat": ("disc", False, "quat")}[tag]
+    K = z["K"]
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    rend, _, _ = O.rasterer_forward(K, Kinv, (W, H), z["points"], z["normals"], z["normals"], z[tag + "_cam"], rot=rot, bg=z["bg"] if use_bg else None,
+                                    output_nocs=True, primitives=prim)
+    near = np.unpackbits(z["near_threshold"])[:H * W].astype(bool)
+    for k in (("color", "mask") if use_bg else ("color", "mask", "depth", "normals")):
+        a, ref = rend[k], z[tag + "_out_" + k]
+        bad = (np.abs(a - ref) > 1e-4).reshape(a.shape[0], -1).any(0)
+        assert not (bad & ~near).any() and bad.mean() <= 1e-3, (k, np.abs(a - ref).max())

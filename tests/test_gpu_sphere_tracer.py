@@ -97,6 +97,35 @@ def test_march_polish_images_and_gradients_against_the_oracle(dec, oracle_layers
         assert np.abs(got - want).max() < 1e-3 * max(1.0, np.abs(want).max()), (got, want)
 
 
+def test_march_against_the_oracle_on_the_second_decoder():
+    """the ellipsoid fit (curved surface, smooth normals; tools/fit_decoder.py --shape ellipsoid): default schedule with speculative passes,
+    hit set / depth / colour / normals against the oracle on every 2nd pixel"""
+    from sdflabel_amd.fixtures import ASSET_ELLIPSOID
+    d, _ = sdflabel_amd.setup_dsdf(ASSET_ELLIPSOID + ".pt", precision=torch.float32)
+    d = d.to(DEV)
+    st, spec = fitted_state(ASSET_ELLIPSOID)
+    layers = O.decoder_layers_from_state(st, spec)
+    H, W = 96, 96
+    K = K_for(H, W)
+    tr = sdflabel_amd.SphereTracer(d, K, (W, H), 1, steps=64, device=DEV, spec_from=12, spec_k=4)
+    out = tr.render(*_args())
+    ys, xs = np.meshgrid(np.arange(0, H, 2), np.arange(0, W, 2), indexing="ij")
+    px = np.stack([xs.reshape(-1), ys.reshape(-1)], 1)
+    lat = np.asarray(LAT[0], np.float32)
+    latn = lat / np.sqrt((lat * lat).sum())
+    ref = O.sphere_trace(layers, spec, latn, O.render_pose(YAW[0], TRANS[0]), np.linalg.inv(K).astype(np.float32), px, steps=64, spec_from=12, spec_k=4)
+    sel = (px[:, 1], px[:, 0])
+    hit = N(out["mask"][0, 0])[sel] > 0
+    safe = ref["margin"] > 1e-4
+    assert ref["hit"].sum() > 300 and safe.mean() > 0.95
+    assert np.array_equal(hit[safe], ref["hit"][safe])
+    good = safe & ref["hit"] & hit & ref["ok"]
+    assert np.abs(N(out["depth"][0, 0])[sel] - ref["depth"])[good].max() < 1e-4
+    assert np.abs(N(out["color"][0])[:, sel[0], sel[1]].T - ref["color"])[good].max() < 1e-4
+    dn = np.abs(N(out["normals"][0])[:, sel[0], sel[1]].T - ref["normals"])[good].max(1)
+    assert np.median(dn) < 1e-6 and (dn > 1e-4).sum() <= 3
+
+
 def dn_all(nrm, ref):
     return np.abs(nrm - ref["normals"]).max(1)
 

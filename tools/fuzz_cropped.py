@@ -1,0 +1,107 @@
+"""Fuzz of the renderer in the camera regime of the reference pipeline: random KITTI-like objects -- any yaw, 8-25 m away,
+up to 5 m off the optical axis -- with crop intrinsics derived as utils/refinement.py:586-609 (adjust_intrinsics_crop) derives them from the
+object's 2-D box, rendered by BatchRenderer (scan and binned paths) and compared with the numpy oracle on a band of image rows through the object:
+identical band lists, images within 1e-4 (pixels attributable to a selection threshold within 1e-5 bounded at 0.1 %), front-facing points within 1e-5.
+    python tools/fuzz_cropped.py [--cases 24] [--seed 0]"""
+import argparse
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import sdflabel_amd
+from oracle import sdf_oracle as O
+from sdflabel_amd.fixtures import ASSET, ASSET_ELLIPSOID, fitted_state
+
+KITTI_K = np.array([[721.5377, 0.0, 609.5593], [0.0, 721.5377, 172.854], [0.0, 0.0, 1.0]], np.float64)
+
+
+def crop_intrinsics(yaw, trans, area, half=(0.56, 0.46, 1.0)):
+    """the 2-D box of the object's cuboid in the full frame and the crop intrinsics adjust_intrinsics_crop makes of it: principal point shifted by the
+    box corner, both focal rows scaled by sqrt(area / (h w)), crop size truncated to integers"""
+    pose = O.render_pose(yaw, trans).astype(np.float64)
+    corners = np.array([[sx * half[0], sy * half[1], sz * half[2], 1.0] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+    cam = (pose[:3] @ corners.T).T
+    uv = (KITTI_K @ cam.T).T
+    uv = uv[:, :2] / uv[:, 2:]
+    l, t = np.floor(uv.min(0)).astype(int)
+    r, b = np.ceil(uv.max(0)).astype(int)
+    h, w = float(b - t), float(r - l)
+    ratio = math.sqrt(area / (h * w))
+    H, W = int(np.float32(h) * np.float32(ratio)), int(np.float32(w) * np.float32(ratio))
+    K = KITTI_K.astype(np.float32).copy()
+    K[0, 2] -= l
+    K[1, 2] -= t
+    K[:2] *= np.float32(ratio)
+    return H, W, K
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=24)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+dev = "cuda"
+rng = np.random.default_rng(args.seed)
+decs = {}
+for name, asset in (("box", ASSET), ("ellipsoid", ASSET_ELLIPSOID)):
+    d, _ = sdflabel_amd.setup_dsdf(asset + ".pt", precision=torch.float32)
+    st, spec = fitted_state(asset)
+    decs[name] = (d.to(dev), O.decoder_layers_from_state(st, spec), spec)
+D = 40
+pts = O.generate_point_grid(D)
+bad = 0
+for case in range(args.cases):
+    name = "box" if case % 3 else "ellipsoid"
+    dec, layers, spec = decs[name]
+    yaw = float(rng.uniform(-math.pi, math.pi))
+    z = float(rng.uniform(4.0, 12.5))
+    trans = np.array([rng.uniform(-2.5, 2.5) * z / 12.5 * 2.0, rng.uniform(0.3, 0.6), z], np.float32)
+    trans[0] = float(np.clip(trans[0], -0.8 * z * 609.0 / 721.5 + 1.2, 0.8 * z * 632.0 / 721.5 - 1.2))       # keep the object inside the 1242-px frame
+    lat = rng.standard_normal(3).astype(np.float32)
+    H, W, K = crop_intrinsics(yaw, trans, float(rng.choice([256 * 192, 128 * 128, 64 * 48])))
+    latn = (lat / np.sqrt((lat * lat).sum())).astype(np.float32)
+    inp = np.concatenate([np.broadcast_to(latn, (pts.shape[0], 3)), pts], 1).astype(np.float32)
+    sdf, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+    J = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(sdf))
+    pm, _, nm, idx, _ = O.get_surface_points(pts, sdf, J[:, 3:], 0.03)
+    margin = np.abs(np.abs(sdf[:, 0]) - 0.03).min()
+    pose = O.render_pose(yaw, trans)
+    Kinv = np.linalg.inv(K).astype(np.float32)
+    proj = O.project_in_2D(K, pose, pm, nm, nm, (W, H), output_nocs=True)
+    v3, nc = proj["points_3d"].astype(np.float32), proj["normals_3d"].astype(np.float32)
+    c_attr = ((proj["colors_3d"] + 1) / 2).astype(np.float32)
+    r0, r1 = max(0, H // 2 - 10), min(H, H // 2 + 10)
+    sub = O.pixel_grid((W, H)).reshape(H, W, 2)[r0:r1].reshape(-1, 2)
+    Wm, aux = O.inside_surfel(Kinv, sub, v3, nc, diam=0.04, want_aux=True)
+    near = (aux["margin_disc"] < 1e-5) | (aux["margin_b"] < 1e-5)
+    ref = {"color": np.minimum((Wm.T @ c_attr).T, 1), "mask": np.minimum(Wm.sum(0), 1)[None], "depth": (Wm.T @ v3[:, 2])[None],
+           "normals": np.minimum((Wm.T @ ((nc + 1) / 2)).T, 1)}
+    msgs = []
+    for binned in (False, True):
+        br = sdflabel_amd.BatchRenderer(dec, D, K, (W, H), 1, device=dev)
+        br.binned = binned
+        out = br.forward(torch.tensor([yaw], device=dev), torch.from_numpy(trans)[None].to(dev), torch.from_numpy(lat)[None].to(dev))
+        n = int(out["n"][0])
+        if margin > 2e-6 and not np.array_equal(br.idx[0, :n].cpu().numpy(), idx):
+            msgs.append("band differs (binned=%s)" % binned)
+            continue
+        if n != idx.shape[0]:
+            continue                                     # a grid point within float rounding of the band threshold: not comparable
+        for k, v in ref.items():
+            a = out[k][0].cpu().numpy()[:, r0:r1].reshape(v.shape[0], -1)
+            wrong = (np.abs(a - v) > 1e-4).any(0)
+            if (wrong & ~near).any() or wrong.mean() > 1e-3:
+                msgs.append("%s: %d pixels beyond 1e-4 away from thresholds (binned=%s)" % (k, int((wrong & ~near).sum()), binned))
+        nf = proj["points_3d_filt"].shape[0]
+        if int(out["nf"][0]) != nf or np.abs(out["xyzf"][0, :nf].cpu().numpy() - proj["points_3d_filt"]).max() > 1e-5:
+            msgs.append("xyzf differs (binned=%s)" % binned)
+        del br
+    bad += bool(msgs)
+    print("%s case %2d %-9s yaw %+.2f t (%+.2f %.2f %5.2f) %3dx%3d cx %+7.1f fx %7.1f N %4d covered %5d%s" % (
+        "FAIL" if msgs else "ok  ", case, name, yaw, trans[0], trans[1], trans[2], H, W, K[0, 2], K[0, 0], idx.shape[0], int((ref["mask"] > 0).sum()),
+        (" :: " + "; ".join(msgs)) if msgs else ""), flush=True)
+print("%d of %d cases failed" % (bad, args.cases))
+sys.exit(1 if bad else 0)

@@ -117,9 +117,10 @@ def test_march_against_the_oracle_on_the_second_decoder():
     sel = (px[:, 1], px[:, 0])
     hit = N(out["mask"][0, 0])[sel] > 0
     safe = ref["margin"] > 1e-4
-    assert ref["hit"].sum() > 300 and safe.mean() > 0.95
+    assert ref["hit"].sum() > 200 and safe.mean() > 0.95
     assert np.array_equal(hit[safe], ref["hit"][safe])
     good = safe & ref["hit"] & hit & ref["ok"]
+    assert good.sum() > 150
     assert np.abs(N(out["depth"][0, 0])[sel] - ref["depth"])[good].max() < 1e-4
     assert np.abs(N(out["color"][0])[:, sel[0], sel[1]].T - ref["color"])[good].max() < 1e-4
     dn = np.abs(N(out["normals"][0])[:, sel[0], sel[1]].T - ref["normals"])[good].max(1)

@@ -90,14 +90,37 @@ for case in range(args.cases):
             continue
         if n != idx.shape[0]:
             continue                                     # a grid point within float rounding of the band threshold: not comparable
+        # the surfels themselves: points to 2e-5; normals to float rounding except for the odd grid point on a ReLU kink of the decoder, whose
+        # normal comes from the other side of the kink in the two summation orders (tests/test_oracle_golden.py: the same between the oracle and
+        # the reference).  The renderer is then compared on the HIP path's OWN surfels, so that such a surfel does not count against it.
+        hp, hn = br.points[0, :n].cpu().numpy(), br.normals[0, :n].cpu().numpy()
+        dn = np.abs(hn - nm).max(1)
+        if np.abs(hp - pm).max() > 2e-5 or np.median(dn) > 1e-6 or (dn > 1e-4).sum() > 3:
+            msgs.append("surfels differ: points %.1e, %d normals beyond 1e-4 (binned=%s)" % (np.abs(hp - pm).max(), int((dn > 1e-4).sum()), binned))
+            continue
+        if (dn > 1e-4).any() or True:
+            proj = O.project_in_2D(K, pose, hp, hn, hn, (W, H), output_nocs=True)
+            v3, nc = proj["points_3d"].astype(np.float32), proj["normals_3d"].astype(np.float32)
+            c_attr = ((proj["colors_3d"] + 1) / 2).astype(np.float32)
+            Wm, aux = O.inside_surfel(Kinv, sub, v3, nc, diam=0.04, want_aux=True)
+            near = (aux["margin_disc"] < 1e-5) | (aux["margin_b"] < 1e-5)
+            ref = {"color": np.minimum((Wm.T @ c_attr).T, 1), "mask": np.minimum(Wm.sum(0), 1)[None], "depth": (Wm.T @ v3[:, 2])[None],
+                   "normals": np.minimum((Wm.T @ ((nc + 1) / 2)).T, 1)}
         for k, v in ref.items():
             a = out[k][0].cpu().numpy()[:, r0:r1].reshape(v.shape[0], -1)
             wrong = (np.abs(a - v) > 1e-4).any(0)
             if (wrong & ~near).any() or wrong.mean() > 1e-3:
                 msgs.append("%s: %d pixels beyond 1e-4 away from thresholds (binned=%s)" % (k, int((wrong & ~near).sum()), binned))
-        nf = proj["points_3d_filt"].shape[0]
-        if int(out["nf"][0]) != nf or np.abs(out["xyzf"][0, :nf].cpu().numpy() - proj["points_3d_filt"]).max() > 1e-5:
-            msgs.append("xyzf differs (binned=%s)" % binned)
+        # front-facing selection n_cam . p_cam < 0 (projection.py:61-70): surfels seen edge-on within float rounding may fall on either side
+        dot = (nc * v3).sum(1)
+        fslot = br.fslot[0, :n].cpu().numpy()
+        differ = (fslot >= 0) != (dot < 0)
+        if (differ & (np.abs(dot) > 1e-5)).any():
+            msgs.append("front-face selection differs on %d surfels away from the threshold (binned=%s)" % (int((differ & (np.abs(dot) > 1e-5)).sum()), binned))
+        elif not differ.any():
+            nf = proj["points_3d_filt"].shape[0]
+            if int(out["nf"][0]) != nf or np.abs(out["xyzf"][0, :nf].cpu().numpy() - proj["points_3d_filt"]).max() > 1e-5:
+                msgs.append("xyzf differs (binned=%s)" % binned)
         del br
     bad += bool(msgs)
     print("%s case %2d %-9s yaw %+.2f t (%+.2f %.2f %5.2f) %3dx%3d cx %+7.1f fx %7.1f N %4d covered %5d%s" % (

@@ -95,8 +95,10 @@ for case in range(args.cases):
         # the reference).  The renderer is then compared on the HIP path's OWN surfels, so that such a surfel does not count against it.
         hp, hn = br.points[0, :n].cpu().numpy(), br.normals[0, :n].cpu().numpy()
         dn = np.abs(hn - nm).max(1)
-        if np.abs(hp - pm).max() > 2e-5 or np.median(dn) > 1e-6 or (dn > 1e-4).sum() > 3:
-            msgs.append("surfels differ: points %.1e, %d normals beyond 1e-4 (binned=%s)" % (np.abs(hp - pm).max(), int((dn > 1e-4).sum()), binned))
+        kink = dn > 1e-4                                 # (their projected points move with the normal: p = x - sdf n, |sdf| < 0.03)
+        if np.abs(hp - pm)[~kink].max() > 2e-5 or np.median(dn) > 1e-6 or kink.sum() > 3 or np.abs(hp - pm).max() > 0.03 * 2 * dn.max() + 2e-5:
+            msgs.append("surfels differ: points %.1e (%.1e away from kinks), %d normals beyond 1e-4 (binned=%s)" % (
+                np.abs(hp - pm).max(), np.abs(hp - pm)[~kink].max(), int(kink.sum()), binned))
             continue
         if (dn > 1e-4).any() or True:
             proj = O.project_in_2D(K, pose, hp, hn, hn, (W, H), output_nocs=True)

@@ -2,7 +2,7 @@
 up to 5 m off the optical axis -- with crop intrinsics derived as utils/refinement.py:586-609 (adjust_intrinsics_crop) derives them from the
 object's 2-D box, rendered by BatchRenderer (scan and binned paths) and compared with the numpy oracle on a band of image rows through the object:
 identical band lists, images within 1e-4 (pixels attributable to a selection threshold within 1e-5 bounded at 0.1 %), front-facing points within 1e-5.
-    python tools/fuzz_cropped.py [--cases 24] [--seed 0]"""
+    python tests/fuzz_cropped.py [--cases 24] [--seed 0]"""
 import argparse
 import math
 import os

@@ -545,18 +545,21 @@ def main():
     # ---- sphere-tracing render mode (BASELINE.json's literal wording; NOT the reference's algorithm, no parity claim against it -- DESIGN.md 3.6;
     # its oracle is oracle/sdf_oracle.py::sphere_trace): one crop, `march steps` decoder evaluations per active ray with ballot compaction and the
     # looping tail kernel, forward + backward to yaw/trans/latent, all HIP kernels, no host synchronisation inside a render.
-    # Default schedules: float16 decoder 4 samples per ray and pass from pass 12 on (speculative passes: accepted while inside the previous sample's
-    # safe sphere; a 64-row half pass costs what a 16-row pass costs), exact-f32 decoder plain sphere tracing; `_plain` = the f16 march without them.
+    # Default schedule: 4 samples per ray and pass from pass 10 on (speculative passes: accepted while inside the previous sample's safe sphere),
+    # 16 from pass 14 on (the survivors re-packed 4 to a tile); hit pass (value + Jacobian at the hits) in the decoder's precision.  `_plain` = the
+    # f16 march without speculative passes, `_exact_polish` = f16 march with the hit pass in exact float32.
     # roofline_march: decoder evaluations of the march (counted on the device, speculative samples included) x 2 M FLOP / march time (events around sdfr_trace_march) against the MFMA
     # peak of the march's operand type; step_kernel_hbm: algorithmic bytes of the advance / compaction kernel per ray-step.
     sphere = None
     if rank == 0 and CB == 1 and not args.no_extras:
         sphere = {}
-        for label, prec, steps, spec_k in (("f32_64_steps", torch.float32, 64, None), ("f16_64_steps", torch.float16, 64, None),
-                                           ("f16_64_steps_plain", torch.float16, 64, 1), ("f16_128_steps", torch.float16, 128, None)):
+        for label, prec, steps, spec_k, polish in (("f32_64_steps", torch.float32, 64, None, None), ("f16_64_steps", torch.float16, 64, None, None),
+                                                   ("f16_64_steps_exact_polish", torch.float16, 64, None, "exact"),
+                                                   ("f16_64_steps_plain", torch.float16, 64, 1, None), ("f32_64_steps_plain", torch.float32, 64, 1, None),
+                                                   ("f16_128_steps", torch.float16, 128, None, None)):
             try:
                 d3, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
-                tr = sdflabel_amd.SphereTracer(d3.to(dev), K_for(H, W), (W, H), 1, steps=steps, device=dev, spec_k=spec_k)
+                tr = sdflabel_amd.SphereTracer(d3.to(dev), K_for(H, W), (W, H), 1, steps=steps, device=dev, spec_k=spec_k, polish=polish)
                 prm = [crop.yaw.detach().clone(), crop.trans.detach().clone().view(1, 3), crop.latent.detach().clone().view(1, -1)]
                 o3, o1 = torch.ones(1, 3, H, W, device=dev), torch.ones(1, 1, H, W, device=dev)
 
@@ -585,6 +588,8 @@ def main():
                                  "hits": st3["hits"], "unresolved_after_last_step": st3["unresolved"], "ray_evaluations": st3["ray_evaluations"],
                                  "head_steps": tr.head_steps, "tail_rows": tr.tail_rows, "samples_per_ray_and_pass_in_the_looping_kernel": tr.spec_k,
                                  "speculative_from_pass": tr.spec_from if tr.spec_k > 1 else None,
+                                 "second_level": {"samples": tr.spec_k2, "from_pass": tr.spec_from2} if tr.spec_k2 > tr.spec_k else None,
+                                 "hit_pass": "float16 (decoder)" if tr.half_polish else "float32",
                                  "roofline_march": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
                                                     "flops": 2.0 * macs * st3["ray_evaluations"]},
                                  "max_abs_sdf_at_marched_hits": float(tr.hit_residual.abs().max())}

@@ -76,6 +76,11 @@ int sdfr_mlp_forward(const sdfr_decoder* dec, const float* inputs, int64_t n, fl
  * ReLU and tanh) -- the decoder precision of the reference's default config (configs/config_refine.ini:19); inputs/outputs stay float32. */
 int sdfr_mlp_forward_f16(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream);
 
+/* sdfr_mlp_forward_f16 over the first *n_dev rows only (n_dev: device int32, clamped to n_max; no host read) -- the sphere tracer's hit pass
+ * in the decoder's own half precision; mask_ws sized for n_max rows. */
+int sdfr_mlp_forward_f16_counted(const sdfr_decoder* dec, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf, uint32_t* mask_ws,
+                                 void* stream);
+
 /* the same with error-compensated float16 operands: each float32 weight and hidden activation x is carried as hi = half(x),
  * lo = half((x - hi) * 2^11) and every product as hi*hi + 2^-11 (hi*lo + lo*hi) on the f16 matrix cores, float32 accumulation
  * (~22 significand bits per product; the output differs from sdfr_mlp_forward by float32 summation-order noise, not by half
@@ -341,19 +346,23 @@ int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int
                     const float* far, float* inputs, float* hit_lam, float* hit_sdf, void* stream);
 
 /* The whole march in ONE call, no host synchronisation (counters: device int32[8], zeroed by sdfr_trace_setup -- [0..2] rotating active
- * counts, [3] rays unresolved when the step budget ran out, [4..5] one uint64 = decoder evaluations of the march, [6] hits).  While the
+ * counts, [3] rays unresolved when the step budget ran out, [4..5] one uint64 = decoder evaluations of the march, [6] hits, [7] rays handed to the looping kernel's second stage).  While the
  * device-side count is >= tail_rows a step is the decoder on the active rows + the step kernel; below it ONE launch of the decoder kernel in
  * its looping mode takes the remaining rays to termination (16-ray tiles, ray state in registers, no per-step launch, no compaction); the
  * gate is evaluated on the device in each of the first head_steps steps, then an unconditional tail launch takes what is left.
  * spec_k = 4: from pass index spec_from on a pass evaluates four samples per ray (p_0 = lam, p_j = p_{j-1} + sigma q^j rho / |d|) and accepts
  * the prefix in which every sample lies inside the previous one's safe sphere -- a valid sphere-tracing sequence, nothing skipped; the pass
  * index alone decides (head_steps is clamped to spec_from), so a ray's samples do not depend on the launch schedule.  spec_k = 1: plain.
- * pix0/lam0 (filled by sdfr_trace_setup) and pix1/lam1 are the ping-pong active lists (lam: ray state float[n][4]), sdf float[B*W*H] scratch,
- * tail_rows_buf float[ceil(B*W*H / 16)][16 * spec_k][L + 3] scratch of the looping kernel. */
+ * spec_k2 = 8 or 16 from pass index spec_from2 > spec_from on (off: spec_k2 <= spec_k): at that pass the looping kernel's survivors -- a few
+ * hundred creeping rays scattered over the tiles -- are re-packed 64 / spec_k2 to a tile by a second launch (list pix2 / lam2, counters[7])
+ * and take spec_k2 samples per pass: fewer, equally long passes for the rays that end the march.
+ * pix0/lam0 (filled by sdfr_trace_setup) and pix1/lam1 are the ping-pong active lists (lam: ray state float[n][4]), pix2/lam2 the second
+ * stage's list (same sizes; may be NULL when it is off), sdf float[B*W*H] scratch, tail_rows_buf float[tiles][16 * spec_k][L + 3] scratch of
+ * the looping kernel with tiles = ceil(B*W*H / 16), or ceil(B*W*H * spec_k2 / 64) with the second level. */
 int sdfr_trace_march(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float eps,
-                     int steps, int head_steps, int tail_rows, int spec_from, int spec_k, float sigma, int half, int32_t* counters, int32_t* pix0,
-                     float* lam0, int32_t* pix1, float* lam1, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
-                     float* hit_sdf, void* stream);
+                     int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2, float sigma, int half,
+                     int32_t* counters, int32_t* pix0, float* lam0, int32_t* pix1, float* lam1, int32_t* pix2, float* lam2, const float* far,
+                     float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam, float* hit_sdf, void* stream);
 /* hit pixels (hit_lam > 0) -> compact list: rows float[n][L+3] = [latn, o + lam d] for sdfr_mlp_jacobian (rows_per_crop = B*W*H, B = 1,
  * idx = the identity written here, cnt = n_hits), hit_slot int32[B*W*H] = list position of the pixel's hit or -1.  n_hits: device int32,
  * zero on entry (counters + 6 after sdfr_trace_setup). */

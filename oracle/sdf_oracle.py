@@ -788,7 +788,13 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
         idx = np.nonzero(active)[0]
         if idx.size == 0:
             break
-        k = int(spec_k) if (spec_from is not None and s >= spec_from) else 1
+        if isinstance(spec_from, (list, tuple)):                  # a schedule [(first pass index, samples per pass), ...], ascending
+            k = 1
+            for s_from, s_k in spec_from:
+                if s >= s_from:
+                    k = int(s_k)
+        else:
+            k = int(spec_k) if (spec_from is not None and s >= spec_from) else 1
         m = idx.size
         P = np.zeros((m, k), f)
         P[:, 0] = lam[idx]

@@ -186,6 +186,21 @@ extern "C" int sdfr_mlp_forward_counted(const sdfr_decoder* d, const float* inpu
     return SDFR_OK;
 }
 
+// sdfr_mlp_forward_f16 over the first *n_dev rows (device count, clamped to n_max), masks saved: the sphere tracer's hit pass in the decoder's
+// own half precision (value + mask-fed half Jacobian at the hits: sdfr_mlp_jacobian with mask_from_f16 = 2)
+extern "C" int sdfr_mlp_forward_f16_counted(const sdfr_decoder* d, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf,
+                                            uint32_t* mask_ws, void* stream) {
+    SDFR_REQUIRE(d && inputs && sdf && n_dev, "sdfr_mlp_forward_f16_counted: NULL argument");
+    SDFR_REQUIRE(n_max >= 0 && n_max < (int64_t)1 << 31, "sdfr_mlp_forward_f16_counted: n_max=%lld out of range", (long long)n_max);
+    SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_f16_counted: half operands need a 512-wide decoder without LayerNorm");
+    if (n_max == 0) return SDFR_OK;
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = mask_ws; P.n_dev = n_dev; P.n_dev_lo = 0; P.n_dev_hi = 0; P.trace = nullptr;
+    sdfr_launch_fwd_f16_512(P, n_max, mask_ws != nullptr, (hipStream_t)stream);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
 // forward with float16 operands (f32 accumulate, f32 bias/ReLU/tanh): 128-point workgroup tiles
 extern "C" int sdfr_mlp_forward_f16(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf, "sdfr_mlp_forward_f16: NULL argument");

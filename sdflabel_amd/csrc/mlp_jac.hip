@@ -49,12 +49,12 @@ void sdfr_launch_fwd_f32_512_tile16(const MlpParams& P, int64_t n, hipStream_t s
                        dim3(64 * SDFR_JAC_SMALL_NW), 0, s, P);
 }
 
-// MODE 4: the persistent tail of the sphere tracer's march (csrc/trace.hip sdfr_trace_march): each workgroup marches the 16 rays of its
-// tile to termination -- decoder pass, step rule, hit / exit test, next pass -- without leaving the kernel.  spec_k = 1: 16 operand rows per
-// tile (the band kernels' geometry); spec_k = 4: four samples per ray and pass, 64 rows (4 point tiles of 16).
+// MODE 4: the persistent tail of the sphere tracer's march (csrc/trace.hip sdfr_trace_march): each workgroup marches the t_rt rays of its
+// tile -- decoder pass, step rule, hit / exit test, next pass -- without leaving the kernel.  spec_k = 1: 16 rays on 16 operand rows per tile
+// (the band kernels' geometry); spec_k > 1: 64 rows (4 point tiles of 16) = t_rt rays x up to 64 / t_rt samples per ray and pass.
 void sdfr_launch_tail_f32_512(const MlpParams& P, int64_t n_rays, int spec_k, hipStream_t s) {
-    const dim3 grid(sdfr_cdiv(n_rays, 16));
-    if (spec_k == 4)
+    const dim3 grid(sdfr_cdiv(n_rays, P.t_rt));
+    if (spec_k > 1)
         hipLaunchKernelGGL((sdfr_mlp_kernel<float, 16, SDFR_JAC_SMALL_FT, 4, SDFR_JAC_SMALL_NW, 2, 4>), grid, dim3(64 * SDFR_JAC_SMALL_NW), 0, s, P);
     else
         hipLaunchKernelGGL((sdfr_mlp_kernel<float, 16, SDFR_JAC_SMALL_FT, 1, SDFR_JAC_SMALL_NW, SDFR_JAC_SMALL_PF, 4>), grid, dim3(64 * SDFR_JAC_SMALL_NW), 0,

@@ -33,8 +33,8 @@ void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s
 #endif
 void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n_rays, int spec_k, hipStream_t s) {
     static_assert(16 * SDFR_T16_FT * SDFR_T16_NW == 512, "padded width 512 = 16 * FT * NW");
-    const dim3 grid(sdfr_cdiv(n_rays, 16));
-    if (spec_k == 4)
+    const dim3 grid(sdfr_cdiv(n_rays, P.t_rt));           // a tile = t_rt rays (16: K <= 4 samples per pass; 8: K <= 8; 4: K <= 16) on 64 rows
+    if (spec_k > 1)
         hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 2, 8, 2, 4, 2>), grid, dim3(512), 0, s, P);
     else
         hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_T16_FT, 1, SDFR_T16_NW, SDFR_T16_PF, 4>), grid, dim3(64 * SDFR_T16_NW), 0, s, P);

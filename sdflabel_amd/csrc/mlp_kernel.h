@@ -77,13 +77,21 @@ struct MlpParams {
     const int32_t* n_dev;        // forward: optional device-side row count (rows >= *n_dev are not evaluated; n is the launch bound)
     int n_dev_lo, n_dev_hi;      // with n_dev and n_dev_hi > 0: the launch runs only while n_dev_lo <= *n_dev < n_dev_hi (two tile geometries of one step)
     unsigned long long* trace;   // builds with -DSDFR_MLP_TRACE: cycle stamps of workgroup 0 (sdfr_debug_set_trace), else unused
-    // MODE 4 (sphere tracing, persistent tail: csrc/trace.hip): the workgroup marches the 16 rays of its tile to termination by itself --
-    // decoder pass on PT = 16 K rows (K samples per ray), step rule, hit / exit test, next pass -- rewriting its own operand rows between passes
-    float* t_rows;               // = inputs: scratch [tile][PT][n_inputs], row j*16 + i = sample j of the tile's ray i
+    // MODE 4 (sphere tracing, persistent tail: csrc/trace.hip): the workgroup marches the t_rt rays of its tile by itself -- decoder pass on
+    // PT rows (up to PT / t_rt samples per ray), step rule, hit / exit test, next pass -- rewriting its own operand rows between passes, until
+    // the rays have terminated, the step budget is spent, or the stage ends (t_stage passes: the survivors are appended to the next stage's list)
+    float* t_rows;               // = inputs: scratch [tile][PT][n_inputs], row j*t_rt + i = sample j of the tile's ray i
+    int t_rt;                    // rays per tile (16, 8 or 4; PT / t_rt = most samples per ray and pass this launch can carry)
     const float* t_latn;         // [B][L] normalised latents
     const int32_t* t_pix;        // active list: crop * W*H + pixel
     const float4* t_lam;         // active list: ray state (lam = next sample, rho = |sdf| of the previous accepted sample, q = ratio of the last two radii, -)
-    int t_step0, t_spec_from;    // pass index of the kernel's first pass; passes with index >= t_spec_from are speculative (K samples per ray)
+    int t_step0;                 // pass index of the kernel's first pass
+    int t_spec_from, t_spec_k;   // passes with index >= t_spec_from take t_spec_k samples per ray ...
+    int t_spec_from2, t_spec_k2; // ... and those with index >= t_spec_from2 (>= t_spec_from) t_spec_k2; the pass INDEX alone decides
+    int t_stage;                 // passes this launch may run (<= t_steps)
+    int32_t* t_next_cnt;         // next stage's active list (NULL: none): count, pixels, states
+    int32_t* t_next_pix;
+    float4* t_next_lam;
     const float* t_far;          // per pixel: ray parameter at which the ray leaves the object cube
     const float* t_pose;         // [B][16]
     const float* t_Kinv;         // [B][9]
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     static_assert(!SAVE || (FT * NP) % 2 == 0, "mask words: FT*NP*16 bits per thread and layer must fill whole words");
     static_assert(!HALF || !JAC || MODE == 3, "with half operands only the mask-fed Jacobian exists (MODE 3)");
     static_assert(!LN || (!HALF && MODE != 1 && MODE != 3 && MODE != 4), "LayerNorm decoders: float32 forward (MODE 0) and recomputing Jacobian (MODE 2)");
-    static_assert(!TAIL || (NP * MS <= 64 && (NP * MS) % 16 == 0), "tail march: the tile's rows (16 rays x K samples) live in wave 0");
+    static_assert(!TAIL || (NP * MS <= 64 && (NP * MS) % 16 == 0), "tail march: the tile's rows (t_rt rays x K samples) live in wave 0");
     constexpr int KV = M::KV;                                      // operand elements per 16-byte fragment
     constexpr int NLG = 64 / MS;                                   // lane groups (k slots per MFMA)
     constexpr int RG = MS / (4 * NLG);                             // register groups of 4 per accumulator (4 or 1)
@@ -233,8 +241,8 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             slots[tid] = v ? (b * P.cap + s) : -1;
         }
     } else {
-        // (MODE 4: a tile is 16 RAYS of the active list -- n / n_dev count rays -- and PT = 16 K operand rows of the tile's own scratch)
-        const int64_t r0 = (int64_t)blockIdx.x * (TAIL ? 16 : PT);
+        // (MODE 4: a tile is t_rt RAYS of the active list -- n / n_dev count rays -- and PT operand rows of the tile's own scratch)
+        const int64_t r0 = (int64_t)blockIdx.x * (TAIL ? P.t_rt : PT);
         const int64_t n_rows = P.n_dev ? min(P.n, (int64_t)*P.n_dev) : P.n;          // sphere tracing: the active-ray count lives on the device
         if (r0 >= n_rows) return;
         if (P.n_dev && P.n_dev_hi > 0 && (*P.n_dev < P.n_dev_lo || *P.n_dev >= P.n_dev_hi)) return;
@@ -247,27 +255,29 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             for (int64_t c = r0 / P.skip_rows; c <= r1 / P.skip_rows; ++c) all_flagged = all_flagged && P.skip[c] != 0;
             if (all_flagged) return;
         }
-        n_valid = (int)min((int64_t)(TAIL ? 16 : PT), n_rows - r0);
+        n_valid = (int)min((int64_t)(TAIL ? P.t_rt : PT), n_rows - r0);
         if (tid < PT) rows[tid] = TAIL ? (int)((int64_t)blockIdx.x * PT + tid) : (int)(r0 + (tid < n_valid ? tid : 0));
     }
-    // ---- MODE 4: the tile's rays.  Lane i < 16 of wave 0 owns ray i: state, ray and the K sample positions of the coming pass in registers ----
-    constexpr int TK = TAIL ? PT / 16 : 1;              // samples per ray and pass
+    // ---- MODE 4: the tile's rays.  Lane i < RT of wave 0 owns ray i: state and ray in registers ----
+    const int RT = TAIL ? P.t_rt : 1;                   // rays of the tile
+    const int KMAX = TAIL ? PT / RT : 1;                // most samples per ray and pass the tile has rows for
+    // samples per ray of the pass with index s: the schedule, a function of s alone (clipped to what the tile can carry: the host picks t_rt so
+    // that it never clips)
+    auto pass_k = [&](int s) { return min(KMAX, s >= P.t_spec_from2 ? P.t_spec_k2 : (s >= P.t_spec_from ? P.t_spec_k : 1)); };
     int t_gp = 0, t_left = 0, t_pass = 0;
     bool t_act = false;
     float4 t_st = make_float4(0.f, 0.f, 1.f, 0.f);
     float t_farl = 0.f, t_idn = 1.f, t_ox = 0.f, t_oy = 0.f, t_oz = 0.f, t_dx = 0.f, t_dy = 0.f, t_dz = 0.f;
-    float t_p[TK];
     unsigned long long t_ev = 0ull;
     // sample positions of a pass with k live samples (p_0 = lam, p_j = p_{j-1} + sigma q^j rho / |d|; slots j >= k repeat p_0) -> operand rows
+    // (the step rule below recomputes the positions with the same operations instead of keeping them in registers)
     auto tail_rows = [&](int k, bool with_latent) {
-        if (tid >= 16) return;
+        if (tid >= RT) return;
         float pj = t_st.x, qp = t_st.z;
-#pragma unroll
-        for (int j = 0; j < TK; ++j) {
+        for (int j = 0; j < KMAX; ++j) {
             if (j > 0 && j < k) { pj = pj + ((P.t_sigma * qp) * t_st.y) / t_idn; qp = qp * t_st.z; }
             const float pos = (j < k) ? pj : t_st.x;
-            t_p[j] = pos;
-            float* row = P.t_rows + ((int64_t)blockIdx.x * PT + j * 16 + tid) * NI;
+            float* row = P.t_rows + ((int64_t)blockIdx.x * PT + j * RT + tid) * NI;
             if (with_latent) {
                 const int P_ = P.t_W * P.t_H;
                 const float* lz = P.t_latn + (int64_t)(t_gp / P_) * (NI - 3);
@@ -277,9 +287,9 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         }
     };
     if constexpr (TAIL) {
-        t_left = P.t_steps;
-        if (tid < 16) {
-            const int64_t s = (int64_t)blockIdx.x * 16 + (tid < n_valid ? tid : 0);        // lanes beyond the tile's rays mirror ray 0 (finite rows), inactive
+        t_left = min(P.t_steps, P.t_stage);
+        if (tid < RT) {
+            const int64_t s = (int64_t)blockIdx.x * RT + (tid < n_valid ? tid : 0);        // lanes beyond the tile's rays mirror ray 0 (finite rows), inactive
             t_gp = P.t_pix[s];
             t_st = P.t_lam[s];
             t_farl = P.t_far[t_gp];
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             t_idn = sqrtf(t_dx * t_dx + t_dy * t_dy + t_dz * t_dz);        // |d| (the step divides by it, as sdfr_trace_step_kernel does)
             t_act = tid < n_valid;
         }
-        tail_rows((TK > 1 && P.t_step0 >= P.t_spec_from) ? TK : 1, true);
+        tail_rows(pass_k(P.t_step0), true);
     }
     __syncthreads();
     if (JAC) {
@@ -768,30 +778,31 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                 if (tid < n_valid && P.sdf_sel) P.sdf_sel[slots[tid]] = o;
             } else if (TAIL) {
                 // The step rule of the march (oracle/sdf_oracle.py::sphere_trace; K = 1: exactly sdfr_trace_step_kernel's trace_advance).  Row
-                // j*16 + i carries sample j of ray i: lane i < 16 collects its K values, walks the accepted prefix -- sample j counts only
+                // j*RT + i carries sample j of ray i: lane i < RT collects its K values, walks the accepted prefix -- sample j counts only
                 // inside the safe sphere of sample j-1 --, retires hits and exits, continues from the last accepted sample.
-                const int k = (TK > 1 && P.t_step0 + t_pass >= P.t_spec_from) ? TK : 1;
-                float v[TK];
-#pragma unroll
-                for (int j = 0; j < TK; ++j) v[j] = (TK > 1) ? __shfl(o, (tid & 15) + 16 * j, 64) : o;
-                const unsigned long long live = __ballot(t_act && tid < 16);
+                const int k = pass_k(P.t_step0 + t_pass);
+                const unsigned long long live = __ballot(t_act && tid < RT);
                 if (tid == 0) t_ev += (unsigned long long)(__popcll(live) * k);
-                if (t_act && tid < 16) {
-                    float vj = v[0], rj = fabsf(v[0]), pj = t_p[0], prev = t_st.y;
+                {
+                    const int li = tid < RT ? tid : 0;
+                    float vj = o, rj = fabsf(o), pj = t_st.x, prev = t_st.y;
                     bool done = rj < P.t_eps, ishit = done;
-#pragma unroll
-                    for (int j = 1; j < TK; ++j) {
-                        if (j < k) {
-                            const float rp = fabsf(v[j - 1]);
-                            const bool cov = ((t_p[j] - t_p[j - 1]) * t_idn <= rp) && (v[j - 1] > 0.f) && (t_p[j] > t_p[j - 1]);
-                            const bool take = cov && !done;
-                            done = done || !cov;
-                            if (take) {
-                                prev = rp; vj = v[j]; rj = fabsf(v[j]); pj = t_p[j];
-                                if (rj < P.t_eps) { ishit = true; done = true; }
-                            }
+                    float pc = t_st.x, qp = t_st.z, vp = o;                 // position / ratio power / value of sample j-1
+                    for (int j = 1; j < k; ++j) {                           // (uniform trip count: the shuffles run in every lane)
+                        const float vc = __shfl(o, li + RT * j, 64);
+                        const float pn = pc + ((P.t_sigma * qp) * t_st.y) / t_idn;
+                        qp = qp * t_st.z;
+                        const float rp = fabsf(vp);
+                        const bool cov = ((pn - pc) * t_idn <= rp) && (vp > 0.f) && (pn > pc);
+                        const bool take = cov && !done;
+                        done = done || !cov;
+                        if (take) {
+                            prev = rp; vj = vc; rj = fabsf(vc); pj = pn;
+                            if (rj < P.t_eps) { ishit = true; done = true; }
                         }
+                        pc = pn; vp = vc;
                     }
+                  if (t_act && tid < RT) {
                     if (ishit) {
                         P.t_hit_lam[t_gp] = pj;
                         P.t_hit_sdf[t_gp] = vj;
@@ -803,6 +814,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                         if ((l2 < t_farl) && (vj == vj)) t_st.x = l2;
                         else t_act = false;
                     }
+                  }
                 }
             } else {
                 if (tid < n_valid) {
@@ -821,17 +833,32 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         __syncthreads();
         if (*t_more == 0) break;
         ++t_pass;
-        tail_rows((TK > 1 && P.t_step0 + t_pass >= P.t_spec_from) ? TK : 1, false);
+        tail_rows(pass_k(P.t_step0 + t_pass), false);
         __syncthreads();
         build_operand();                                  // the rows this workgroup has just rewritten (same CU: its L1 is coherent for it)
         __syncthreads();
     }
     } while (TAIL);
     if constexpr (TAIL) {
-        const unsigned long long left_over = __ballot(t_act && tid < 16);
-        if (tid == 0) {
-            if (P.t_evals) atomicAdd(P.t_evals, t_ev);
-            if (left_over && P.t_unresolved) atomicAdd(P.t_unresolved, (int)__popcll(left_over));
+        // rays still marching: out of budget -> unresolved; end of the stage -> appended to the next stage's list (the order of the tiles'
+        // appends varies from run to run -- which rays share a tile does not enter any ray's arithmetic)
+        if (tid < 64) {
+            const unsigned long long left_over = __ballot(t_act && tid < RT);
+            const bool hand_over = P.t_next_cnt && (P.t_stage < P.t_steps);
+            int base = 0;
+            if (tid == 0) {
+                if (P.t_evals) atomicAdd(P.t_evals, t_ev);
+                if (left_over && !hand_over && P.t_unresolved) atomicAdd(P.t_unresolved, (int)__popcll(left_over));
+                if (left_over && hand_over) base = atomicAdd(P.t_next_cnt, (int)__popcll(left_over));
+            }
+            if (hand_over && left_over) {
+                base = __shfl(base, 0, 64);
+                if (t_act && tid < RT) {
+                    const int at = base + (int)__popcll(left_over & ((1ull << tid) - 1ull));
+                    P.t_next_pix[at] = t_gp;
+                    P.t_next_lam[at] = t_st;
+                }
+            }
         }
         return;
     }

@@ -350,7 +350,8 @@ extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float
 
 // ---- the whole march in one call: no host synchronisation -------------------------------------------------------------------------------
 // counters (device int32[SDFR_TRACE_COUNTERS], zeroed by sdfr_trace_setup): [0..2] rotating active counts, [3] rays left unresolved when the
-// step budget ran out, [4..5] one uint64: decoder evaluations of the march (speculative samples included), [6] hits, [7] spare.
+// step budget ran out, [4..5] one uint64: decoder evaluations of the march (speculative samples included), [6] hits, [7] rays handed to the
+// looping kernel's second stage.
 // While the device-side count is >= tail_rows a step is two launches: the decoder on the active rows (64- / 128-row tiles, MFMA-bound)
 // and sdfr_trace_step_kernel (advance, retire, ballot compaction).  Once it drops below tail_rows -- every 16-ray tile then has a CU to
 // itself -- ONE launch of the decoder kernel in MODE 4 takes the remaining rays to termination: the workgroup loops over decoder pass ->
@@ -360,15 +361,22 @@ extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float
 // pass of the half kernel costs what a 16-row pass costs: both are paced by the weight stream through the CU) and accepts the prefix that
 // stays inside the previous samples' safe spheres; the rays creeping along a face at grazing incidence, which keep a march alive for dozens
 // of steps, advance four samples per pass.  The pass index alone decides (head_steps is clamped to spec_from), so a ray's sample sequence
-// does not depend on the launch schedule.  tail_rows_buf: scratch float[ceil(n / 16)][16 spec_k][L + 3].
+// does not depend on the launch schedule.
+// Second level (spec_k2 = 8 or 16 from pass spec_from2 > spec_from on; off with spec_k2 <= spec_k): what keeps the looping kernel alive is a few
+// hundred creeping rays scattered over the tiles -- the chip idles while each of them pays ~55 us per pass -- so at pass spec_from2 the first
+// stage ends, its survivors are appended to a third list (pix2 / lam2, counters[7]) and a second launch marches them 64 / spec_k2 to a tile
+// with spec_k2 samples per pass: the 256x256 bench crop ends at pass 21 instead of 31 for 3 % more decoder evaluations.
+// tail_rows_buf: scratch float[tiles][16 spec_k][L + 3], tiles = ceil(n / 16), or ceil(n spec_k2 / 64) with the second level.
 extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H,
-                                float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, float sigma, int half,
-                                int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_, const float* far, float* inputs,
-                                float* sdf, float* tail_rows_buf, float* hit_lam, float* hit_sdf, void* stream) {
+                                float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2,
+                                float sigma, int half, int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_,
+                                int32_t* pix2, float* lam2_, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
+                                float* hit_sdf, void* stream) {
     SDFR_REQUIRE(d && pose && Kinv && latn && counters && pix0 && lam0_ && pix1 && lam1_ && far && inputs && sdf && tail_rows_buf && hit_lam &&
                      hit_sdf, "sdfr_trace_march: NULL argument");
     float4* lam0 = reinterpret_cast<float4*>(lam0_);
     float4* lam1 = reinterpret_cast<float4*>(lam1_);
+    float4* lam2 = reinterpret_cast<float4*>(lam2_);
     SDFR_REQUIRE(B > 0 && W > 0 && H > 0 && steps > 0 && head_steps >= 0 && tail_rows >= 0, "sdfr_trace_march: bad size");
     SDFR_REQUIRE(spec_k == 1 || spec_k == 4, "sdfr_trace_march: spec_k = %d (1: plain tracing, 4: four samples per ray and pass)", spec_k);
     SDFR_REQUIRE(d->HP == 512 && !d->has_ln && d->n_inputs == L + 3, "sdfr_trace_march: 512-wide decoder without LayerNorm, L + 3 inputs");
@@ -377,19 +385,34 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
     hipStream_t s = (hipStream_t)stream;
     if (spec_k == 1) spec_from = 0x7fffffff;
     if (spec_from < 0) spec_from = 0;
+    // second speculation level (spec_k2 = 8 or 16 samples per pass from pass spec_from2 >= spec_from on): a second stage of the looping kernel
+    // with 64 / spec_k2 rays per tile takes over the rays that are still marching then.  Off: spec_k2 <= spec_k.
+    const bool two = spec_k > 1 && spec_k2 > spec_k && spec_from2 < steps;
+    if (two) {
+        SDFR_REQUIRE(spec_k2 == 8 || spec_k2 == 16, "sdfr_trace_march: spec_k2 = %d (8 or 16 samples per ray and pass, or <= spec_k: off)", spec_k2);
+        SDFR_REQUIRE(pix2 && lam2, "sdfr_trace_march: the second speculation level needs its ray list (pix2, lam2)");
+        SDFR_REQUIRE(spec_from2 > spec_from, "sdfr_trace_march: spec_from2 = %d must lie behind spec_from = %d", spec_from2, spec_from);
+    } else { spec_from2 = 0x7fffffff; spec_k2 = spec_k; }
     if (head_steps > steps) head_steps = steps;
     if (head_steps > spec_from) head_steps = spec_from;          // speculative passes exist in the looping kernel only
     unsigned long long* evals = reinterpret_cast<unsigned long long*>(counters + 4);
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.trace = nullptr;
     P.t_far = far; P.t_pose = pose; P.t_Kinv = Kinv; P.t_latn = latn; P.t_hit_lam = hit_lam; P.t_hit_sdf = hit_sdf; P.t_W = W; P.t_H = H;
-    P.t_eps = eps; P.t_sigma = sigma; P.t_evals = evals; P.t_unresolved = counters + 3; P.t_spec_from = spec_from;
+    P.t_eps = eps; P.t_sigma = sigma; P.t_evals = evals; P.t_unresolved = counters + 3;
+    P.t_spec_from = spec_from; P.t_spec_k = spec_k; P.t_spec_from2 = spec_from2; P.t_spec_k2 = spec_k2;
+    auto launch_tail = [&](const MlpParams& T) {
+        if (half) sdfr_launch_tail_f16_512(T, n_max, spec_k, s); else sdfr_launch_tail_f32_512(T, n_max, spec_k, s);
+    };
+    // first stage: 16 rays per tile, from pass `step` (whichever step the device-side count picks) to the end of the budget or to spec_from2
     auto tail = [&](int step, int hi) {
         MlpParams T = P;
-        T.inputs = tail_rows_buf; T.t_rows = tail_rows_buf;
+        T.inputs = tail_rows_buf; T.t_rows = tail_rows_buf; T.t_rt = 16;
         T.n_dev = counters + step % 3; T.n_dev_lo = 1; T.n_dev_hi = hi;
         T.t_pix = (step & 1) ? pix1 : pix0; T.t_lam = (step & 1) ? lam1 : lam0; T.t_steps = steps - step; T.t_step0 = step;
-        if (half) sdfr_launch_tail_f16_512(T, n_max, spec_k, s); else sdfr_launch_tail_f32_512(T, n_max, spec_k, s);
+        T.t_stage = T.t_steps; T.t_next_cnt = nullptr; T.t_next_pix = nullptr; T.t_next_lam = nullptr;
+        if (two && step < spec_from2) { T.t_stage = spec_from2 - step; T.t_next_cnt = counters + 7; T.t_next_pix = pix2; T.t_next_lam = lam2; }
+        launch_tail(T);
     };
     for (int step = 0; step < head_steps; ++step) {
         MlpParams F = P;
@@ -412,8 +435,18 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
                            counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? pix1 : pix0, a ? lam1 : lam0,
                            a ? pix0 : pix1, a ? lam0 : lam1, far, inputs, hit_lam, hit_sdf, tail_rows > 0 ? tail_rows : 1, evals);
     }
-    if (head_steps < steps) tail(head_steps, 0x7fffffff);
-    else {
+    if (head_steps < steps) {
+        tail(head_steps, 0x7fffffff);
+        if (two) {
+            // second stage: the survivors of the first (list pix2 / lam2, count in counters[7]), 64 / spec_k2 rays per tile, to the end
+            MlpParams T = P;
+            T.inputs = tail_rows_buf; T.t_rows = tail_rows_buf; T.t_rt = 64 / spec_k2;
+            T.n_dev = counters + 7; T.n_dev_lo = 1; T.n_dev_hi = 0x7fffffff;
+            T.t_pix = pix2; T.t_lam = lam2; T.t_steps = steps - spec_from2; T.t_step0 = spec_from2;
+            T.t_stage = T.t_steps; T.t_next_cnt = nullptr; T.t_next_pix = nullptr; T.t_next_lam = nullptr;
+            launch_tail(T);
+        }
+    } else {
         // the step budget ended in the head: the rays still listed are unresolved
         hipLaunchKernelGGL(sdfr_trace_leftover_kernel, dim3(1), dim3(64), 0, s, counters + steps % 3, counters + 3);
     }

@@ -13,10 +13,13 @@ Everything is a HIP kernel behind the C ABI (csrc/trace.hip, csrc/mlp_kernel.h M
   sdfr_trace_setup      pixel rays in object space (o = -R^T t, d = R^T K^-1 [x, y, 1]) clipped against the cube [-1, 1]^3 -> active list
   sdfr_trace_march      while the device-side active count is >= tail_rows: decoder on the active rows (MFMA) + advance / retire / ballot
                         compaction per step; below it ONE launch of the decoder kernel in its looping mode marches the remaining rays to
-                        termination (16-ray tiles, no per-step launch); from pass `spec_from` on with `spec_k` samples per ray and pass
-                        (accepted while each lies inside the previous one's safe sphere: the creeping grazing rays advance 4 samples a pass)
+                        termination (16-ray tiles, no per-step launch); from pass `spec_from` on with `spec_k` = 4 samples per ray and pass
+                        (accepted while each lies inside the previous one's safe sphere: the creeping grazing rays advance 4 samples a
+                        pass), from pass `spec_from2` on the survivors re-packed 4 to a tile with `spec_k2` = 16 samples per pass
   sdfr_trace_hits       hit pixels -> compact rows [latent, x0]
-  sdfr_mlp_jacobian     exact-f32 decoder value and input Jacobian at the hits (normals, d sdf / d latent)
+  hit pass              decoder value and input Jacobian at the hits (Newton polish, normals, d sdf / d latent): polish="decoder" in the
+                        decoder's precision (float16: sdfr_mlp_forward_f16_counted with ReLU masks + the mask-fed half Jacobian),
+                        polish="exact" always float32 (sdfr_mlp_jacobian, recomputing kernel)
   sdfr_trace_composite  one Newton step along non-grazing rays, then depth / NOCS colour / normals / mask images
   sdfr_trace_backward   image gradients -> pose and latent gradients through the implicit function f(o(θ) + λ d(θ), z(θ)) = 0 at the fixed
                         hit set (silhouette changes carry no gradient, as in the splat path), fixed-order sums; sdfr_params_backward
@@ -50,7 +53,7 @@ class _TraceFn(torch.autograd.Function):
 
 class SphereTracer:
     def __init__(self, decoder, K, resolution_px, batch=1, steps=64, eps=2e-3, bound=1.0, near=1e-3, device="cuda", head_steps=None,
-                 tail_rows=4096, spec_from=12, spec_k=None, sigma=0.9):
+                 tail_rows=4096, spec_from=10, spec_k=None, sigma=0.9, spec_from2=None, spec_k2=None, polish=None):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise _lib.SdfrError("SphereTracer runs on the GPU only")
@@ -65,12 +68,28 @@ class SphereTracer:
         self.handle = decoder.handle(dev)
         self.half = 1 if getattr(decoder, "mlp_precision", torch.float32) == torch.float16 else 0
         # speculative passes: from pass index spec_from on, spec_k samples per ray and pass in the looping kernel (accepted while each lies inside
-        # the previous one's safe sphere).  Default: 4 with the float16 decoder -- a 64-row half pass costs what a 16-row pass costs (both are
-        # paced by the weight stream) --, 1 (plain sphere tracing) with the exact-f32 decoder, whose 64-row pass is matrix-bound (4x the time).
-        self.spec_k = int(spec_k) if spec_k is not None else (4 if self.half else 1)
+        # the previous one's safe sphere).  Default 4 (with the second level below; one 256x256 crop, fwd+bwd: float16 3.76 -> 2.55 ms incl.
+        # the half hit pass, float32 20.1 -> 18.5 ms); 1 = plain sphere tracing.
+        self.spec_k = int(spec_k) if spec_k is not None else 4
         self.spec_from, self.sigma = int(spec_from), float(sigma)
         if self.spec_k not in (1, 4):
             raise ValueError("spec_k must be 1 or 4")
+        # second level: from pass index spec_from2 on (default spec_from + 4) the looping kernel's survivors -- the creeping rays that end the
+        # march, scattered over the tiles -- are re-packed 64 / spec_k2 to a tile and take spec_k2 samples per pass (default 16 with spec_k 4)
+        self.spec_k2 = int(spec_k2) if spec_k2 is not None else (16 if self.spec_k == 4 else 1)
+        self.spec_from2 = int(spec_from2) if spec_from2 is not None else self.spec_from + 4
+        if self.spec_k2 <= self.spec_k:
+            self.spec_k2 = self.spec_k                                              # off
+        elif self.spec_k2 not in (8, 16) or self.spec_from2 <= self.spec_from:
+            raise ValueError("spec_k2 must be 8 or 16 (or <= spec_k: off), spec_from2 > spec_from")
+        # the hit pass (decoder value + input Jacobian at the marched points: Newton polish, normals, implicit-function gradients): "exact" =
+        # float32 whatever the decoder's precision; "decoder" = in the decoder's own precision -- with a float16 decoder the half forward with
+        # ReLU masks + the mask-fed half Jacobian (what the splat path does at float16: 0.1 ms instead of 1.25 ms for 18 k hits; the surface
+        # is then the HALF decoder's level set: depths within ~1e-3 of the exact polish).  Default: "decoder".
+        self.polish = "decoder" if polish is None else str(polish)
+        if self.polish not in ("exact", "decoder"):
+            raise ValueError("polish must be 'exact' or 'decoder'")
+        self.half_polish = bool(self.half) and self.polish == "decoder"
         self.L = decoder.latent_size
         self.NI = self.L + 3
         K = torch.as_tensor(K, dtype=torch.float32)
@@ -85,14 +104,16 @@ class SphereTracer:
         self.yaw, self.trans, self.latent = f(B), f(B, 3), f(B, self.L)
         self.pose, self.latnorm, self.latn = f(B, 16), f(B), f(B, self.L)
         self.counters = i(_COUNTERS)
-        self.pix, self.lam = [i(n), i(n)], [f(n, 4), f(n, 4)]                 # active lists: pixel, ray state (lam, rho, q, -)
+        self.pix, self.lam = [i(n), i(n), i(n)], [f(n, 4), f(n, 4), f(n, 4)]   # active lists (ping, pong, second tail stage): pixel, ray state (lam, rho, q, -)
         self.far, self.inputs, self.sdf = f(n), f(n, self.NI), f(n)
-        self.tail_rows_buf = f((n + 15) // 16, 16 * self.spec_k, self.NI)          # operand rows of the looping kernel's tiles
+        tiles = (n + 15) // 16 if self.spec_k2 == self.spec_k else (n * self.spec_k2 + 63) // 64
+        self.tail_rows_buf = f(tiles, 16 * self.spec_k, self.NI)                   # operand rows of the looping kernel's tiles
         self.hit_lam, self.hit_sdf, self.lam_s = f(n), f(n), f(n)
         self.hit_slot, self.idx = i(n), i(n)
         self.rows, self.J, self.f0 = f(n, self.NI), f(n, self.NI), f(n)
         self.color, self.mask, self.depth, self.normals = f(B, 3, H, W), f(B, 1, H, W), f(B, 1, H, W), f(B, 3, H, W)
         self.ws = f(int(_lib.lib().sdfr_trace_backward_ws_floats(B, W, H)))
+        self.mask_ws = i(int(_lib.lib().sdfr_decoder_mask_words(self.handle.h, n))) if self.half_polish else None
         self.g_pose, self.g_latn = f(B, 16), f(B, self.L)
         self.g_yaw, self.g_trans, self.g_latent = f(B), f(B, 3), f(B, self.L)
 
@@ -117,18 +138,26 @@ class SphereTracer:
             if "march" in events:
                 events["march"][0].record()
             ck(L.sdfr_trace_march(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.eps, self.steps,
-                                  self.head_steps, self.tail_rows, self.spec_from, self.spec_k, self.sigma, self.half, P(self.counters),
-                                  P(self.pix[0]), P(self.lam[0]), P(self.pix[1]), P(self.lam[1]), P(self.far), P(self.inputs), P(self.sdf),
+                                  self.head_steps, self.tail_rows, self.spec_from, self.spec_k, self.spec_from2, self.spec_k2, self.sigma,
+                                  self.half, P(self.counters), P(self.pix[0]), P(self.lam[0]), P(self.pix[1]), P(self.lam[1]), P(self.pix[2]),
+                                  P(self.lam[2]), P(self.far), P(self.inputs), P(self.sdf),
                                   P(self.tail_rows_buf), P(self.hit_lam), P(self.hit_sdf), st), "sdfr_trace_march")
             if "march" in events:
                 events["march"][1].record()
             n_hits = self.counters[6:7]
             ck(L.sdfr_trace_hits(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, P(self.hit_lam), P(n_hits), P(self.hit_slot),
                                  P(self.idx), P(self.rows), st), "sdfr_trace_hits")
-            # exact-f32 decoder value and input Jacobian at the hits (recomputing kernel; rows beyond the device-side count are not touched)
-            ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.rows), n, 1, P(self.idx), n, P(n_hits), P(self.J), P(self.f0), None, None,
-                                   16 if self.jac_rows32 else 0, st),      # [SDFR_JAC_MANY_ROWS]: thousands of hits -> 32-row tiles
-               "sdfr_mlp_jacobian")
+            if self.half_polish:
+                # half decoder value (+ ReLU masks) and mask-fed half Jacobian at the hits; both launches take the device-side count
+                ck(L.sdfr_mlp_forward_f16_counted(self.handle.h, P(self.rows), n, P(n_hits), P(self.sdf), P(self.mask_ws), st),
+                   "sdfr_mlp_forward_f16_counted")
+                ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.rows), n, 1, P(self.idx), n, P(n_hits), P(self.J), P(self.f0), P(self.sdf),
+                                       P(self.mask_ws), 2, st), "sdfr_mlp_jacobian")
+            else:
+                # exact-f32 decoder value and input Jacobian at the hits (recomputing kernel; rows beyond the device-side count are not touched)
+                ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.rows), n, 1, P(self.idx), n, P(n_hits), P(self.J), P(self.f0), None, None,
+                                       16 if self.jac_rows32 else 0, st),      # [SDFR_JAC_MANY_ROWS]: thousands of hits -> 32-row tiles
+                   "sdfr_mlp_jacobian")
             ck(L.sdfr_trace_composite(P(self.pose), P(self.Kinv), self.L, B, W, H, P(self.hit_lam), P(self.hit_slot), P(self.J), P(self.f0),
                                       P(self.color), P(self.mask), P(self.depth), P(self.normals), P(self.lam_s), st), "sdfr_trace_composite")
         return {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.normals}

@@ -36,16 +36,19 @@ def _args(yaw=YAW, trans=TRANS, lat=LAT, grad=False):
     return [t.requires_grad_(True) for t in a] if grad else a
 
 
-@pytest.mark.parametrize("head_steps,tail_rows,spec_k", [(24, 4096, 1), (0, 4096, 1), (64, 0, 1), (24, 4096, 4), (0, 4096, 4), (64, 0, 4)])
-def test_march_polish_images_and_gradients_against_the_oracle(dec, oracle_layers, head_steps, tail_rows, spec_k):
+@pytest.mark.parametrize("head_steps,tail_rows,spec_k,spec_k2", [(24, 4096, 1, 1), (0, 4096, 1, 1), (64, 0, 1, 1), (24, 4096, 4, 1), (0, 4096, 4, 1),
+                                                                 (64, 0, 4, 1), (24, 4096, 4, 16), (0, 4096, 4, 16), (64, 0, 4, 8)])
+def test_march_polish_images_and_gradients_against_the_oracle(dec, oracle_layers, head_steps, tail_rows, spec_k, spec_k2):
     """head 24 / tail 4096: the default (per-step launches while >= 4096 rays are active, then the looping tail kernel); head 0: EVERY ray is
     marched by the looping kernel alone; tail_rows 0: per-step launches only (until the speculative passes start, which exist in the looping
-    kernel only).  spec_k = 4: from pass 16 on four samples per ray and pass.  All schedules must reproduce the oracle -- and each other."""
+    kernel only).  spec_k = 4: from pass 16 on four samples per ray and pass; spec_k2 = 8 / 16: from pass 20 on the survivors are re-packed into
+    tiles of 8 / 4 rays by a second launch of the looping kernel and take 8 / 16 samples per pass.  All schedules must reproduce the oracle."""
     layers, spec = oracle_layers
     H, W = 96, 128
     K = K_for(H, W)
     K[0, 2] += 9.0                                             # principal point off the image centre
-    tr = sdflabel_amd.SphereTracer(dec, K, (W, H), 1, steps=64, device=DEV, head_steps=head_steps, tail_rows=tail_rows, spec_from=16, spec_k=spec_k)
+    tr = sdflabel_amd.SphereTracer(dec, K, (W, H), 1, steps=64, device=DEV, head_steps=head_steps, tail_rows=tail_rows, spec_from=16, spec_k=spec_k,
+                                  spec_from2=20, spec_k2=spec_k2)
     a = _args(grad=True)
     out = tr(*a)
     # ---- the oracle on a subset of > 2000 rays: every 2nd row and column (the object's silhouette crosses them: grazing rays included)
@@ -56,7 +59,8 @@ def test_march_polish_images_and_gradients_against_the_oracle(dec, oracle_layers
     latn = lat / np.sqrt((lat * lat).sum())
     pose = O.render_pose(YAW[0], TRANS[0])
     Kinv = np.linalg.inv(K).astype(np.float32)
-    ref = O.sphere_trace(layers, spec, latn, pose, Kinv, px, steps=64, spec_from=16 if spec_k > 1 else None, spec_k=spec_k)
+    ref = O.sphere_trace(layers, spec, latn, pose, Kinv, px, steps=64,
+                         spec_from=[(16, spec_k), (20, max(spec_k, spec_k2))] if spec_k > 1 else None)
     sel = (px[:, 1], px[:, 0])
     hit = N(out["mask"][0, 0])[sel] > 0
     safe = ref["margin"] > 1e-4
@@ -107,13 +111,14 @@ def test_march_against_the_oracle_on_the_second_decoder():
     layers = O.decoder_layers_from_state(st, spec)
     H, W = 96, 96
     K = K_for(H, W)
-    tr = sdflabel_amd.SphereTracer(d, K, (W, H), 1, steps=64, device=DEV, spec_from=12, spec_k=4)
+    tr = sdflabel_amd.SphereTracer(d, K, (W, H), 1, steps=64, device=DEV, spec_from=12, spec_k=4, spec_from2=15, spec_k2=16)
     out = tr.render(*_args())
     ys, xs = np.meshgrid(np.arange(0, H, 2), np.arange(0, W, 2), indexing="ij")
     px = np.stack([xs.reshape(-1), ys.reshape(-1)], 1)
     lat = np.asarray(LAT[0], np.float32)
     latn = lat / np.sqrt((lat * lat).sum())
-    ref = O.sphere_trace(layers, spec, latn, O.render_pose(YAW[0], TRANS[0]), np.linalg.inv(K).astype(np.float32), px, steps=64, spec_from=12, spec_k=4)
+    ref = O.sphere_trace(layers, spec, latn, O.render_pose(YAW[0], TRANS[0]), np.linalg.inv(K).astype(np.float32), px, steps=64,
+                         spec_from=[(12, 4), (15, 16)])
     sel = (px[:, 1], px[:, 0])
     hit = N(out["mask"][0, 0])[sel] > 0
     safe = ref["margin"] > 1e-4
@@ -166,7 +171,7 @@ def test_speculative_passes_find_the_same_surface_and_resolve_the_creeping_rays(
     d = (oa["depth"] - ob["depth"]).abs().view(-1)[both]
     # (the few grazing hits are not polished: their marched points differ by up to eps / sin(incidence) along the ray)
     assert float(d.median()) < 1e-5 and float(torch.quantile(d, 0.98)) < 1e-4 and float(d.max()) < 5e-2
-    assert sb["ray_evaluations"] < 1.1 * sa["ray_evaluations"], (sa, sb)
+    assert sb["ray_evaluations"] < 1.15 * sa["ray_evaluations"], (sa, sb)     # (16 samples per pass from pass 14 on: the last ones are often wasted)
     assert sb["unresolved"] <= sa["unresolved"] and sb["unresolved"] <= 1, (sa, sb)
     # the speculative march needs about half the passes: with a budget of 36 it still resolves every ray, plain tracing does not
     a36 = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 1, steps=36, device=DEV, spec_k=1)
@@ -250,16 +255,31 @@ def test_gradients_match_finite_differences_on_the_common_hit_set(dec, which, in
 
 
 def test_half_operand_march_and_batches(dec):
-    """float16 decoder on the march (the hit polish stays exact f32): same image up to half precision; a batch renders each crop as alone,
+    """float16 decoder on the march, hit pass exact or in half as well: same image up to half precision; a batch renders each crop as alone,
     gradients included (fixed-order sums per crop)"""
     H = W = 96
     d16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
     s32 = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 1, steps=64, device=DEV)
-    s16 = sdflabel_amd.SphereTracer(d16.to(DEV), K_for(H, W), (W, H), 1, steps=64, device=DEV)
-    a, b = s32(*_args()), s16(*_args())
-    assert s16.half == 1 and float((a["mask"] != b["mask"]).float().mean()) < 0.01
-    both = (a["mask"] > 0) & (b["mask"] > 0)
-    assert float(((a["depth"] - b["depth"]).abs() * both).max()) < 5e-3
+    a = s32(*_args())
+    # polish "exact": the hit pass (value + Jacobian at the marched points) in float32 whatever the decoder; "decoder" (default): in half too
+    for polish, tol_med, tol_n in (("exact", 2e-5, 2e-3), ("decoder", 1e-3, 2e-2)):
+        s16 = sdflabel_amd.SphereTracer(d16.to(DEV), K_for(H, W), (W, H), 1, steps=64, device=DEV, polish=polish)
+        a16 = _args(grad=True)
+        b = s16(*a16)
+        assert s16.half == 1 and s16.half_polish == (polish == "decoder") and float((a["mask"] != b["mask"]).float().mean()) < 0.01
+        both = (a["mask"] > 0) & (b["mask"] > 0)
+        dd = (a["depth"] - b["depth"]).abs()[both]
+        assert float(dd.max()) < 5e-3 and float(dd.median()) < tol_med, (polish, float(dd.max()), float(dd.median()))
+        dn = (a["normals"] - b["normals"]).abs().amax(1, keepdim=True)[both]
+        assert float(dn.median()) < tol_n, (polish, float(dn.median()))
+        # gradients of a smooth functional: the half hit pass stays within half precision of the exact one
+        a32 = _args(grad=True)
+        o32 = s32(*a32)
+        keep = both.float()
+        ((o32["color"] * keep).sum() + (o32["depth"] * keep).sum()).backward()
+        ((b["color"] * keep).sum() + (b["depth"] * keep).sum()).backward()
+        for g32, g16 in zip(a32, a16):
+            assert float((g32.grad - g16.grad).abs().max()) < 2e-2 * max(1.0, float(g32.grad.abs().max())), (polish, g32.grad, g16.grad)
     yaw, trans, lat = [0.6, -0.4], [[0.05, -0.03, 3.5], [0.1, 0.0, 3.0]], [[0.3, -0.5, 0.8], [-0.2, 0.6, 0.4]]
     s2 = sdflabel_amd.SphereTracer(dec, K_for(H, W), (W, H), 2, steps=64, device=DEV)
     wts = torch.randn(2, 3, H, W, generator=torch.Generator().manual_seed(5)).to(DEV)

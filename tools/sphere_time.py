@@ -30,8 +30,14 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
     d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
     d = d.to(dev)
     macs = d.handle(torch.device(dev)).macs
-    for head, tail, spec_k, spec_from in [(24, 4096, k, 16) for k in args.spec] + ([(24, 4096, 4, 12), (24, 4096, 4, 20), (24, 2048, 4, 16), (args.steps, 0, 1, 16)] if not args.only else []):
-        tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, head_steps=head, tail_rows=tail, spec_k=spec_k, spec_from=spec_from)
+    scheds = [dict(spec_k=k) for k in args.spec]                              # the defaults (spec_k 4: second level 16 from spec_from + 4)
+    if not args.only:
+        scheds += [dict(spec_k=4, spec_k2=1), dict(spec_k=4, spec_k2=8), dict(spec_k=4, spec_from2=14), dict(spec_k=4, spec_from2=18),
+                   dict(spec_k=4, spec_from=10, spec_from2=14), dict(spec_k=4, spec_from=16, spec_from2=20), dict(spec_k=4, tail_rows=2048),
+                   dict(spec_k=4, tail_rows=8192), dict(spec_k=1, head_steps=args.steps, tail_rows=0), dict(spec_k=4, polish="exact")]
+    for sch in scheds:
+        tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, **sch)
+        head, tail, spec_k, spec_from = tr.head_steps, tr.tail_rows, tr.spec_k, tr.spec_from
 
         def step(ev=None):
             tr.render(*prm, events=ev)
@@ -53,7 +59,7 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
         mm = float(np.mean([e["march"][0].elapsed_time(e["march"][1]) for e in evs]))
         s = tr.stats()
         tf = 2.0 * macs * s["ray_evaluations"] / (mm * 1e-3) / 1e12
-        print("%s spec_k %d from %2d head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
-              % (str(prec).replace("torch.", ""), spec_k, spec_from, head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
+        print("%s polish %s spec_k %d from %2d (then %2d from %2d) head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
+              % (str(prec).replace("torch.", ""), tr.polish, spec_k, spec_from, tr.spec_k2, tr.spec_from2, head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
                  100 * tf / (2500.0 if prec == torch.float16 else 157.3), s["hits"], s["unresolved"]), flush=True)
         del tr

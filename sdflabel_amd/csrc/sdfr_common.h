@@ -40,6 +40,25 @@ struct SdfrDeviceGuard {
 
 static inline int sdfr_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// XCD-aware crop mapping of a (x = work item of a crop, y = crop) grid.  MI355X deals the workgroups of a launch round-robin to its 8 XCDs by
+// their linear index, and each XCD has its own L2: with the plain mapping the workgroups of ONE crop land on all eight and every L2 fetches
+// that crop's data (surfel arrays in the splat forward, pixel records in its backward) for itself.  Re-deal the indices so that crop 8g + x
+// is served by XCD x alone.  Crops beyond the last full group of 8 keep the plain mapping.  A bijection of the grid: kernels whose results
+// do not depend on which workgroup computes what (all of ours) return the same bits.
+#define SDFR_XCDS 8
+#ifdef __HIPCC__
+__device__ __forceinline__ void sdfr_xcd_crop_map(int& xb, int& b) {
+    const int nbx = gridDim.x, full = (gridDim.y / SDFR_XCDS) * SDFR_XCDS;
+    const int64_t lin = (int64_t)blockIdx.y * nbx + blockIdx.x;
+    xb = blockIdx.x; b = blockIdx.y;
+    if (lin < (int64_t)nbx * full) {
+        const int64_t j = lin / SDFR_XCDS;
+        b = (int)(j / nbx) * SDFR_XCDS + (int)(lin % SDFR_XCDS);
+        xb = (int)(j % nbx);
+    }
+}
+#endif
+
 // number of valid items of crop b in a [B][cap] ragged array
 __device__ __forceinline__ int sdfr_count(const int32_t* cnt, int b, int cap) {
     if (cnt == nullptr) return cap;

@@ -209,10 +209,11 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
     constexpr int SPW = SPL_NS / PW;                   // shares per wave
     constexpr int NT = 64 * PW;
     constexpr int LCOV = (PW == 1) ? 64 : SPL_LC;      // coverage ballots kept per tile
-    const int b = blockIdx.y;
+    int tile, b;
+    sdfr_xcd_crop_map(tile, b);        // a crop's tiles on one XCD: its surfel arrays / tile lists are fetched by one L2
     const int W = A.W, H = A.H;
     const int tilesX = (W + 7) >> 3;
-    const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
+    const int tx = tile % tilesX, ty = tile / tilesX;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int X0 = tx * 8, Y0 = ty * 8;
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
         const int32_t* toff = bins + (int64_t)b * sdfr_splat_bin_stride(A.cap, W, H);
         if (toff[T + 1] == 1) {
             binned = true;
-            const int o0 = toff[blockIdx.x];
-            nc = toff[blockIdx.x + 1] - o0;
+            const int o0 = toff[tile];
+            nc = toff[tile + 1] - o0;
             const int32_t* tl = toff + T + 2 + o0;
             if (PW == 1) {
                 if (nc > 0 && nc <= 64) {                  // ranks through lane reads
@@ -538,9 +539,10 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
                                                             float* __restrict__ g_p, float* __restrict__ g_n, float* __restrict__ g_attr,
                                                             const float* __restrict__ gW = nullptr, const float* __restrict__ Sd = nullptr,
                                                             int rows = 0) {
-    const int b = blockIdx.y;
+    int xb, b;
+    sdfr_xcd_crop_map(xb, b);          // a crop's surfels on one XCD: its pixel records (aux, images, upstream gradients) are fetched by one L2
     const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int s = xb * 4 + (threadIdx.x >> 6);
     if (s >= sdfr_count(A.cnt, b, A.cap)) return;
     const int W = A.W, H = A.H;
     const float diam = A.diam, C = A.depth_constant;

@@ -504,6 +504,19 @@ def test_sphere_trace_oracle_self_consistency():
             dR = np.array([[-s, 0, c], [0, 0, 0], [-c, 0, -s]])
             an = float((g_pose[:3, :3] * dR).sum())
         assert abs(an - fd) < 0.05 * max(1.0, abs(fd)), (which, an, fd)
+    # speculative passes: a schedule [(first pass, samples per pass), ...] is the general form of (spec_from, spec_k); the accepted prefix is a
+    # valid sphere-tracing sequence, so every schedule finds the same surface (to eps along the ray before the polish), in fewer passes
+    one = O.sphere_trace(layers, spec, lat, O.render_pose(yaw, t), Kinv, px, spec_from=12, spec_k=4)
+    same = O.sphere_trace(layers, spec, lat, O.render_pose(yaw, t), Kinv, px, spec_from=[(12, 4)])
+    two = O.sphere_trace(layers, spec, lat, O.render_pose(yaw, t), Kinv, px, spec_from=[(10, 4), (14, 16)])
+    assert np.array_equal(one["lam0"], same["lam0"]) and one["evals"] == same["evals"]
+    for sp in (one, two):
+        assert sp["unresolved"].sum() == 0 and (sp["hit"] != tr["hit"]).sum() <= 3
+        both = sp["hit"] & tr["hit"] & sp["ok"] & tr["ok"]
+        dd = np.abs(sp["depth"] - tr["depth"])[both]                   # (one Newton step from marched points up to eps apart: second order)
+        assert dd.max() < 1e-3 and np.quantile(dd, 0.98) < 1e-4
+    assert two["n_steps"].max() < one["n_steps"].max() < tr["n_steps"].max()
+    assert two["evals"] < 1.2 * tr["evals"]
 
 
 @pytest.mark.parametrize("tag", ["circle_bg0", "circle_bg1", "disc_quat"])

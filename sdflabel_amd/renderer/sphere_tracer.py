@@ -74,10 +74,10 @@ class SphereTracer:
         self.spec_from, self.sigma = int(spec_from), float(sigma)
         if self.spec_k not in (1, 4):
             raise ValueError("spec_k must be 1 or 4")
-        # second level: from pass index spec_from2 on (default spec_from + 4) the looping kernel's survivors -- the creeping rays that end the
+        # second level: from pass index spec_from2 on (default spec_from + 3) the looping kernel's survivors -- the creeping rays that end the
         # march, scattered over the tiles -- are re-packed 64 / spec_k2 to a tile and take spec_k2 samples per pass (default 16 with spec_k 4)
         self.spec_k2 = int(spec_k2) if spec_k2 is not None else (16 if self.spec_k == 4 else 1)
-        self.spec_from2 = int(spec_from2) if spec_from2 is not None else self.spec_from + 4
+        self.spec_from2 = int(spec_from2) if spec_from2 is not None else self.spec_from + 3
         if self.spec_k2 <= self.spec_k:
             self.spec_k2 = self.spec_k                                              # off
         elif self.spec_k2 not in (8, 16) or self.spec_from2 <= self.spec_from:

@@ -17,6 +17,7 @@ ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--spec", type=int, nargs="*", default=[1, 4], help="samples per ray and pass in the looping kernel")
+ap.add_argument("--scan", default="", help="'from:from2,from:from2,...' -- schedules to time instead of the built-in list")
 ap.add_argument("--only", default="", help="f32 | f16: one precision, default schedule only (profiling runs)")
 args = ap.parse_args()
 dev = "cuda"
@@ -31,7 +32,9 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
     d = d.to(dev)
     macs = d.handle(torch.device(dev)).macs
     scheds = [dict(spec_k=k) for k in args.spec]                              # the defaults (spec_k 4: second level 16 from spec_from + 4)
-    if not args.only:
+    if args.scan:
+        scheds = [dict(spec_k=4, spec_from=int(a.split(":")[0]), spec_from2=int(a.split(":")[1])) for a in args.scan.split(",")]
+    elif not args.only:
         scheds += [dict(spec_k=4, spec_k2=1), dict(spec_k=4, spec_k2=8), dict(spec_k=4, spec_from2=14), dict(spec_k=4, spec_from2=18),
                    dict(spec_k=4, spec_from=10, spec_from2=14), dict(spec_k=4, spec_from=16, spec_from2=20), dict(spec_k=4, tail_rows=2048),
                    dict(spec_k=4, tail_rows=8192), dict(spec_k=1, head_steps=args.steps, tail_rows=0), dict(spec_k=4, polish="exact")]

@@ -402,7 +402,10 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
     P.t_eps = eps; P.t_sigma = sigma; P.t_evals = evals; P.t_unresolved = counters + 3;
     P.t_spec_from = spec_from; P.t_spec_k = spec_k; P.t_spec_from2 = spec_from2; P.t_spec_k2 = spec_k2;
     auto launch_tail = [&](const MlpParams& T) {
-        if (half) sdfr_launch_tail_f16_512(T, n_max, spec_k, s); else sdfr_launch_tail_f32_512(T, n_max, spec_k, s);
+        // (a launch gated to counts below n_dev_hi needs workgroups for that many rays only: an empty 256-workgroup launch is cheaper to skip
+        // than an empty 4096-workgroup one, and the march enqueues one per head step)
+        const int64_t n_grid = n_max < (int64_t)T.n_dev_hi ? n_max : (int64_t)T.n_dev_hi;
+        if (half) sdfr_launch_tail_f16_512(T, n_grid, spec_k, s); else sdfr_launch_tail_f32_512(T, n_grid, spec_k, s);
     };
     // first stage: 16 rays per tile, from pass `step` (whichever step the device-side count picks) to the end of the budget or to spec_from2
     auto tail = [&](int step, int hi) {

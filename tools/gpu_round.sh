@@ -20,6 +20,8 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 # the same two passes at 64 crops per launch (splat / Jacobian in the throughput regime)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch64_$TAG -o pmc -- python $R/bench.py --crops-per-gpu 64 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_fetch64_$TAG.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write64_$TAG -o pmc -- python $R/bench.py --crops-per-gpu 64 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_write64_$TAG.log 2>&1
+# the sphere march: HBM bytes and matrix-pipe counters (three --pmc passes)
+bash $R/tools/sphere_pmc.sh $TAG > $O/pmcsph_$TAG.log 2>&1
 cd $R
 cat $O/pytest_$TAG.log | tail -3; tail -c 600 $O/bench_$TAG.json; tail -3 $O/bench_$TAG.err
 f=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -24 "$f"

@@ -100,3 +100,7 @@ for name in ("bench_%s.json" % tag,):
     if os.path.isfile(os.path.join(G, name)):
         shutil.copy(os.path.join(G, name), os.path.join(P, "%s_bench.json" % rnd))
 print("wrote profiles/%s_*" % rnd)
+
+sph = os.path.join(G, "pmc_sphere_%s.json" % tag)
+if os.path.isfile(sph):
+    shutil.copy(sph, os.path.join(P, "%s_pmc_sphere.json" % rnd))

@@ -278,7 +278,8 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
         }
         P.ln_ws = d->ln_ws;
         sdfr_launch_ln(P, d->HP, true, gx, B, s);
-    } else if (d->HP == 512 && mask_from_f16 == 2 && from_masks) sdfr_launch_jac_f16_512(P, cap, B, s);      // half operands, like the forward
+    } else if (d->HP == 512 && mask_from_f16 == 2 && from_masks && many_rows) sdfr_launch_jac_f16_512_many(P, cap, B, s);
+    else if (d->HP == 512 && mask_from_f16 == 2 && from_masks) sdfr_launch_jac_f16_512(P, cap, B, s);      // half operands, like the forward
     else if (d->HP == 512 && !from_masks && many_rows) sdfr_launch_jac_f32_512_recompute32(P, cap, B, s);
     else if (d->HP == 512) sdfr_launch_jac_f32_512(P, cap, B, from_masks, s);
     else sdfr_launch_small(P, d->HP, from_masks ? 3 : 2, sdfr_cdiv(cap, 32), B, s);

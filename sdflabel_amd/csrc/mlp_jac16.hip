@@ -16,6 +16,16 @@ void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s) 
     hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 1, SDFR_J16_NW, SDFR_J16_PF, 3>), grid, dim3(64 * SDFR_J16_NW), 0, s, P);
 }
 
+// The same backward on 32- / 64-row tiles (v_mfma_f32_32x32x16_f16, one or two 32-point tiles per workgroup): launches with many thousands of
+// selected rows (the sphere tracer's hit pass: 18 k - 73 k hits), where 16-row tiles pay the weight stream of a tile per 16 rows.
+#ifndef SDFR_J16_MANY_NP
+#define SDFR_J16_MANY_NP 2
+#endif
+void sdfr_launch_jac_f16_512_many(const MlpParams& P, int cap, int B, hipStream_t s) {
+    const dim3 grid(sdfr_cdiv(cap, 32 * SDFR_J16_MANY_NP), B);
+    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, SDFR_J16_MANY_NP, 8, 2, 3>), grid, dim3(512), 0, s, P);
+}
+
 // Forward with half operands on 16-row tiles (MODE 0): the thin steps of the sphere tracer's march with the float16 decoder -- one
 // decoder pass of latency per workgroup, paced by the 3.7 MB weight stream of a tile instead of the 128-point tile's matrix work.
 void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s) {

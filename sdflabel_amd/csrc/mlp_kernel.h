@@ -1108,6 +1108,7 @@ void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s);
 void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s);
 void sdfr_launch_fwd_f16_512_tile64(const MlpParams& P, int64_t n, hipStream_t s);                // mlp_jac16.hip (half forward on 64-row tiles: the march's middle steps)                // mlp_jac16.hip (half forward on 16-row tiles)
 void sdfr_launch_tail_f32_512(const MlpParams& P, int64_t n_rays, int spec_k, hipStream_t s);                      // mlp_jac.hip (MODE 4: sphere tracer's persistent tail)
+void sdfr_launch_jac_f16_512_many(const MlpParams& P, int cap, int B, hipStream_t s);                                     // mlp_jac16.hip (32x32 tiles: many rows)
 void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n_rays, int spec_k, hipStream_t s);                      // mlp_jac16.hip
 void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)
 void sdfr_launch_ln(const MlpParams& P, int HP, bool jac, int grid_x, int grid_y, hipStream_t s);        // mlp_ln.hip (LayerNorm decoders)

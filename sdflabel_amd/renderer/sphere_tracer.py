@@ -152,7 +152,7 @@ class SphereTracer:
                 ck(L.sdfr_mlp_forward_f16_counted(self.handle.h, P(self.rows), n, P(n_hits), P(self.sdf), P(self.mask_ws), st),
                    "sdfr_mlp_forward_f16_counted")
                 ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.rows), n, 1, P(self.idx), n, P(n_hits), P(self.J), P(self.f0), P(self.sdf),
-                                       P(self.mask_ws), 2, st), "sdfr_mlp_jacobian")
+                                       P(self.mask_ws), 2 | 16, st), "sdfr_mlp_jacobian")     # [SDFR_JAC_MANY_ROWS]: 64-row tiles
             else:
                 # exact-f32 decoder value and input Jacobian at the hits (recomputing kernel; rows beyond the device-side count are not touched)
                 ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.rows), n, 1, P(self.idx), n, P(n_hits), P(self.J), P(self.f0), None, None,

@@ -302,3 +302,35 @@ def test_half_operand_march_and_batches(dec):
             assert float((ref - g2.grad[i]).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max())), (g1.grad, g2.grad)
             other = g2.grad[1 - i]
             assert float(other.abs().max()) == 0.0                      # a crop's functional has no gradient in the other crop's parameters
+
+
+def test_half_hit_pass_tile_geometries_agree():
+    """the mask-fed half Jacobian at the hits on 64-row tiles (SDFR_JAC_MANY_ROWS, what the tracer launches for its thousands of hits) against
+    the band geometry's 16-row tiles on the same masks: the same in-gradients up to the summation order of half products"""
+    from sdflabel_amd import _lib
+    H = W = 128
+    d16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    tr = sdflabel_amd.SphereTracer(d16.to(DEV), K_for(H, W), (W, H), 1, steps=64, device=DEV)
+    tr.render(*_args())
+    n_hits = int(tr.counters[6])
+    assert tr.half_polish and n_hits > 3000
+    L_, P = _lib.lib(), _lib.ptr
+    n = H * W
+    J64, f64_ = tr.J[:n_hits].clone(), tr.f0[:n_hits].clone()
+    J16, f16_ = torch.zeros_like(tr.J), torch.zeros_like(tr.f0)
+    with _lib.guard(tr.dev):
+        _lib.check(L_.sdfr_mlp_jacobian(tr.handle.h, P(tr.rows), n, 1, P(tr.idx), n, P(tr.counters[6:7]), P(J16), P(f16_), P(tr.sdf), P(tr.mask_ws), 2,
+                                        _lib.stream_ptr()), "sdfr_mlp_jacobian")
+    assert torch.equal(f16_[:n_hits], f64_)                                      # the value is the forward's
+    scale = float(J16[:n_hits].abs().max())
+    assert float((J16[:n_hits] - J64).abs().max()) < 4e-3 * scale and float((J16[:n_hits] - J64).abs().mean()) < 2e-4 * scale
+    # ... and against the exact-f32 Jacobian at the same rows: half precision
+    Jx, fx = torch.zeros_like(tr.J), torch.zeros_like(tr.f0)
+    with _lib.guard(tr.dev):
+        _lib.check(L_.sdfr_mlp_jacobian(tr.handle.h, P(tr.rows), n, 1, P(tr.idx), n, P(tr.counters[6:7]), P(Jx), P(fx), None, None, 0, _lib.stream_ptr()),
+                   "sdfr_mlp_jacobian")
+    # (a handful of hits sit next to a ReLU kink of some hidden unit: the half pre-activation has the other sign there and the Jacobian jumps)
+    dj = (Jx[:n_hits] - J64).abs().amax(1)
+    assert float(torch.quantile(dj, 0.99)) < 3e-2 * scale and float(dj.median()) < 1e-3 * scale and float(dj.mean()) < 3e-3 * scale and float(dj.max()) < 0.3 * scale, \
+        (float(torch.quantile(dj, 0.99)), float(dj.mean()), float(dj.max()), scale)
+    assert float((fx[:n_hits] - f64_).abs().max()) < 5e-3

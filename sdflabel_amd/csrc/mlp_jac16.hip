@@ -10,20 +10,35 @@
 #define SDFR_J16_FT 4
 #define SDFR_J16_NW 8
 #endif
+#ifndef SDFR_J16_SWITCH_CROPS
+#define SDFR_J16_SWITCH_CROPS 2       // 64-row tiles from this many crops per launch (tools/jac16_time.py, us per launch, 16-row / 64-row tiles:
+#endif                                // 1 crop 50 / 81, 2 crops 97 / 80, 4: 144 / 81, 8: 287 / 157, 64: 2148 / 1090)
+void sdfr_launch_jac_f16_512_many(const MlpParams& P, int cap, int B, hipStream_t s);
 void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s) {
     static_assert(16 * SDFR_J16_FT * SDFR_J16_NW == 512, "padded width 512 = 16 * FT * NW");
+    if (B >= SDFR_J16_SWITCH_CROPS) { sdfr_launch_jac_f16_512_many(P, cap, B, s); return; }
     const dim3 grid(sdfr_cdiv(cap, 16), B);
     hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 1, SDFR_J16_NW, SDFR_J16_PF, 3>), grid, dim3(64 * SDFR_J16_NW), 0, s, P);
 }
 
-// The same backward on 32- / 64-row tiles (v_mfma_f32_32x32x16_f16, one or two 32-point tiles per workgroup): launches with many thousands of
-// selected rows (the sphere tracer's hit pass: 18 k - 73 k hits), where 16-row tiles pay the weight stream of a tile per 16 rows.
+// The same backward on 64-row tiles (v_mfma_f32_32x32x16_f16, two 32-point tiles per workgroup): launches with many thousands of selected
+// rows (two or more crops' bands; the sphere tracer's hit pass: 18 k - 73 k hits), where 16-row tiles pay the weight stream of a tile per 16
+// rows.  One 32-point tile per workgroup (-DSDFR_J16_MANY_NP=1) measured 59 / 61 / 118 / 177 / 1340 us at 1 / 2 / 4 / 8 / 64 crops.
 #ifndef SDFR_J16_MANY_NP
 #define SDFR_J16_MANY_NP 2
 #endif
+#ifndef SDFR_J16_MANY_PF
+#define SDFR_J16_MANY_PF 2
+#endif
 void sdfr_launch_jac_f16_512_many(const MlpParams& P, int cap, int B, hipStream_t s) {
     const dim3 grid(sdfr_cdiv(cap, 32 * SDFR_J16_MANY_NP), B);
+#ifdef SDFR_J16_MANY_32
     hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, SDFR_J16_MANY_NP, 8, 2, 3>), grid, dim3(512), 0, s, P);
+#else
+    // 16x16x32 products like the 16-row kernel -- every in-gradient is accumulated in the same order, so a crop's Jacobian has the same bits
+    // whichever geometry the launch picked (batch-independent results) -- on 2 * NP point tiles of 16 per workgroup
+    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 2 * SDFR_J16_MANY_NP, SDFR_J16_NW, SDFR_J16_MANY_PF, 3>), grid, dim3(64 * SDFR_J16_NW), 0, s, P);
+#endif
 }
 
 // Forward with half operands on 16-row tiles (MODE 0): the thin steps of the sphere tracer's march with the float16 decoder -- one

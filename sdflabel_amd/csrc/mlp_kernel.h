@@ -1027,10 +1027,12 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             // which one wave would do alone on the matrix pipe, K tile after K tile (20 k cycles of exposed latency).  Here every thread
             // takes one point and HP / (NT / PT) features on the VALU, and the partial sums are added in a fixed order.
             // Partition of the HP in-gradients of a point into PARTS contiguous blocks summed in order, then the blocks in order: for the
-            // 512-wide Jacobian variants the partition is fixed at 16 blocks whatever the workgroup shape (threads per point TPP = 16 or 8),
-            // so that all of them round identically.
+            // 512-wide Jacobian variants the partition is fixed whatever the workgroup shape -- 16 blocks for the float32 kernels (threads per
+            // point TPP = 16 or 8), 32 for the half ones (TPP = 32 on 16-row tiles, 8 on 64-row tiles) -- so that the tile geometries of one
+            // precision round identically.
             constexpr int TPP = NT / PT;
-            constexpr int PARTS = (HP == 512 && TPP < 16) ? 16 : TPP, PPT = PARTS / TPP, JS = HP / PARTS;
+            constexpr int PMIN = (HP == 512) ? (HALF ? 32 : 16) : 1;
+            constexpr int PARTS = (TPP < PMIN) ? PMIN : TPP, PPT = PARTS / TPP, JS = HP / PARTS;
             static_assert(NT % PT == 0 && HP % PARTS == 0 && PARTS % TPP == 0 && 8 * PT <= NT && PARTS * 8 * PT * 4 <= KG * PT * 16,
                           "first-layer reduction scratch fits the operand tile");
             const int pt = tid % PT, t0 = tid / PT;

@@ -8,6 +8,7 @@ dev = "cuda"
 dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16); dec = dec.to(dev)
 L = sdflabel_amd._lib.lib(); P = sdflabel_amd._lib.ptr
 out = []
+FLAG = int(os.environ.get("SDFR_JAC_FLAG", "2"))     # 2: half backward on 16-row tiles; 18 (= 2 | SDFR_JAC_MANY_ROWS): 32x32 tiles
 for B in [int(a) for a in sys.argv[1:]] or [1]:
     br = sdflabel_amd.BatchRenderer(dec, 40, K_for(64, 64), (64, 64), B, device=dev)
     g = torch.Generator().manual_seed(1)
@@ -15,7 +16,7 @@ for B in [int(a) for a in sys.argv[1:]] or [1]:
     br.set_params(torch.full((B,), 0.7, device=dev), torch.tensor([[0.05, 0.02, 3.3]], device=dev).expand(B, 3), lat.to(dev))
     br.forward(); torch.cuda.synchronize()
     def jac():
-        L.sdfr_mlp_jacobian(br.handle.h, P(br.inputs), br.G, B, P(br.idx), br.cap, P(br.cnt), P(br.J), P(br.sdf_band), P(br.sdf), P(br.mask_ws), 2,
+        L.sdfr_mlp_jacobian(br.handle.h, P(br.inputs), br.G, B, P(br.idx), br.cap, P(br.cnt), P(br.J), P(br.sdf_band), P(br.sdf), P(br.mask_ws), FLAG,
                             sdflabel_amd._lib.stream_ptr())
     for _ in range(3): jac()
     n = 50 if B < 16 else 10
@@ -28,4 +29,4 @@ for B in [int(a) for a in sys.argv[1:]] or [1]:
     cs = float(sum(br.J[b, :int(br.cnt[b])].double().sum() for b in range(B)))
     out.append("B=%d: %.1f us (%.1f us/crop) checksum %.8g" % (B, min(ts), min(ts) / B, cs))
     del br
-print(os.path.basename(os.environ.get("SDFR_LIB", "default")), " | ".join(out))
+print(os.path.basename(os.environ.get("SDFR_LIB", "default")), "flag", FLAG, " | ".join(out))

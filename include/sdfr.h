@@ -353,6 +353,8 @@ int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int
  * spec_k = 4: from pass index spec_from on a pass evaluates four samples per ray (p_0 = lam, p_j = p_{j-1} + sigma q^j rho / |d|) and accepts
  * the prefix in which every sample lies inside the previous one's safe sphere -- a valid sphere-tracing sequence, nothing skipped; the pass
  * index alone decides (head_steps is clamped to spec_from), so a ray's samples do not depend on the launch schedule.  spec_k = 1: plain.
+ * Decoders with LayerNorm or a hidden width below 257 march with per-step launches of their own float32 forward kernels (plain tracing, no
+ * looping kernel; half must be 0).
  * spec_k2 = 8 or 16 from pass index spec_from2 > spec_from on (off: spec_k2 <= spec_k): at that pass the looping kernel's survivors -- a few
  * hundred creeping rays scattered over the tiles -- are re-packed 64 / spec_k2 to a tile by a second launch (list pix2 / lam2, counters[7])
  * and take spec_k2 samples per pass: fewer, equally long passes for the rays that end the march.

@@ -379,10 +379,29 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
     float4* lam2 = reinterpret_cast<float4*>(lam2_);
     SDFR_REQUIRE(B > 0 && W > 0 && H > 0 && steps > 0 && head_steps >= 0 && tail_rows >= 0, "sdfr_trace_march: bad size");
     SDFR_REQUIRE(spec_k == 1 || spec_k == 4, "sdfr_trace_march: spec_k = %d (1: plain tracing, 4: four samples per ray and pass)", spec_k);
-    SDFR_REQUIRE(d->HP == 512 && !d->has_ln && d->n_inputs == L + 3, "sdfr_trace_march: 512-wide decoder without LayerNorm, L + 3 inputs");
+    SDFR_REQUIRE(d->n_inputs == L + 3, "sdfr_trace_march: decoder with L + 3 = %d inputs expected, it has %d", L + 3, d->n_inputs);
     const int64_t n_max = (int64_t)B * W * H;
     SDFR_REQUIRE(n_max < (int64_t)1 << 31, "sdfr_trace_march: too many rays");
     hipStream_t s = (hipStream_t)stream;
+    if (d->HP != 512 || d->has_ln) {
+        // LayerNorm decoders and hidden widths below 257: the looping kernel (MODE 4) is built for the 512-wide weight-norm / plain decoders
+        // only; these march with per-step launches of their own forward kernels (device-side count, float32, plain sphere tracing -- the
+        // oracle's arithmetic with spec_k = 1), all `steps` of them: correct, not tuned
+        SDFR_REQUIRE(!half, "sdfr_trace_march: half operands need a 512-wide decoder without LayerNorm");
+        unsigned long long* evals_ = reinterpret_cast<unsigned long long*>(counters + 4);
+        for (int step = 0; step < steps; ++step) {
+            int rc = sdfr_mlp_forward_counted(d, inputs, n_max, counters + step % 3, sdf, 0, stream);
+            if (rc != SDFR_OK) return rc;
+            const int a = step & 1;
+            hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, eps, sdf,
+                               counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? pix1 : pix0,
+                               a ? reinterpret_cast<float4*>(lam1_) : reinterpret_cast<float4*>(lam0_), a ? pix0 : pix1,
+                               a ? reinterpret_cast<float4*>(lam0_) : reinterpret_cast<float4*>(lam1_), far, inputs, hit_lam, hit_sdf, 1, evals_);
+        }
+        hipLaunchKernelGGL(sdfr_trace_leftover_kernel, dim3(1), dim3(64), 0, s, counters + steps % 3, counters + 3);
+        SDFR_LAUNCH_CHECK();
+        return SDFR_OK;
+    }
     if (spec_k == 1) spec_from = 0x7fffffff;
     if (spec_from < 0) spec_from = 0;
     // second speculation level (spec_k2 = 8 or 16 samples per pass from pass spec_from2 >= spec_from on): a second stage of the looping kernel

@@ -71,6 +71,12 @@ class SphereTracer:
         # the previous one's safe sphere).  Default 4 (with the second level below; one 256x256 crop, fwd+bwd: float16 3.76 -> 2.55 ms incl.
         # the half hit pass, float32 20.1 -> 18.5 ms); 1 = plain sphere tracing.
         self.spec_k = int(spec_k) if spec_k is not None else 4
+        # LayerNorm decoders and hidden widths below 257 march with per-step launches of their own forward kernels: float32, plain tracing
+        self.generic_march = bool(self.handle.has_ln or self.handle.hp != 512)
+        if self.generic_march:
+            if self.half:
+                raise _lib.SdfrError("SphereTracer: the float16 march needs a 512-wide decoder without LayerNorm")
+            self.spec_k, spec_k2 = 1, 1
         self.spec_from, self.sigma = int(spec_from), float(sigma)
         if self.spec_k not in (1, 4):
             raise ValueError("spec_k must be 1 or 4")

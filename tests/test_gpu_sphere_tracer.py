@@ -132,6 +132,39 @@ def test_march_against_the_oracle_on_the_second_decoder():
     assert np.median(dn) < 1e-6 and (dn > 1e-4).sum() <= 3
 
 
+def test_march_with_a_layernorm_decoder():
+    """the reference's LayerNorm decoder variant (weight_norm=False; the ellipsoid fit): no looping kernel for it -- per-step launches of its own
+    forward kernel, plain tracing -- same oracle, same tolerances"""
+    from sdflabel_amd.fixtures import ASSET_ELLIPSOID_LN
+    d, _ = sdflabel_amd.setup_dsdf(ASSET_ELLIPSOID_LN + ".pt", precision=torch.float32)
+    d = d.to(DEV)
+    st, spec = fitted_state(ASSET_ELLIPSOID_LN)
+    layers = O.decoder_layers_from_state(st, spec)
+    H, W = 64, 80
+    K = K_for(H, W)
+    tr = sdflabel_amd.SphereTracer(d, K, (W, H), 1, steps=64, device=DEV)
+    assert tr.generic_march and tr.spec_k == 1
+    a = _args(grad=True)
+    out = tr(*a)
+    ys, xs = np.meshgrid(np.arange(0, H, 2), np.arange(0, W, 2), indexing="ij")
+    px = np.stack([xs.reshape(-1), ys.reshape(-1)], 1)
+    lat = np.asarray(LAT[0], np.float32)
+    latn = lat / np.sqrt((lat * lat).sum())
+    ref = O.sphere_trace(layers, spec, latn, O.render_pose(YAW[0], TRANS[0]), np.linalg.inv(K).astype(np.float32), px, steps=64)
+    sel = (px[:, 1], px[:, 0])
+    hit = N(out["mask"][0, 0])[sel] > 0
+    safe = ref["margin"] > 1e-4
+    assert ref["hit"].sum() > 100 and safe.mean() > 0.9
+    assert np.array_equal(hit[safe], ref["hit"][safe])
+    good = safe & ref["hit"] & hit & ref["ok"]
+    assert good.sum() > 80
+    assert np.abs(N(out["depth"][0, 0])[sel] - ref["depth"])[good].max() < 1e-4
+    assert np.abs(N(out["color"][0])[:, sel[0], sel[1]].T - ref["color"])[good].max() < 1e-4
+    # gradients flow (finite, non-zero) through the LayerNorm decoder's recomputing Jacobian
+    (out["depth"].sum() + out["color"].sum()).backward()
+    assert all(bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0 for t in a)
+
+
 def dn_all(nrm, ref):
     return np.abs(nrm - ref["normals"]).max(1)
 

@@ -120,34 +120,49 @@ def check(rc, what):
 
 
 def ptr(t):
-    """device (or host) pointer of a torch tensor / None"""
-    return None if t is None else c_void_p(t.data_ptr())
+    """device (or host) pointer of a torch tensor / None (a plain int: ctypes converts it for the c_void_p parameters)"""
+    return None if t is None else t.data_ptr()
 
 
 def stream_ptr():
     """the current stream of the CURRENT device: call it inside `with guard(tensor):` so that device is the tensors' one"""
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
 
 
 def guard(t):
     """Context manager making the device of tensor (or torch.device) `t` current, as every kernel launch needs: the launch stream
     (stream_ptr) and any allocation inside the library then belong to the device that holds the data, whatever the caller's current
-    device is (the reference works on any device the tensors live on)."""
+    device is (the reference works on any device the tensors live on).  Nothing to do when that device is current already."""
     import torch
     dev = t.device if hasattr(t, "device") else torch.device(t)
+    if dev.type == "cuda" and (dev.index is None or dev.index == torch._C._cuda_getDevice()):
+        return _NO_GUARD
     return torch.cuda.device(dev)
 
 
 def traced(name):
-    """decorator: run the function inside torch.profiler.record_function('sdfr::<name>') -- a no-op unless a profiler is active; bench.py's
-    dropin_api section uses the ranges to tell the library's launches from the caller's own torch ops"""
+    """decorator: run the function inside torch.profiler.record_function('sdfr::<name>') while a profiler is active (bench.py's dropin_api
+    section uses the ranges to tell the library's launches from the caller's own torch ops); a plain call otherwise"""
     import functools
 
     def deco(fn):
         @functools.wraps(fn)
         def wrapped(*a, **k):
             import torch
+            if not torch.autograd._profiler_enabled():
+                return fn(*a, **k)
             with torch.profiler.record_function("sdfr::" + name):
                 return fn(*a, **k)
         return wrapped

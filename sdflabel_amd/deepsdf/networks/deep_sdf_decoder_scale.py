@@ -41,6 +41,7 @@ class _DecoderHandle:
         self.h = h
         self.n_inputs = n_inputs
         self.macs = int(L.sdfr_decoder_macs(h))
+        self.mask_words = {}                                    # rows -> sdfr_decoder_mask_words (cached per size)
         width = max(max(int(W.shape[0]) for W, _ in layers[:-1]), max(int(W.shape[1]) for W, _ in layers))
         self.hp = 128 if width <= 128 else (256 if width <= 256 else 512)       # padded hidden width the kernels were built for
         self._keep = None
@@ -125,7 +126,9 @@ class _DeepSDFFn(torch.autograd.Function):
         L = _lib.lib()
         sdf = torch.empty((state.G, 1), dtype=torch.float32, device=inputs.device)
         if not state.handle.has_ln:
-            nw = int(L.sdfr_decoder_mask_words(state.handle.h, state.G))
+            nw = state.handle.mask_words.get(state.G)
+            if nw is None:
+                nw = state.handle.mask_words[state.G] = int(L.sdfr_decoder_mask_words(state.handle.h, state.G))
             state.mask_ws = torch.empty((nw,), dtype=torch.int32, device=inputs.device)
         fwd = L.sdfr_mlp_forward_f16 if state.f16 else (L.sdfr_mlp_forward_split if state.split else L.sdfr_mlp_forward)
         with _lib.guard(inputs):
@@ -261,8 +264,27 @@ class Decoder(nn.Module):
                 inj.append((0, 0))
         return inj
 
+    def _params_two_levels(self):
+        """this module's parameters by direct dictionary access (lin*, bn* and the Linear layers of scale_net: two levels) -- what
+        self.parameters() yields, without its recursive named_modules walk (40 us per forward); None if the tree is deeper than that"""
+        out = []
+        for m in self._modules.values():
+            if m is None:
+                continue
+            out.extend(m._parameters.values())
+            for mm in m._modules.values():
+                if mm is None:
+                    continue
+                if mm._modules:
+                    return None
+                out.extend(mm._parameters.values())
+        return out
+
     def _param_key(self, device):
-        return (str(device),) + tuple((id(p), p._version) for p in self.parameters())
+        ps = self._params_two_levels()
+        if ps is None:
+            ps = self.parameters()
+        return (device.type, device.index) + tuple((id(p), p._version) for p in ps if p is not None)
 
     def handle(self, device):
         key = self._param_key(device)
@@ -275,6 +297,15 @@ class Decoder(nn.Module):
                                           device.index if device.index is not None else torch.cuda.current_device(), ln)
             self._handle_key = key
         return self._handle
+
+    def _scale_net_fused(self, device):
+        """the one-launch scale head needs float32, contiguous parameters on the input's device (checked once per parameter set)"""
+        ps = [p for m in self.scale_net._modules.values() for p in m._parameters.values() if p is not None]
+        key = (device.type, device.index) + tuple((id(p), p._version) for p in ps)
+        if getattr(self, "_scale_key", None) != key:
+            self._scale_ok = all(p.dtype == torch.float32 and p.is_contiguous() and p.device == device for p in self.scale_net.parameters())
+            self._scale_key = key
+        return self._scale_ok
 
     # input: N x (L+3)
     @_lib.traced("Decoder.forward")
@@ -296,7 +327,7 @@ class Decoder(nn.Module):
         lat = x32[:, :-3]
         if self.samples_per_scene:
             scale = self.scale_net(lat.view(-1, self.samples_per_scene, lat.size(1))[:, 0, :])
-        elif all(p.dtype == torch.float32 and p.is_contiguous() and p.device == x32.device for p in self.scale_net.parameters()):
+        elif self._scale_net_fused(x32.device):
             scale = _ScaleNetFn.apply(lat[0], self.scale_net)          # one launch; frozen weights as everywhere on this path
         else:
             scale = self.scale_net(lat[0])

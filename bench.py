@@ -593,6 +593,17 @@ def main():
                                  "roofline_march": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
                                                     "flops": 2.0 * macs * st3["ray_evaluations"]},
                                  "max_abs_sdf_at_marched_hits": float(tr.hit_residual.abs().max())}
+                # the advance / compaction kernel of the head steps against the HBM roofline: algorithmic bytes per active ray and step (read: pixel 4,
+                # state 16, sdf 4, far 4; written for a surviving ray: pixel 4, state 16, decoder row 4 (L + 3)) and, from the PMC passes of an
+                # earlier run of tools/sphere_pmc.sh (not measured in this run), the counter bytes and rate per launch
+                sps = os.path.join(ROOT, "profiles", "traffic_sphere_step.json")
+                if label == "f16_64_steps" and os.path.isfile(sps):
+                    tj = json.load(open(sps))
+                    sphere[label]["step_kernel_hbm"] = {"bound": "hbm", "algorithmic_bytes_per_ray_step": 28 + 20 + 4 * (tr.L + 3),
+                                                        "achieved": tj.get("GBps"), "peak": 8000.0, "unit": "GB/s",
+                                                        "frac": (tj.get("GBps") or 0.0) / 8000.0, "traffic": tj.get("hbm_bytes_per_launch"),
+                                                        "duration_us": tj.get("duration_us"),
+                                                        "traffic_source": "profiles/traffic_sphere_step.json (PMC passes of an earlier run; a 13 us launch: latency-, not bandwidth-bound)"}
                 del tr, d3
             except Exception as e:
                 sphere[label] = {"error": repr(e)[:200]}

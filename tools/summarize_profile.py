@@ -104,3 +104,11 @@ print("wrote profiles/%s_*" % rnd)
 sph = os.path.join(G, "pmc_sphere_%s.json" % tag)
 if os.path.isfile(sph):
     shutil.copy(sph, os.path.join(P, "%s_pmc_sphere.json" % rnd))
+    ks = json.load(open(sph))["kernels"]
+    st = ks.get("sdfr_trace_step_kernel")
+    if st and "hbm_bytes_per_launch" in st:
+        # the march's advance / compaction kernel against the HBM roofline (read by bench.py: sphere_trace.*.step_kernel_hbm)
+        json.dump({"source": "%s_pmc_sphere.json" % rnd, "what": "sdfr_trace_step_kernel, one 256x256 crop, float16 march: HBM bytes (2*FETCH_SIZE + WRITE_SIZE) "
+                   "and duration per launch, means over the launches of the march (the active count shrinks from 65 k rays to a few thousand)",
+                   "hbm_bytes_per_launch": st["hbm_bytes_per_launch"], "duration_us": st.get("duration_us_fetch_mean"), "GBps": st.get("hbm_GBps")},
+                  open(os.path.join(P, "traffic_sphere_step.json"), "w"), indent=1)

@@ -18,4 +18,4 @@ torch.cuda.synchronize(); print("ms/step", (time.perf_counter()-t)/20*1e3)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(20): bench.crop_iteration(dec, grid, renderer, crop)
 torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22); print(s.getvalue()[:3500])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(48); print(s.getvalue()[:9000])

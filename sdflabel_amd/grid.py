@@ -6,16 +6,11 @@ Same interface: Grid3D(density, device, precision), .points (leaf, requires_grad
 by sdfr_mlp_jacobian for the band rows only; for any other differentiable SDF they come from torch.autograd.grad.  Band selection,
 compaction and projection run in sdflabel_amd/csrc/surface.hip.
 """
-import os
-
 import numpy as np
 import torch
 
 from . import _lib
 from .deepsdf.networks.deep_sdf_decoder_scale import mlp_jacobian, sdf_state_of
-
-
-_DEFER = os.environ.get("SDFR_NO_DEFER", "") == ""      # (A/B switch of tools/prof_dropin.py: queue the band kernels ahead of the host read of N)
 
 
 class _SurfaceFn(torch.autograd.Function):
@@ -28,16 +23,9 @@ class _SurfaceFn(torch.autograd.Function):
         G = sdf.shape[0]
         ctx.dtypes = (sdf.dtype, gridpoints.dtype)
         sdf = sdf_vals
-        pre = getattr(state, "surface_pre", None) if state is not None else None
-        if pre is not None:
-            # get_surface_points queued the projection ahead of its host read of N (device-side count, capacity-sized slab): narrow it
-            state.surface_pre = None
-            slab = pre
-            pts, nocs, nrm = slab[0][:n], slab[1][:n], slab[2][:n]
-        else:
-            slab = torch.empty((3, n, 3), dtype=torch.float32, device=dev)
-            pts, nocs, nrm = slab[0], slab[1], slab[2]
-        if n > 0 and pre is None:
+        slab = torch.empty((3, n, 3), dtype=torch.float32, device=dev)
+        pts, nocs, nrm = slab[0], slab[1], slab[2]
+        if n > 0:
             with _lib.guard(sdf):
                 _lib.check(L.sdfr_surface_project(_lib.ptr(xyz_src), xyz_stride, _lib.ptr(sdf), G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
                                                   Jstride, Joff, _lib.ptr(pts), _lib.ptr(nocs), _lib.ptr(nrm), _lib.stream_ptr()),
@@ -74,9 +62,9 @@ class _SurfaceFn(torch.autograd.Function):
         return g_sdf, g_xyz, None, None, None, None, None, None, None, None, None
 
 
-def band_select(sdf_flat, threshold, want_slot=True, defer=False):
+def band_select(sdf_flat, threshold, want_slot=True):
     """(idx int32 (N,), N, slot int32 (G,)) -- ascending rows with |sdf| < threshold.  One host sync for N (the reference's
-    masked_select, grid.py:65, synchronises as well).  defer: return the device count tensor instead of N (the caller reads it later)."""
+    masked_select, grid.py:65, synchronises as well)."""
     L = _lib.lib()
     G = sdf_flat.shape[0]
     dev = sdf_flat.device
@@ -87,8 +75,6 @@ def band_select(sdf_flat, threshold, want_slot=True, defer=False):
     with _lib.guard(sdf_flat):
         _lib.check(L.sdfr_band_select(_lib.ptr(sdf_flat), G, 1, float(threshold), _lib.ptr(idx), G, _lib.ptr(cnt), _lib.ptr(slot),
                                       _lib.ptr(scratch), _lib.stream_ptr()), "sdfr_band_select")
-    if defer:
-        return idx, cnt, slot
     n = int(cnt.item())
     return idx, n, slot
 
@@ -96,7 +82,6 @@ def band_select(sdf_flat, threshold, want_slot=True, defer=False):
 class Grid3D:
     def __init__(self, density=30, device='cpu', precision=torch.float32):
         self.points = self.generate_point_grid(density).to(device, precision).requires_grad_(True)
-        self._band_hint = 0          # capacity for the launches get_surface_points queues ahead of its host read of N (0: first call)
 
     def generate_point_grid(self, grid_density):
         """Staggered grid, z fastest; every odd flat index is shifted by 1/D in x and y (reference grid.py:22-41)."""
@@ -118,39 +103,7 @@ class Grid3D:
         fused = state is not None and state.G == self.points.shape[0] and state.sdf is not None
         # float32 values for the kernels: the decoder's own output when available (a half `pred_sdf_grid` is a rounded copy of it)
         sdf_c = state.sdf if fused else pred_sdf_grid.detach().float().contiguous().view(-1)
-        cap = self._band_hint if (fused and _DEFER) else 0
-        if cap > 0:
-            # Everything that follows the band selection is queued BEFORE the host reads N, with the device-side count and a capacity taken
-            # from this grid's previous calls: the launches (and this code) run while the GPU is still busy with the decoder pass, instead of
-            # after the pipeline has drained.  N above the capacity (the band grew by more than a quarter): the ordinary path below redoes it.
-            L = _lib.lib()
-            idx, cnt, slot = band_select(sdf_c, threshold, defer=True)
-            NI = state.inputs.shape[1]
-            dev = sdf_c.device
-            Jc = torch.empty((cap, NI), dtype=torch.float32, device=dev)
-            sel = torch.empty((cap,), dtype=torch.float32, device=dev)
-            slab = torch.empty((3, cap, 3), dtype=torch.float32, device=dev)
-            um = state.mask_ws is not None
-            with _lib.guard(sdf_c):
-                st_ = _lib.stream_ptr()
-                _lib.check(L.sdfr_mlp_jacobian(state.handle.h, _lib.ptr(state.inputs), state.G, 1, _lib.ptr(idx), cap, _lib.ptr(cnt), _lib.ptr(Jc),
-                                               _lib.ptr(sel), _lib.ptr(state.sdf) if um else None, _lib.ptr(state.mask_ws) if um else None,
-                                               (2 if state.f16 else 0) if um else 0, st_), "sdfr_mlp_jacobian")
-                _lib.check(L.sdfr_surface_project(_lib.ptr(state.inputs) + 4 * (NI - 3), NI, _lib.ptr(sdf_c), state.G, 1, _lib.ptr(idx), cap,
-                                                  _lib.ptr(cnt), _lib.ptr(Jc), NI, NI - 3, _lib.ptr(slab[0]), _lib.ptr(slab[1]), _lib.ptr(slab[2]),
-                                                  st_), "sdfr_surface_project")
-            n = int(cnt.item())
-            self._band_hint = max(1024, n + n // 4 + 256)
-            if n <= cap:
-                J = Jc[:n]
-                state.idx, state.slot, state.J, state.cap = idx, slot, J, max(n, 1)
-                state.surface_pre = slab
-                out = _SurfaceFn.apply(pred_sdf_grid, self.points, sdf_c, state.inputs[:, NI - 3:], NI, idx, n, J, NI, NI - 3, state)
-                return out if out_dtype == torch.float32 else tuple(t.to(out_dtype) for t in out)
-        else:
-            idx, n, slot = band_select(sdf_c, threshold)
-            if fused:
-                self._band_hint = max(1024, n + n // 4 + 256)
+        idx, n, slot = band_select(sdf_c, threshold)
 
         def narrow(ts):
             return ts if out_dtype == torch.float32 else tuple(t.to(out_dtype) for t in ts)

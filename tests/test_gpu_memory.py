@@ -2,7 +2,6 @@
 per-iteration buffer without the help of Python's cycle collector (a cycle through a tensor's C++ base pointer is invisible to it)."""
 import gc
 
-import numpy as np
 import pytest
 import torch
 

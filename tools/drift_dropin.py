@@ -1,7 +1,7 @@
 """ms per drop-in crop-iteration, event-timed decoder kernel and allocated device memory per block of 100 iterations (development aid: a leak
 or a slow drift shows up here, not in a 20-step timing)."""
-import sys, time, gc
-sys.path.insert(0, "/root/repo")
+import os, sys, time, gc
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench, sdflabel_amd
 from sdflabel_amd.fixtures import ASSET

@@ -556,7 +556,8 @@ def main():
         for label, prec, steps, spec_k, polish in (("f32_64_steps", torch.float32, 64, None, None), ("f16_64_steps", torch.float16, 64, None, None),
                                                    ("f16_64_steps_exact_polish", torch.float16, 64, None, "exact"),
                                                    ("f16_64_steps_plain", torch.float16, 64, 1, None), ("f32_64_steps_plain", torch.float32, 64, 1, None),
-                                                   ("f16_128_steps", torch.float16, 128, None, None)):
+                                                   ("f16_128_steps", torch.float16, 128, None, None),          # (configs[1]'s step budget)
+                                                   ("f16_256_steps", torch.float16, 256, None, None)):         # (configs[4]'s; with --crop-size 512 its ray count)
             try:
                 d3, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
                 tr = sdflabel_amd.SphereTracer(d3.to(dev), K_for(H, W), (W, H), 1, steps=steps, device=dev, spec_k=spec_k, polish=polish)

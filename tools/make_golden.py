@@ -974,7 +974,9 @@ def g11g():
 def g14p():
     """the secondary configurations in the cropped camera regime: primitives 'circle' (with and without a background image) and the quaternion
     pose path with the disc primitive, crop intrinsics of case a at ~48x64 rays, D = 20 surfels: images + autograd gradients w.r.t. the surfel
-    positions and the pose (the weights of the functional vanish on pixels that hold a pair within 1e-5 of a disc-edge / |n.ray| threshold)"""
+    positions and the pose (the weights of the functional vanish on pixels that hold a pair within 1e-5 of a disc-edge / |n.ray| threshold).
+    ('circle_opt' is not part of it: with these intrinsics the reference itself raises -- "numel: integer multiplication overflow" from the
+    torch.sparse.FloatTensor it builds at primitives.py:135 -- so there is nothing to pin.)"""
     dec = load_fitted()[0]
     c = G14_CASES["a"]
     (H, W), K, bbox = kitti_crop_intrinsics(c["K_full"], c["yaw"], list(c["trans"]), 48 * 64)

@@ -51,6 +51,17 @@ class _TraceFn(torch.autograd.Function):
         return None, g[0].clone(), g[1].clone(), g[2].clone()
 
 
+def default_spec_from(rays_per_crop, half):
+    """first speculative pass of the default schedule.  Where the speculative passes pay depends on how many rays are still marching at that
+    pass: K samples per ray cost K rows, and only once a pass is latency-bound (few tiles) are they free.  Measured optimum
+    (tools/sphere_time.py --scan, one crop): 128x128 rays 8, 256x256 10, 512x512 13-14 (float16) / 18 (float32, whose 64-row passes are
+    matrix-bound) -- a function of the crop's ray count alone, fixed at construction, so the pass index still decides."""
+    import math
+    r = math.log2(max(int(rays_per_crop), 1) / 65536.0)
+    s = 10 + (round((1.5 if half else 4.0) * r) if r >= 0 else round(r))
+    return max(4, min(s, 24))
+
+
 class SphereTracer:
     def __init__(self, decoder, K, resolution_px, batch=1, steps=64, eps=2e-3, bound=1.0, near=1e-3, device="cuda", head_steps=None,
                  tail_rows=4096, spec_from=None, spec_k=None, sigma=0.9, spec_from2=None, spec_k2=None, polish=None):
@@ -78,14 +89,7 @@ class SphereTracer:
                 raise _lib.SdfrError("SphereTracer: the float16 march needs a 512-wide decoder without LayerNorm")
             self.spec_k, spec_k2 = 1, 1
         if spec_from is None:
-            # where the speculative passes pay depends on how many rays are still marching at that pass: K samples per ray cost K rows, and only
-            # once a pass is latency-bound (few tiles) are they free.  Measured optimum (tools/sphere_time.py --scan, one crop): 128x128 rays 8,
-            # 256x256 10, 512x512 14 (float16) / 18 (float32, whose 64-row passes are matrix-bound) -- a function of the crop's ray count alone, fixed
-            # at construction, so the pass index still decides.
-            import math
-            r = math.log2(max(self.W * self.H, 1) / 65536.0)           # (per crop, not per batch: a crop renders the same alone or in a batch)
-            spec_from = 10 + (round((1.5 if self.half else 4.0) * r) if r >= 0 else round(r))
-            spec_from = max(4, min(spec_from, 24))
+            spec_from = default_spec_from(self.W * self.H, bool(self.half))   # (per crop, not per batch: a crop renders the same alone or in a batch)
         self.spec_from, self.sigma = int(spec_from), float(sigma)
         if self.spec_k not in (1, 4):
             raise ValueError("spec_k must be 1 or 4")

@@ -158,3 +158,11 @@ def test_public_header_is_strict_c_and_cxx(tmp_path, compiler, std, ext):
     r = subprocess.run([compiler, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_sphere_tracer_default_schedule_is_a_function_of_the_crop_size_alone():
+    """host logic of the sphere-tracing mode: the first speculative pass of the default schedule (measured optima per crop size)"""
+    from sdflabel_amd.renderer.sphere_tracer import default_spec_from
+    assert [default_spec_from(n * n, True) for n in (64, 128, 256, 512)] == [6, 8, 10, 13]
+    assert [default_spec_from(n * n, False) for n in (64, 128, 256, 512)] == [6, 8, 10, 18]
+    assert default_spec_from(1, True) == 4 and default_spec_from(1 << 30, False) == 24

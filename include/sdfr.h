@@ -333,11 +333,23 @@ int sdfr_solver_step(float* params, const float* grads, int L, const float* loss
  * (a thin step is one decoder pass of latency per workgroup: 0.12 ms on 16-row tiles, 0.44 ms on 64-row tiles). */
 int sdfr_mlp_forward_counted(const sdfr_decoder* dec, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf, int half,
                              void* stream);
-/* all pixels of all crops: slab test against the cube [-bound, bound]^3; hits enter the active list (counters[0]) at lam = max(entry, near) */
+/* all pixels of all crops: slab test against the cube [-bound, bound]^3; hits enter the active list (counters[0]) at lam = max(entry, near).
+ * cone (optional, from sdfr_trace_cone with the same cone_block): per pixel block the parameter its rays start from instead, or -1: the
+ * block's rays are misses. */
 int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
                      int32_t* counters, int32_t* pix,
                      float* lam /* ray state float[n][4]: lam = next sample, rho = |sdf| of the previous sample, q = ratio of the last two radii, - */,
-                     float* far, float* inputs, void* stream);
+                     float* far, float* inputs, const float* cone, int cone_block, void* stream);
+/* Cone marching ahead of the per-ray march (optional): ONE ray through the centre of every block x block pixel tile stands for its pixels --
+ * all pixel rays share origin and parametrisation, so the tile's rays at parameter lam lie within lam * delta of the centre ray's point
+ * (delta = max |d_corner - d_centre|).  v = decoder(centre point): v - lam delta > eps -> nothing within the cone's cross-section, advance by
+ * (v - lam delta) / (|d_c| + delta); <= eps -> the tile's rays start their own march there; past the cube's far side for all of them ->
+ * culled; after cone_steps passes the cones stop where they are.  cone float[B][ceil(W/block) * ceil(H/block)]: start parameter or -1.
+ * counters: device int32[8] (zeroed here; [4..5] one uint64 = decoder evaluations); ids0/st0, ids1/st1: ping-pong cone lists (int32[n],
+ * float[n][4], n = B * tiles); inputs float[n][L+3], sdf float[n] scratch.  No host synchronisation. */
+int sdfr_trace_cone(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound,
+                    float near, float eps, int block, int cone_steps, int half, int32_t* counters, int32_t* ids0, float* st0, int32_t* ids1,
+                    float* st1, float* inputs, float* sdf, float* cone, void* stream);
 /* march step `step` (0, 1, ...): sdf = decoder values of the active rays (counters[step % 3] of them); lam += sdf / |d|; rays with
  * |sdf| < eps are recorded in hit_lam / hit_sdf and retired, rays past `far` are retired, the rest are compacted into pix_out / lam_out /
  * inputs (count in counters[(step + 1) % 3]) */

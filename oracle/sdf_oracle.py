@@ -741,26 +741,9 @@ def trace_rays(pose, Kinv, pixels_xy):
     return o, d, r
 
 
-def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, bound=1.0, near=1e-3, spec_from=None, spec_k=1, sigma=0.9):
-    """March every ray: x = o + lam d, v = decoder(latn, x); |v| < eps -> hit at lam; else lam += v / |d|; lam >= far (exit of the cube
-    [-bound, bound]^3) or NaN -> miss; out of steps -> miss (unresolved).
-    Speculative passes (spec_k > 1, from pass index spec_from on): a pass evaluates spec_k samples of the ray at once, p_0 = lam and
-    p_j = p_{j-1} + sigma q^j rho / |d| with rho = |v| of the ray's previous accepted sample and q = the ratio of its last two radii (clamped
-    to [0.5, 1]) -- a guess of where plain tracing would put its next samples.  Sample j counts only if it lies INSIDE the safe sphere of sample
-    j-1 ((p_j - p_{j-1}) |d| <= |v_{j-1}|, v_{j-1} > 0): the accepted prefix is a valid (slightly shorter-stepped) sphere-tracing sequence,
-    nothing is skipped; the first accepted sample with |v| < eps is the hit; otherwise the ray continues from the last accepted sample.  Rays
-    creeping along a face at grazing incidence -- the ones that keep a march alive for dozens of steps -- advance spec_k samples per pass.
-    Which passes are speculative depends on the pass INDEX only, so the sample sequence of a ray is a function of the ray alone.
-    Then one Newton step along non-grazing rays with the decoder value f0 and input gradient at the marched point: lam_s = lam0 - f0 / (gx . d)
-    where |gx . d| > 0.1 |gx| |d|.
-    Returns a dict of per-ray arrays: hit (bool), lam0, lam_s, ok (Newton step taken), x_s (n,3), depth, color (NOCS, n,3), normals ((R n + 1)/2,
-    n,3), n_hat, gx (n,3), gz (n,L), f0, c (= 1 / (gx . d) or 0), margin (distance of the closest hit / coverage / exit / grazing decision to its
-    threshold, in the decision's own units: rays with a small margin may legitimately decide differently under float rounding), n_steps (passes),
-    evals (total decoder evaluations, speculative samples included)."""
+def _trace_slab(o, d, bound, near):
+    """slab test of rays o + lam d against the cube [-bound, bound]^3: (l0, l1, enters) -- lam of entry (>= near) and exit"""
     f = np.float32
-    latn = np.asarray(latn, f).reshape(-1)
-    L = latn.shape[0]
-    o, d, r = trace_rays(pose, Kinv, pixels_xy)
     n = d.shape[0]
     l0 = np.full(n, near, f)
     l1 = np.full(n, np.finfo(f).max, f)
@@ -776,14 +759,130 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
         l0 = np.where(par, l0, np.maximum(l0, lo)).astype(f)
         l1 = np.where(par, l1, np.minimum(l1, hi)).astype(f)
     active &= l0 < l1
+    return l0, l1, active
+
+
+def cone_march(layers, spec, latn, pose, Kinv, image_wh, block, blocks, cone_steps=10, eps=2e-3, bound=1.0, near=1e-3):
+    """Cone marching of the pixel blocks `blocks` (ids by * nbx + bx of block x block pixel tiles of a W x H image): ONE ray through the centre
+    of the (image-clipped) block stands for all its pixels.  All pixel rays share the origin and the parametrisation (lam = camera depth), so
+    the block's rays at parameter lam lie within lam * delta of the centre ray's point, delta = max over the block's corner pixels of
+    |d_corner - d_centre|.  With v = decoder(centre point): free = v - lam * delta > eps means no surface within the cone's cross-section at
+    lam, and the cone may advance to lam + free / (|d_c| + delta) (the sphere of radius v around the centre point covers the cross-sections
+    up to there).  A cone stops where free <= eps (or NaN): its pixels start their own march at that lam; a cone that advances past the far
+    side of the cube for ALL its pixels is culled: none of its pixels can hit; cones still marching after cone_steps passes stop where they are.
+    Returns start (per block: lam >= 0 to start from, or -1: culled / no pixel's ray enters the cube), margin (distance of the block's closest
+    decision to its threshold), evals."""
+    f = np.float32
+    W_, H_ = int(image_wh[0]), int(image_wh[1])
+    BL = int(block)
+    nbx = (W_ + BL - 1) // BL
+    blocks = np.asarray(blocks, np.int64)
+    nb = blocks.shape[0]
+    x0 = ((blocks % nbx) * BL).astype(np.int64)
+    y0 = ((blocks // nbx) * BL).astype(np.int64)
+    x1 = np.minimum(x0 + BL - 1, W_ - 1)
+    y1 = np.minimum(y0 + BL - 1, H_ - 1)
+    cx = (f(0.5) * (x0 + x1).astype(f)).astype(f)
+    cy = (f(0.5) * (y0 + y1).astype(f)).astype(f)
+    o, dc, _ = trace_rays(pose, Kinv, np.stack([cx, cy], 1))
+    delta = np.zeros(nb, f)
+    for xs_, ys_ in ((x0, y0), (x1, y0), (x0, y1), (x1, y1)):
+        _, dk, _ = trace_rays(pose, Kinv, np.stack([xs_, ys_], 1).astype(f))
+        e = (dk - dc).astype(f)
+        delta = np.maximum(delta, np.sqrt(e[:, 0] * e[:, 0] + e[:, 1] * e[:, 1] + e[:, 2] * e[:, 2]).astype(f))
+    near_b = np.full(nb, np.finfo(f).max, f)
+    far_b = np.zeros(nb, f)
+    any_in = np.zeros(nb, bool)
+    for j in range(BL):
+        for i in range(BL):
+            px_, py_ = x0 + i, y0 + j
+            ins = (px_ <= x1) & (py_ <= y1)
+            _, dk, _ = trace_rays(pose, Kinv, np.stack([px_, py_], 1).astype(f))
+            l0, l1, act = _trace_slab(o, dk, bound, near)
+            act &= ins
+            near_b = np.where(act, np.minimum(near_b, l0), near_b).astype(f)
+            far_b = np.where(act, np.maximum(far_b, l1), far_b).astype(f)
+            any_in |= act
+    dn = np.sqrt(dc[:, 0] * dc[:, 0] + dc[:, 1] * dc[:, 1] + dc[:, 2] * dc[:, 2]).astype(f)
+    latn = np.asarray(latn, f).reshape(-1)
+    L = latn.shape[0]
+    start = np.full(nb, -1.0, f)
+    margin = np.full(nb, np.inf)
+    lam = np.where(any_in, near_b, 0).astype(f)
+    active = any_in.copy()
+    evals = 0
+    for s in range(int(cone_steps)):
+        idx = np.nonzero(active)[0]
+        if idx.size == 0:
+            break
+        X = (o[None] + lam[idx, None] * dc[idx]).astype(f)
+        rows = np.concatenate([np.broadcast_to(latn, (idx.size, L)), X], 1).astype(f)
+        v = decoder_forward(layers, spec, rows)[:, 0].astype(f)
+        evals += idx.size
+        free = (v - (lam[idx] * delta[idx]).astype(f)).astype(f)
+        go = free > f(eps)                                   # (NaN: stop)
+        adv = (lam[idx] + (free / (dn[idx] + delta[idx]).astype(f)).astype(f)).astype(f)
+        out = go & ~(adv < far_b[idx])
+        margin[idx] = np.minimum(margin[idx], np.abs(free - f(eps)))
+        margin[idx[go]] = np.minimum(margin[idx[go]], np.abs(adv - far_b[idx])[go])
+        start[idx[~go]] = lam[idx[~go]]
+        start[idx[out]] = -1.0
+        keep = go & ~out
+        lam[idx[keep]] = adv[keep]
+        active[idx] = keep
+    start[active] = lam[active]
+    return start, margin, evals
+
+
+def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, bound=1.0, near=1e-3, spec_from=None, spec_k=1, sigma=0.9,
+                 cone_block=None, cone_steps=10, image_wh=None):
+    """March every ray: x = o + lam d, v = decoder(latn, x); |v| < eps -> hit at lam; else lam += v / |d|; lam >= far (exit of the cube
+    [-bound, bound]^3) or NaN -> miss; out of steps -> miss (unresolved).
+    Speculative passes (spec_k > 1, from pass index spec_from on): a pass evaluates spec_k samples of the ray at once, p_0 = lam and
+    p_j = p_{j-1} + sigma q^j rho / |d| with rho = |v| of the ray's previous accepted sample and q = the ratio of its last two radii (clamped
+    to [0.5, 1]) -- a guess of where plain tracing would put its next samples.  Sample j counts only if it lies INSIDE the safe sphere of sample
+    j-1 ((p_j - p_{j-1}) |d| <= |v_{j-1}|, v_{j-1} > 0): the accepted prefix is a valid (slightly shorter-stepped) sphere-tracing sequence,
+    nothing is skipped; the first accepted sample with |v| < eps is the hit; otherwise the ray continues from the last accepted sample.  Rays
+    creeping along a face at grazing incidence -- the ones that keep a march alive for dozens of steps -- advance spec_k samples per pass.
+    Which passes are speculative depends on the pass INDEX only, so the sample sequence of a ray is a function of the ray alone.
+    cone_block (with image_wh = (W, H)): cone marching first (cone_march above) -- the rays of culled pixel blocks are misses without a single
+    evaluation of their own, the others start at max(cube entry, the block's cone stop).
+    Then one Newton step along non-grazing rays with the decoder value f0 and input gradient at the marched point: lam_s = lam0 - f0 / (gx . d)
+    where |gx . d| > 0.1 |gx| |d|.
+    Returns a dict of per-ray arrays: hit (bool), lam0, lam_s, ok (Newton step taken), x_s (n,3), depth, color (NOCS, n,3), normals ((R n + 1)/2,
+    n,3), n_hat, gx (n,3), gz (n,L), f0, c (= 1 / (gx . d) or 0), margin (distance of the closest hit / coverage / exit / grazing decision to its
+    threshold, in the decision's own units: rays with a small margin may legitimately decide differently under float rounding), n_steps (passes),
+    evals (total decoder evaluations, speculative samples included)."""
+    f = np.float32
+    latn = np.asarray(latn, f).reshape(-1)
+    L = latn.shape[0]
+    o, d, r = trace_rays(pose, Kinv, pixels_xy)
+    n = d.shape[0]
+    l0, l1, active = _trace_slab(o, d, bound, near)
+    cone_evals = 0
+    cone_culled = np.zeros(n, bool)
+    cone_margin = np.full(n, np.inf)
+    if cone_block:
+        W_ = int(image_wh[0])
+        BL = int(cone_block)
+        nbx = (W_ + BL - 1) // BL
+        pxy = np.asarray(pixels_xy, np.int64)
+        bid = (pxy[:, 1] // BL) * nbx + pxy[:, 0] // BL
+        ub, inv = np.unique(bid, return_inverse=True)
+        cstart, cmarg, cone_evals = cone_march(layers, spec, latn, pose, Kinv, image_wh, BL, ub, cone_steps, eps, bound, near)
+        cs = cstart[inv]
+        cone_margin = cmarg[inv]
+        cone_culled = active & (cs < 0)
+        l0 = np.where(cs >= 0, np.maximum(l0, cs), l0).astype(f)
+        active &= (cs >= 0) & (l0 < l1)
     dn = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(f)
     lam = l0.copy()
     rho, q = np.zeros(n, f), np.ones(n, f)                        # radius of the previous accepted sample, ratio of the last two radii
     hit = np.zeros(n, bool)
     lam0 = np.zeros(n, f)
-    margin = np.full(n, np.inf)
+    margin = cone_margin.copy()
     n_steps = np.zeros(n, np.int32)
-    evals = 0
+    evals = cone_evals
     for s in range(steps):
         idx = np.nonzero(active)[0]
         if idx.size == 0:
@@ -839,7 +938,8 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
         q[idx] = qn
         active[idx] = keep
     unresolved = active.copy()
-    out = {"hit": hit, "lam0": lam0, "unresolved": unresolved, "n_steps": n_steps, "evals": evals, "far": l1, "entered": l0 < l1}
+    out = {"hit": hit, "lam0": lam0, "unresolved": unresolved, "n_steps": n_steps, "evals": evals, "far": l1, "entered": l0 < l1, "cone_culled": cone_culled,
+           "cone_evals": cone_evals}
     hi_ = np.nonzero(hit)[0]
     x0 = (o[None] + lam0[hi_, None] * d[hi_]).astype(f)
     rows = np.concatenate([np.broadcast_to(latn, (hi_.size, L)), x0], 1).astype(f)

@@ -18,7 +18,9 @@ _PROTOS = {
     "sdfr_debug_set_trace": (c_int, [c_void_p]),
     "sdfr_mlp_forward_counted": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     "sdfr_trace_setup": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "sdfr_trace_cone": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_int,
+                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_trace_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_trace_march": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int,

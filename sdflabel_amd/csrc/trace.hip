@@ -64,11 +64,28 @@ __device__ __forceinline__ void trace_write_row(float* __restrict__ row, const f
     row[L] = r.ox + lam * r.dx; row[L + 1] = r.oy + lam * r.dy; row[L + 2] = r.oz + lam * r.dz;
 }
 
-// every pixel of every crop: slab test against the cube [-bound, bound]^3 the SDF is defined on; rays that hit it enter the active list
+// slab test of a ray against the cube [-bound, bound]^3 the SDF is defined on: entry (>= near) and exit parameters
+__device__ __forceinline__ bool trace_slab(const TraceRay& r, float bound, float near, float& l0, float& l1) {
+    l0 = near; l1 = FLT_MAX;
+    const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+    bool active = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (fabsf(d[a]) < 1e-12f) { active = active && (fabsf(o[a]) <= bound); continue; }
+        float ta = (-bound - o[a]) / d[a], tb = (bound - o[a]) / d[a];
+        if (ta > tb) { const float t = ta; ta = tb; tb = t; }
+        l0 = fmaxf(l0, ta); l1 = fminf(l1, tb);
+    }
+    return active && (l0 < l1);
+}
+
+// every pixel of every crop: slab test against the cube; rays that hit it enter the active list.  cone (optional, sdfr_trace_cone): per
+// cone_block x cone_block pixel block the parameter its cone march stopped at (the block's rays start there) or -1 (no ray of the block can hit)
 __global__ __launch_bounds__(256) void sdfr_trace_setup_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
                                                               const float* __restrict__ latn, int L, int W, int H, float bound, float near,
                                                               int32_t* __restrict__ counters, int32_t* __restrict__ pix,
-                                                              float4* __restrict__ lam, float* __restrict__ far, float* __restrict__ inputs) {
+                                                              float4* __restrict__ lam, float* __restrict__ far, float* __restrict__ inputs,
+                                                              const float* __restrict__ cone, int cone_block) {
     const int b = blockIdx.y;
     const int P_ = W * H;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -76,18 +93,15 @@ __global__ __launch_bounds__(256) void sdfr_trace_setup_kernel(const float* __re
     TraceRay r = {};
     float l0 = 0.f, l1 = 0.f;
     if (p < P_) {
-        r = trace_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, (float)(p % W), (float)(p / W));
-        l0 = near; l1 = FLT_MAX;
-        const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
-        active = true;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (fabsf(d[a]) < 1e-12f) { active = active && (fabsf(o[a]) <= bound); continue; }
-            float ta = (-bound - o[a]) / d[a], tb = (bound - o[a]) / d[a];
-            if (ta > tb) { const float t = ta; ta = tb; tb = t; }
-            l0 = fmaxf(l0, ta); l1 = fminf(l1, tb);
+        const int x = p % W, y = p / W;
+        r = trace_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, (float)x, (float)y);
+        active = trace_slab(r, bound, near, l0, l1);
+        if (cone && active) {
+            const int nbx = (W + cone_block - 1) / cone_block, nby = (H + cone_block - 1) / cone_block;
+            const float c = cone[(int64_t)b * nbx * nby + (y / cone_block) * nbx + x / cone_block];
+            if (c < 0.f) active = false;
+            else { l0 = fmaxf(l0, c); active = l0 < l1; }
         }
-        active = active && (l0 < l1);
         far[(int64_t)b * P_ + p] = active ? l1 : 0.f;
     }
     const int slot = trace_append(active, counters);
@@ -95,6 +109,98 @@ __global__ __launch_bounds__(256) void sdfr_trace_setup_kernel(const float* __re
         pix[slot] = b * P_ + p;
         lam[slot] = make_float4(l0, 0.f, 1.f, 0.f);
         trace_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, r, l0);
+    }
+}
+
+// ---- cone marching (optional first phase): ONE ray through the centre of a block x block pixel tile stands for all its pixels ----------------
+// All pixel rays share the origin and the parametrisation (lam = camera depth), so the block's rays at parameter lam lie within lam * delta of
+// the centre ray's point (delta = max over the block's corner pixels of |d_corner - d_centre|).  v = decoder(centre point): free = v - lam delta
+// > eps -> no surface within the cone's cross-section there, advance to lam + free / (|d_c| + delta); free <= eps -> the block's rays start their
+// own march at lam; past the far side of the cube for ALL the block's rays -> culled (oracle/sdf_oracle.py::cone_march).
+// cone state float4: (lam, delta, far of the block, |d_c|); list entry: crop * blocks + block
+__device__ __forceinline__ TraceRay cone_centre_ray(const float* __restrict__ P, const float* __restrict__ Ki, int k, int nbx, int BL, int W, int H,
+                                                   int& x0, int& y0, int& x1, int& y1) {
+    x0 = (k % nbx) * BL; y0 = (k / nbx) * BL;
+    x1 = min(x0 + BL - 1, W - 1); y1 = min(y0 + BL - 1, H - 1);
+    return trace_ray(P, Ki, 0.5f * (float)(x0 + x1), 0.5f * (float)(y0 + y1));
+}
+
+__global__ __launch_bounds__(256) void sdfr_trace_cone_setup_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
+                                                                   const float* __restrict__ latn, int L, int W, int H, int BL, float bound,
+                                                                   float near, int32_t* __restrict__ counters, int32_t* __restrict__ ids,
+                                                                   float4* __restrict__ st, float* __restrict__ cone, float* __restrict__ inputs) {
+    const int b = blockIdx.y;
+    const int nbx = (W + BL - 1) / BL, nby = (H + BL - 1) / BL, nblk = nbx * nby;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    TraceRay rc = {};
+    float near_b = FLT_MAX, far_b = 0.f, delta = 0.f;
+    if (k < nblk) {
+        const float* Pm = pose + (int64_t)b * 16;
+        const float* Ki = Kinv + (int64_t)b * 9;
+        int x0, y0, x1, y1;
+        rc = cone_centre_ray(Pm, Ki, k, nbx, BL, W, H, x0, y0, x1, y1);
+        const int cxs[4] = {x0, x1, x0, x1}, cys[4] = {y0, y0, y1, y1};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const TraceRay rk = trace_ray(Pm, Ki, (float)cxs[c], (float)cys[c]);
+            const float ex = rk.dx - rc.dx, ey = rk.dy - rc.dy, ez = rk.dz - rc.dz;
+            delta = fmaxf(delta, sqrtf(ex * ex + ey * ey + ez * ez));
+        }
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                const TraceRay rk = trace_ray(Pm, Ki, (float)x, (float)y);
+                float l0, l1;
+                if (trace_slab(rk, bound, near, l0, l1)) { near_b = fminf(near_b, l0); far_b = fmaxf(far_b, l1); keep = true; }
+            }
+        cone[(int64_t)b * nblk + k] = -1.f;                     // until the march says where the block's rays start
+    }
+    const int slot = trace_append(keep, counters);
+    if (keep) {
+        ids[slot] = b * nblk + k;
+        st[slot] = make_float4(near_b, delta, far_b, sqrtf(rc.dx * rc.dx + rc.dy * rc.dy + rc.dz * rc.dz));
+        trace_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, rc, near_b);
+    }
+}
+
+__global__ __launch_bounds__(256) void sdfr_trace_cone_step_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
+                                                                  const float* __restrict__ latn, int L, int W, int H, int BL, float eps,
+                                                                  const float* __restrict__ sdf, const int32_t* __restrict__ n_cur,
+                                                                  int32_t* __restrict__ n_next, int32_t* __restrict__ n_zero,
+                                                                  const int32_t* __restrict__ ids_in, const float4* __restrict__ st_in,
+                                                                  int32_t* __restrict__ ids_out, float4* __restrict__ st_out,
+                                                                  float* __restrict__ inputs, float* __restrict__ cone, int last,
+                                                                  unsigned long long* __restrict__ evals) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int n = *n_cur;
+    if (s == 0) *n_zero = 0;
+    if (s == 0 && evals) atomicAdd(evals, (unsigned long long)n);
+    if (blockIdx.x * 256 >= n) return;
+    bool keep = false;
+    int id = 0;
+    float4 st = make_float4(0.f, 0.f, 0.f, 1.f);
+    if (s < n) {
+        id = ids_in[s];
+        st = st_in[s];
+        const float v = sdf[s];
+        const float free_ = v - __fmul_rn(st.x, st.y);
+        if (!(free_ > eps)) cone[id] = st.x;                       // the cone touches the tolerance band (or NaN): its rays take over here
+        else {
+            const float adv = st.x + free_ / (st.w + st.y);
+            if (!(adv < st.z)) cone[id] = -1.f;                    // past the cube for every ray of the block: culled
+            else if (last) cone[id] = adv;                         // out of cone passes: the rays start where the cone got to
+            else { keep = true; st.x = adv; }
+        }
+    }
+    const int slot = trace_append(keep, n_next);
+    if (keep) {
+        const int nbx = (W + BL - 1) / BL, nby = (H + BL - 1) / BL, nblk = nbx * nby;
+        const int b = id / nblk, k = id - b * nblk;
+        int x0, y0, x1, y1;
+        const TraceRay rc = cone_centre_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, k, nbx, BL, W, H, x0, y0, x1, y1);
+        ids_out[slot] = id;
+        st_out[slot] = st;
+        trace_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, rc, st.x);
     }
 }
 
@@ -322,13 +428,44 @@ __global__ __launch_bounds__(256) void sdfr_trace_backward_sum_kernel(const floa
 }
 
 extern "C" int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
-                                int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, void* stream) {
+                                int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, const float* cone, int cone_block,
+                                void* stream) {
     SDFR_REQUIRE(pose && Kinv && latn && counters && pix && lam && far && inputs, "sdfr_trace_setup: NULL argument");
     SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0 && bound > 0.f, "sdfr_trace_setup: bad size");
+    SDFR_REQUIRE(!cone || cone_block >= 2, "sdfr_trace_setup: cone starts need their block size (>= 2), got %d", cone_block);
     hipStream_t s = (hipStream_t)stream;
     SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
     hipLaunchKernelGGL(sdfr_trace_setup_kernel, dim3(sdfr_cdiv((int64_t)W * H, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, W, H, bound, near,
-                       counters, pix, reinterpret_cast<float4*>(lam), far, inputs);
+                       counters, pix, reinterpret_cast<float4*>(lam), far, inputs, cone, cone_block);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// Cone marching ahead of the per-ray march: cone float[B][ceil(W/block)*ceil(H/block)] receives per pixel block the parameter its rays start
+// from, or -1 (no ray of the block can hit).  counters: device int32[8] (zeroed here; [0..2] rotating counts, [4..5] one uint64: decoder
+// evaluations), ids0/st0, ids1/st1: ping-pong cone lists (int32[n] / float[n][4], n = B * blocks), inputs float[n][L+3], sdf float[n].
+extern "C" int sdfr_trace_cone(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H,
+                               float bound, float near, float eps, int block, int cone_steps, int half, int32_t* counters, int32_t* ids0,
+                               float* st0, int32_t* ids1, float* st1, float* inputs, float* sdf, float* cone, void* stream) {
+    SDFR_REQUIRE(d && pose && Kinv && latn && counters && ids0 && st0 && ids1 && st1 && inputs && sdf && cone, "sdfr_trace_cone: NULL argument");
+    SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0 && bound > 0.f && block >= 2 && cone_steps >= 1, "sdfr_trace_cone: bad size");
+    SDFR_REQUIRE(d->n_inputs == L + 3, "sdfr_trace_cone: decoder with L + 3 = %d inputs expected, it has %d", L + 3, d->n_inputs);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = sdfr_cdiv(W, block) * sdfr_cdiv(H, block);
+    const int64_t n_max = (int64_t)B * nblk;
+    SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
+    hipLaunchKernelGGL(sdfr_trace_cone_setup_kernel, dim3(sdfr_cdiv(nblk, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, W, H, block, bound, near,
+                       counters, ids0, reinterpret_cast<float4*>(st0), cone, inputs);
+    unsigned long long* evals = reinterpret_cast<unsigned long long*>(counters + 4);
+    for (int step = 0; step < cone_steps; ++step) {
+        const int rc = sdfr_mlp_forward_counted(d, inputs, n_max, counters + step % 3, sdf, half, stream);
+        if (rc != SDFR_OK) return rc;
+        const int a = step & 1;
+        hipLaunchKernelGGL(sdfr_trace_cone_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, block, eps, sdf,
+                           counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? ids1 : ids0,
+                           reinterpret_cast<const float4*>(a ? st1 : st0), a ? ids0 : ids1, reinterpret_cast<float4*>(a ? st0 : st1), inputs, cone,
+                           step == cone_steps - 1 ? 1 : 0, evals);
+    }
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

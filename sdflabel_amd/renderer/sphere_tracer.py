@@ -64,7 +64,8 @@ def default_spec_from(rays_per_crop, half):
 
 class SphereTracer:
     def __init__(self, decoder, K, resolution_px, batch=1, steps=64, eps=2e-3, bound=1.0, near=1e-3, device="cuda", head_steps=None,
-                 tail_rows=4096, spec_from=None, spec_k=None, sigma=0.9, spec_from2=None, spec_k2=None, polish=None):
+                 tail_rows=4096, spec_from=None, spec_k=None, sigma=0.9, spec_from2=None, spec_k2=None, polish=None,
+                 cone_block=None, cone_steps=10):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise _lib.SdfrError("SphereTracer runs on the GPU only")
@@ -109,6 +110,12 @@ class SphereTracer:
         if self.polish not in ("exact", "decoder"):
             raise ValueError("polish must be 'exact' or 'decoder'")
         self.half_polish = bool(self.half) and self.polish == "decoder"
+        # cone marching ahead of the per-ray march (opt-in): one ray per cone_block x cone_block pixel tile until the SDF falls below the cone's
+        # radius; tiles whose cone leaves the cube are culled, the others' rays start where their cone stopped (csrc/trace.hip sdfr_trace_cone)
+        self.cone_block = int(cone_block) if cone_block else 0
+        self.cone_steps = int(cone_steps)
+        if self.cone_block and (self.cone_block < 2 or self.cone_steps < 1):
+            raise ValueError("cone_block >= 2 (pixels), cone_steps >= 1")
         self.L = decoder.latent_size
         self.NI = self.L + 3
         K = torch.as_tensor(K, dtype=torch.float32)
@@ -127,6 +134,12 @@ class SphereTracer:
         self.far, self.inputs, self.sdf = f(n), f(n, self.NI), f(n)
         tiles = (n + 15) // 16 if self.spec_k2 == self.spec_k else (n * self.spec_k2 + 63) // 64
         self.tail_rows_buf = f(tiles, 16 * self.spec_k, self.NI)                   # operand rows of the looping kernel's tiles
+        if self.cone_block:
+            nc = B * ((W + self.cone_block - 1) // self.cone_block) * ((H + self.cone_block - 1) // self.cone_block)
+            self.cone = f(nc)                                                  # per pixel tile: start parameter or -1 (culled)
+            self.cone_counters = i(_COUNTERS)
+            self.cone_ids, self.cone_st = [i(nc), i(nc)], [f(nc, 4), f(nc, 4)]
+            self.cone_inputs, self.cone_sdf = f(nc, self.NI), f(nc)
         self.hit_lam, self.hit_sdf, self.lam_s = f(n), f(n), f(n)
         self.hit_slot, self.idx = i(n), i(n)
         self.rows, self.J, self.f0 = f(n, self.NI), f(n, self.NI), f(n)
@@ -152,10 +165,16 @@ class SphereTracer:
                "sdfr_params_forward")
             torch.div(self.latent, self.latnorm.unsqueeze(1), out=self.latn)                    # F.normalize (optimizer.py:96)
             self.hit_lam.zero_(); self.hit_sdf.zero_()
-            ck(L.sdfr_trace_setup(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, P(self.counters), P(self.pix[0]),
-                                  P(self.lam[0]), P(self.far), P(self.inputs), st), "sdfr_trace_setup")
             if "march" in events:
                 events["march"][0].record()
+            if self.cone_block:
+                ck(L.sdfr_trace_cone(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, self.eps,
+                                     self.cone_block, self.cone_steps, self.half, P(self.cone_counters), P(self.cone_ids[0]), P(self.cone_st[0]),
+                                     P(self.cone_ids[1]), P(self.cone_st[1]), P(self.cone_inputs), P(self.cone_sdf), P(self.cone), st),
+                   "sdfr_trace_cone")
+            ck(L.sdfr_trace_setup(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, P(self.counters), P(self.pix[0]),
+                                  P(self.lam[0]), P(self.far), P(self.inputs), P(self.cone) if self.cone_block else None, self.cone_block, st),
+               "sdfr_trace_setup")
             ck(L.sdfr_trace_march(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.eps, self.steps,
                                   self.head_steps, self.tail_rows, self.spec_from, self.spec_k, self.spec_from2, self.spec_k2, self.sigma,
                                   self.half, P(self.counters), P(self.pix[0]), P(self.lam[0]), P(self.pix[1]), P(self.lam[1]), P(self.pix[2]),
@@ -212,7 +231,13 @@ class SphereTracer:
     def stats(self):
         c = self.counters.cpu().numpy()
         evals = int(c[4:6].view("uint64")[0])
-        return {"hits": int(c[6]), "unresolved": int(c[3]), "ray_evaluations": evals}
+        out = {"hits": int(c[6]), "unresolved": int(c[3]), "ray_evaluations": evals}
+        if self.cone_block:
+            cc = self.cone_counters.cpu().numpy()
+            out["cone_evaluations"] = int(cc[4:6].view("uint64")[0])
+            out["ray_evaluations"] += out["cone_evaluations"]                   # (decoder evaluations of the render: cones + rays)
+            out["culled_tiles"] = int((self.cone < 0).sum())
+        return out
 
     @property
     def n_hit(self):

@@ -165,6 +165,48 @@ def test_march_with_a_layernorm_decoder():
     assert all(bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0 for t in a)
 
 
+@pytest.mark.parametrize("block,size", [(4, (94, 126)), (8, (96, 128))])
+def test_cone_marching_first_phase_against_the_oracle(dec, oracle_layers, block, size):
+    """cone_block: one ray per pixel tile first (tiles clipped by the image border at 94x126); culled tiles' rays are misses without an
+    evaluation of their own, the others start where their cone stopped.  Against the oracle's cone_march + sphere_trace on every 2nd pixel:
+    hit set on the safe rays, depth / colour 1e-4 on the non-grazing hits; against plain tracing: the same image, fewer evaluations."""
+    layers, spec = oracle_layers
+    H, W = size
+    K = K_for(H, W)
+    K[0, 2] += 9.0
+    kw = dict(steps=64, device=DEV, spec_from=16, spec_k=4, spec_from2=20, spec_k2=16)
+    tr = sdflabel_amd.SphereTracer(dec, K, (W, H), 1, cone_block=block, cone_steps=10, **kw)
+    plain = sdflabel_amd.SphereTracer(dec, K, (W, H), 1, **kw)
+    a = _args(grad=True)
+    out = tr(*a)
+    ref_img = {k: v.clone() for k, v in plain.render(*_args()).items()}
+    st_c, st_p = tr.stats(), plain.stats()
+    assert st_c["culled_tiles"] > 0.3 * tr.cone.numel() and st_c["ray_evaluations"] < 0.75 * st_p["ray_evaluations"], (st_c, st_p)
+    assert abs(st_c["hits"] - st_p["hits"]) <= 3 and st_c["unresolved"] <= 1
+    flips = (out["mask"] != ref_img["mask"])
+    assert int(flips.sum()) <= 3
+    both = ((out["mask"] > 0) & (ref_img["mask"] > 0)).view(-1)
+    dd = (out["depth"] - ref_img["depth"]).abs().view(-1)[both]
+    assert float(dd.median()) < 1e-5 and float(torch.quantile(dd, 0.98)) < 1e-4 and float(dd.max()) < 5e-2
+    ys, xs = np.meshgrid(np.arange(0, H, 2), np.arange(0, W, 2), indexing="ij")
+    px = np.stack([xs.reshape(-1), ys.reshape(-1)], 1)
+    lat = np.asarray(LAT[0], np.float32)
+    latn = lat / np.sqrt((lat * lat).sum())
+    ref = O.sphere_trace(layers, spec, latn, O.render_pose(YAW[0], TRANS[0]), np.linalg.inv(K).astype(np.float32), px, steps=64,
+                         spec_from=[(16, 4), (20, 16)], cone_block=block, cone_steps=10, image_wh=(W, H))
+    sel = (px[:, 1], px[:, 0])
+    hit = N(out["mask"][0, 0])[sel] > 0
+    safe = ref["margin"] > 1e-4
+    assert ref["hit"].sum() > 400 and ref["cone_culled"].sum() > 500 and safe.mean() > 0.9
+    assert np.array_equal(hit[safe], ref["hit"][safe]), int((hit[safe] != ref["hit"][safe]).sum())
+    good = safe & ref["hit"] & hit & ref["ok"]
+    assert good.sum() > 300
+    assert np.abs(N(out["depth"][0, 0])[sel] - ref["depth"])[good].max() < 1e-4
+    assert np.abs(N(out["color"][0])[:, sel[0], sel[1]].T - ref["color"])[good].max() < 1e-4
+    (out["depth"].sum() + out["color"].sum()).backward()
+    assert all(bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().max()) > 0 for t in a)
+
+
 def dn_all(nrm, ref):
     return np.abs(nrm - ref["normals"]).max(1)
 

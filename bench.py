@@ -547,20 +547,24 @@ def main():
     # looping tail kernel, forward + backward to yaw/trans/latent, all HIP kernels, no host synchronisation inside a render.
     # Default schedule: 4 samples per ray and pass from pass 10 on (speculative passes: accepted while inside the previous sample's safe sphere),
     # 16 from pass 14 on (the survivors re-packed 4 to a tile); hit pass (value + Jacobian at the hits) in the decoder's precision.  `_plain` = the
-    # f16 march without speculative passes, `_exact_polish` = f16 march with the hit pass in exact float32.
+    # f16 march without speculative passes, `_exact_polish` = f16 march with the hit pass in exact float32, `_cone4` = cone marching on 4x4 pixel
+    # tiles ahead of the per-ray march (opt-in: culled tiles' rays cost no evaluation; ray_evaluations then counts cones + rays).
     # roofline_march: decoder evaluations of the march (counted on the device, speculative samples included) x 2 M FLOP / march time (events around sdfr_trace_march) against the MFMA
     # peak of the march's operand type; step_kernel_hbm: algorithmic bytes of the advance / compaction kernel per ray-step.
     sphere = None
     if rank == 0 and CB == 1 and not args.no_extras:
         sphere = {}
         for label, prec, steps, spec_k, polish in (("f32_64_steps", torch.float32, 64, None, None), ("f16_64_steps", torch.float16, 64, None, None),
+                                                   ("f16_64_steps_cone4", torch.float16, 64, None, None),      # + cone marching on 4x4 pixel tiles first (opt-in)
+                                                   ("f32_64_steps_cone4", torch.float32, 64, None, None),
                                                    ("f16_64_steps_exact_polish", torch.float16, 64, None, "exact"),
                                                    ("f16_64_steps_plain", torch.float16, 64, 1, None), ("f32_64_steps_plain", torch.float32, 64, 1, None),
                                                    ("f16_128_steps", torch.float16, 128, None, None),          # (configs[1]'s step budget)
                                                    ("f16_256_steps", torch.float16, 256, None, None)):         # (configs[4]'s; with --crop-size 512 its ray count)
             try:
                 d3, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
-                tr = sdflabel_amd.SphereTracer(d3.to(dev), K_for(H, W), (W, H), 1, steps=steps, device=dev, spec_k=spec_k, polish=polish)
+                tr = sdflabel_amd.SphereTracer(d3.to(dev), K_for(H, W), (W, H), 1, steps=steps, device=dev, spec_k=spec_k, polish=polish,
+                                                cone_block=4 if label.endswith("_cone4") else None)
                 prm = [crop.yaw.detach().clone(), crop.trans.detach().clone().view(1, 3), crop.latent.detach().clone().view(1, -1)]
                 o3, o1 = torch.ones(1, 3, H, W, device=dev), torch.ones(1, 1, H, W, device=dev)
 
@@ -591,6 +595,8 @@ def main():
                                  "speculative_from_pass": tr.spec_from if tr.spec_k > 1 else None,
                                  "second_level": {"samples": tr.spec_k2, "from_pass": tr.spec_from2} if tr.spec_k2 > tr.spec_k else None,
                                  "hit_pass": "float16 (decoder)" if tr.half_polish else "float32",
+                                 "cone_marching": {"tile_px": tr.cone_block, "passes": tr.cone_steps, "cone_evaluations": st3.get("cone_evaluations"),
+                                                   "culled_tiles": st3.get("culled_tiles")} if tr.cone_block else None,
                                  "roofline_march": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak,
                                                     "flops": 2.0 * macs * st3["ray_evaluations"]},
                                  "max_abs_sdf_at_marched_hits": float(tr.hit_residual.abs().max())}

@@ -18,6 +18,8 @@ ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--spec", type=int, nargs="*", default=[1, 4], help="samples per ray and pass in the looping kernel")
 ap.add_argument("--scan", default="", help="'from:from2,from:from2,...' -- schedules to time instead of the built-in list")
+ap.add_argument("--cone", type=int, nargs="*", default=[0], help="cone_block values to time (0: no cone phase)")
+ap.add_argument("--cone-steps", type=int, default=10)
 ap.add_argument("--only", default="", help="f32 | f16: one precision, default schedule only (profiling runs)")
 args = ap.parse_args()
 dev = "cuda"
@@ -38,7 +40,7 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
         scheds += [dict(spec_k=4, spec_k2=1), dict(spec_k=4, spec_k2=8), dict(spec_k=4, spec_from2=14), dict(spec_k=4, spec_from2=18),
                    dict(spec_k=4, spec_from=10, spec_from2=14), dict(spec_k=4, spec_from=16, spec_from2=20), dict(spec_k=4, tail_rows=2048),
                    dict(spec_k=4, tail_rows=8192), dict(spec_k=1, head_steps=args.steps, tail_rows=0), dict(spec_k=4, polish="exact")]
-    for sch in scheds:
+    for sch in [dict(s_, cone_block=c, cone_steps=args.cone_steps) for s_ in scheds for c in args.cone]:
         tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, **sch)
         head, tail, spec_k, spec_from = tr.head_steps, tr.tail_rows, tr.spec_k, tr.spec_from
 
@@ -62,7 +64,7 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
         mm = float(np.mean([e["march"][0].elapsed_time(e["march"][1]) for e in evs]))
         s = tr.stats()
         tf = 2.0 * macs * s["ray_evaluations"] / (mm * 1e-3) / 1e12
-        print("%s polish %s spec_k %d from %2d (then %2d from %2d) head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
-              % (str(prec).replace("torch.", ""), tr.polish, spec_k, spec_from, tr.spec_k2, tr.spec_from2, head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
+        print("%s cone %d polish %s spec_k %d from %2d (then %2d from %2d) head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
+              % (str(prec).replace("torch.", ""), tr.cone_block, tr.polish, spec_k, spec_from, tr.spec_k2, tr.spec_from2, head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
                  100 * tf / (2500.0 if prec == torch.float16 else 157.3), s["hits"], s["unresolved"]), flush=True)
         del tr

@@ -517,6 +517,15 @@ def test_sphere_trace_oracle_self_consistency():
         assert dd.max() < 1e-3 and np.quantile(dd, 0.98) < 1e-4
     assert two["n_steps"].max() < one["n_steps"].max() < tr["n_steps"].max()
     assert two["evals"] < 1.2 * tr["evals"]
+    # cone marching first (one ray per 4x4 / 8x8 pixel tile): no culled ray is a hit of plain tracing, the same surface, far fewer evaluations
+    for block in (4, 8):
+        cn = O.sphere_trace(layers, spec, lat, O.render_pose(yaw, t), Kinv, px, cone_block=block, cone_steps=10, image_wh=(W, H))
+        assert cn["cone_culled"].sum() > 0.3 * px.shape[0] and not (cn["cone_culled"] & tr["hit"]).any()
+        assert (cn["hit"] != tr["hit"]).sum() <= 2 and cn["unresolved"].sum() <= tr["unresolved"].sum()
+        both = cn["hit"] & tr["hit"] & cn["ok"] & tr["ok"]
+        dd = np.abs(cn["depth"] - tr["depth"])[both]
+        assert dd.max() < 1e-3 and np.quantile(dd, 0.98) < 1e-4
+        assert cn["evals"] < 0.8 * tr["evals"] and cn["cone_evals"] < 0.3 * tr["evals"]        # (a 40x40 image: 100 tiles; 3x fewer at 256x256)
 
 
 @pytest.mark.parametrize("tag", ["circle_bg0", "circle_bg1", "disc_quat"])

@@ -104,9 +104,11 @@ def cpu_baseline():
     out, n_surf = {}, 0
 
     def run():
-        yaw = torch.tensor([0.6], requires_grad=True)
-        trans = torch.tensor([0.0, 0.0, 3.5], requires_grad=True)
-        lat = torch.tensor([0.3, -0.5, 0.8], requires_grad=True)
+        # exactly the GPU step's input: synthetic crop 0's perturbed start (the same surfel count N as the timed GPU step)
+        y0, t0_, l0 = crop_start(0)
+        yaw = torch.from_numpy(y0.copy()).requires_grad_(True)
+        trans = torch.from_numpy(t0_.copy()).requires_grad_(True)
+        lat = torch.from_numpy(l0.copy()).requires_grad_(True)
         t0 = time.perf_counter()
         rend, pts, n, loss = TP.crop_iteration(decoder, gp, K, (W, H), yaw, trans, lat)
         dt = time.perf_counter() - t0
@@ -134,7 +136,7 @@ def cpu_baseline():
             "seconds_per_crop_iteration_samples": samples,
             "by_threads": {str(k): {"rays_per_s": v[0], "seconds_per_crop_iteration": v[1]} for k, v in out.items()},
             "host_cores": ncpu,
-            "sample": "1 full crop-iteration (fwd+bwd to yaw/trans/latent) of the bench workload, all %dx%d rays, D=%d, N=%d surfels, dense "
+            "sample": "1 full crop-iteration (fwd+bwd to yaw/trans/latent) of the bench workload (synthetic crop 0's start, the GPU step's input), all %dx%d rays, D=%d, N=%d surfels, dense "
                       "N x P formulation as the reference, torch CPU ops + autograd (oracle/torch_cpu_port.py); 1 warm-up + 3 timed "
                       "iterations on %d threads, value = their median; one more timed iteration on %d threads in by_threads" % (H, W, D, n_surf, t8, t32)}
 
@@ -361,6 +363,38 @@ def main():
         del rf
     res = None
 
+    # the same loop with the sphere tracer as its renderer (BatchRefiner(render="trace"): traced NOCS image -> 2-D loss, hit points -> 3-D loss,
+    # surfel-semantics backward -> the same solver step; float16 decoder = the reference's shipped precision; NOT the reference's algorithm)
+    def traced_setup():
+        d16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+        rf = sdflabel_amd.BatchRefiner(d16.to(dev), D, K_for(H, W), (H, W), CB, lidar_cap=4096, device=dev, render="trace")
+        nocs1, lidar = synthetic_targets(dec, D, K_for(H, W), H, W, dev)
+        nocs_t = nocs1.expand(CB, 3, H, W).clone()
+        p0 = {"yaw": torch.cat([c.yaw.detach() for c in crops]), "trans": torch.stack([c.trans.detach() for c in crops]),
+              "scale": torch.full((CB,), 2.0), "latent": torch.stack([c.latent.detach() for c in crops])}
+        rf.set_crops(p0, nocs_t, [lidar] * CB)
+        rf.capture()
+        rf.optimize(3)
+        rf.set_crops(p0, nocs_t, [lidar] * CB)
+        return rf, p0["yaw"].to(dev).clone(), p0["trans"].to(dev).clone()
+
+    res, err = timed_section(traced_setup, lambda st: st[0].optimize(iters)) if not args.no_extras else (None, "skipped (--no-extras)")
+    if res is None:
+        refine_traced = {"error": err}
+    else:
+        (rf, y0, t0v), dt_r = res
+        gt_t = torch.tensor([0.0, 0.0, 3.5], device=dev)
+        refine_traced = {"value": CB * world / dt_r, "unit": "crops/s", "iterations_per_crop": iters, "ms_per_iteration": dt_r / iters * 1e3,
+                         "crops": CB * world, "renderer": "sphere tracer (cone marching on %dx%d-pixel tiles, speculative passes), float16 decoder, "
+                         "surfel-semantics backward; reference losses + solver on device; HIP-graph replay" % (rf.tr.cone_block, rf.tr.cone_block),
+                         "rays_per_s_incl_losses_and_solver": CB * world * H * W * iters / dt_r,
+                         "yaw_error_before_after": [float((y0 - 0.6).abs().mean()), float((rf.yaw - 0.6).abs().mean())],
+                         "trans_error_before_after": [float((t0v - gt_t).abs().max(1)[0].mean()), float((rf.trans - gt_t).abs().max(1)[0].mean())],
+                         "hits_per_crop_last_iteration": float(rf.tr.ecnt.float().mean()),
+                         "crops_stepped_last_iteration": int(rf.stepped.sum())}
+        del rf
+    res = None
+
     # ---- BASELINE configs[3]: `--total-crops` crops sharded over the ranks (crop i -> rank i mod N), refined for the reference's 60 iterations
     # in chunks of 64 by BatchRefiner, ONE all_gather of the per-crop result rows at the end (sdflabel_amd.parallel.refine_sharded).
     # Strong scaling: the total is fixed, so seconds(N=1) / seconds(N) is the north_star's "x at 8 GPUs over 1 GPU on a 1024-crop batch".
@@ -547,26 +581,31 @@ def main():
     # looping tail kernel, forward + backward to yaw/trans/latent, all HIP kernels, no host synchronisation inside a render.
     # Default schedule: 4 samples per ray and pass from pass 10 on (speculative passes: accepted while inside the previous sample's safe sphere),
     # 16 from pass 14 on (the survivors re-packed 4 to a tile); hit pass (value + Jacobian at the hits) in the decoder's precision.  `_plain` = the
-    # f16 march without speculative passes, `_exact_polish` = f16 march with the hit pass in exact float32, `_cone4` = cone marching on 4x4 pixel
-    # tiles ahead of the per-ray march (opt-in: culled tiles' rays cost no evaluation; ray_evaluations then counts cones + rays).
+    # f16 march without cones and speculative passes, `_exact_polish` = f16 march with the hit pass in exact float32, `_nocone` = without the cone
+    # phase.  Cone marching on 4x4-pixel tiles ahead of the per-ray march is the default since r04 (culled tiles' rays cost no evaluation;
+    # ray_evaluations counts cones + rays).  `configs4_*` = BASELINE configs[4]'s shape (512x512 rays, 256-step budget, fp16 MLP on MFMA).
     # roofline_march: decoder evaluations of the march (counted on the device, speculative samples included) x 2 M FLOP / march time (events around sdfr_trace_march) against the MFMA
     # peak of the march's operand type; step_kernel_hbm: algorithmic bytes of the advance / compaction kernel per ray-step.
     sphere = None
     if rank == 0 and CB == 1 and not args.no_extras:
         sphere = {}
-        for label, prec, steps, spec_k, polish in (("f32_64_steps", torch.float32, 64, None, None), ("f16_64_steps", torch.float16, 64, None, None),
-                                                   ("f16_64_steps_cone4", torch.float16, 64, None, None),      # + cone marching on 4x4 pixel tiles first (opt-in)
-                                                   ("f32_64_steps_cone4", torch.float32, 64, None, None),
-                                                   ("f16_64_steps_exact_polish", torch.float16, 64, None, "exact"),
-                                                   ("f16_64_steps_plain", torch.float16, 64, 1, None), ("f32_64_steps_plain", torch.float32, 64, 1, None),
-                                                   ("f16_128_steps", torch.float16, 128, None, None),          # (configs[1]'s step budget)
-                                                   ("f16_256_steps", torch.float16, 256, None, None)):         # (configs[4]'s; with --crop-size 512 its ray count)
+        # (label, decoder precision, step budget, samples per pass (None: default schedule), hit pass, cone tile (None: default 4; 0: off), crop edge)
+        for label, prec, steps, spec_k, polish, cone, size in (
+                ("f16_64_steps", torch.float16, 64, None, None, None, H),                 # the default tracer
+                ("f32_64_steps", torch.float32, 64, None, None, None, H),
+                ("configs4_f16_512x512_256_steps", torch.float16, 256, None, None, None, 512),      # BASELINE configs[4]'s shape: 512x512 rays, 256-step budget, fp16 MLP
+                ("f16_64_steps_nocone", torch.float16, 64, None, None, 0, H),              # without the cone phase (the r03 default)
+                ("f32_64_steps_nocone", torch.float32, 64, None, None, 0, H),
+                ("f16_64_steps_exact_polish", torch.float16, 64, None, "exact", None, H),
+                ("f16_64_steps_plain", torch.float16, 64, 1, None, 0, H),                  # plain sphere tracing: no cones, no speculative passes
+                ("f16_128_steps", torch.float16, 128, None, None, None, H)):                # (configs[1]'s step budget)
             try:
+                Hs = Ws = size
                 d3, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
-                tr = sdflabel_amd.SphereTracer(d3.to(dev), K_for(H, W), (W, H), 1, steps=steps, device=dev, spec_k=spec_k, polish=polish,
-                                                cone_block=4 if label.endswith("_cone4") else None)
+                tr = sdflabel_amd.SphereTracer(d3.to(dev), K_for(Hs, Ws), (Ws, Hs), 1, steps=steps, device=dev, spec_k=spec_k, polish=polish,
+                                                cone_block=cone)
                 prm = [crop.yaw.detach().clone(), crop.trans.detach().clone().view(1, 3), crop.latent.detach().clone().view(1, -1)]
-                o3, o1 = torch.ones(1, 3, H, W, device=dev), torch.ones(1, 1, H, W, device=dev)
+                o3, o1 = torch.ones(1, 3, Hs, Ws, device=dev), torch.ones(1, 1, Hs, Ws, device=dev)
 
                 def tstep(ev=None):
                     tr.render(*prm, events=ev)
@@ -589,7 +628,7 @@ def main():
                 st3 = tr.stats()
                 peak = 2500.0 if prec == torch.float16 else F32_MFMA_PEAK_TFLOPS
                 tfl = 2.0 * macs * st3["ray_evaluations"] / (march_ms * 1e-3) / 1e12
-                sphere[label] = {"value": H * W / dt_t, "unit": "rays/s", "ms_per_render_fwd_bwd": dt_t * 1e3, "march_steps": steps, "march_ms": march_ms,
+                sphere[label] = {"value": Hs * Ws / dt_t, "unit": "rays/s", "rays": Hs * Ws, "ms_per_render_fwd_bwd": dt_t * 1e3, "march_steps": steps, "march_ms": march_ms,
                                  "hits": st3["hits"], "unresolved_after_last_step": st3["unresolved"], "ray_evaluations": st3["ray_evaluations"],
                                  "head_steps": tr.head_steps, "tail_rows": tr.tail_rows, "samples_per_ray_and_pass_in_the_looping_kernel": tr.spec_k,
                                  "speculative_from_pass": tr.spec_from if tr.spec_k > 1 else None,
@@ -610,6 +649,7 @@ def main():
                                                         "achieved": tj.get("GBps"), "peak": 8000.0, "unit": "GB/s",
                                                         "frac": (tj.get("GBps") or 0.0) / 8000.0, "traffic": tj.get("hbm_bytes_per_launch"),
                                                         "duration_us": tj.get("duration_us"),
+                                                        "note": "a 13 us launch: latency-bound, not bandwidth-bound -- the fraction is informational",
                                                         "traffic_source": "profiles/traffic_sphere_step.json (PMC passes of an earlier run; a 13 us launch: latency-, not bandwidth-bound)"}
                 del tr, d3
             except Exception as e:
@@ -720,11 +760,16 @@ def main():
                                   "algorithmic_bytes_per_launch_pair": nbytes, "fwd_ms": kms["splat_fwd"], "bwd_ms": kms["splat_bwd"],
                                   "crops_per_launch": CB, "at_64_crops_per_launch": splat64,
                                   "traffic_source": "profiles/traffic_splat.json (PMC passes of an earlier run; not measured in this run)",
-                                  "note": "latency-bound at one crop (candidate evaluation chains, not bytes); see DESIGN.md 3.4"}
+                                  "note": "north_star's '>= 40 % HBM roofline on the march kernel': NOT APPLICABLE to this kernel pair -- it is instruction-bound "
+                                          "(candidate evaluation chains: ~250 cycles per candidate and sweep with the reference's exact division / square root; "
+                                          "~3100 SIMD-cycles per surfel wave in the backward), moves 4.4 MB per crop and is 2 % of the step; counter traffic is at "
+                                          "1.1x the algorithmic bytes at 64 crops per launch.  DESIGN.md 3.4"}
         line["jacobian"] = {"avg_launch_ms": kms["jacobian"], "tflops": 2.0 * macs * float(br.cnt.sum()) / (kms["jacobian"] * 1e-3) / 1e12,
                             "f32_mfma_peak_tflops": F32_MFMA_PEAK_TFLOPS, "rows": int(br.cnt.sum())}
+        line["long_run_ms_per_step"] = dt_long / long_steps * 1e3          # (the same step over >= 200 steps / >= 0.5 s; ms_per_step above is over exactly --steps)
         line["dropin_api"] = dropin
         line["refine_demo"] = refine
+        line["refine_demo_traced"] = refine_traced
         line["refine_sharded"] = sharded
         line["refine_sharded_float16"] = sharded16
         line["refine_sharded_prefilter"] = sharded_pf

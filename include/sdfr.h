@@ -330,7 +330,10 @@ int sdfr_solver_step(float* params, const float* grads, int L, const float* loss
  */
 /* decoder forward over the first *n_dev rows (device int32, clamped to n_max); half != 0: half operands on the matrix cores.
  * float32, 512-wide decoders: two launches per call, 64-row and 16-row tiles; the one that does not fit the count exits at once
- * (a thin step is one decoder pass of latency per workgroup: 0.12 ms on 16-row tiles, 0.44 ms on 64-row tiles). */
+ * (a thin step is one decoder pass of latency per workgroup: 0.12 ms on 16-row tiles, 0.44 ms on 64-row tiles).
+ * half | 2 (half operands only): one product shape whatever the count -- 128-row tiles while they fill the chip, 64-row tiles of the same
+ * 32x32x16 products below -- so that a row's value has the same bits in every launch (a crop then marches identically alone and in a batch;
+ * the 16-row tiles of plain `half` use 16x16x32 products, whose summation order differs). */
 int sdfr_mlp_forward_counted(const sdfr_decoder* dec, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf, int half,
                              void* stream);
 /* all pixels of all crops: slab test against the cube [-bound, bound]^3; hits enter the active list (counters[0]) at lam = max(entry, near).
@@ -394,6 +397,27 @@ int64_t sdfr_trace_backward_ws_floats(int B, int W, int H);
 int sdfr_trace_backward(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
                         const float* J, const float* f0, const float* g_color, const float* g_depth, const float* g_normals, float* ws,
                         float* g_pose, float* g_latn, void* stream);
+
+/* The sphere tracer as a backend of the refinement loop (pipelines/optimizer.py:110-146 reads rendering['color'] and points['xyzf'] from its
+ * renderer).  sdfr_trace_points gives points['xyzf'] of a traced render: the camera-frame hit points p_cam = lam_s K^-1 [x, y, 1] of each crop's
+ * hit pixels, compacted in pixel (row-major) order into xyzf [B][ecap][3]; ecnt [B] = the crop's TRUE hit count (surplus beyond ecap dropped:
+ * callers compare), pt_slot int32[B*W*H] = a pixel's row or -1.  hit_slot / lam_s: from sdfr_trace_hits / sdfr_trace_composite. */
+int sdfr_trace_points(const float* Kinv, int B, int W, int H, const int32_t* hit_slot, const float* lam_s, float* xyzf, int ecap,
+                      int32_t* ecnt, int32_t* pt_slot, void* stream);
+/* sdfr_trace_backward with the gradient arriving through those points (g_xyzf [B][ecap][3] + pt_slot, both may be NULL) and a choice of
+ * derivative semantics:
+ *   surfel = 0  image-space derivative at the fixed pixels through the implicit function f(o + lam d, z) = 0 (what sdfr_trace_backward computes;
+ *               a hit point then moves along its fixed pixel ray only: g_lam += g_xyzf . r);
+ *   surfel = 1  the autograd semantics of the reference's surface points (sdfrenderer/grid.py:61 p = x - sdf n_hat with n_hat constant;
+ *               sdfrenderer/renderer/projection.py:53-58 colour = the point's own object coordinates, p_cam = R p + t): every hit is a MATERIAL
+ *               point x_s that moves rigidly with the pose and along its normal with the latent, d x_s = -n_hat (d f/d z . dz) / |grad f|; its
+ *               NOCS colour does not depend on the pose; depth = (R x_s + t)_z; normals = (R n_hat + 1) / 2 with n_hat constant.
+ *               This is the mode the refinement loop converges with (the loop's one-directional nearest-neighbour 3-D loss needs points that
+ *               can move laterally). */
+int sdfr_trace_refine_backward(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
+                               const float* J, const float* f0, const float* g_color, const float* g_depth, const float* g_normals,
+                               const float* g_xyzf, const int32_t* pt_slot, int ecap, int surfel, float* ws, float* g_pose, float* g_latn,
+                               void* stream);
 
 /* The decoder's scale head on one latent row (deep_sdf_decoder_scale.py:68-75,110-112): out[0] = W3 relu(W2 relu(W1 lat + b1) + b2) + b3 with
  * W1 [3][L], W2 [3][3], W3 [1][3] row-major as nn.Linear stores them.  Returned by Decoder.forward next to the SDF values; unused by the loop. */

@@ -816,8 +816,17 @@ def cone_march(layers, spec, latn, pose, Kinv, image_wh, block, blocks, cone_ste
         if idx.size == 0:
             break
         X = (o[None] + lam[idx, None] * dc[idx]).astype(f)
-        rows = np.concatenate([np.broadcast_to(latn, (idx.size, L)), X], 1).astype(f)
+        # the centre point x may lie outside the cube the decoder is defined on (the block's range is the union of its pixels' ranges): evaluate
+        # at c = x clamped into the cube -- no extrapolated value is trusted.  The rendered surface lies inside the cube (rays are clipped to
+        # it), the cube is convex and c is its nearest point to x, so |x - s|^2 >= cd^2 + |c - s|^2 >= cd^2 + max(f(c), 0)^2 for every surface
+        # point s: a valid distance bound at x (inside the cube cd is exactly 0 and the value is the decoder's)
+        Xc = np.minimum(np.maximum(X, -f(bound)), f(bound)).astype(f)
+        e = (X - Xc).astype(f)
+        cd = np.sqrt(((e[:, 0] * e[:, 0]).astype(f) + (e[:, 1] * e[:, 1]).astype(f)).astype(f) + (e[:, 2] * e[:, 2]).astype(f)).astype(f)
+        rows = np.concatenate([np.broadcast_to(latn, (idx.size, L)), Xc], 1).astype(f)
         v = decoder_forward(layers, spec, rows)[:, 0].astype(f)
+        vp = np.maximum(v, f(0))
+        v = np.where(cd > 0, np.sqrt(((cd * cd).astype(f) + (vp * vp).astype(f)).astype(f)).astype(f), v).astype(f)
         evals += idx.size
         free = (v - (lam[idx] * delta[idx]).astype(f)).astype(f)
         go = free > f(eps)                                   # (NaN: stop)
@@ -995,3 +1004,113 @@ def sphere_trace_backward(tr, pose, g_color=None, g_depth=None, g_normals=None):
     g_pose[:3, :3], g_pose[:3, 3] = gR, gt
     g_latn = -((k * hit)[:, None] * gz).sum(0)
     return g_pose, g_latn
+
+
+# ---- refinement driven by the sphere tracer (the tracer as a backend of the loop of pipelines/optimizer.py:79-157) -------------------------
+# The caller contract is the reference loop's: the renderer hands the loop rendering['color'] (NOCS image -> compute_loss_2d, optimizer.py:132-141)
+# and points['xyzf'] (camera-frame surface points -> compute_loss_3d, :125-130); with the tracer those are the traced NOCS image and the hit
+# points p_cam = lam_s K^-1 [x, y, 1] of the hit pixels in pixel order.  PARITY UNPINNED (the reference has no tracer); the losses, the pose
+# construction, the latent normalisation and the solver are the reference's and pinned by goldens G8 / G12.
+
+def traced_points(tr, H, W):
+    """points['xyzf'] of a traced render: camera-frame hit points lam_s * r_cam of the hit pixels, in pixel (row-major) order; tr = the dict of
+    sphere_trace over ALL H*W pixels in row-major order.  Returns (xyzf (n_hit,3), pixel index of each row)."""
+    hit = tr["hit"]
+    assert hit.shape[0] == H * W
+    pix = np.nonzero(hit)[0]
+    return (tr["lam_s"][pix, None] * tr["r_cam"][pix]).astype(np.float32), pix
+
+
+def traced_refine_gradients(layers, spec, yaw, trans, scale, latent, K, H, W, target, lidar, w2=0.3, w3=0.5, trace_kwargs=None, points_grad="material", color_grad="material"):
+    """One iteration of the loop up to the solver step, rendered by the tracer: returns (weighted loss_2d, weighted loss_3d, g_yaw, g_trans (3,),
+    g_scale, g_latent (L,), n_hit) -- the gradients of w3 loss_3d + w2 loss_2d (optimizer.py:144-146) -- or None where the loop skips the frame
+    (no hit or no lidar point, :127-129).  Pose optimizer.py:86-90, latent normalisation :96, lidar / scale :84."""
+    f = np.float32
+    lat = np.asarray(latent, f).reshape(-1)
+    nl = max(float(np.sqrt((lat.astype(np.float64) ** 2).sum())), 1e-12)
+    latn = (lat / f(nl)).astype(f)
+    pose = render_pose(float(np.asarray(yaw).reshape(-1)[0]), np.asarray(trans, f).reshape(3))
+    Kinv = np.linalg.inv(np.asarray(K, f)).astype(f)
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    px = np.stack([xs.reshape(-1), ys.reshape(-1)], 1)
+    tr = sphere_trace(layers, spec, latn, pose, Kinv, px, image_wh=(W, H), **(trace_kwargs or {}))
+    est, pix = traced_points(tr, H, W)
+    lidar = np.asarray(lidar, f).reshape(-1, 3)
+    if est.shape[0] == 0 or lidar.shape[0] == 0:
+        return None
+    color = np.ascontiguousarray(tr["color"].T.reshape(3, H, W))
+    l2, g_color = loss_2d(color, target, want_grad=True)
+    s = float(np.asarray(scale).reshape(-1)[0])
+    l3, g_est, g_scale, _, _ = loss_3d(est, lidar, s, want_grad=True)
+    gC = (w2 * g_color.astype(np.float64)).reshape(3, -1).T
+    ge = w3 * g_est.astype(np.float64)
+    if points_grad == "ray":
+        # p_cam = lam r with the pixel ray r fixed: only lam moves; sphere_trace_backward takes it as a depth gradient (depth = lam r_z)
+        g_depth = np.zeros(H * W, np.float64)
+        r = tr["r_cam"].astype(np.float64)
+        g_depth[pix] = (ge * r[pix]).sum(1) / r[pix, 2]
+        g_pose, g_latn = sphere_trace_backward(tr, pose, g_color=gC, g_depth=g_depth)
+    else:
+        # material points, the autograd semantics of the reference's points['xyzf'] (grid.py:61 p = x - sdf n_hat with n_hat constant, then
+        # projection.py:58 p_cam = R p + t): the hit point x_s moves rigidly with the pose and along its normal with the latent,
+        # d x_s = -n_hat (gz . dz) / |gx|
+        P64 = pose.astype(np.float64)
+        if color_grad == "image":
+            g_pose, g_latn = sphere_trace_backward(tr, pose, g_color=gC)
+        else:
+            # ... and so does the pixel's NOCS colour (projection.py:53-55 colours = the surfel's own object coordinates: pose-independent)
+            g_pose = np.zeros((4, 4))
+            hitm = tr["hit"]
+            gxs = gC * np.array([-0.5, 0.5, 0.5]) * hitm[:, None]
+            gna = np.sqrt((tr["gx"].astype(np.float64) ** 2).sum(1))
+            kc = -(gxs * tr["n_hat"].astype(np.float64)).sum(1) / np.maximum(gna, 1e-12) * hitm
+            g_latn = (kc[:, None] * tr["gz"].astype(np.float64)).sum(0)
+        xs = tr["x_s"][pix].astype(np.float64)
+        g_pose[:3, :3] += ge.T @ xs
+        g_pose[:3, 3] += ge.sum(0)
+        go = ge @ P64[:3, :3]                                   # R^T g per point
+        gn = np.sqrt((tr["gx"][pix].astype(np.float64) ** 2).sum(1))
+        k = -(go * tr["n_hat"][pix].astype(np.float64)).sum(1) / np.maximum(gn, 1e-12)
+        g_latn = g_latn + (k[:, None] * tr["gz"][pix].astype(np.float64)).sum(0)
+    y = float(np.asarray(yaw).reshape(-1)[0])
+    c, sn = np.cos(y), np.sin(y)
+    dR = np.array([[-sn, 0, c], [0, 0, 0], [-c, 0, -sn]])                 # d [R_y(yaw) with row 1 negated] / d yaw
+    g_yaw = float((g_pose[:3, :3] * dR).sum())
+    g_lat = (g_latn - latn.astype(np.float64) * (latn.astype(np.float64) @ g_latn)) / nl
+    return f(w2) * l2, f(w3) * l3, g_yaw, g_pose[:3, 3].copy(), float(w3 * g_scale), g_lat, int(est.shape[0])
+
+
+class TracedRefiner:
+    """The reference loop's solver (MultipleOptimizer: Adam lr .01 on yaw and trans, SGD lr .01 on scale and 3e-5 on the latent,
+    optimizer.py:13-23,34-52) and skip rules (:127-129,149-151) around traced_refine_gradients; float64 state, one crop."""
+
+    def __init__(self, layers, spec, params, K, H, W, target, lidar, w2=0.3, w3=0.5, trace_kwargs=None, points_grad="material", color_grad="material"):
+        self.points_grad, self.color_grad = points_grad, color_grad
+        self.layers, self.spec, self.K, self.H, self.W = layers, spec, np.asarray(K, np.float32), int(H), int(W)
+        self.target, self.lidar, self.w2, self.w3 = np.asarray(target, np.float32), np.asarray(lidar, np.float32), w2, w3
+        self.kw = trace_kwargs or {}
+        self.p = np.concatenate([np.asarray(params[k], np.float64).reshape(-1) for k in ("yaw", "trans", "scale", "latent")])
+        self.m, self.v, self.t = np.zeros(4), np.zeros(4), 0
+        self.log = []
+
+    def step(self):
+        p = self.p.astype(np.float32)
+        out = traced_refine_gradients(self.layers, self.spec, p[0:1], p[1:4], p[4:5], p[5:], self.K, self.H, self.W, self.target, self.lidar,
+                                      self.w2, self.w3, self.kw, self.points_grad, self.color_grad)
+        if out is None:
+            return False
+        l2, l3, g_yaw, g_trans, g_scale, g_lat, n_hit = out
+        total = float(l2) + float(l3)
+        if np.isnan(total) or total == 0:
+            return False
+        self.log.append((float(l2), float(l3), n_hit))
+        g = np.concatenate([[g_yaw], g_trans])
+        self.t += 1
+        b1, b2 = 0.9, 0.999
+        self.m = b1 * self.m + (1 - b1) * g
+        self.v = b2 * self.v + (1 - b2) * g * g
+        denom = np.sqrt(self.v) / np.sqrt(1 - b2 ** self.t) + 1e-8
+        self.p[0:4] -= (0.01 / (1 - b1 ** self.t)) * (self.m / denom)
+        self.p[4] -= 0.01 * g_scale
+        self.p[5:] -= 0.00003 * g_lat
+        return True

@@ -168,7 +168,16 @@ extern "C" int sdfr_mlp_forward_counted(const sdfr_decoder* d, const float* inpu
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.n_dev = n_dev; P.trace = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (half) {
+    if (half & 2) {
+        // one product shape whatever the count (half | 2): 128-row tiles while they fill the chip, 64-row tiles of the SAME 32x32x16 products
+        // below -- a row's value then has the same bits in every launch, so a crop marches identically alone and inside a batch (the 16-row
+        // tiles below use 16x16x32 products, whose summation order differs)
+        const int mid = 64 * 256;
+        P.n_dev_lo = mid; P.n_dev_hi = 0x7fffffff;
+        if (n_max >= mid) sdfr_launch_fwd_f16_512(P, n_max, false, s);
+        P.n_dev_lo = 0; P.n_dev_hi = mid;
+        sdfr_launch_fwd_f16_512_tile64(P, n_max < mid ? n_max : (int64_t)mid, s);
+    } else if (half) {
         P.n_dev_lo = SDFR_COUNTED_TILE16_ROWS; P.n_dev_hi = 0x7fffffff;
         if (n_max >= SDFR_COUNTED_TILE16_ROWS) sdfr_launch_fwd_f16_512(P, n_max, false, s);
         P.n_dev_lo = 0; P.n_dev_hi = SDFR_COUNTED_TILE16_ROWS;

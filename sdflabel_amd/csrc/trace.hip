@@ -64,6 +64,30 @@ __device__ __forceinline__ void trace_write_row(float* __restrict__ row, const f
     row[L] = r.ox + lam * r.dx; row[L + 1] = r.oy + lam * r.dy; row[L + 2] = r.oz + lam * r.dz;
 }
 
+// the cone march evaluates the decoder on a block's CENTRE ray anywhere between the block's nearest entry and farthest exit, so the centre
+// point x can lie outside the cube [-bound, bound]^3 the decoder was trained on.  The row then holds c = x clamped into the cube
+// and no extrapolated decoder value is ever trusted: the rendered surface lies inside the cube (the rays are clipped to it), the cube is
+// convex and c is its nearest point to x, so for every surface point s:  |x - s|^2 >= |x - c|^2 + |c - s|^2 >= cd^2 + max(f(c), 0)^2
+// (cone_value below).  Inside the cube cd is exactly 0 and the value is the decoder's.
+__device__ __forceinline__ float cone_write_row(float* __restrict__ row, const float* __restrict__ latn, int L, const TraceRay& r, float lam, float bound) {
+    for (int c = 0; c < L; ++c) row[c] = latn[c];
+    const float x = r.ox + lam * r.dx, y = r.oy + lam * r.dy, z = r.oz + lam * r.dz;
+    const float cx = fminf(fmaxf(x, -bound), bound), cy = fminf(fmaxf(y, -bound), bound), cz = fminf(fmaxf(z, -bound), bound);
+    row[L] = cx; row[L + 1] = cy; row[L + 2] = cz;
+    const float ex = x - cx, ey = y - cy, ez = z - cz;
+    return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)));
+}
+__device__ __forceinline__ float cone_value(float v, float cd) {
+    if (!(cd > 0.f)) return v;
+    const float vp = fmaxf(v, 0.f);
+    return sqrtf(__fadd_rn(__fmul_rn(cd, cd), __fmul_rn(vp, vp)));
+}
+__device__ __forceinline__ float cone_clamp_dist(const TraceRay& r, float lam, float bound) {
+    const float x = r.ox + lam * r.dx, y = r.oy + lam * r.dy, z = r.oz + lam * r.dz;
+    const float ex = x - fminf(fmaxf(x, -bound), bound), ey = y - fminf(fmaxf(y, -bound), bound), ez = z - fminf(fmaxf(z, -bound), bound);
+    return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)));
+}
+
 // slab test of a ray against the cube [-bound, bound]^3 the SDF is defined on: entry (>= near) and exit parameters
 __device__ __forceinline__ bool trace_slab(const TraceRay& r, float bound, float near, float& l0, float& l1) {
     l0 = near; l1 = FLT_MAX;
@@ -159,13 +183,13 @@ __global__ __launch_bounds__(256) void sdfr_trace_cone_setup_kernel(const float*
     if (keep) {
         ids[slot] = b * nblk + k;
         st[slot] = make_float4(near_b, delta, far_b, sqrtf(rc.dx * rc.dx + rc.dy * rc.dy + rc.dz * rc.dz));
-        trace_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, rc, near_b);
+        (void)cone_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, rc, near_b, bound);
     }
 }
 
 __global__ __launch_bounds__(256) void sdfr_trace_cone_step_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
                                                                   const float* __restrict__ latn, int L, int W, int H, int BL, float eps,
-                                                                  const float* __restrict__ sdf, const int32_t* __restrict__ n_cur,
+                                                                  float bound, const float* __restrict__ sdf, const int32_t* __restrict__ n_cur,
                                                                   int32_t* __restrict__ n_next, int32_t* __restrict__ n_zero,
                                                                   const int32_t* __restrict__ ids_in, const float4* __restrict__ st_in,
                                                                   int32_t* __restrict__ ids_out, float4* __restrict__ st_out,
@@ -179,10 +203,16 @@ __global__ __launch_bounds__(256) void sdfr_trace_cone_step_kernel(const float* 
     bool keep = false;
     int id = 0;
     float4 st = make_float4(0.f, 0.f, 0.f, 1.f);
+    const int nbx = (W + BL - 1) / BL, nby = (H + BL - 1) / BL, nblk = nbx * nby;
+    TraceRay rc = {};
+    int b = 0;
     if (s < n) {
         id = ids_in[s];
         st = st_in[s];
-        const float v = sdf[s];
+        b = id / nblk;
+        int x0, y0, x1, y1;
+        rc = cone_centre_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, id - b * nblk, nbx, BL, W, H, x0, y0, x1, y1);
+        const float v = cone_value(sdf[s], cone_clamp_dist(rc, st.x, bound));     // (the row held the point clamped into the cube)
         const float free_ = v - __fmul_rn(st.x, st.y);
         if (!(free_ > eps)) cone[id] = st.x;                       // the cone touches the tolerance band (or NaN): its rays take over here
         else {
@@ -194,13 +224,9 @@ __global__ __launch_bounds__(256) void sdfr_trace_cone_step_kernel(const float* 
     }
     const int slot = trace_append(keep, n_next);
     if (keep) {
-        const int nbx = (W + BL - 1) / BL, nby = (H + BL - 1) / BL, nblk = nbx * nby;
-        const int b = id / nblk, k = id - b * nblk;
-        int x0, y0, x1, y1;
-        const TraceRay rc = cone_centre_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, k, nbx, BL, W, H, x0, y0, x1, y1);
         ids_out[slot] = id;
         st_out[slot] = st;
-        trace_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, rc, st.x);
+        (void)cone_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, rc, st.x, bound);
     }
 }
 
@@ -340,7 +366,8 @@ __global__ __launch_bounds__(TRB_THREADS) void sdfr_trace_backward_kernel(const 
                                                                          const int32_t* __restrict__ hit_slot, const float* __restrict__ J,
                                                                          const float* __restrict__ f0, const float* __restrict__ g_color,
                                                                          const float* __restrict__ g_depth, const float* __restrict__ g_normals,
-                                                                         float* __restrict__ partial) {
+                                                                         const float* __restrict__ g_xyzf, const int32_t* __restrict__ pt_slot,
+                                                                         int ecap, int surfel, float* __restrict__ partial) {
     constexpr int NV = 12 + TRB_MAXL;
     const int b = blockIdx.y, P_ = W * H, tid = threadIdx.x;
     const int p = blockIdx.x * TRB_THREADS + tid;
@@ -361,24 +388,56 @@ __global__ __launch_bounds__(TRB_THREADS) void sdfr_trace_backward_kernel(const 
         float gxs[3] = {0.f, 0.f, 0.f}, gn[3] = {0.f, 0.f, 0.f};
         if (g_color) { const float* g = g_color + (int64_t)b * 3 * P_; gxs[0] = -g[p] / 2.f; gxs[1] = g[P_ + p] / 2.f; gxs[2] = g[2 * P_ + p] / 2.f; }
         if (g_normals) { const float* g = g_normals + (int64_t)b * 3 * P_; gn[0] = g[p] / 2.f; gn[1] = g[P_ + p] / 2.f; gn[2] = g[2 * P_ + p] / 2.f; }
-        float gl = gxs[0] * r.dx + gxs[1] * r.dy + gxs[2] * r.dz;
-        if (g_depth) gl += g_depth[gp] * rz;
-        // d λ = -c [ gx . (d o + λ_s d d) + gz . d z ]  ->  adjoint on w = o + λ_s d:  g_w = g_x - c g_λ gx
-        const float k = h.c * gl;
-        const float gw[3] = {gxs[0] - k * Jr[L], gxs[1] - k * Jr[L + 1], gxs[2] - k * Jr[L + 2]};
-        const float go[3] = {gw[0], gw[1], gw[2]};
-        const float gd[3] = {h.lam_s * gw[0], h.lam_s * gw[1], h.lam_s * gw[2]};
-        const float t[3] = {Pm[3], Pm[7], Pm[11]}, rr[3] = {rx, ry, rz}, nh[3] = {h.nx, h.ny, h.nz};
-        // o_j = -sum_i R_ij t_i,  d_j = sum_i R_ij r_i,  n_cam_i = sum_j R_ij n_j
+        // gradient arriving through the hit's camera-frame point (points['xyzf'] of the refinement loop: sdfr_trace_points)
+        float ge[3] = {0.f, 0.f, 0.f};
+        if (g_xyzf) {
+            const int ps = pt_slot[gp];
+            if (ps >= 0 && ps < ecap) { const float* g = g_xyzf + ((int64_t)b * ecap + ps) * 3; ge[0] = g[0]; ge[1] = g[1]; ge[2] = g[2]; }
+        }
+        const float nh[3] = {h.nx, h.ny, h.nz};
+        if (!surfel) {
+            // image-space derivative at the fixed pixel: p_cam = lam r with the pixel ray r fixed, so the point only moves along its ray
+            float gl = gxs[0] * r.dx + gxs[1] * r.dy + gxs[2] * r.dz + (ge[0] * rx + ge[1] * ry + ge[2] * rz);
+            if (g_depth) gl += g_depth[gp] * rz;
+            // d λ = -c [ gx . (d o + λ_s d d) + gz . d z ]  ->  adjoint on w = o + λ_s d:  g_w = g_x - c g_λ gx
+            const float k = h.c * gl;
+            const float gw[3] = {gxs[0] - k * Jr[L], gxs[1] - k * Jr[L + 1], gxs[2] - k * Jr[L + 2]};
+            const float go[3] = {gw[0], gw[1], gw[2]};
+            const float gd[3] = {h.lam_s * gw[0], h.lam_s * gw[1], h.lam_s * gw[2]};
+            const float t[3] = {Pm[3], Pm[7], Pm[11]}, rr[3] = {rx, ry, rz};
+            // o_j = -sum_i R_ij t_i,  d_j = sum_i R_ij r_i,  n_cam_i = sum_j R_ij n_j
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) v[i * 3 + j] = -t[i] * go[j] + rr[i] * gd[j] + gn[i] * nh[j];
+                for (int j = 0; j < 3; ++j) v[i * 3 + j] = -t[i] * go[j] + rr[i] * gd[j] + gn[i] * nh[j];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) v[9 + i] = -(Pm[i * 4] * go[0] + Pm[i * 4 + 1] * go[1] + Pm[i * 4 + 2] * go[2]);
+            for (int i = 0; i < 3; ++i) v[9 + i] = -(Pm[i * 4] * go[0] + Pm[i * 4 + 1] * go[1] + Pm[i * 4 + 2] * go[2]);
 #pragma unroll
-        for (int c = 0; c < TRB_MAXL; ++c)
-            if (c < L) v[12 + c] = -k * Jr[c];
+            for (int c = 0; c < TRB_MAXL; ++c)
+                if (c < L) v[12 + c] = -k * Jr[c];
+        } else {
+            // surfel semantics -- the autograd semantics of the reference's surface points (grid.py:61 p = x - sdf n_hat with n_hat constant,
+            // projection.py:53-58 colour = the point's own object coordinates, p_cam = R p + t): the hit point x_s is a MATERIAL point that
+            // moves rigidly with the pose and along its normal with the latent, d x_s = -n_hat (gz . dz) / |gx|; its colour does not depend
+            // on the pose at all.  depth = (R x_s + t)_z.
+            if (g_depth) ge[2] += g_depth[gp];
+            const float xs[3] = {r.ox + h.lam_s * r.dx, r.oy + h.lam_s * r.dy, r.oz + h.lam_s * r.dz};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v[i * 3 + j] = ge[i] * xs[j] + gn[i] * nh[j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) v[9 + i] = ge[i];
+            // object-space gradient on x_s: R^T ge + the colour's
+            const float gox = Pm[0] * ge[0] + Pm[4] * ge[1] + Pm[8] * ge[2] + gxs[0];
+            const float goy = Pm[1] * ge[0] + Pm[5] * ge[1] + Pm[9] * ge[2] + gxs[1];
+            const float goz = Pm[2] * ge[0] + Pm[6] * ge[1] + Pm[10] * ge[2] + gxs[2];
+            const float gnorm = sqrtf(Jr[L] * Jr[L] + Jr[L + 1] * Jr[L + 1] + Jr[L + 2] * Jr[L + 2]);
+            const float k = (gox * nh[0] + goy * nh[1] + goz * nh[2]) / fmaxf(gnorm, 1e-12f);
+#pragma unroll
+            for (int c = 0; c < TRB_MAXL; ++c)
+                if (c < L) v[12 + c] = -k * Jr[c];
+        }
     }
     __shared__ float red[NV][TRB_THREADS];
 #pragma unroll
@@ -461,7 +520,7 @@ extern "C" int sdfr_trace_cone(const sdfr_decoder* d, const float* pose, const f
         const int rc = sdfr_mlp_forward_counted(d, inputs, n_max, counters + step % 3, sdf, half, stream);
         if (rc != SDFR_OK) return rc;
         const int a = step & 1;
-        hipLaunchKernelGGL(sdfr_trace_cone_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, block, eps, sdf,
+        hipLaunchKernelGGL(sdfr_trace_cone_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, block, eps, bound, sdf,
                            counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? ids1 : ids0,
                            reinterpret_cast<const float4*>(a ? st1 : st0), a ? ids0 : ids1, reinterpret_cast<float4*>(a ? st0 : st1), inputs, cone,
                            step == cone_steps - 1 ? 1 : 0, evals);
@@ -642,15 +701,74 @@ extern "C" int64_t sdfr_trace_backward_ws_floats(int B, int W, int H) {
 
 // image gradients (any of them may be NULL) -> g_pose [B][16] (row-major 4x4: rotation and translation entries) and g_latn [B][L] (gradient
 // w.r.t. the NORMALISED latent); sdfr_params_backward turns them into the gradients of yaw, trans and the latent.
+extern "C" int sdfr_trace_refine_backward(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam,
+                                          const int32_t* hit_slot, const float* J, const float* f0, const float* g_color, const float* g_depth,
+                                          const float* g_normals, const float* g_xyzf, const int32_t* pt_slot, int ecap, int surfel, float* ws,
+                                          float* g_pose, float* g_latn, void* stream) {
+    SDFR_REQUIRE(pose && Kinv && hit_lam && hit_slot && J && f0 && ws && g_pose && g_latn, "sdfr_trace_refine_backward: NULL argument");
+    SDFR_REQUIRE(L >= 0 && L <= TRB_MAXL && B > 0 && W > 0 && H > 0, "sdfr_trace_refine_backward: latent size 0..%d", TRB_MAXL);
+    SDFR_REQUIRE(!g_xyzf || (pt_slot && ecap > 0), "sdfr_trace_refine_backward: g_xyzf needs pt_slot and ecap (sdfr_trace_points)");
+    const int nblk = sdfr_cdiv((int64_t)W * H, TRB_THREADS);
+    hipLaunchKernelGGL(sdfr_trace_backward_kernel, dim3(nblk, B), dim3(TRB_THREADS), 0, (hipStream_t)stream, pose, Kinv, L, W, H, hit_lam, hit_slot,
+                       J, f0, g_color, g_depth, g_normals, g_xyzf, pt_slot, ecap, surfel, ws);
+    hipLaunchKernelGGL(sdfr_trace_backward_sum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ws, nblk, L, g_pose, g_latn);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
 extern "C" int sdfr_trace_backward(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
                                    const float* J, const float* f0, const float* g_color, const float* g_depth, const float* g_normals,
                                    float* ws, float* g_pose, float* g_latn, void* stream) {
-    SDFR_REQUIRE(pose && Kinv && hit_lam && hit_slot && J && f0 && ws && g_pose && g_latn, "sdfr_trace_backward: NULL argument");
-    SDFR_REQUIRE(L >= 0 && L <= TRB_MAXL && B > 0 && W > 0 && H > 0, "sdfr_trace_backward: latent size 0..%d", TRB_MAXL);
-    const int nblk = sdfr_cdiv((int64_t)W * H, TRB_THREADS);
-    hipLaunchKernelGGL(sdfr_trace_backward_kernel, dim3(nblk, B), dim3(TRB_THREADS), 0, (hipStream_t)stream, pose, Kinv, L, W, H, hit_lam, hit_slot,
-                       J, f0, g_color, g_depth, g_normals, ws);
-    hipLaunchKernelGGL(sdfr_trace_backward_sum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ws, nblk, L, g_pose, g_latn);
+    return sdfr_trace_refine_backward(pose, Kinv, L, B, W, H, hit_lam, hit_slot, J, f0, g_color, g_depth, g_normals, nullptr, nullptr, 0, 0, ws,
+                                      g_pose, g_latn, stream);
+}
+
+// points['xyzf'] of a traced render (what the refinement loop's 3-D loss consumes, pipelines/optimizer.py:125-130): the camera-frame hit
+// points p_cam = lam_s K^-1 [x, y, 1] of a crop's hit pixels, compacted in PIXEL ORDER (row-major; deterministic, unlike the hit list of
+// sdfr_trace_hits) into xyzf [B][ecap][3]; ecnt [B] = the crop's TRUE hit count (callers compare against ecap; surplus rows are dropped);
+// pt_slot [B*W*H] = a pixel's row or -1.  One workgroup per crop: ballot + running offset.
+#define TRP_THREADS 1024
+__global__ __launch_bounds__(TRP_THREADS) void sdfr_trace_points_kernel(const float* __restrict__ Kinv, int W, int H,
+                                                                       const int32_t* __restrict__ hit_slot, const float* __restrict__ lam_s,
+                                                                       float* __restrict__ xyzf, int ecap, int32_t* __restrict__ ecnt,
+                                                                       int32_t* __restrict__ pt_slot) {
+    const int b = blockIdx.x, P_ = W * H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Ki = Kinv + (int64_t)b * 9;
+    __shared__ int wcnt[TRP_THREADS / 64];
+    __shared__ int base;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < P_; p0 += TRP_THREADS) {
+        const int p = p0 + tid;
+        const int64_t gp = (int64_t)b * P_ + p;
+        const bool hit = p < P_ && hit_slot[gp] >= 0;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wcnt[w];
+        const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (p < P_) pt_slot[gp] = (hit && pos < ecap) ? pos : -1;
+        if (hit && pos < ecap) {
+            const float x = (float)(p % W), y = (float)(p / W), l = lam_s[gp];
+            float* o = xyzf + ((int64_t)b * ecap + pos) * 3;
+            o[0] = l * (fmaf(Ki[1], y, Ki[0] * x) + Ki[2]);
+            o[1] = l * (fmaf(Ki[4], y, Ki[3] * x) + Ki[5]);
+            o[2] = l * (fmaf(Ki[7], y, Ki[6] * x) + Ki[8]);
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < TRP_THREADS / 64; ++w) t += wcnt[w]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) ecnt[b] = base;
+}
+
+extern "C" int sdfr_trace_points(const float* Kinv, int B, int W, int H, const int32_t* hit_slot, const float* lam_s, float* xyzf, int ecap,
+                                 int32_t* ecnt, int32_t* pt_slot, void* stream) {
+    SDFR_REQUIRE(Kinv && hit_slot && lam_s && xyzf && ecnt && pt_slot, "sdfr_trace_points: NULL argument");
+    SDFR_REQUIRE(B > 0 && W > 0 && H > 0 && ecap > 0, "sdfr_trace_points: bad size");
+    hipLaunchKernelGGL(sdfr_trace_points_kernel, dim3(B), dim3(TRP_THREADS), 0, (hipStream_t)stream, Kinv, W, H, hit_slot, lam_s, xyzf, ecap, ecnt,
+                       pt_slot);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

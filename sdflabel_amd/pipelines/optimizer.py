@@ -42,7 +42,12 @@ def get_opt_params(params, device):
 
 
 class Optimizer:
-    def __init__(self, params, device, weights, rot='dcm'):
+    def __init__(self, params, device, weights, rot='dcm', render='splat', trace_grad='surfel', tracer_kwargs=None):
+        """render='trace' (extension): the loop's renderer is the sphere tracer instead of the reference's surfel splat -- same losses, same
+        solver, same call (BatchRefiner(render='trace')); not the reference's algorithm, so no parity claim goes with it."""
+        if render not in ('splat', 'trace'):
+            raise ValueError("render must be 'splat' or 'trace'")
+        self.render, self.trace_grad, self.tracer_kwargs = render, trace_grad, dict(tracer_kwargs or {})
         if rot != 'dcm':
             raise NotImplementedError("the refinement loop optimises a yaw angle (rot='dcm', optimizer.py:44,86-90); the quaternion "
                                       "variant is commented out in the reference (optimizer.py:92-93)")
@@ -64,13 +69,15 @@ class Optimizer:
         cap = max(256, 1 << (max(n_lidar, 1) - 1).bit_length())       # lidar capacity, rounded up so that a refiner is reused across crops
         Kn = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32)
         key = (id(dsdf), D, tuple(int(c) for c in crop_size), cap, Kn.tobytes(), str(dev), dsdf._param_key(dev),
-               float(self.weights.get('2d', 0.3)), float(self.weights.get('3d', 0.5)), getattr(dsdf, 'mlp_precision', None), bool(optimize_latent))
+               float(self.weights.get('2d', 0.3)), float(self.weights.get('3d', 0.5)), getattr(dsdf, 'mlp_precision', None), bool(optimize_latent),
+               self.render, self.trace_grad, tuple(sorted(self.tracer_kwargs.items())))
         if self._key != key:
             hit = _REFINERS.get(key)
             if hit is not None and hit[0]() is dsdf:
                 rf = hit[1]
             else:
-                rf = BatchRefiner(dsdf, D, Kn, crop_size, 1, lidar_cap=cap, weights=self.weights, device=dev, optimize_latent=optimize_latent)
+                rf = BatchRefiner(dsdf, D, Kn, crop_size, 1, lidar_cap=cap, weights=self.weights, device=dev, optimize_latent=optimize_latent,
+                                  render=self.render, trace_grad=self.trace_grad, tracer_kwargs=self.tracer_kwargs)
                 while len(_REFINERS) >= _REFINERS_MAX:
                     _REFINERS.pop(next(iter(_REFINERS)))
                 _REFINERS[key] = (weakref.ref(dsdf), rf)
@@ -78,7 +85,7 @@ class Optimizer:
             # callers pass Grid3D(grid_density, device, precision) with the config's float16 default, refine_css.py:148): compare in the
             # caller's dtype -- the same float32 -> precision rounding produced both
             pts = grid.points.detach()
-            if pts.shape != rf.br.grid.shape or not torch.equal(rf.br.grid.to(pts.dtype), pts.to(rf.br.grid.device)):
+            if rf.br is not None and (pts.shape != rf.br.grid.shape or not torch.equal(rf.br.grid.to(pts.dtype), pts.to(rf.br.grid.device))):
                 raise _lib.SdfrError("grid.points is not the Grid3D(%d) point set the kernels index" % D)
             self._refiner, self._key = rf, key
         return self._refiner
@@ -115,7 +122,7 @@ class Optimizer:
                 if iters_optim > 3 and rf._replay is None:
                     rf.capture()                              # once per refiner: later crops replay the same graph
                 rf.optimize(iters_optim)
-            rf.br.check_overflow()                            # a truncated band must not pass silently (one sync, after the loop)
+            rf.check_overflow()                               # a truncated band must not pass silently (one sync, after the loop)
             self._adam = (rf.adam_m.clone(), rf.adam_v.clone(), rf.adam_t.clone())
             p['yaw'].copy_(rf.yaw.view_as(p['yaw']))
             p['trans'].copy_(rf.trans.view_as(p['trans']))

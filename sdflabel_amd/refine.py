@@ -18,21 +18,41 @@ from .batch import BatchRenderer
 
 
 class BatchRefiner:
-    def __init__(self, decoder, density, K, crop_size, batch, lidar_cap, weights=None, cap=None, device="cuda", optimize_latent=True):
+    def __init__(self, decoder, density, K, crop_size, batch, lidar_cap, weights=None, cap=None, device="cuda", optimize_latent=True,
+                 render="splat", trace_grad="surfel", tracer_kwargs=None):
         """crop_size = (H, W) as the reference passes it (optimizer.py:56,72 builds the Rasterer with crop_size[::-1]).
         optimize_latent=False: pose-only refinement (yaw, trans, scale; the latent parameter group of optimizer.py:38 gets no update), so
-        the shape is evaluated once per set_crops() and every iteration only re-projects, splats and differentiates the pose."""
+        the shape is evaluated once per set_crops() and every iteration only re-projects, splats and differentiates the pose.
+        render="splat" (default): the reference's renderer (decoder on the grid -> surfels -> splat), reproduces its trajectories (G8*).
+        render="trace": the sphere tracer (renderer/sphere_tracer.py; NOT the reference's algorithm, no parity claim) supplies what the loop
+        reads from its renderer (optimizer.py:110-141): rendering['color'] = the traced NOCS image -> 2-D loss, points['xyzf'] = the
+        camera-frame hit points in pixel order -> 3-D loss; its backward feeds the same solver step.  `density` is unused then.
+        trace_grad="surfel" (default): hits differentiate as material points, the autograd semantics of the reference's surfels -- the mode
+        the loop converges with; "image": image-space implicit-function gradients at the fixed pixels (DESIGN.md 3.6 has the comparison).
+        tracer_kwargs: SphereTracer options (steps, cone_block, polish, ...)."""
         self.H, self.W = int(crop_size[0]), int(crop_size[1])
         self.B = int(batch)
         self.w2 = float((weights or {}).get('2d', 0.3))          # configs/config_refine.ini:26-27
         self.w3 = float((weights or {}).get('3d', 0.5))
-        self.br = BatchRenderer(decoder, density, K, (self.W, self.H), batch, cap=cap, device=device)
         self.optimize_latent = bool(optimize_latent)
-        self.br.freeze_shape = not self.optimize_latent
-        br, B = self.br, self.B
-        dev = br.dev
+        if render not in ("splat", "trace"):
+            raise ValueError("render must be 'splat' or 'trace'")
+        if trace_grad not in ("surfel", "image"):
+            raise ValueError("trace_grad must be 'surfel' or 'image'")
+        self.render, self.surfel = render, trace_grad == "surfel"
+        B = self.B
+        if render == "trace":
+            from .renderer.sphere_tracer import SphereTracer
+            self.br = None
+            self.tr = SphereTracer(decoder, K, (self.W, self.H), batch, device=device, points=True, **(tracer_kwargs or {}))
+            dev, self.L, est_cap = self.tr.dev, self.tr.L, self.tr.ecap
+        else:
+            self.tr = None
+            self.br = BatchRenderer(decoder, density, K, (self.W, self.H), batch, cap=cap, device=device)
+            self.br.freeze_shape = not self.optimize_latent
+            dev, self.L, est_cap = self.br.dev, self.br.L, self.br.cap
+        br = self.br
         self.dev = dev
-        self.L = br.L
         n = (5 + self.L) * B
         self.params = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -43,8 +63,9 @@ class BatchRefiner:
         self.yaw, self.trans, self.scale, self.latent = sections(self.params)
         self.g_yaw, self.g_trans, self.g_scale, self.g_latent = sections(self.grads)
         # the renderer reads / writes the sections of the flat buffers directly
-        br.yaw, br.trans, br.latent = self.yaw, self.trans, self.latent
-        br.g_yaw, br.g_trans, br.g_latent = self.g_yaw, self.g_trans, self.g_latent
+        rd = br if br is not None else self.tr
+        rd.yaw, rd.trans, rd.latent = self.yaw, self.trans, self.latent
+        rd.g_yaw, rd.g_trans, rd.g_latent = self.g_yaw, self.g_trans, self.g_latent
         self.lidar_cap = int(lidar_cap)
         self.lidar = torch.zeros((B, self.lidar_cap, 3), dtype=torch.float32, device=dev)
         self.lcnt = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -57,8 +78,8 @@ class BatchRefiner:
         self.stepped = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.g_color = torch.zeros((B, 3, self.H, self.W), dtype=torch.float32, device=dev)
         self.l2_scratch = torch.zeros((3 * B * ((self.W + 15) // 16) * ((self.H + 15) // 16),), dtype=torch.float32, device=dev)
-        self.l3_scratch = torch.zeros((3 * B * ((br.cap + 63) // 64),), dtype=torch.float32, device=dev)
-        self.g_xyzf = torch.zeros((B, br.cap, 3), dtype=torch.float32, device=dev)
+        self.l3_scratch = torch.zeros((3 * B * ((est_cap + 63) // 64),), dtype=torch.float32, device=dev)
+        self.g_xyzf = torch.zeros((B, est_cap, 3), dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros((B, 4), dtype=torch.float32, device=dev)
         self.adam_v = torch.zeros((B, 4), dtype=torch.float32, device=dev)
         self.adam_t = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -84,8 +105,9 @@ class BatchRefiner:
             self.lidar[b, :l.shape[0]] = l
             self.lcnt[b] = l.shape[0]
         self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t.zero_()
-        self.br.invalidate_shape()
-        self.br.reset_guard()                   # per-crop device state of the two-stage mode (violation counters, margins) starts clean
+        if self.br is not None:
+            self.br.invalidate_shape()
+            self.br.reset_guard()               # per-crop device state of the two-stage mode (violation counters, margins) starts clean
         # a captured graph stays valid: every buffer it reads or writes is static and was updated in place above
 
     def iteration(self):
@@ -97,6 +119,9 @@ class BatchRefiner:
         L = _lib.lib()
         P, st, ck = _lib.ptr, _lib.stream_ptr(), _lib.check
         br, B = self.br, self.B
+        if br is None:
+            self._iteration_traced(L, P, st, ck)
+            return
         out = br.forward()
         ck(L.sdfr_loss_2d(P(out["color"]), P(self.target), B, self.H, self.W, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color),
                           P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d")
@@ -109,13 +134,28 @@ class BatchRefiner:
                               P(self.adam_m), P(self.adam_v), P(self.adam_t), 0.01, 0.01, 0.00003 if self.optimize_latent else 0.0, B,
                               P(self.total), P(self.stepped), st), "sdfr_solver_step")
 
+    def _iteration_traced(self, L, P, st, ck):
+        """the same iteration with the sphere tracer as the loop's renderer (optimizer.py:110-123 -> rendering['color'], points['xyzf'])"""
+        tr, B = self.tr, self.B
+        out = tr.render()
+        ck(L.sdfr_loss_2d(P(out["color"]), P(self.target), B, self.H, self.W, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color),
+                          P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d")
+        ck(L.sdfr_loss_3d(P(out["xyzf"]), P(tr.ecnt), tr.ecap, P(self.lidar), P(self.lcnt), self.lidar_cap, P(self.scale), 0.2, self.w3, B,
+                          P(self.loss3d), P(self.g_xyzf), P(self.g_scale), P(self.npairs), P(self.l3_scratch), st), "sdfr_loss_3d")
+        tr.backward(g_color=self.g_color, g_xyzf=self.g_xyzf, surfel=self.surfel)
+        if not self.optimize_latent:
+            self.g_latent.zero_()
+        ck(L.sdfr_solver_step(P(self.params), P(self.grads), self.L, P(self.loss2d), P(self.loss3d), P(self.npairs), self.w2, self.w3,
+                              P(self.adam_m), P(self.adam_v), P(self.adam_t), 0.01, 0.01, 0.00003 if self.optimize_latent else 0.0, B,
+                              P(self.total), P(self.stepped), st), "sdfr_solver_step")
+
     def capture(self):
         """Capture one iteration in a HIP graph; optimize() then replays it."""
         s = torch.cuda.Stream(device=self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         snap = (self.params.clone(), self.adam_m.clone(), self.adam_v.clone(), self.adam_t.clone())
         br = self.br
-        guard = (br.violations.clone(), br.margin_dev.clone(), br.max_dev.clone()) if br.prefilter else None
+        guard = (br.violations.clone(), br.margin_dev.clone(), br.max_dev.clone()) if (br is not None and br.prefilter) else None
         with torch.cuda.stream(s):
             self.iteration()
         torch.cuda.current_stream(self.dev).wait_stream(s)
@@ -131,7 +171,7 @@ class BatchRefiner:
 
     def optimize(self, iters_optim):
         for _ in range(iters_optim):
-            if self._replay is not None and self.br.freeze_shape and not self.br._shape_valid:
+            if self._replay is not None and self.br is not None and self.br.freeze_shape and not self.br._shape_valid:
                 self.iteration()                        # pose-only: the captured graph holds the steady state; a new latent needs one full pass
                 continue
             if self._replay is not None:
@@ -142,6 +182,12 @@ class BatchRefiner:
     def results(self):
         """(B, 5+L) rows [yaw, trans(3), scale, latent(L)] and the last (B,) weighted losses (2d, 3d).  Synchronises; raises if a crop's
         band overflowed the surfel capacity in the last iteration (its shape would have been truncated)."""
-        self.br.check_overflow()
+        self.check_overflow()
         rows = torch.cat([self.yaw.view(-1, 1), self.trans, self.scale.view(-1, 1), self.latent], dim=1)
         return rows.clone(), (self.w2 * self.loss2d).clone(), (self.w3 * self.loss3d).clone()
+
+    def check_overflow(self):
+        """splat: raise if a crop's band exceeded the surfel capacity (BatchRenderer.check_overflow).  trace: nothing can overflow (the point
+        list holds every pixel).  One synchronisation."""
+        if self.br is not None:
+            self.br.check_overflow()

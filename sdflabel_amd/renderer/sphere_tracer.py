@@ -65,7 +65,7 @@ def default_spec_from(rays_per_crop, half):
 class SphereTracer:
     def __init__(self, decoder, K, resolution_px, batch=1, steps=64, eps=2e-3, bound=1.0, near=1e-3, device="cuda", head_steps=None,
                  tail_rows=4096, spec_from=None, spec_k=None, sigma=0.9, spec_from2=None, spec_k2=None, polish=None,
-                 cone_block=None, cone_steps=10):
+                 cone_block=None, cone_steps=10, uniform_tiles=True, points=False):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise _lib.SdfrError("SphereTracer runs on the GPU only")
@@ -110,10 +110,17 @@ class SphereTracer:
         if self.polish not in ("exact", "decoder"):
             raise ValueError("polish must be 'exact' or 'decoder'")
         self.half_polish = bool(self.half) and self.polish == "decoder"
-        # cone marching ahead of the per-ray march (opt-in): one ray per cone_block x cone_block pixel tile until the SDF falls below the cone's
-        # radius; tiles whose cone leaves the cube are culled, the others' rays start where their cone stopped (csrc/trace.hip sdfr_trace_cone)
-        self.cone_block = int(cone_block) if cone_block else 0
+        # cone marching ahead of the per-ray march (default since r04: 4x4-pixel tiles; cone_block=0 turns it off): one ray per cone_block x
+        # cone_block pixel tile until the SDF falls below the cone's radius; tiles whose cone leaves the cube are culled, the others' rays start
+        # where their cone stopped (csrc/trace.hip sdfr_trace_cone; 3.2x fewer decoder evaluations on the bench crop)
+        self.cone_block = 4 if cone_block is None else int(cone_block)
         self.cone_steps = int(cone_steps)
+        # uniform_tiles: the cone passes of a float16 decoder use ONE product shape whatever the device-side count (sdfr_mlp_forward_counted
+        # half | 2), like the per-ray march (32x32x16 products in its 128- and 64-row head tiles and in the looping kernel with spec_k = 4):
+        # a crop's rays then see the same decoder bits alone and inside a batch -> BatchRefiner(render="trace") refines a crop bit-identically
+        # at any batch size.  False: 16-row tiles of 16x16x32 products for thin cone passes (a few us per pass faster at one crop, values
+        # equal to float rounding only).
+        self.uniform_tiles = bool(uniform_tiles)
         if self.cone_block and (self.cone_block < 2 or self.cone_steps < 1):
             raise ValueError("cone_block >= 2 (pixels), cone_steps >= 1")
         self.L = decoder.latent_size
@@ -148,11 +155,18 @@ class SphereTracer:
         self.mask_ws = i(int(_lib.lib().sdfr_decoder_mask_words(self.handle.h, n))) if self.half_polish else None
         self.g_pose, self.g_latn = f(B, 16), f(B, self.L)
         self.g_yaw, self.g_trans, self.g_latent = f(B), f(B, 3), f(B, self.L)
+        # points['xyzf'] of the refinement loop (optimizer.py:125): camera-frame hit points per crop in pixel order (sdfr_trace_points)
+        self.ecap = H * W
+        if points:
+            self.xyzf, self.ecnt, self.pt_slot = f(B, self.ecap, 3), i(B), i(n)
+        else:
+            self.xyzf = self.ecnt = self.pt_slot = None
 
     # ------------------------------------------------------------------------------------------------------------------
-    def render(self, yaw, trans, latent, events=None):
-        """forward without autograd: fills and returns the static image buffers.  events: optional {'march': (start, end)} torch.cuda.Event
-        pairs recorded around the march (bench.py)."""
+    def render(self, yaw=None, trans=None, latent=None, events=None):
+        """forward without autograd: fills and returns the static image buffers.  yaw=None: the parameters already sit in self.yaw / .trans /
+        .latent (BatchRefiner binds those to its flat parameter buffer).  events: optional {'march': (start, end)} torch.cuda.Event pairs
+        recorded around the march (bench.py)."""
         L = _lib.lib()
         P, ck = _lib.ptr, _lib.check
         B, W, H = self.B, self.W, self.H
@@ -160,7 +174,8 @@ class SphereTracer:
         events = events or {}
         with _lib.guard(self.dev):
             st = _lib.stream_ptr()
-            self.yaw.copy_(yaw.reshape(B)); self.trans.copy_(trans.reshape(B, 3)); self.latent.copy_(latent.reshape(B, self.L))
+            if yaw is not None:
+                self.yaw.copy_(yaw.reshape(B)); self.trans.copy_(trans.reshape(B, 3)); self.latent.copy_(latent.reshape(B, self.L))
             ck(L.sdfr_params_forward(P(self.yaw), P(self.trans), P(self.latent), self.L, None, 1, B, None, P(self.pose), P(self.latnorm), st),
                "sdfr_params_forward")
             torch.div(self.latent, self.latnorm.unsqueeze(1), out=self.latn)                    # F.normalize (optimizer.py:96)
@@ -169,7 +184,8 @@ class SphereTracer:
                 events["march"][0].record()
             if self.cone_block:
                 ck(L.sdfr_trace_cone(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, self.eps,
-                                     self.cone_block, self.cone_steps, self.half, P(self.cone_counters), P(self.cone_ids[0]), P(self.cone_st[0]),
+                                     self.cone_block, self.cone_steps, (self.half | 2) if (self.half and self.uniform_tiles) else self.half,
+                                     P(self.cone_counters), P(self.cone_ids[0]), P(self.cone_st[0]),
                                      P(self.cone_ids[1]), P(self.cone_st[1]), P(self.cone_inputs), P(self.cone_sdf), P(self.cone), st),
                    "sdfr_trace_cone")
             ck(L.sdfr_trace_setup(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, P(self.counters), P(self.pix[0]),
@@ -198,11 +214,21 @@ class SphereTracer:
                    "sdfr_mlp_jacobian")
             ck(L.sdfr_trace_composite(P(self.pose), P(self.Kinv), self.L, B, W, H, P(self.hit_lam), P(self.hit_slot), P(self.J), P(self.f0),
                                       P(self.color), P(self.mask), P(self.depth), P(self.normals), P(self.lam_s), st), "sdfr_trace_composite")
-        return {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.normals}
+            if self.xyzf is not None:
+                ck(L.sdfr_trace_points(P(self.Kinv), B, W, H, P(self.hit_slot), P(self.lam_s), P(self.xyzf), self.ecap, P(self.ecnt),
+                                       P(self.pt_slot), st), "sdfr_trace_points")
+        out = {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.normals}
+        if self.xyzf is not None:
+            out["xyzf"], out["nf"] = self.xyzf, self.ecnt
+        return out
 
-    def backward(self, g_color=None, g_depth=None, g_normals=None, state=None):
+    def backward(self, g_color=None, g_depth=None, g_normals=None, state=None, g_xyzf=None, surfel=False):
         """gradients of the last render() w.r.t. yaw [B], trans [B,3], latent [B,L] (static buffers).  state: saved copies of the buffers of an
-        earlier render (the autograd path)."""
+        earlier render (the autograd path).  g_xyzf [B, ecap, 3]: gradient w.r.t. the hit points (constructed with points=True).
+        surfel=False: image-space derivative at the fixed pixels through the implicit function (a hit point moves along its pixel ray only);
+        surfel=True: the hits are material points that move rigidly with the pose and along their normal with the latent, their NOCS colour is
+        pose-independent -- the autograd semantics of the reference's surfels (grid.py:61, projection.py:53-58), the mode the refinement loop
+        uses (include/sdfr.h sdfr_trace_refine_backward)."""
         L = _lib.lib()
         P, ck = _lib.ptr, _lib.check
         B, W, H = self.B, self.W, self.H
@@ -214,8 +240,13 @@ class SphereTracer:
         g_color, g_depth, g_normals = c(g_color, self.color.shape), c(g_depth, self.depth.shape), c(g_normals, self.normals.shape)
         with _lib.guard(self.dev):
             st = _lib.stream_ptr()
-            ck(L.sdfr_trace_backward(P(S["pose"]), P(self.Kinv), self.L, B, W, H, P(S["hit_lam"]), P(S["hit_slot"]), P(S["J"]), P(S["f0"]),
-                                     P(g_color), P(g_depth), P(g_normals), P(self.ws), P(self.g_pose), P(self.g_latn), st), "sdfr_trace_backward")
+            if g_xyzf is not None:
+                if self.xyzf is None:
+                    raise _lib.SdfrError("SphereTracer: g_xyzf needs a tracer built with points=True")
+                g_xyzf = c(g_xyzf, self.xyzf.shape)
+            ck(L.sdfr_trace_refine_backward(P(S["pose"]), P(self.Kinv), self.L, B, W, H, P(S["hit_lam"]), P(S["hit_slot"]), P(S["J"]), P(S["f0"]),
+                                            P(g_color), P(g_depth), P(g_normals), P(g_xyzf), P(self.pt_slot), self.ecap, 1 if surfel else 0,
+                                            P(self.ws), P(self.g_pose), P(self.g_latn), st), "sdfr_trace_refine_backward")
             ck(L.sdfr_params_backward(P(S["yaw"]), P(S["latent"]), self.L, P(S["latnorm"]), P(self.g_pose), P(self.g_latn), B, P(self.g_yaw),
                                       P(self.g_trans), P(self.g_latent), st), "sdfr_params_backward")
         return self.g_yaw, self.g_trans, self.g_latent
@@ -249,5 +280,6 @@ class SphereTracer:
 
     @property
     def hit_residual(self):
-        """exact-f32 decoder value at the marched hit points (before the polish)"""
+        """decoder value at the marched hit points (before the polish), in the hit pass's precision: exact float32 with polish="exact" or
+        a float32 decoder, the half forward's value with polish="decoder" on a float16 decoder"""
         return self.f0[:self.n_hit]

@@ -59,8 +59,10 @@ def test_march_polish_images_and_gradients_against_the_oracle(dec, oracle_layers
     latn = lat / np.sqrt((lat * lat).sum())
     pose = O.render_pose(YAW[0], TRANS[0])
     Kinv = np.linalg.inv(K).astype(np.float32)
+    # (r04: cone marching on 4x4-pixel tiles is the tracer's default; the oracle takes the same cone phase)
     ref = O.sphere_trace(layers, spec, latn, pose, Kinv, px, steps=64,
-                         spec_from=[(16, spec_k), (20, max(spec_k, spec_k2))] if spec_k > 1 else None)
+                         spec_from=[(16, spec_k), (20, max(spec_k, spec_k2))] if spec_k > 1 else None, cone_block=4, cone_steps=10, image_wh=(W, H))
+    assert tr.cone_block == 4 and ref["cone_culled"].sum() > 200
     sel = (px[:, 1], px[:, 0])
     hit = N(out["mask"][0, 0])[sel] > 0
     safe = ref["margin"] > 1e-4
@@ -118,7 +120,7 @@ def test_march_against_the_oracle_on_the_second_decoder():
     lat = np.asarray(LAT[0], np.float32)
     latn = lat / np.sqrt((lat * lat).sum())
     ref = O.sphere_trace(layers, spec, latn, O.render_pose(YAW[0], TRANS[0]), np.linalg.inv(K).astype(np.float32), px, steps=64,
-                         spec_from=[(12, 4), (15, 16)])
+                         spec_from=[(12, 4), (15, 16)], cone_block=4, cone_steps=10, image_wh=(W, H))
     sel = (px[:, 1], px[:, 0])
     hit = N(out["mask"][0, 0])[sel] > 0
     safe = ref["margin"] > 1e-4
@@ -150,7 +152,8 @@ def test_march_with_a_layernorm_decoder():
     px = np.stack([xs.reshape(-1), ys.reshape(-1)], 1)
     lat = np.asarray(LAT[0], np.float32)
     latn = lat / np.sqrt((lat * lat).sum())
-    ref = O.sphere_trace(layers, spec, latn, O.render_pose(YAW[0], TRANS[0]), np.linalg.inv(K).astype(np.float32), px, steps=64)
+    ref = O.sphere_trace(layers, spec, latn, O.render_pose(YAW[0], TRANS[0]), np.linalg.inv(K).astype(np.float32), px, steps=64,
+                         cone_block=4, cone_steps=10, image_wh=(W, H))
     sel = (px[:, 1], px[:, 0])
     hit = N(out["mask"][0, 0])[sel] > 0
     safe = ref["margin"] > 1e-4
@@ -176,7 +179,7 @@ def test_cone_marching_first_phase_against_the_oracle(dec, oracle_layers, block,
     K[0, 2] += 9.0
     kw = dict(steps=64, device=DEV, spec_from=16, spec_k=4, spec_from2=20, spec_k2=16)
     tr = sdflabel_amd.SphereTracer(dec, K, (W, H), 1, cone_block=block, cone_steps=10, **kw)
-    plain = sdflabel_amd.SphereTracer(dec, K, (W, H), 1, **kw)
+    plain = sdflabel_amd.SphereTracer(dec, K, (W, H), 1, cone_block=0, **kw)
     a = _args(grad=True)
     out = tr(*a)
     ref_img = {k: v.clone() for k, v in plain.render(*_args()).items()}

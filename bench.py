@@ -395,6 +395,72 @@ def main():
         del rf
     res = None
 
+    # ---- the product-side Optimizer on crops as the reference PIPELINE produces them: every annotation its own crop size and
+    # intrinsics (utils/refinement.py:586-609 adjust_intrinsics_crop: area-normalised to rendering_area^2, aspect of the 2-D box kept, principal
+    # point moved by the box corner; pipelines/refine_css.py:203-223 constructs an Optimizer per annotation).  32 KITTI-like boxes, one
+    # Optimizer(...).optimize(60, ...) call per crop as the pipeline issues them; the time INCLUDES building the refiner (buffers + HIP-graph
+    # capture), which ragged extents make a once-per-capacity cost: refiners_built / graph_captures should read 1 / 1 per rendering area.
+    def varied_crops(area):
+        from sdflabel_amd.pipelines import optimizer as OP
+        OP.clear_refiner_cache()
+        OP.STATS["refiners_built"] = 0
+        d16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+        d16 = d16.to(dev)
+        rng = np.random.default_rng(11)
+        n = 32
+        boxes_w = rng.uniform(60, 420, n)
+        boxes_h = boxes_w / rng.uniform(1.2, 3.2, n)                                         # cars: 1.2 ... 3.2 times as wide as high
+        shapes, Ks, gts = [], [], []
+        for bw, bh in zip(boxes_w, boxes_h):
+            r = np.sqrt(area * area / (bh * bw))
+            Hc, Wc = int(bh * r), int(bw * r)                                                 # crop_size.int() (:603)
+            f = 1.15 * Hc * 3.5 / 2.0                                                         # the object (a 2-unit cube at z = 3.5) about fills the crop's height
+            cx, cy = rng.uniform(-1.0 * Wc, 2.0 * Wc), rng.uniform(0.2 * Hc, 0.8 * Hc)        # principal point far outside the crop, as after the box-corner shift
+            shapes.append((Hc, Wc))
+            Ks.append(np.array([[f, 0, cx], [0, f, cy], [0, 0, 1]], np.float32))
+            gts.append(np.array([3.5 * (Wc / 2.0 - cx) / f, 3.5 * (Hc / 2.0 - cy) / f, 3.5], np.float32))
+        pmax = 1 << (max(h * w for h, w in shapes) - 1).bit_length()
+        # targets: the ground-truth pose of every crop rendered in ONE ragged batch (exact-f32 decoder)
+        gtr = sdflabel_amd.BatchRenderer(dec, D, np.stack(Ks), (shapes[0][1], shapes[0][0]), n, device=dev, max_pixels=pmax)
+        gtr.set_extents([(w, h) for h, w in shapes], np.stack(Ks))
+        o = gtr.forward(torch.full((n,), 0.6, device=dev), torch.from_numpy(np.stack(gts)).to(dev), torch.tensor([[0.3, -0.5, 0.8]] * n, device=dev))
+        nfs = o["nf"].tolist()
+        targets = [gtr.image(b, "color").clone().cpu() for b in range(n)]
+        lidars = [(o["xyzf"][b, :nfs[b]] * 2.0)[::2].cpu().numpy() for b in range(n)]
+        del gtr
+        grid = sdflabel_amd.Grid3D(D, dev)
+        starts = [crop_start(i) for i in range(n)]
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        errs0, errs1, caps = [], [], set()
+        for b in range(n):
+            y0, t0_, l0 = starts[b]
+            p = {"yaw": y0.copy(), "trans": (gts[b] + (t0_ - np.asarray([0.0, 0.0, 3.5], np.float32))).astype(np.float32), "scale": np.array([2.0], np.float32),
+                 "latent": l0.copy()}
+            opt = OP.Optimizer(p, dev, {"2d": 0.3, "3d": 0.5})
+            out = opt.optimize(iters, targets[b], lidars[b], d16, grid, torch.from_numpy(Ks[b]), list(shapes[b]))
+            caps.add(id(opt._refiner))
+            errs0.append(abs(float(y0[0]) - 0.6)); errs1.append(abs(float(out["yaw"][0]) - 0.6))
+        torch.cuda.synchronize()
+        dt_v = time.perf_counter() - t_
+        captures = sum(getattr(v[1], "captures", 0) for v in OP._REFINERS.values())
+        res_ = {"value": n / dt_v, "unit": "crops/s", "crops": n, "iterations_per_crop": iters, "rendering_area": area, "seconds_incl_refiner_construction": dt_v,
+                "crop_sizes_h_w_min_max": [list(min(shapes)), list(max(shapes))], "distinct_crop_sizes": len(set(shapes)), "pixel_capacity": pmax,
+                "refiners_built": OP.STATS["refiners_built"], "graph_captures": captures, "distinct_refiners_used": len(caps),
+                "decoder_precision": "float16 (the reference's shipped precision)", "mean_abs_yaw_error_before_after": [float(np.mean(errs0)), float(np.mean(errs1))],
+                "call": "Optimizer(params, device, weights).optimize(60, nocs, lidar, dsdf, grid, K_b, [H_b, W_b]) per crop, as pipelines/refine_css.py:203-223"}
+        OP.clear_refiner_cache()
+        return res_
+
+    varied = None
+    if rank == 0 and CB == 1 and not args.no_extras:
+        varied = {}
+        for area in (32, 256):
+            try:
+                varied["rendering_area_%d" % area] = varied_crops(area)
+            except Exception as e:
+                varied["rendering_area_%d" % area] = {"error": repr(e)[:300]}
+
     # ---- BASELINE configs[3]: `--total-crops` crops sharded over the ranks (crop i -> rank i mod N), refined for the reference's 60 iterations
     # in chunks of 64 by BatchRefiner, ONE all_gather of the per-crop result rows at the end (sdflabel_amd.parallel.refine_sharded).
     # Strong scaling: the total is fixed, so seconds(N=1) / seconds(N) is the north_star's "x at 8 GPUs over 1 GPU on a 1024-crop batch".
@@ -770,6 +836,7 @@ def main():
         line["dropin_api"] = dropin
         line["refine_demo"] = refine
         line["refine_demo_traced"] = refine_traced
+        line["optimizer_mirror_varied_crops"] = varied
         line["refine_sharded"] = sharded
         line["refine_sharded_float16"] = sharded16
         line["refine_sharded_prefilter"] = sharded_pf

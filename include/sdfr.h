@@ -243,6 +243,35 @@ int sdfr_splat_backward(int primitive, const float* K, const float* Kinv, const 
                         const float* g_color, const float* g_mask, const float* g_depth, const float* g_normals,
                         float* g_p_cam, float* g_n_cam, float* g_attr, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Ragged extents (r04): every crop of a batch its OWN image size and intrinsics, as the crops of the reference pipeline have
+ * (utils/refinement.py:586-609 adjust_intrinsics_crop: area-normalised, aspect kept; pipelines/refine_css.py:117-129,203-223 builds a
+ * Rasterer per crop).  The `_r` entry points take the extents as DATA -- wh int32[B][2] = (W_b, H_b) on the device, next to the per-crop
+ * K / Kinv [B][9] -- instead of launch constants, so one captured launch sequence serves any crop sizes within the caps:
+ *   images / aux / gradients live in slots of pix_stride pixels per channel: color [B][3][pix_stride], mask / depth [B][pix_stride],
+ *   aux [B][pix_stride][4]; crop b uses the first W_b H_b entries of each channel, rows of W_b pixels;
+ *   tiles_cap >= ceil(W_b / 8) ceil(H_b / 8) for every crop (launch bound and tile-list layout of the splat workspace,
+ *   sdfr_splat_ws_words_r words); tiles16_cap likewise for the 16 x 16 tiles of the 2-D loss.
+ * Arithmetic per crop exactly as the fixed-extent calls: a crop's results are bit-identical to rendering it alone at its own size.
+ * Disc primitive (the optimizer's), no background. */
+int64_t sdfr_splat_ws_words_r(int B, int cap, int tiles_cap);
+int sdfr_surfels_forward_r(const float* xyz, int xyz_stride, const float* sdf, int64_t G, const int32_t* idx, const float* J, int Jstride,
+                           int Joff, const float* pose, const float* K, int B, int cap, const int32_t* cnt, int output_nocs,
+                           const int32_t* wh, int tiles_cap, float diam, float* points, float* normals, float* p_cam, float* n_cam, float* col,
+                           int32_t* fidx, int32_t* fcnt, float* xyzf, int32_t* fslot, int32_t* bbox, void* stream);
+int sdfr_splat_forward_r(int flags /* SDFR_PRIM_BOXES_READY | SDFR_PRIM_BINS */, const float* K, const float* Kinv, const float* p_cam,
+                         const float* n_cam, const float* attr, int B, int cap, const int32_t* cnt, const int32_t* wh, int pix_stride,
+                         int tiles_cap, float diam, float depth_constant, int32_t* bbox_ws, float* color, float* mask, float* depth,
+                         float* normals, float* aux, void* stream);
+int sdfr_splat_backward_r(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr, int B, int cap,
+                          const int32_t* cnt, const int32_t* wh, int pix_stride, float diam, float depth_constant, const float* aux,
+                          const float* color, const float* mask, const float* depth, const float* normals, const float* g_color,
+                          const float* g_mask, const float* g_depth, const float* g_normals, float* g_p_cam, float* g_n_cam, float* g_attr,
+                          void* stream);
+/* sdfr_loss_2d on ragged extents; scratch float[3 * B * tiles16_cap] */
+int sdfr_loss_2d_r(const float* rend, const float* target, int B, const int32_t* wh, int pix_stride, int tiles16_cap, float diam,
+                   float threshold_nocs, float weight, float* loss, float* g_rend, int32_t* nvalid, float* scratch, void* stream);
+
 /* The dense weight matrix the reference's standalone primitives return (prob_color[:, 0, :] of inside_surfel / inside_circle /
  * inside_circle_opt, primitives.py:71,162,243): weights [B][rows][W*H], rows = cap (+1 background row when bg_logit != NULL), from the
  * per-pixel state `aux` of a sdfr_splat_forward call over the same surfels (with the same bg_logit).  `weights` must be zero-filled; only

@@ -35,6 +35,17 @@ _PROTOS = {
     "sdfr_trace_points": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "sdfr_trace_refine_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_ws_words_r": (c_int64, [c_int, c_int, c_int]),
+    "sdfr_surfels_forward_r": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                       c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_forward_r": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                     c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_backward_r": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
+    "sdfr_loss_2d_r": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
     "sdfr_scale_net": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_decoder_create": (c_int, [POINTER(c_void_p), c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                     POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int]),

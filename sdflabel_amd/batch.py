@@ -30,7 +30,14 @@ _DEPTH_CONSTANT = 150.0
 
 
 class BatchRenderer:
-    def __init__(self, decoder, density, K, resolution_px, batch, cap=None, device="cuda", threshold=0.03, output_nocs=True):
+    def __init__(self, decoder, density, K, resolution_px, batch, cap=None, device="cuda", threshold=0.03, output_nocs=True,
+                 max_pixels=None, max_side=None):
+        """max_pixels (r04, ragged extents): every crop of the batch may have its OWN image size (W_b, H_b) with W_b H_b <= max_pixels and
+        W_b, H_b <= max_side (default 4 sqrt(max_pixels)), and its own intrinsics -- what the reference pipeline's crops look like
+        (utils/refinement.py:586-609).  Images then live in slots of max_pixels pixels per channel ([B, C, max_pixels]; image(b, name) gives
+        the (C, H_b, W_b) view), the extents sit on the device (set_extents) and the kernels read them there: one set of buffers and ONE
+        captured HIP graph serve any crop sizes within the caps.  A crop's results are bit-identical to rendering it alone at its size.
+        resolution_px is then the initial extent of every crop."""
         dev = torch.device(device)
         if dev.type != "cuda":
             raise _lib.SdfrError("BatchRenderer runs on the GPU only")
@@ -56,6 +63,20 @@ class BatchRenderer:
         self.G = self.grid.shape[0]
         self.cap = int(cap) if cap is not None else max(256, self.G // 8)
         B, G, cap, H, W, NI = self.B, self.G, self.cap, self.H, self.W, self.NI
+        self.ragged = max_pixels is not None
+        if self.ragged:
+            import math
+            self.PS = int(max_pixels)
+            self.max_side = int(max_side) if max_side is not None else min(self.PS, 4 * int(math.ceil(math.sqrt(self.PS))))
+            if W * H > self.PS or max(W, H) > self.max_side:
+                raise _lib.SdfrError("resolution_px %dx%d exceeds max_pixels %d / max_side %d" % (W, H, self.PS, self.max_side))
+            # tile counts any admissible shape can reach: ceil(W/t) ceil(H/t) <= W H / t^2 + (W + H) / t + 1
+            self.tiles_cap = (self.PS + 63) // 64 + (2 * self.max_side + 7) // 8 + 2
+            self.tiles16_cap = (self.PS + 255) // 256 + (2 * self.max_side + 15) // 16 + 2
+            self.wh = torch.tensor([[W, H]] * B, dtype=torch.int32, device=dev)
+            self.sizes = [(W, H)] * B
+        else:
+            self.PS = W * H
         K = torch.as_tensor(K, dtype=torch.float32)
         if K.dim() == 2:
             K = K.unsqueeze(0).expand(B, 3, 3)
@@ -116,13 +137,20 @@ class BatchRenderer:
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.p_cam, self.n_cam, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.fidx, self.fcnt, self.fslot = i(B, cap), i(B), i(B, cap)
-        self.bbox = _lib.splat_ws(B, cap, W, H, dev)          # screen boxes + per-tile surfel lists (SDFR_PRIM_BINS workspace)
+        if self.ragged:
+            self.bbox = torch.empty((int(_lib.lib().sdfr_splat_ws_words_r(B, max(cap, 1), self.tiles_cap)),), dtype=torch.int32, device=dev)
+        else:
+            self.bbox = _lib.splat_ws(B, cap, W, H, dev)      # screen boxes + per-tile surfel lists (SDFR_PRIM_BINS workspace)
         # per-tile surfel lists (count -> scan -> fill, one workgroup per crop inside sdfr_surfels_forward) instead of every tile scanning
         # all boxes: same bits either way; the lists pay from a few crops per launch (B=64: splat forward 947 -> 551 us), at one crop the
         # distributed scan is the faster of the two (building the lists is a 13 us latency chain on one CU)
         self.binned = B >= 4
-        self.color, self.mask, self.depth, self.nimg = f(B, 3, H, W), f(B, 1, H, W), f(B, 1, H, W), f(B, 3, H, W)
-        self.aux = f(B, H * W, 4)
+        if self.ragged:
+            PS = self.PS
+            self.color, self.mask, self.depth, self.nimg = f(B, 3, PS), f(B, 1, PS), f(B, 1, PS), f(B, 3, PS)
+        else:
+            self.color, self.mask, self.depth, self.nimg = f(B, 3, H, W), f(B, 1, H, W), f(B, 1, H, W), f(B, 3, H, W)
+        self.aux = f(B, self.PS, 4)
         self.xyzf = f(B, cap, 3)
         # backward
         self.g_p, self.g_n, self.g_a = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
@@ -144,6 +172,34 @@ class BatchRenderer:
         return self.bbox[:self.B * self.cap * 4].view(self.B, self.cap, 4)
 
     # ------------------------------------------------------------------------------------------------------------------
+    def set_extents(self, sizes_wh, K=None):
+        """ragged mode: per-crop image sizes [(W_b, H_b)] * B and (optionally) intrinsics K (B,3,3) or (3,3); in place, so a captured graph
+        stays valid.  Image regions beyond a crop's W_b H_b pixels are left as they are (never read)."""
+        if not self.ragged:
+            raise _lib.SdfrError("set_extents needs a BatchRenderer built with max_pixels")
+        sizes = [(int(w), int(h)) for w, h in sizes_wh]
+        if len(sizes) != self.B:
+            raise _lib.SdfrError("set_extents: %d sizes for %d crops" % (len(sizes), self.B))
+        for w, h in sizes:
+            if w < 1 or h < 1 or w * h > self.PS or max(w, h) > self.max_side:
+                raise _lib.SdfrError("crop of %dx%d pixels exceeds max_pixels %d / max_side %d" % (w, h, self.PS, self.max_side))
+        self.sizes = sizes
+        self.wh.copy_(torch.tensor(sizes, dtype=torch.int32))
+        if K is not None:
+            K = torch.as_tensor(K, dtype=torch.float32).cpu()
+            if K.dim() == 2:
+                K = K.unsqueeze(0).expand(self.B, 3, 3)
+            self.K.copy_(K.contiguous())
+            self.Kinv.copy_(torch.linalg.inv(K.float()).contiguous())            # primitives.py:204, on the host, once per crop set
+
+    def image(self, b, name="color"):
+        """(C, H_b, W_b) view of crop b's image `name` in 'color' | 'mask' | 'depth' | 'normals' (both layouts)"""
+        t = {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.nimg}[name]
+        if not self.ragged:
+            return t[b]
+        w, h = self.sizes[b]
+        return t[b, :, :w * h].view(t.shape[1], h, w)
+
     def set_params(self, yaw, trans, latent):
         self.yaw.copy_(yaw.reshape(self.B))
         self.trans.copy_(trans.reshape(self.B, 3))
@@ -229,7 +285,13 @@ class BatchRenderer:
         self._shape_valid = True
         xyz = self.inputs[:, self.NI - 3:]
         prim = 512 if self.binned else 0                                              # [SDFR_PRIM_BINS]
-        if self.fused_head:
+        if self.ragged:
+            ck(L.sdfr_surfels_forward_r(P(xyz), self.NI, P(self.sdf), G, P(self.idx), P(self.J), self.NI, self.NI - 3, P(self.pose), P(self.K), B,
+                                        cap, P(self.cnt), self.nocs_mode | 4 | (8 if self.binned else 0), P(self.wh), self.tiles_cap, _DIAM_DISC,
+                                        P(self.points), P(self.normals), P(self.p_cam), P(self.n_cam), P(self.attr), P(self.fidx), P(self.fcnt),
+                                        P(self.xyzf), P(self.fslot), P(self.bbox), st), "sdfr_surfels_forward_r")
+            prim |= 256
+        elif self.fused_head:
             # band rows -> surfels -> camera frame -> front-facing list -> screen boxes in one launch; nocs_mode | 4: the composited
             # attribute (col + 1) / 2 (rasterer.py:113-114) is written directly
             ck(L.sdfr_surfels_forward(P(xyz), self.NI, P(self.sdf), G, P(self.idx), P(self.J), self.NI, self.NI - 3, P(self.pose), P(self.K), B,
@@ -246,9 +308,14 @@ class BatchRenderer:
                "sdfr_project_dcm")
         if "splat_fwd" in events:
             events["splat_fwd"][0].record()
-        ck(L.sdfr_splat_forward(prim, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
-                                _DEPTH_CONSTANT, P(self.bbox), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(self.aux), st),
-           "sdfr_splat_forward")
+        if self.ragged:
+            ck(L.sdfr_splat_forward_r(prim, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), B, cap, P(self.cnt), P(self.wh),
+                                      self.PS, self.tiles_cap, _DIAM_DISC, _DEPTH_CONSTANT, P(self.bbox), P(self.color), P(self.mask), P(self.depth),
+                                      P(self.nimg), P(self.aux), st), "sdfr_splat_forward_r")
+        else:
+            ck(L.sdfr_splat_forward(prim, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
+                                    _DEPTH_CONSTANT, P(self.bbox), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(self.aux), st),
+               "sdfr_splat_forward")
         if "splat_fwd" in events:
             events["splat_fwd"][1].record()
         return {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.nimg, "xyzf": self.xyzf, "nf": self.fcnt,
@@ -269,9 +336,15 @@ class BatchRenderer:
         g_depth, g_normals = c(g_depth, self.depth.shape), c(g_normals, self.nimg.shape)
         if "splat_bwd" in events:
             events["splat_bwd"][0].record()
-        ck(L.sdfr_splat_backward(0, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
-                                 _DEPTH_CONSTANT, P(self.aux), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(g_color),
-                                 P(g_mask), P(g_depth), P(g_normals), P(self.g_p), P(self.g_n), P(self.g_a), st), "sdfr_splat_backward")
+        if self.ragged:
+            ck(L.sdfr_splat_backward_r(P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), B, cap, P(self.cnt), P(self.wh), self.PS,
+                                       _DIAM_DISC, _DEPTH_CONSTANT, P(self.aux), P(self.color), P(self.mask), P(self.depth), P(self.nimg),
+                                       P(g_color), P(g_mask), P(g_depth), P(g_normals), P(self.g_p), P(self.g_n), P(self.g_a), st),
+               "sdfr_splat_backward_r")
+        else:
+            ck(L.sdfr_splat_backward(0, P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), None, None, None, None, B, cap, P(self.cnt), W, H, _DIAM_DISC,
+                                     _DEPTH_CONSTANT, P(self.aux), P(self.color), P(self.mask), P(self.depth), P(self.nimg), P(g_color),
+                                     P(g_mask), P(g_depth), P(g_normals), P(self.g_p), P(self.g_n), P(self.g_a), st), "sdfr_splat_backward")
         if "splat_bwd" in events:
             events["splat_bwd"][1].record()
         if g_xyzf is not None:

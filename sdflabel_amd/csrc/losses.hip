@@ -159,10 +159,20 @@ extern "C" int sdfr_loss_3d(const float* est, const int32_t* ecnt, int ecap, con
 template <bool LDS, int RADC>       // RADC > 0: window radius known at compile time (the loops unroll and the LDS reads of a row batch up); LDS: window radius <= L2_RMAX, taps come from the staged tile (two instantiations: a run-time choice per tap would
                           // turn the loads into flat accesses with a full wait after each)
 __global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const float* __restrict__ rend, const float* __restrict__ target,
-                                                                         int H, int W, float diam, float threshold_nocs,
-                                                                         float* __restrict__ g_rend, float* __restrict__ partial) {
+                                                                         int H, int W, const int32_t* __restrict__ wh, int pst, float diam,
+                                                                         float threshold_nocs, float* __restrict__ g_rend,
+                                                                         float* __restrict__ partial) {
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int P = H * W;
+    int P = H * W;                                                       // pixel stride of the image channels
+    if (wh) {
+        // ragged extents (r04): crop b is W_b x H_b pixels in a slot of pst pixels per channel; the launch covers the largest tile count, the
+        // tiles beyond this crop's contribute exact zeros (the fixed-order sums below then equal the crop's own launch bit for bit)
+        W = wh[2 * b]; H = wh[2 * b + 1]; P = pst;
+        if ((int)blockIdx.x >= ((W + L2_T - 1) / L2_T) * ((H + L2_T - 1) / L2_T)) {
+            if (tid < 3) partial[((int64_t)b * gridDim.x + blockIdx.x) * 3 + tid] = 0.f;
+            return;
+        }
+    }
     const float* R = rend + (int64_t)b * 3 * P;
     const float* Tg = target + (int64_t)b * 3 * P;
     float* G = g_rend + (int64_t)b * 3 * P;
@@ -275,28 +285,43 @@ __global__ __launch_bounds__(256) void sdfr_loss_2d_finalize_kernel(const float*
     }
 }
 
-extern "C" int sdfr_loss_2d(const float* rend, const float* target, int B, int H, int W, float diam, float threshold_nocs, float weight,
-                            float* loss, float* g_rend, int32_t* nvalid, float* scratch, void* stream) {
-    SDFR_REQUIRE(rend && target && loss && g_rend && nvalid && scratch, "sdfr_loss_2d: NULL argument");
-    SDFR_REQUIRE(H > 0 && W > 0 && diam > 0.f, "sdfr_loss_2d: bad size");
+static int loss_2d_impl(const char* who, const float* rend, const float* target, int B, int H, int W, const int32_t* wh, int pst, int nblk,
+                        float diam, float threshold_nocs, float weight, float* loss, float* g_rend, int32_t* nvalid, float* scratch, void* stream) {
+    SDFR_REQUIRE(rend && target && loss && g_rend && nvalid && scratch, "%s: NULL argument", who);
+    SDFR_REQUIRE(H > 0 && W > 0 && diam > 0.f && pst > 0 && nblk > 0, "%s: bad size", who);
     if (B <= 0) return SDFR_OK;
-    const int P = H * W, nblk = sdfr_cdiv(W, L2_T) * sdfr_cdiv(H, L2_T);
     hipStream_t s = (hipStream_t)stream;
     const int rad = (int)ceilf(diam) - 1;
     if (rad == 4)                                                        // the loop's diam = 5 (optimizer.py:200)
-        hipLaunchKernelGGL((sdfr_loss_2d_pixels_kernel<true, 4>), dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, diam,
+        hipLaunchKernelGGL((sdfr_loss_2d_pixels_kernel<true, 4>), dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, wh, pst, diam,
                            threshold_nocs, g_rend, scratch);
     else if (rad <= L2_RMAX)
-        hipLaunchKernelGGL((sdfr_loss_2d_pixels_kernel<true, 0>), dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, diam,
+        hipLaunchKernelGGL((sdfr_loss_2d_pixels_kernel<true, 0>), dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, wh, pst, diam,
                            threshold_nocs, g_rend, scratch);
     else
-        hipLaunchKernelGGL((sdfr_loss_2d_pixels_kernel<false, 0>), dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, diam,
+        hipLaunchKernelGGL((sdfr_loss_2d_pixels_kernel<false, 0>), dim3(nblk, B), dim3(L2_T * L2_T), 0, s, rend, target, H, W, wh, pst, diam,
                            threshold_nocs, g_rend, scratch);
     SDFR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sdfr_loss_2d_finalize_kernel, dim3(sdfr_cdiv(3 * P, 256), B), dim3(256), 0, s, scratch, nblk, P, weight, loss, g_rend,
+    hipLaunchKernelGGL(sdfr_loss_2d_finalize_kernel, dim3(sdfr_cdiv(3 * pst, 256), B), dim3(256), 0, s, scratch, nblk, pst, weight, loss, g_rend,
                        nvalid);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
+}
+
+extern "C" int sdfr_loss_2d(const float* rend, const float* target, int B, int H, int W, float diam, float threshold_nocs, float weight,
+                            float* loss, float* g_rend, int32_t* nvalid, float* scratch, void* stream) {
+    SDFR_REQUIRE(H > 0 && W > 0, "sdfr_loss_2d: bad size");
+    return loss_2d_impl("sdfr_loss_2d", rend, target, B, H, W, nullptr, H * W, sdfr_cdiv(W, L2_T) * sdfr_cdiv(H, L2_T), diam, threshold_nocs,
+                        weight, loss, g_rend, nvalid, scratch, stream);
+}
+
+// ragged extents: crop b compares its own W_b x H_b image (wh int32[B][2] on the device); rend / target / g_rend in slots of pix_stride
+// pixels per channel ([B][3][pix_stride]); tiles16_cap >= ceil(W_b/16) ceil(H_b/16) for every crop; scratch float[3 * B * tiles16_cap].
+extern "C" int sdfr_loss_2d_r(const float* rend, const float* target, int B, const int32_t* wh, int pix_stride, int tiles16_cap, float diam,
+                              float threshold_nocs, float weight, float* loss, float* g_rend, int32_t* nvalid, float* scratch, void* stream) {
+    SDFR_REQUIRE(wh, "sdfr_loss_2d_r: NULL extents");
+    return loss_2d_impl("sdfr_loss_2d_r", rend, target, B, 1, 1, wh, pix_stride, tiles16_cap, diam, threshold_nocs, weight, loss, g_rend, nvalid,
+                        scratch, stream);
 }
 
 // ---- solver step -------------------------------------------------------------------------------------------------------

@@ -741,17 +741,24 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             if (tid < n_valid && P.sdf_sel) P.sdf_sel[slots[tid]] = o;
         }
     } else {
-        constexpr int SL = NT / PT;                       // k slices
+        // k slices of the last linear's dot product.  Half operands: ONE partition (4 slices of 128 k, summed in order) for every tile
+        // geometry, so that a row's value has the same bits whether a 128-, 64- or 16-row tile evaluated it (r04: the sphere tracer's
+        // march picks the tile size by the device-side row count, and a crop must march the same alone and in a batch); float32: as many
+        // slices as the workgroup has threads per point (unchanged bits).
+        constexpr int SL = HALF ? 4 : NT / PT;
+        static_assert(SL * PT <= NT, "last linear: one thread per (slice, point)");
         constexpr int KGS = KG / SL;
         const int sl = tid / PT, pt = tid - sl * PT;
-        const float* wl = P.w_last + sl * KGS * KV;
-        const vec_t* a4 = act + (sl * KGS) * PT + pt;
         float s = 0.f;
+        if (sl < SL) {
+            const float* wl = P.w_last + sl * KGS * KV;
+            const vec_t* a4 = act + (sl * KGS) * PT + pt;
 #pragma unroll 4
-        for (int g = 0; g < KGS; ++g) {
-            const vec_t a = a4[g * PT];
+            for (int g = 0; g < KGS; ++g) {
+                const vec_t a = a4[g * PT];
 #pragma unroll
-            for (int i = 0; i < KV; ++i) s = fmaf((float)a[i], wl[g * KV + i], s);
+                for (int i = 0; i < KV; ++i) s = fmaf((float)a[i], wl[g * KV + i], s);
+            }
         }
         red[tid] = s;
         __syncthreads();

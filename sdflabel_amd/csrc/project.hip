@@ -18,6 +18,8 @@ struct SurfArgs {
     const float* xyz; int xyz_stride; const float* sdf; int64_t G; const int32_t* idx; const float* J; int Jstride, Joff;
     float* points_w; float* normals_w; int4* bbox; float diam;
     int32_t* bins;            // per-crop tile lists behind the boxes (splat_bbox.h), or NULL
+    const int32_t* wh;        // ragged extents (r04): int32[B][2] = (W_b, H_b) per crop on the device, or NULL (every crop res_x x res_y)
+    int64_t bin_stride;       // words per crop of the tile-list workspace
 };
 
 template <bool SURF>
@@ -31,6 +33,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int count = sdfr_count(cnt, b, cap);
+    if (SURF && S.wh) { res_x = (float)S.wh[2 * b]; res_y = (float)S.wh[2 * b + 1]; }     // this crop's own image size
     const float* P = pose + (int64_t)b * 16;
     const float* Kb = K + (int64_t)b * 9;
     const float r00 = P[0], r01 = P[1], r02 = P[2], t0 = P[3];
@@ -123,8 +126,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
         // the crop's boxes (written above by this workgroup) -> per-tile surfel lists for the splat kernel
         __threadfence_block();
         __syncthreads();
-        sdfr_bin_boxes<PROJ_THREADS>(S.bbox + (int64_t)b * cap, count, (int)res_x, (int)res_y, cap,
-                                     S.bins + (int64_t)b * sdfr_splat_bin_stride(cap, (int)res_x, (int)res_y), tile_cnt, wc);
+        sdfr_bin_boxes<PROJ_THREADS>(S.bbox + (int64_t)b * cap, count, (int)res_x, (int)res_y, cap, S.bins + (int64_t)b * S.bin_stride, tile_cnt, wc);
     }
 }
 
@@ -148,24 +150,47 @@ extern "C" int sdfr_project_dcm(const float* pose, const float* K, const float* 
 
 // Band rows -> surfels -> camera frame -> front-face list -> screen boxes in ONE launch (batched path): sdfr_surface_project +
 // sdfr_project_dcm (NOCS colour modes) + the box pass of sdfr_splat_forward (disc primitive), same arithmetic, same outputs.
+static int surfels_forward_impl(const char* who, const float* xyz, int xyz_stride, const float* sdf, int64_t G, const int32_t* idx, const float* J,
+                                int Jstride, int Joff, const float* pose, const float* K, int B, int cap, const int32_t* cnt, int output_nocs,
+                                int res_x, int res_y, const int32_t* wh, int tiles_cap, float diam, float* points, float* normals, float* p_cam,
+                                float* n_cam, float* col, int32_t* fidx, int32_t* fcnt, float* xyzf, int32_t* fslot, int32_t* bbox,
+                                void* stream) {
+    SDFR_REQUIRE(xyz && sdf && idx && J && pose && K && points && normals && p_cam && n_cam && col, "%s: NULL argument", who);
+    const bool no_bins = (output_nocs & 8) == 0;          // | 8: bbox is the large workspace, build the tile lists too (SDFR_PRIM_BINS)
+    output_nocs &= ~8;
+    SDFR_REQUIRE(output_nocs == 1 || output_nocs == 2 || output_nocs == 5 || output_nocs == 6, "%s: NOCS colour modes only", who);
+    SDFR_REQUIRE((fidx == nullptr) == (fcnt == nullptr), "%s: fidx and fcnt must be given together", who);
+    SDFR_REQUIRE(fidx || (!xyzf && !fslot), "%s: xyzf / fslot need fidx and fcnt", who);
+    SDFR_REQUIRE(!wh || no_bins || (tiles_cap > 0 && tiles_cap <= SPL_BIN_MAX_TILES), "%s: tile lists need 0 < tiles_cap <= %d", who, SPL_BIN_MAX_TILES);
+    if (B <= 0) return SDFR_OK;
+    SurfArgs S = {xyz, xyz_stride, sdf, G, idx, J, Jstride, Joff, points, normals, reinterpret_cast<int4*>(bbox), diam,
+                  (bbox && !no_bins) ? bbox + (int64_t)B * cap * 4 : nullptr, wh,
+                  wh ? (int64_t)tiles_cap + 2 + (int64_t)SPL_LM * cap : sdfr_splat_bin_stride(cap, res_x, res_y)};
+    hipLaunchKernelGGL(sdfr_project_dcm_kernel<true>, dim3(B), dim3(PROJ_THREADS), 0, (hipStream_t)stream, pose, K, nullptr, nullptr,
+                       nullptr, cap, cnt, output_nocs, (float)res_x, (float)res_y, p_cam, n_cam, col, nullptr, fidx, fcnt, xyzf, fslot, S);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
 extern "C" int sdfr_surfels_forward(const float* xyz, int xyz_stride, const float* sdf, int64_t G, const int32_t* idx, const float* J,
                                     int Jstride, int Joff, const float* pose, const float* K, int B, int cap, const int32_t* cnt,
                                     int output_nocs, int res_x, int res_y, float diam, float* points, float* normals, float* p_cam,
                                     float* n_cam, float* col, int32_t* fidx, int32_t* fcnt, float* xyzf, int32_t* fslot,
                                     int32_t* bbox, void* stream) {
-    SDFR_REQUIRE(xyz && sdf && idx && J && pose && K && points && normals && p_cam && n_cam && col, "sdfr_surfels_forward: NULL argument");
-    const bool no_bins = (output_nocs & 8) == 0;          // | 8: bbox is the large workspace, build the tile lists too (SDFR_PRIM_BINS)
-    output_nocs &= ~8;
-    SDFR_REQUIRE(output_nocs == 1 || output_nocs == 2 || output_nocs == 5 || output_nocs == 6, "sdfr_surfels_forward: NOCS colour modes only");
-    SDFR_REQUIRE((fidx == nullptr) == (fcnt == nullptr), "sdfr_surfels_forward: fidx and fcnt must be given together");
-    SDFR_REQUIRE(fidx || (!xyzf && !fslot), "sdfr_surfels_forward: xyzf / fslot need fidx and fcnt");
-    if (B <= 0) return SDFR_OK;
-    SurfArgs S = {xyz, xyz_stride, sdf, G, idx, J, Jstride, Joff, points, normals, reinterpret_cast<int4*>(bbox), diam,
-                  (bbox && !no_bins) ? bbox + (int64_t)B * cap * 4 : nullptr};
-    hipLaunchKernelGGL(sdfr_project_dcm_kernel<true>, dim3(B), dim3(PROJ_THREADS), 0, (hipStream_t)stream, pose, K, nullptr, nullptr,
-                       nullptr, cap, cnt, output_nocs, (float)res_x, (float)res_y, p_cam, n_cam, col, nullptr, fidx, fcnt, xyzf, fslot, S);
-    SDFR_LAUNCH_CHECK();
-    return SDFR_OK;
+    return surfels_forward_impl("sdfr_surfels_forward", xyz, xyz_stride, sdf, G, idx, J, Jstride, Joff, pose, K, B, cap, cnt, output_nocs, res_x,
+                                res_y, nullptr, 0, diam, points, normals, p_cam, n_cam, col, fidx, fcnt, xyzf, fslot, bbox, stream);
+}
+
+// ragged extents: crop b projects into its own W_b x H_b image (wh int32[B][2] on the device); the tile-list workspace is laid out for
+// tiles_cap tiles per crop (sdfr_splat_ws_words_r)
+extern "C" int sdfr_surfels_forward_r(const float* xyz, int xyz_stride, const float* sdf, int64_t G, const int32_t* idx, const float* J,
+                                      int Jstride, int Joff, const float* pose, const float* K, int B, int cap, const int32_t* cnt,
+                                      int output_nocs, const int32_t* wh, int tiles_cap, float diam, float* points, float* normals,
+                                      float* p_cam, float* n_cam, float* col, int32_t* fidx, int32_t* fcnt, float* xyzf, int32_t* fslot,
+                                      int32_t* bbox, void* stream) {
+    SDFR_REQUIRE(wh, "sdfr_surfels_forward_r: NULL extents");
+    return surfels_forward_impl("sdfr_surfels_forward_r", xyz, xyz_stride, sdf, G, idx, J, Jstride, Joff, pose, K, B, cap, cnt, output_nocs, 1, 1,
+                                wh, tiles_cap, diam, points, normals, p_cam, n_cam, col, fidx, fcnt, xyzf, fslot, bbox, stream);
 }
 
 // ---- backward ----------------------------------------------------------------------------------------------------

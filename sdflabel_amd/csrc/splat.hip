@@ -41,7 +41,18 @@ struct SplatArgs {
     int cap; const int32_t* cnt; int W, H;
     float diam, depth_constant;
     float cover_sq;                               // PRIM 0: coverage threshold on the squared distance (disc_cover_sq)
+    // ragged extents (r04): wh != NULL -> crop b renders W_b = wh[2b] x H_b = wh[2b+1] pixels (every crop of a batch its own image size, as
+    // the reference pipeline's crops have: utils/refinement.py:586-609); its images live in slots of `pst` pixels per channel
+    // ([B][C][pst], rows of W_b pixels in the first W_b H_b entries).  wh == NULL: every crop W x H, pst = W H (the dense layout).
+    const int32_t* wh; int pst;
+    int64_t bin_stride;                           // words per crop of the tile-list workspace (splat_bbox.h)
 };
+
+// image extents of crop b and the pixel stride of its image channels
+__device__ __forceinline__ void splat_dims(const SplatArgs& A, int b, int& W, int& H, int& PS) {
+    W = A.W; H = A.H; PS = W * H;
+    if (A.wh) { W = A.wh[2 * b]; H = A.wh[2 * b + 1]; PS = A.pst; }
+}
 
 struct Hit {
     bool m;        // covered
@@ -126,7 +137,8 @@ __device__ __forceinline__ bool interval(float lo_f, float hi_f, int n, int& lo,
 
 template <int PRIM>
 __device__ __forceinline__ bool surfel_bbox(const SplatArgs& A, int b, int64_t e, int& x0, int& y0, int& x1, int& y1) {
-    const int W = A.W, H = A.H;
+    int W, H, PS_;
+    splat_dims(A, b, W, H, PS_);
     x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
     const float* K = A.K + (int64_t)b * 9;
     if (PRIM == 0) {
@@ -165,8 +177,9 @@ __global__ __launch_bounds__(1024) void sdfr_splat_bin_kernel(const SplatArgs A,
     __shared__ int tile_cnt[SPL_BIN_MAX_TILES];
     __shared__ int wsum[1024 / 64 + 1];
     const int b = blockIdx.x;
-    sdfr_bin_boxes<1024>(bbox + (int64_t)b * A.cap, sdfr_count(A.cnt, b, A.cap), A.W, A.H, A.cap,
-                         bins + (int64_t)b * sdfr_splat_bin_stride(A.cap, A.W, A.H), tile_cnt, wsum);
+    int W, H, PS_;
+    splat_dims(A, b, W, H, PS_);
+    sdfr_bin_boxes<1024>(bbox + (int64_t)b * A.cap, sdfr_count(A.cnt, b, A.cap), W, H, A.cap, bins + (int64_t)b * A.bin_stride, tile_cnt, wsum);
 }
 
 extern "C" int64_t sdfr_splat_ws_words(int B, int cap, int W, int H) {
@@ -211,8 +224,10 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
     constexpr int LCOV = (PW == 1) ? 64 : SPL_LC;      // coverage ballots kept per tile
     int tile, b;
     sdfr_xcd_crop_map(tile, b);        // a crop's tiles on one XCD: its surfel arrays / tile lists are fetched by one L2
-    const int W = A.W, H = A.H;
+    int W, H, PS;
+    splat_dims(A, b, W, H, PS);
     const int tilesX = (W + 7) >> 3;
+    if (tile >= tilesX * ((H + 7) >> 3)) return;       // (ragged extents: the launch covers the largest crop's tile count)
     const int tx = tile % tilesX, ty = tile / tilesX;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
     bool binned = false;
     if (bins) {
         const int T = tilesX * ((H + 7) >> 3);
-        const int32_t* toff = bins + (int64_t)b * sdfr_splat_bin_stride(A.cap, W, H);
+        const int32_t* toff = bins + (int64_t)b * A.bin_stride;
         if (toff[T + 1] == 1) {
             binned = true;
             const int o0 = toff[tile];
@@ -307,7 +322,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
     __syncthreads();
     if (total == 0 && !A.bg && !(PRIM == 1 && count > 0)) {          // nothing can touch this tile: all outputs are zero
         if (wave != 0 || !inside) return;
-        const int P0 = W * H, pix0 = y * W + x;
+        const int P0 = PS, pix0 = y * W + x;
         if (color) { float* o = color + (int64_t)b * 3 * P0 + pix0; o[0] = 0.f; o[P0] = 0.f; o[2 * P0] = 0.f; }
         if (mask) mask[(int64_t)b * P0 + pix0] = 0.f;
         if (depth) depth[(int64_t)b * P0 + pix0] = 0.f;
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
     const float lbg = A.bg ? A.bg_logit[b] : 0.f;
     if (A.bg && lbg > lmax) rescale(lbg);
     if (!inside) return;
-    const int P = W * H;
+    const int P = PS;
     const int pix = y * W + x;
     float den = cs;
     if (PRIM == 1 && nunc > 0) den += (float)nunc * expf(0.f - lmax);
@@ -544,7 +559,8 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
     const int lane = threadIdx.x & 63;
     const int s = xb * 4 + (threadIdx.x >> 6);
     if (s >= sdfr_count(A.cnt, b, A.cap)) return;
-    const int W = A.W, H = A.H;
+    int W, H, PS;
+    splat_dims(A, b, W, H, PS);
     const float diam = A.diam, C = A.depth_constant;
     const int64_t e1 = (int64_t)b * A.cap + s;
     const int64_t e = e1 * 3;
@@ -554,7 +570,7 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
     const float m0 = (nx + 1.f) / 2.f, m1 = (ny + 1.f) / 2.f, m2 = (nz + 1.f) / 2.f;
     const float a = nx * px + ny * py + nz * pz;
     const float* Ki = A.Kinv + (int64_t)b * 9;
-    const int P = W * H;
+    const int P = PS;
     // PRIM 1,2: pixel-independent logit
     float u = 0.f, v = 0.f, rad = 0.f, zl = 0.f, q0 = 0.f, zn = 0.f;
     if (PRIM != 0) {
@@ -725,6 +741,7 @@ static int fill_args(SplatArgs& A, const char* who, int primitive, const float* 
     A.K = K; A.Kinv = Kinv; A.p_cam = p_cam; A.n_cam = n_cam; A.attr = attr; A.uv = uv; A.znorm = znorm; A.bg = bg; A.bg_logit = bg_logit;
     A.cap = cap; A.cnt = cnt; A.W = W; A.H = H; A.diam = diam; A.depth_constant = depth_constant;
     A.cover_sq = disc_cover_sq(diam);
+    A.wh = nullptr; A.pst = W * H; A.bin_stride = sdfr_splat_bin_stride(cap, W, H);
     return SDFR_OK;
 }
 
@@ -739,17 +756,8 @@ static int64_t splat_serial_tiles() {
     return v;
 }
 
-extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam,
-                                  const float* attr, const float* uv, const float* znorm, const float* bg, const float* bg_logit, int B,
-                                  int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant, int32_t* bbox_ws,
-                                  float* color, float* mask, float* depth, float* normals, float* aux, void* stream) {
-    const bool boxes_ready = (primitive & SDFR_PRIM_BOXES_READY) != 0;      // bbox_ws already holds boxes and tile lists (sdfr_surfels_forward)
-    const bool use_bins = (primitive & SDFR_PRIM_BINS) != 0;
-    primitive &= ~(SDFR_PRIM_BOXES_READY | SDFR_PRIM_BINS);
-    SplatArgs A;
-    int rc = fill_args(A, "sdfr_splat_forward", primitive, K, Kinv, p_cam, n_cam, attr, uv, znorm, bg, bg_logit, B, cap, cnt, W, H, diam,
-                       depth_constant);
-    if (rc) return rc;
+static int splat_forward_launch(const SplatArgs& A, int primitive, bool boxes_ready, bool use_bins, int B, int cap, int tiles, int32_t* bbox_ws,
+                                float* color, float* mask, float* depth, float* normals, float* aux, void* stream) {
     SDFR_REQUIRE(cap == 0 || bbox_ws, "sdfr_splat_forward: NULL bbox workspace");
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -757,7 +765,7 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
     // SDFR_PRIM_BINS: tile lists behind the boxes (splat_bbox.h); otherwise the workspace holds the boxes only and every tile scans all boxes
     int32_t* bins = (cap > 0 && use_bins) ? bbox_ws + (int64_t)B * cap * 4 : nullptr;
     const dim3 gb(sdfr_cdiv(cap > 0 ? cap : 1, 256), B);
-    const dim3 gt(((W + 7) / 8) * ((H + 7) / 8), B);
+    const dim3 gt(tiles, B);
     // launch geometry (same results bit for bit): one wave per candidate share while the tiles do not fill the chip, one wave per tile beyond
     const bool serial = (int64_t)gt.x * B >= splat_serial_tiles();
 #define SPL_LAUNCH_FWD(P)                                                                                                              \
@@ -773,6 +781,70 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
         default: SPL_LAUNCH_FWD(2); break;
     }
 #undef SPL_LAUNCH_FWD
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam,
+                                  const float* attr, const float* uv, const float* znorm, const float* bg, const float* bg_logit, int B,
+                                  int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant, int32_t* bbox_ws,
+                                  float* color, float* mask, float* depth, float* normals, float* aux, void* stream) {
+    const bool boxes_ready = (primitive & SDFR_PRIM_BOXES_READY) != 0;      // bbox_ws already holds boxes and tile lists (sdfr_surfels_forward)
+    const bool use_bins = (primitive & SDFR_PRIM_BINS) != 0;
+    primitive &= ~(SDFR_PRIM_BOXES_READY | SDFR_PRIM_BINS);
+    SplatArgs A;
+    int rc = fill_args(A, "sdfr_splat_forward", primitive, K, Kinv, p_cam, n_cam, attr, uv, znorm, bg, bg_logit, B, cap, cnt, W, H, diam,
+                       depth_constant);
+    if (rc) return rc;
+    return splat_forward_launch(A, primitive, boxes_ready, use_bins, B, cap, ((W + 7) / 8) * ((H + 7) / 8), bbox_ws, color, mask, depth, normals,
+                                aux, stream);
+}
+
+// ---- ragged extents: every crop of the batch its own image size (W_b, H_b) and intrinsics, read from device memory ------------------------
+// wh int32[B][2] (device); images / aux in slots of pix_stride pixels per channel; tiles_cap >= ceil(W_b/8) ceil(H_b/8) for every crop
+// (launch bound and tile-list layout).  One captured launch sequence serves any crop sizes within the caps.
+extern "C" int64_t sdfr_splat_ws_words_r(int B, int cap, int tiles_cap) {
+    return (int64_t)B * ((int64_t)cap * 4 + (int64_t)tiles_cap + 2 + (int64_t)SPL_LM * cap);
+}
+
+static int fill_args_r(SplatArgs& A, const char* who, const float* K, const float* Kinv, const float* p_cam, const float* n_cam,
+                       const float* attr, int B, int cap, const int32_t* cnt, const int32_t* wh, int pix_stride, int tiles_cap, float diam,
+                       float depth_constant) {
+    int rc = fill_args(A, who, 0, K, Kinv, p_cam, n_cam, attr, nullptr, nullptr, nullptr, nullptr, B, cap, cnt, 1, 1, diam, depth_constant);
+    if (rc) return rc;
+    SDFR_REQUIRE(wh && pix_stride > 0 && tiles_cap > 0, "%s: ragged extents need wh, pix_stride and tiles_cap", who);
+    A.wh = wh; A.pst = pix_stride; A.W = 0; A.H = 0;
+    A.bin_stride = (int64_t)tiles_cap + 2 + (int64_t)SPL_LM * cap;
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_splat_forward_r(int flags, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
+                                    int B, int cap, const int32_t* cnt, const int32_t* wh, int pix_stride, int tiles_cap, float diam,
+                                    float depth_constant, int32_t* bbox_ws, float* color, float* mask, float* depth, float* normals, float* aux,
+                                    void* stream) {
+    const bool boxes_ready = (flags & SDFR_PRIM_BOXES_READY) != 0;
+    const bool use_bins = (flags & SDFR_PRIM_BINS) != 0;
+    SDFR_REQUIRE((flags & ~(SDFR_PRIM_BOXES_READY | SDFR_PRIM_BINS)) == 0, "sdfr_splat_forward_r: disc primitive only (flags = BOXES_READY | BINS)");
+    SplatArgs A;
+    int rc = fill_args_r(A, "sdfr_splat_forward_r", K, Kinv, p_cam, n_cam, attr, B, cap, cnt, wh, pix_stride, tiles_cap, diam, depth_constant);
+    if (rc) return rc;
+    return splat_forward_launch(A, 0, boxes_ready, use_bins, B, cap, tiles_cap, bbox_ws, color, mask, depth, normals, aux, stream);
+}
+
+extern "C" int sdfr_splat_backward_r(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr, int B, int cap,
+                                     const int32_t* cnt, const int32_t* wh, int pix_stride, float diam, float depth_constant, const float* aux,
+                                     const float* color, const float* mask, const float* depth, const float* normals, const float* g_color,
+                                     const float* g_mask, const float* g_depth, const float* g_normals, float* g_p_cam, float* g_n_cam,
+                                     float* g_attr, void* stream) {
+    SplatArgs A;
+    int rc = fill_args_r(A, "sdfr_splat_backward_r", K, Kinv, p_cam, n_cam, attr, B, cap, cnt, wh, pix_stride, 1, diam, depth_constant);
+    if (rc) return rc;
+    SDFR_REQUIRE(aux && g_p_cam && g_n_cam && g_attr, "sdfr_splat_backward_r: NULL argument");
+    SDFR_REQUIRE((!g_color || color) && (!g_mask || mask) && (!g_depth || depth) && (!g_normals || normals),
+                 "sdfr_splat_backward_r: an image gradient was given without the forward image");
+    if (B == 0 || cap == 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_splat_bwd_kernel<0>, dim3(sdfr_cdiv(cap, 4), B), dim3(256), 0, (hipStream_t)stream, A, aux, color, mask, depth, normals,
+                       g_color, g_mask, g_depth, g_normals, g_p_cam, g_n_cam, g_attr);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

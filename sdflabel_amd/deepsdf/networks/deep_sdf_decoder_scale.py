@@ -73,6 +73,21 @@ class SdfState:
         self.split = False            # the forward launch used error-compensated float16 operand pairs (float32-equivalent)
 
 
+class BandTag:
+    """What Grid3D.get_surface_points' backward attaches to the gradient it returns: "this tensor is non-zero on the band rows of `state`'s
+    band cache number `token` only".  The decoder's backward trusts it only if the tensor it receives is that very tensor, unmodified:
+    same storage pointer, same version counter, and the state's cache has not been re-written since.  `base` keeps the gradient's storage
+    shared, which stops autograd from accumulating into the tensor in place."""
+    __slots__ = ("state", "token", "base", "ptr", "version")
+
+    def __init__(self, state, token, base, ptr, version):
+        self.state, self.token, self.base, self.ptr, self.version = state, token, base, ptr, version
+
+    def vouches_for(self, tensor, state):
+        return (self.state is state and self.token == getattr(state, "band_token", None) and tensor.data_ptr() == self.ptr
+                and tensor._version == self.version and tensor.dtype == torch.float32 and tensor.is_contiguous())
+
+
 # autograd nodes that hand their input's VALUES on unchanged (up to a dtype rounding): a tensor reached from the decoder output through
 # these only is still "the decoder output" for Grid3D.get_surface_points
 _PASS_THROUGH = ("CloneBackward", "ToCopyBackward", "ViewBackward", "UnsafeViewBackward", "ReshapeAliasBackward", "AliasBackward",
@@ -148,16 +163,15 @@ class _DeepSDFFn(torch.autograd.Function):
         st = ctx.state
         L = _lib.lib()
         tag = getattr(g_sdf, "_sdfr_band_of", None)
+        band_only = isinstance(tag, BandTag) and tag.vouches_for(g_sdf, st)     # judged on the tensor autograd handed over, before any copy
         g_sdf = g_sdf.contiguous().float()
-        if tag is not None:
-            g_sdf._sdfr_band_of = tag                  # (.contiguous() / .float() of an already contiguous float32 tensor return it unchanged)
         NI = st.inputs.shape[1]
         g_in = torch.empty((st.G, NI), dtype=torch.float32, device=g_sdf.device)
         if st.J is not None and st.J.shape[0] > 0:
             # A gradient that comes straight from Grid3D.get_surface_points' backward is non-zero on the cached band rows only (it says so
-            # itself: the tensor carries the state it was built for) -- no need to count uncovered rows, i.e. no host synchronisation.  Any
-            # other gradient (another loss on sdf added to it, a dtype round trip) is checked as before.
-            band_only = getattr(g_sdf, "_sdfr_band_of", None) is st
+            # itself: BandTag) -- no need to count uncovered rows, i.e. no host synchronisation.  Any other gradient (another consumer of
+            # the decoder output added to it -- autograd then builds a NEW, untagged tensor --, a dtype round trip, a stale band cache) is
+            # checked on the device as before.
             miss = None if band_only else torch.zeros((1,), dtype=torch.int32, device=g_sdf.device)
             with _lib.guard(g_sdf):
                 _lib.check(L.sdfr_sdf_input_grad(_lib.ptr(g_sdf), _lib.ptr(st.slot), _lib.ptr(st.J), NI, st.G, 1, st.cap, _lib.ptr(g_in),
@@ -176,10 +190,12 @@ class _DeepSDFFn(torch.autograd.Function):
 
 class _ScaleNetFn(torch.autograd.Function):
     """scale_net(lat_row) in ONE launch (sdfr_scale_net) instead of five ATen ops per Decoder.forward.  The backward -- nobody on the renderer
-    path differentiates the scale (pipelines/optimizer.py:101 drops it) -- re-evaluates the three linears with torch ops under autograd."""
+    path differentiates the scale (pipelines/optimizer.py:101 drops it) -- re-evaluates the three linears with torch ops under autograd, for the
+    latent row AND the head's own parameters (they are inputs of the Function)."""
 
     @staticmethod
-    def forward(ctx, lat_row, net):
+    def forward(ctx, lat_row, net, *params):
+        # (params: the head's parameters, passed so that autograd knows the output depends on them -- ADVICE r03)
         out = torch.empty((1,), dtype=torch.float32, device=lat_row.device)
         l1, l2, l3 = net[0], net[2], net[4]
         row = lat_row.detach().contiguous()
@@ -194,10 +210,17 @@ class _ScaleNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (row,) = ctx.saved_tensors
+        # the scale head's own parameters are leaves of the reference module's graph: whoever back-propagates through `scale` (fine-tuning the
+        # head through Decoder.forward) gets their gradients too, accumulated into .grad as autograd would (they were dropped)
+        params = list(ctx.net.parameters())                       # (the order they were passed in: Module.parameters() is deterministic)
+        need = [i for i, p in enumerate(params) if ctx.needs_input_grad[2 + i]]
         with torch.enable_grad():
             x = row.clone().requires_grad_(True)
-            (gx,) = torch.autograd.grad(ctx.net(x), x, g)
-        return gx, None
+            grads = torch.autograd.grad(ctx.net(x), [x] + [params[i] for i in need], g, allow_unused=True)
+        gp = [None] * len(params)
+        for i, gi in zip(need, grads[1:]):
+            gp[i] = gi
+        return (grads[0], None) + tuple(gp)
 
 
 class Decoder(nn.Module):
@@ -307,6 +330,7 @@ class Decoder(nn.Module):
         ps = [p for m in self.scale_net._modules.values() for p in m._parameters.values() if p is not None]
         key = (device.type, device.index) + tuple((id(p), p._version) for p in ps)
         if getattr(self, "_scale_key", None) != key:
+            self._scale_ps = list(self.scale_net.parameters())
             self._scale_ok = all(p.dtype == torch.float32 and p.is_contiguous() and p.device == device for p in self.scale_net.parameters())
             self._scale_key = key
         return self._scale_ok
@@ -332,7 +356,7 @@ class Decoder(nn.Module):
         if self.samples_per_scene:
             scale = self.scale_net(lat.view(-1, self.samples_per_scene, lat.size(1))[:, 0, :])
         elif self._scale_net_fused(x32.device):
-            scale = _ScaleNetFn.apply(lat[0], self.scale_net)          # one launch; frozen weights as everywhere on this path
+            scale = _ScaleNetFn.apply(lat[0], self.scale_net, *self._scale_ps)       # one launch
         else:
             scale = self.scale_net(lat[0])
         return x, scale.to(in_dtype)

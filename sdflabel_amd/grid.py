@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .deepsdf.networks.deep_sdf_decoder_scale import mlp_jacobian, sdf_state_of
+from .deepsdf.networks.deep_sdf_decoder_scale import BandTag, mlp_jacobian, sdf_state_of
 
 
 class _SurfaceFn(torch.autograd.Function):
@@ -18,6 +18,7 @@ class _SurfaceFn(torch.autograd.Function):
     def forward(ctx, sdf, gridpoints, sdf_vals, xyz_src, xyz_stride, idx, n, J, Jstride, Joff, state=None):
         """sdf / gridpoints carry the autograd graph (any float dtype); sdf_vals is the float32 (G,) array the kernels read."""
         ctx.state = state
+        ctx.token = getattr(state, "band_token", None)       # which band cache of the state this call's backward refers to
         L = _lib.lib()
         dev = sdf.device
         G = sdf.shape[0]
@@ -46,7 +47,12 @@ class _SurfaceFn(torch.autograd.Function):
             # empty band: zero gradients, as the reference's ops on (0,3) tensors give (no kernel to launch; empty tensors have no address)
             return (torch.zeros((G, 1), dtype=ctx.dtypes[0], device=dev),
                     torch.zeros((G, 3), dtype=ctx.dtypes[1], device=dev) if ctx.needs_input_grad[1] else None) + (None,) * 9
-        g_sdf = torch.empty((G, 1), dtype=torch.float32, device=dev)
+        # g_sdf is a VIEW of `base`, and the tag below keeps `base` alive: autograd may accumulate another gradient INTO a gradient tensor in
+        # place only when nothing else shares its storage (its InputBuffer checks the storage's use count), so a tagged tensor can never be
+        # turned into "band rows + something else" behind the tag's back (with a plain tensor, (s * 3).sum() + Surf(s).sum()
+        # left gradient 3.0 on the out-of-band rows of the still-tagged tensor, and the fast path dropped it)
+        base = torch.empty((G,), dtype=torch.float32, device=dev)
+        g_sdf = base.view(G, 1)
         g_xyz = torch.empty((G, 3), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         if g_pts is None:
             g_pts = torch.zeros((n, 3), dtype=torch.float32, device=dev)
@@ -58,7 +64,10 @@ class _SurfaceFn(torch.autograd.Function):
         g_sdf = g_sdf.to(ctx.dtypes[0])
         g_xyz = None if g_xyz is None else g_xyz.to(ctx.dtypes[1])
         if ctx.state is not None and g_sdf.dtype == torch.float32:
-            g_sdf._sdfr_band_of = ctx.state             # non-zero on this state's band rows only: the decoder's backward needs no coverage check
+            # non-zero on this state's band rows only: the decoder's backward needs no coverage check -- PROVIDED the tensor it receives is
+            # this very tensor, unmodified (storage pointer and version counter recorded), and the state's band cache is still the one of
+            # this call (token).  Anything else takes the checked path.
+            g_sdf._sdfr_band_of = BandTag(ctx.state, ctx.token, base, g_sdf.data_ptr(), g_sdf._version)
         return g_sdf, g_xyz, None, None, None, None, None, None, None, None, None
 
 
@@ -113,6 +122,7 @@ class Grid3D:
             J, _ = mlp_jacobian(state, idx, n)
             J = J.contiguous()
             state.idx, state.slot, state.J, state.cap = idx, slot, J, max(n, 1)
+            state.band_token = getattr(state, "band_token", 0) + 1      # a second get_surface_points on the same state re-writes the cache
             NI = state.inputs.shape[1]
             xyz_src = state.inputs[:, NI - 3:]
             return narrow(_SurfaceFn.apply(pred_sdf_grid, self.points, sdf_c, xyz_src, NI, idx, n, J, NI, NI - 3, state))

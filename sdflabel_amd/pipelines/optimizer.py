@@ -23,6 +23,7 @@ from ..refine import BatchRefiner
 # the buffers and the captured launches depend on; a few entries at most.
 _REFINERS = {}
 _REFINERS_MAX = 4
+STATS = {"refiners_built": 0}     # (bench / tests)
 
 
 def clear_refiner_cache():
@@ -66,9 +67,19 @@ class Optimizer:
         if D ** 3 != G:
             raise _lib.SdfrError("grid of %d points is not a D^3 Grid3D" % G)
         dev = grid.points.device
-        cap = max(256, 1 << (max(n_lidar, 1) - 1).bit_length())       # lidar capacity, rounded up so that a refiner is reused across crops
+        cap = max(1024, 1 << (max(n_lidar, 1) - 1).bit_length())      # lidar capacity, rounded up so that a refiner is reused across crops
         Kn = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32)
-        key = (id(dsdf), D, tuple(int(c) for c in crop_size), cap, Kn.tobytes(), str(dev), dsdf._param_key(dev),
+        # splat renderer: ragged extents -- the refiner is keyed on a pixel CAPACITY (next power of two of the crop's area), not on the crop's
+        # size or intrinsics, which reach the kernels as data (set_crops): the pipeline's crops all have their own (H, W) and K
+        # (utils/refinement.py:586-609), yet share one set of buffers and one captured graph.  Tracer backend: fixed extents.
+        ragged = self.render == 'splat'
+        H_, W_ = int(crop_size[0]), int(crop_size[1])
+        pmax = max(1024, 1 << (max(H_ * W_, 1) - 1).bit_length())
+        side = 4 * int(np.ceil(np.sqrt(pmax)))
+        if ragged and max(H_, W_) > side:
+            ragged = False                                            # (a crop more elongated than 16:1: its own fixed-size refiner)
+        shape_key = (pmax,) if ragged else (H_, W_, Kn.tobytes())
+        key = (id(dsdf), D, shape_key, cap, str(dev), dsdf._param_key(dev),
                float(self.weights.get('2d', 0.3)), float(self.weights.get('3d', 0.5)), getattr(dsdf, 'mlp_precision', None), bool(optimize_latent),
                self.render, self.trace_grad, tuple(sorted(self.tracer_kwargs.items())))
         if self._key != key:
@@ -77,7 +88,9 @@ class Optimizer:
                 rf = hit[1]
             else:
                 rf = BatchRefiner(dsdf, D, Kn, crop_size, 1, lidar_cap=cap, weights=self.weights, device=dev, optimize_latent=optimize_latent,
-                                  render=self.render, trace_grad=self.trace_grad, tracer_kwargs=self.tracer_kwargs)
+                                  render=self.render, trace_grad=self.trace_grad, tracer_kwargs=self.tracer_kwargs,
+                                  max_pixels=pmax if ragged else None, max_side=side if ragged else None)
+                STATS["refiners_built"] += 1
                 while len(_REFINERS) >= _REFINERS_MAX:
                     _REFINERS.pop(next(iter(_REFINERS)))
                 _REFINERS[key] = (weakref.ref(dsdf), rf)
@@ -105,7 +118,9 @@ class Optimizer:
         with torch.no_grad():
             rf.set_crops({'yaw': p['yaw'].detach().reshape(1, -1), 'trans': p['trans'].detach().reshape(1, 3),
                           'scale': p['scale'].detach().reshape(1, -1), 'latent': p['latent'].detach().reshape(1, -1)},
-                         torch.as_tensor(nocs_pred, dtype=torch.float32)[None], [lidar])
+                         torch.as_tensor(nocs_pred, dtype=torch.float32)[None], [lidar],
+                         **({'K': np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32),
+                             'crop_sizes': [(int(crop_size[0]), int(crop_size[1]))]} if rf.ragged else {}))
             if self._adam is not None:                        # refiners are shared between Optimizer objects; the solver state is not
                 rf.adam_m.copy_(self._adam[0]); rf.adam_v.copy_(self._adam[1]); rf.adam_t.copy_(self._adam[2])
             self.log = []

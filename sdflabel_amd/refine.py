@@ -19,7 +19,7 @@ from .batch import BatchRenderer
 
 class BatchRefiner:
     def __init__(self, decoder, density, K, crop_size, batch, lidar_cap, weights=None, cap=None, device="cuda", optimize_latent=True,
-                 render="splat", trace_grad="surfel", tracer_kwargs=None):
+                 render="splat", trace_grad="surfel", tracer_kwargs=None, max_pixels=None, max_side=None):
         """crop_size = (H, W) as the reference passes it (optimizer.py:56,72 builds the Rasterer with crop_size[::-1]).
         optimize_latent=False: pose-only refinement (yaw, trans, scale; the latent parameter group of optimizer.py:38 gets no update), so
         the shape is evaluated once per set_crops() and every iteration only re-projects, splats and differentiates the pose.
@@ -29,7 +29,11 @@ class BatchRefiner:
         camera-frame hit points in pixel order -> 3-D loss; its backward feeds the same solver step.  `density` is unused then.
         trace_grad="surfel" (default): hits differentiate as material points, the autograd semantics of the reference's surfels -- the mode
         the loop converges with; "image": image-space implicit-function gradients at the fixed pixels (DESIGN.md 3.6 has the comparison).
-        tracer_kwargs: SphereTracer options (steps, cone_block, polish, ...)."""
+        tracer_kwargs: SphereTracer options (steps, cone_block, polish, ...).
+        max_pixels / max_side (splat renderer; r04): ragged extents -- every crop of a batch its own image size (H_b, W_b) and intrinsics K_b,
+        given to set_crops(); buffers are sized for max_pixels pixels per crop and the captured graph serves every crop set within the caps
+        (the reference pipeline's crops all differ: utils/refinement.py:586-609, pipelines/refine_css.py:117-129).  crop_size is then the
+        default extent.  A crop refines bit-identically to the same crop alone in a fixed-size refiner."""
         self.H, self.W = int(crop_size[0]), int(crop_size[1])
         self.B = int(batch)
         self.w2 = float((weights or {}).get('2d', 0.3))          # configs/config_refine.ini:26-27
@@ -48,7 +52,7 @@ class BatchRefiner:
             dev, self.L, est_cap = self.tr.dev, self.tr.L, self.tr.ecap
         else:
             self.tr = None
-            self.br = BatchRenderer(decoder, density, K, (self.W, self.H), batch, cap=cap, device=device)
+            self.br = BatchRenderer(decoder, density, K, (self.W, self.H), batch, cap=cap, device=device, max_pixels=max_pixels, max_side=max_side)
             self.br.freeze_shape = not self.optimize_latent
             dev, self.L, est_cap = self.br.dev, self.br.L, self.br.cap
         br = self.br
@@ -69,15 +73,17 @@ class BatchRefiner:
         self.lidar_cap = int(lidar_cap)
         self.lidar = torch.zeros((B, self.lidar_cap, 3), dtype=torch.float32, device=dev)
         self.lcnt = torch.zeros((B,), dtype=torch.int32, device=dev)
-        self.target = torch.zeros((B, 3, self.H, self.W), dtype=torch.float32, device=dev)
+        self.ragged = br is not None and br.ragged
+        img_shape = (B, 3, br.PS) if self.ragged else (B, 3, self.H, self.W)
+        self.target = torch.zeros(img_shape, dtype=torch.float32, device=dev)
         self.loss2d = torch.zeros((B,), dtype=torch.float32, device=dev)
         self.loss3d = torch.zeros((B,), dtype=torch.float32, device=dev)
         self.total = torch.zeros((B,), dtype=torch.float32, device=dev)
         self.nvalid = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.npairs = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.stepped = torch.zeros((B,), dtype=torch.int32, device=dev)
-        self.g_color = torch.zeros((B, 3, self.H, self.W), dtype=torch.float32, device=dev)
-        self.l2_scratch = torch.zeros((3 * B * ((self.W + 15) // 16) * ((self.H + 15) // 16),), dtype=torch.float32, device=dev)
+        self.g_color = torch.zeros(img_shape, dtype=torch.float32, device=dev)
+        self.l2_scratch = torch.zeros((3 * B * (br.tiles16_cap if self.ragged else ((self.W + 15) // 16) * ((self.H + 15) // 16)),), dtype=torch.float32, device=dev)
         self.l3_scratch = torch.zeros((3 * B * ((est_cap + 63) // 64),), dtype=torch.float32, device=dev)
         self.g_xyzf = torch.zeros((B, est_cap, 3), dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros((B, 4), dtype=torch.float32, device=dev)
@@ -86,17 +92,30 @@ class BatchRefiner:
         self._replay = None
 
     # ------------------------------------------------------------------------------------------------------------------
-    def set_crops(self, params, nocs_pred, lidars):
+    def set_crops(self, params, nocs_pred, lidars, K=None, crop_sizes=None):
         """params: dict of (B, .) arrays 'yaw' (B,1|B), 'trans' (B,3), 'scale' (B,1|B), 'latent' (B,L)  (optimizer.py:26-40);
-        nocs_pred: (B,3,h,w) CSS-net NOCS predictions, resized with nearest-neighbour interpolation to the crop (optimizer.py:135-137);
-        lidars: list of B (M_b,3) arrays (camera-frame lidar points of each crop's frustum)."""
+        nocs_pred: (B,3,h,w) CSS-net NOCS predictions -- or, with ragged extents, a list of B (3,h_b,w_b) predictions -- resized with
+        nearest-neighbour interpolation to each crop's size (optimizer.py:135-137);
+        lidars: list of B (M_b,3) arrays (camera-frame lidar points of each crop's frustum);
+        K (B,3,3) | (3,3) and crop_sizes [(H_b, W_b)] * B (ragged extents only): the crops' own intrinsics and image sizes as the reference
+        passes them to Optimizer.optimize (refine_css.py:203-223); default: those given at construction."""
         B, dev = self.B, self.dev
         t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)
+        if (K is not None or crop_sizes is not None) and not self.ragged:
+            raise _lib.SdfrError("per-crop K / crop_sizes need a BatchRefiner built with max_pixels (ragged extents)")
         self.yaw.copy_(t(params['yaw']).reshape(B))
         self.trans.copy_(t(params['trans']).reshape(B, 3))
         self.scale.copy_(t(params['scale']).reshape(B))
         self.latent.copy_(t(params['latent']).reshape(B, self.L))
-        self.target.copy_(F.interpolate(t(nocs_pred), size=(self.H, self.W), mode='nearest'))
+        if self.ragged:
+            sizes = [(int(h), int(w)) for h, w in crop_sizes] if crop_sizes is not None else [(self.H, self.W)] * B
+            self.br.set_extents([(w, h) for h, w in sizes], K)
+            self.target.zero_()
+            for b, (h, w) in enumerate(sizes):
+                pred = t(nocs_pred[b])
+                self.target[b, :, :h * w] = F.interpolate(pred[None], size=(h, w), mode='nearest')[0].reshape(3, h * w)
+        else:
+            self.target.copy_(F.interpolate(t(nocs_pred), size=(self.H, self.W), mode='nearest'))
         self.lidar.zero_()
         for b, l in enumerate(lidars):
             l = t(l).reshape(-1, 3)
@@ -123,8 +142,12 @@ class BatchRefiner:
             self._iteration_traced(L, P, st, ck)
             return
         out = br.forward()
-        ck(L.sdfr_loss_2d(P(out["color"]), P(self.target), B, self.H, self.W, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color),
-                          P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d")
+        if self.ragged:
+            ck(L.sdfr_loss_2d_r(P(out["color"]), P(self.target), B, P(br.wh), br.PS, br.tiles16_cap, 5.0, 1.0, self.w2, P(self.loss2d),
+                                P(self.g_color), P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d_r")
+        else:
+            ck(L.sdfr_loss_2d(P(out["color"]), P(self.target), B, self.H, self.W, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color),
+                              P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d")
         ck(L.sdfr_loss_3d(P(out["xyzf"]), P(br.fcnt), br.cap, P(self.lidar), P(self.lcnt), self.lidar_cap, P(self.scale), 0.2, self.w3, B,
                           P(self.loss3d), P(self.g_xyzf), P(self.g_scale), P(self.npairs), P(self.l3_scratch), st), "sdfr_loss_3d")
         br.backward(g_color=self.g_color, g_xyzf=self.g_xyzf)
@@ -167,6 +190,7 @@ class BatchRefiner:
         if guard is not None:                   # ... nor feed the two-stage mode's guard counters
             br.violations.copy_(guard[0]); br.margin_dev.copy_(guard[1]); br.max_dev.copy_(guard[2]); br.age.zero_()
         self._replay = g.replay
+        self.captures = getattr(self, "captures", 0) + 1          # (bench / tests: how often this refiner had to capture)
         return g.replay
 
     def optimize(self, iters_optim):

@@ -210,10 +210,12 @@ class _RasterDiscFn(torch.autograd.Function):
                 nf = int(fcnt.item())                                 # the one synchronisation: xyzf / rgbf are (N_f, 3) tensors
         ctx.save_for_backward(coords_c, normals_c, pose_c, K, Kinv, slab, imgs, aux, fslot)
         ctx.cfg = (n, nf, W, H, int(nocs_mode), want_mask, want_depth, want_normals)
-        zero = color.new_zeros(())
-        outs = (color, mask if want_mask else zero, depth if want_depth else zero, nimg if want_normals else zero, p_cam[:n], n_cam[:n], attr[:n],
+        # (images that were not asked for: DISTINCT placeholder tensors, marked non-differentiable -- the same object in several output slots
+        #  would make autograd route a gradient for any of them to the last duplicate)
+        zm, zd, zn = (None if want_mask else color.new_zeros(())), (None if want_depth else color.new_zeros(())), (None if want_normals else color.new_zeros(()))
+        outs = (color, mask if want_mask else zm, depth if want_depth else zd, nimg if want_normals else zn, p_cam[:n], n_cam[:n], attr[:n],
                 xyzf[:nf], rgbf[:nf])
-        ctx.mark_non_differentiable(outs[5])
+        ctx.mark_non_differentiable(outs[5], *[z for z in (zm, zd, zn) if z is not None])
         return outs
 
     @staticmethod

@@ -121,6 +121,10 @@ class SphereTracer:
         # at any batch size.  False: 16-row tiles of 16x16x32 products for thin cone passes (a few us per pass faster at one crop, values
         # equal to float rounding only).
         self.uniform_tiles = bool(uniform_tiles)
+        # ... and the hand-over from per-step launches to the looping kernel happens at a fixed PASS INDEX (spec_from) instead of when the
+        # device-side TOTAL count drops below tail_rows: the two sides apply the same step rule but round a ray's state differently in the last
+        # bit (separately compiled arithmetic), so a count-driven hand-over would make a crop's march depend on its batch mates
+        self.march_tail_rows = 0 if (self.uniform_tiles and self.half and not self.generic_march and self.spec_k > 1) else self.tail_rows
         if self.cone_block and (self.cone_block < 2 or self.cone_steps < 1):
             raise ValueError("cone_block >= 2 (pixels), cone_steps >= 1")
         self.L = decoder.latent_size
@@ -192,7 +196,7 @@ class SphereTracer:
                                   P(self.lam[0]), P(self.far), P(self.inputs), P(self.cone) if self.cone_block else None, self.cone_block, st),
                "sdfr_trace_setup")
             ck(L.sdfr_trace_march(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.eps, self.steps,
-                                  self.head_steps, self.tail_rows, self.spec_from, self.spec_k, self.spec_from2, self.spec_k2, self.sigma,
+                                  self.head_steps, self.march_tail_rows, self.spec_from, self.spec_k, self.spec_from2, self.spec_k2, self.sigma,
                                   self.half, P(self.counters), P(self.pix[0]), P(self.lam[0]), P(self.pix[1]), P(self.lam[1]), P(self.pix[2]),
                                   P(self.lam[2]), P(self.far), P(self.inputs), P(self.sdf),
                                   P(self.tail_rows_buf), P(self.hit_lam), P(self.hit_sdf), st), "sdfr_trace_march")

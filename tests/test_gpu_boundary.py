@@ -61,6 +61,42 @@ def test_fused_band_path_survives_value_preserving_ops(dec, how):
     assert np.abs(N(p3) - N(ref_pts)).max() < 1e-5
 
 
+def test_second_consumer_of_the_decoder_output_keeps_its_gradient(dec):
+    """the sync-free fast path of the decoder's backward trusts a gradient that says "band rows only".  With a second consumer
+    of the decoder output (a regulariser on sdf) autograd adds the two gradients -- the sum must not pass as band-only (its out-of-band
+    rows would be dropped), in either order of the two consumers; nor may a gradient built for an earlier band cache of the same state
+    (get_surface_points called twice on one decoder output).  Checked against the gradients of the pieces taken separately."""
+    grid = sdflabel_amd.Grid3D(16, DEV)
+
+    def grad_of(build):
+        lat = torch.tensor([0.3, -0.5, 0.8], device=DEV, requires_grad=True)
+        grid.points.grad = None
+        sdf, _ = dec(_inputs(grid, lat))
+        build(sdf).backward()
+        return lat.grad.clone(), grid.points.grad.clone()
+
+    w = torch.linspace(-1.0, 2.0, grid.points.size(0), device=DEV).view(-1, 1)         # non-zero on every row, band or not
+    reg = lambda sdf: (sdf * w).sum()
+    surf = lambda sdf: (grid.get_surface_points(sdf)[0] * torch.tensor([1.0, -2.0, 0.5], device=DEV)).sum()
+    wide = lambda sdf: grid.get_surface_points(sdf, threshold=0.06)[0].sum()
+    g_reg, g_surf, g_wide = grad_of(reg), grad_of(surf), grad_of(wide)
+    assert float(g_reg[0].abs().max()) > 1e-3 and float(g_surf[0].abs().max()) > 1e-3
+    for combo, parts in ((lambda s: reg(s) + surf(s), (g_reg, g_surf)), (lambda s: surf(s) + reg(s), (g_reg, g_surf)),
+                         (lambda s: surf(s) + wide(s), (g_surf, g_wide)), (lambda s: wide(s) + surf(s) + reg(s), (g_wide, g_surf, g_reg))):
+        got = grad_of(combo)
+        for k in range(2):
+            want = sum(p_[k] for p_ in parts)
+            assert torch.allclose(got[k], want, rtol=1e-4, atol=1e-5 * float(want.abs().max())), (k, (got[k] - want).abs().max())
+    # the fast path itself still runs for the plain loop (one consumer): its tag vouches for the very tensor the decoder backward receives
+    from sdflabel_amd.deepsdf.networks.deep_sdf_decoder_scale import BandTag
+    seen = {}
+    lat = torch.tensor([0.3, -0.5, 0.8], device=DEV, requires_grad=True)
+    sdf, _ = dec(_inputs(grid, lat))
+    sdf.register_hook(lambda g: seen.setdefault("tag", getattr(g, "_sdfr_band_of", None)))
+    surf(sdf).backward()
+    assert isinstance(seen["tag"], BandTag)
+
+
 def test_empty_band_gives_empty_tensors_and_zero_gradients(dec):
     """optimizer.py:127: the caller checks nelement() == 0; backward through an empty selection must give zeros, not raise"""
     grid = sdflabel_amd.Grid3D(8, DEV)
@@ -350,6 +386,23 @@ def test_decoder_scale_head_fused_kernel_equals_the_torch_modules():
     (g,) = torch.autograd.grad(scale.sum(), lat, retain_graph=True)
     (gr,) = torch.autograd.grad(ref.sum(), lat)
     assert float((g - gr).abs().max()) < 1e-6
+    # the head's own parameters get their gradients too (fine-tuning the scale head through Decoder.forward), accumulated as
+    # autograd accumulates into leaves
+    params = list(d.scale_net.parameters())
+    assert all(p_.requires_grad for p_ in params)
+    for p_ in params:
+        p_.grad = None
+    d.scale_net(lat.detach()).sum().backward()
+    want = [p_.grad.clone() for p_ in params]
+    for p_ in params:
+        p_.grad = None
+    _, scale2 = d(inp.detach())
+    scale2.sum().backward()
+    scale3 = d(inp.detach())[1]
+    scale3.sum().backward()                                     # a second backward accumulates
+    for p_, w_ in zip(params, want):
+        assert p_.grad is not None and float((p_.grad - 2 * w_).abs().max()) < 1e-6 * max(1.0, float(w_.abs().max()))
+        p_.grad = None
 
 
 def test_drop_in_iterations_do_not_accumulate_device_memory():

@@ -20,8 +20,9 @@ reference's surfels it reproduces the reference's 5.2277).  So three gradient ch
   r_g_*   the same functional with zero weight on the pixels that hold a pair within 1e-5 of a selection threshold (stored bitmap): 1e-3,
           end to end (decoder -> surfels -> render -> backward to yaw, trans, latent)
   g_pcd / g_yaw / g_trans of the FULL functional with the reference's own surfels fed to the renderer: 1e-3 (renderer-level parity)
-  g_*     the FULL functional end to end: 5e-2, a sanity bound only (case b, 25 m away with 6-pixel discs and 22 % of its pixels within 1e-5
-          of a threshold, moves by 2e-2 between the reference's surfels and ours)
+  g_*     the FULL functional end to end: (counted flips x 4e-3 + 1e-3) relative -- the pixels whose composite differs visibly from the
+          reference's are counted (each holds a pair decided differently within float rounding) and only what they explain is allowed
+          (r04; r03 used a flat 5e-2)
 """
 import os
 
@@ -59,6 +60,21 @@ def grads_close(got, z, prefix, rel):
     for g, key in zip(got, ("yaw", "trans", "latent")):
         ref = z[prefix + key]
         assert np.abs(N(g).reshape(ref.shape) - ref).max() < rel * max(1.0, np.abs(ref).max()), (prefix + key, N(g), ref)
+
+
+FLIP_COST = 4e-3     # what ONE (pixel, surfel) pair flipping across the disc edge moves the +-1-weighted functional by, relative (measured: module docstring)
+
+
+def count_flips(images, z, H, W):
+    """pixels whose composite differs visibly (> 1e-5: float noise is ~1e-6) from the reference's in any of the four images: each holds at least
+    one (pixel, surfel) pair that the two sides decided differently -- a disc-edge, front-face or band flip within float rounding"""
+    return int(np.any([(np.abs(N(images[k]).reshape(-1, H * W) - z["out_" + k].reshape(-1, H * W)) > 1e-5).any(0) for k in ("color", "mask", "depth", "normals")], axis=0).sum())
+
+
+def full_functional_grads_close(got, z, flips):
+    """the ill-posed full functional end to end, bounded by what the COUNTED flips explain -- |g - g_ref| <= (flips x 4e-3 +
+    1e-3) max(1, |g_ref|) -- instead of a flat 5e-2 that would also hide a real 1-2 % error of the xyz -> latent chain"""
+    grads_close(got, z, "g_", flips * FLIP_COST + 1e-3)
 
 
 def _weights(z, out, near):
@@ -99,7 +115,7 @@ def _dropin_case(dec, z):
     for t in (yaw, trans, lat):
         t.grad = None
     loss.backward()
-    grads_close((yaw.grad, trans.grad, lat.grad), z, "g_", 5e-2)               # full functional: sanity bound (flipped pairs at 4e-3 each)
+    full_functional_grads_close((yaw.grad, trans.grad, lat.grad), z, count_flips(rendering, z, H, W))      # full functional: what the counted flips explain
     assert float(rendering["mask"].sum()) > 2000
     # renderer-level parity of the FULL functional: the reference's own surfels in, gradients w.r.t. them and the pose out
     pcd_r, nrm_r = T(z["pcd"]).requires_grad_(True), T(z["normals"])
@@ -140,7 +156,8 @@ def _batch_case(decoder, z, B, binned=None):
         grads_close([t[b] for t in g], z, "r_g_", 1e-3)                        # well-posed functional (see the module docstring)
     g = br.backward(g_color=w["color"], g_mask=w["mask"], g_depth=w["depth"], g_normals=w["normals"], g_xyzf=gx)
     for b in sorted({0, B // 2, B - 1}):
-        grads_close([t[b] for t in g], z, "g_", 5e-2)                          # full functional: sanity bound (flipped pairs at 4e-3 each)
+        flips = count_flips({k: out[k][b] for k in ("color", "mask", "depth", "normals")}, z, H, W)
+        full_functional_grads_close([t[b] for t in g], z, flips)               # full functional: what the counted flips explain
     return br, out
 
 

@@ -21,6 +21,8 @@ ap.add_argument("--scan", default="", help="'from:from2,from:from2,...' -- sched
 ap.add_argument("--cone", type=int, nargs="*", default=[0], help="cone_block values to time (0: no cone phase)")
 ap.add_argument("--cone-steps", type=int, default=10)
 ap.add_argument("--only", default="", help="f32 | f16: one precision, default schedule only (profiling runs)")
+ap.add_argument("--kw", default="", help="JSON list of SphereTracer keyword dicts to time instead of the built-in schedules, e.g. '[{\"tail_rows\": 0}, {\"uniform_tiles\": false}]'")
+ap.add_argument("--reps", type=int, default=10)
 args = ap.parse_args()
 dev = "cuda"
 H = W = args.size
@@ -34,13 +36,16 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
     d = d.to(dev)
     macs = d.handle(torch.device(dev)).macs
     scheds = [dict(spec_k=k) for k in args.spec]                              # the defaults (spec_k 4: second level 16 from spec_from + 4)
-    if args.scan:
+    if args.kw:
+        import json
+        scheds = json.loads(args.kw)
+    elif args.scan:
         scheds = [dict(spec_k=4, spec_from=int(a.split(":")[0]), spec_from2=int(a.split(":")[1])) for a in args.scan.split(",")]
     elif not args.only:
         scheds += [dict(spec_k=4, spec_k2=1), dict(spec_k=4, spec_k2=8), dict(spec_k=4, spec_from2=14), dict(spec_k=4, spec_from2=18),
                    dict(spec_k=4, spec_from=10, spec_from2=14), dict(spec_k=4, spec_from=16, spec_from2=20), dict(spec_k=4, tail_rows=2048),
                    dict(spec_k=4, tail_rows=8192), dict(spec_k=1, head_steps=args.steps, tail_rows=0), dict(spec_k=4, polish="exact")]
-    for sch in [dict(s_, cone_block=c, cone_steps=args.cone_steps) for s_ in scheds for c in args.cone]:
+    for sch in [dict(dict(cone_block=c, cone_steps=args.cone_steps), **s_) for s_ in scheds for c in args.cone]:
         tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, **sch)
         head, tail, spec_k, spec_from = tr.head_steps, tr.tail_rows, tr.spec_k, tr.spec_from
 
@@ -52,7 +57,7 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 10
+        n = args.reps
         for _ in range(n):
             step()
         torch.cuda.synchronize()
@@ -64,7 +69,7 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
         mm = float(np.mean([e["march"][0].elapsed_time(e["march"][1]) for e in evs]))
         s = tr.stats()
         tf = 2.0 * macs * s["ray_evaluations"] / (mm * 1e-3) / 1e12
-        print("%s cone %d polish %s spec_k %d from %2d (then %2d from %2d) head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
-              % (str(prec).replace("torch.", ""), tr.cone_block, tr.polish, spec_k, spec_from, tr.spec_k2, tr.spec_from2, head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
+        print("%s uniform %d cone %d polish %s spec_k %d from %2d (then %2d from %2d) head %2d tail_rows %5d: fwd+bwd %.2f ms (%.1f M rays/s), march %.2f ms, %d ray evaluations -> %.0f TFLOP/s (%.1f %% of peak), hits %d unresolved %d"
+              % (str(prec).replace("torch.", ""), int(tr.uniform_tiles), tr.cone_block, tr.polish, spec_k, spec_from, tr.spec_k2, tr.spec_from2, head, tail, dt * 1e3, B * H * W / dt / 1e6, mm, s["ray_evaluations"], tf,
                  100 * tf / (2500.0 if prec == torch.float16 else 157.3), s["hits"], s["unresolved"]), flush=True)
         del tr

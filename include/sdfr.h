@@ -164,6 +164,19 @@ int sdfr_prefilter_guard2(float* sdf_grid, const float* sdf_exact, const int32_t
                           float* margin, float* max_dev, int32_t* violations, const int32_t* reused, void* stream);
 int sdfr_gather_rows(float* out, const float* src, int ncol, const int32_t* idx, const int32_t* slot, int64_t G, int B, int cap,
                      int src_cap, const int32_t* cnt, void* stream);
+/* Audit of the two-stage evaluation (r04): the guard above observes the half pass only at the candidates; a row outside them that the half
+ * pass misplaced by more than the margin is invisible to it.  Every step the NON-candidate rows of one residue class g = *phase (mod stride)
+ * -- a rotating 1/stride slice of the grid: every row once per `stride` steps -- are listed by sdfr_prefilter_audit_select (rows
+ * float[cap_rows][n_inputs] = their decoder input rows, src int32[cap_rows] = b * G + g, *n_audit = how many; cslot: the grid-row ->
+ * candidate-slot map of the candidate selection), evaluated exactly by the caller (sdfr_mlp_forward_counted(dec, rows, cap_rows, n_audit,
+ * sdf_exact, 0)) and judged by sdfr_prefilter_audit_check: |exact| < thr on such a row = a band row was excluded in this step ->
+ * violations[2b+1] += 1 (a hard violation, like the guard's); audit_dev[b] = the largest |half - exact| seen on crops that ran the half pass
+ * (reused[b] == 0; reused may be NULL); then *phase += 1.  phase, n_audit: device int32; no host synchronisation. */
+int sdfr_prefilter_audit_select(const float* inputs, const int32_t* cslot, int64_t G, int n_inputs, int B, int stride, const int32_t* phase,
+                                float* rows, int32_t* src, int32_t* n_audit, int cap_rows, void* stream);
+int sdfr_prefilter_audit_check(const float* sdf_grid, const float* sdf_exact, const int32_t* src, const int32_t* n_audit, int cap_rows,
+                               int64_t G, int B, float thr, const int32_t* reused, float* audit_dev, int32_t* violations, int32_t* phase,
+                               void* stream);
 
 /* g_inputs[r][:] = g_sdf[r] * J[slot[r]][:]  for rows with slot[r] >= 0, else 0   (DeepSDF backward through the
  * cached band Jacobian).  n_uncached (device int32, may be NULL) receives the number of rows with g_sdf != 0 and
@@ -377,11 +390,16 @@ int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, in
  * (delta = max |d_corner - d_centre|).  v = decoder(centre point): v - lam delta > eps -> nothing within the cone's cross-section, advance by
  * (v - lam delta) / (|d_c| + delta); <= eps -> the tile's rays start their own march there; past the cube's far side for all of them ->
  * culled; after cone_steps passes the cones stop where they are.  cone float[B][ceil(W/block) * ceil(H/block)]: start parameter or -1.
- * counters: device int32[8] (zeroed here; [4..5] one uint64 = decoder evaluations); ids0/st0, ids1/st1: ping-pong cone lists (int32[n],
- * float[n][4], n = B * tiles); inputs float[n][L+3], sdf float[n] scratch.  No host synchronisation. */
+ * A centre point outside the cube is evaluated clamped into it, v = sqrt(clamp distance^2 + max(f, 0)^2): no extrapolated decoder value is trusted.
+ * spec_k (1 ... 8; r04): speculative cone passes -- a pass evaluates spec_k samples of a cone, p_0 = lam, p_j = p_{j-1} + sigma q^j a_prev
+ * (a_prev = the cone's previous advance, q = ratio of its last two advances in [0.5, 1.5]); sample j counts only inside the range its
+ * predecessor proved free, so the accepted prefix is a valid, shorter-stepped cone march (4 samples x 4 passes cull what 10 plain passes cull).
+ * counters: device int32[8] (zeroed here; [0..2] rotating ROW counts, [4..5] one uint64 = decoder evaluations); ids0/st0/aux0, ids1/st1/aux1:
+ * ping-pong cone lists (int32[n], float[n][4], float[n][2], n = B * tiles); inputs float[n * spec_k][L+3], sdf float[n * spec_k] scratch.
+ * half | 2: see sdfr_mlp_forward_counted.  No host synchronisation. */
 int sdfr_trace_cone(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound,
-                    float near, float eps, int block, int cone_steps, int half, int32_t* counters, int32_t* ids0, float* st0, int32_t* ids1,
-                    float* st1, float* inputs, float* sdf, float* cone, void* stream);
+                    float near, float eps, int block, int cone_steps, int spec_k, float sigma, int half, int32_t* counters, int32_t* ids0,
+                    float* st0, float* aux0, int32_t* ids1, float* st1, float* aux1, float* inputs, float* sdf, float* cone, void* stream);
 /* march step `step` (0, 1, ...): sdf = decoder values of the active rays (counters[step % 3] of them); lam += sdf / |d|; rays with
  * |sdf| < eps are recorded in hit_lam / hit_sdf and retired, rays past `far` are retired, the rest are compacted into pix_out / lam_out /
  * inputs (count in counters[(step + 1) % 3]) */

@@ -762,19 +762,31 @@ def _trace_slab(o, d, bound, near):
     return l0, l1, active
 
 
-def cone_march(layers, spec, latn, pose, Kinv, image_wh, block, blocks, cone_steps=10, eps=2e-3, bound=1.0, near=1e-3):
+def cone_march(layers, spec, latn, pose, Kinv, image_wh, block, blocks, cone_steps=10, eps=2e-3, bound=1.0, near=1e-3, spec_k=1, sigma=0.9):
     """Cone marching of the pixel blocks `blocks` (ids by * nbx + bx of block x block pixel tiles of a W x H image): ONE ray through the centre
     of the (image-clipped) block stands for all its pixels.  All pixel rays share the origin and the parametrisation (lam = camera depth), so
     the block's rays at parameter lam lie within lam * delta of the centre ray's point, delta = max over the block's corner pixels of
-    |d_corner - d_centre|.  With v = decoder(centre point): free = v - lam * delta > eps means no surface within the cone's cross-section at
-    lam, and the cone may advance to lam + free / (|d_c| + delta) (the sphere of radius v around the centre point covers the cross-sections
-    up to there).  A cone stops where free <= eps (or NaN): its pixels start their own march at that lam; a cone that advances past the far
-    side of the cube for ALL its pixels is culled: none of its pixels can hit; cones still marching after cone_steps passes stop where they are.
+    |d_corner - d_centre|.  With v = the distance bound at the centre point: free = v - lam * delta > eps means no surface within the cone's
+    cross-section at lam, and the cone may advance by a = free / (|d_c| + delta) (the sphere of radius v around the centre point covers the
+    cross-sections up to there).  A cone stops where free <= eps (or NaN): its pixels start their own march at that lam; a cone that advances
+    past the far side of the cube for ALL its pixels is culled: none of its pixels can hit; cones still marching after cone_steps passes stop
+    where they are.
+    The centre point x may lie outside the cube the decoder is defined on (the block's range is the union of its pixels' ranges): the decoder
+    is evaluated at c = x clamped into the cube -- no extrapolated value is trusted.  The rendered surface lies inside the cube (rays are clipped
+    to it), the cube is convex and c is its nearest point to x, so |x - s|^2 >= cd^2 + |c - s|^2 >= cd^2 + max(f(c), 0)^2 for every surface
+    point s: v = sqrt(cd^2 + max(f(c), 0)^2) is a valid distance bound at x (inside the cube cd is exactly 0 and v = f(c)).
+    Speculative passes (spec_k > 1; r04): a pass evaluates spec_k samples of a cone at once, p_0 = lam, p_j = p_{j-1} + sigma q^j a_prev
+    (a_prev = the cone's previous advance, q = the ratio of its last two advances clamped to [0.5, 1.5]; before the first pass a_prev = 0.1 of the
+    block's parameter range).  Sample j counts only inside the range its predecessor proved free, p_{j-1} < p_j <= p_{j-1} + a_{j-1}: the
+    accepted prefix is a valid, shorter-stepped cone march; the cone continues from the last accepted sample's full advance.  One cone pass is
+    one decoder pass of latency whatever the row count (4096 cones of a 256x256 crop fill a quarter of the chip), so the ~10 sequential
+    passes of a cone march become ~4.
     Returns start (per block: lam >= 0 to start from, or -1: culled / no pixel's ray enters the cube), margin (distance of the block's closest
     decision to its threshold), evals."""
     f = np.float32
     W_, H_ = int(image_wh[0]), int(image_wh[1])
     BL = int(block)
+    K_ = int(spec_k)
     nbx = (W_ + BL - 1) // BL
     blocks = np.asarray(blocks, np.int64)
     nb = blocks.shape[0]
@@ -809,42 +821,70 @@ def cone_march(layers, spec, latn, pose, Kinv, image_wh, block, blocks, cone_ste
     start = np.full(nb, -1.0, f)
     margin = np.full(nb, np.inf)
     lam = np.where(any_in, near_b, 0).astype(f)
+    aprev = np.where(any_in, (f(0.1) * (far_b - near_b).astype(f)).astype(f), 0).astype(f)
+    q = np.ones(nb, f)
     active = any_in.copy()
     evals = 0
     for s in range(int(cone_steps)):
         idx = np.nonzero(active)[0]
         if idx.size == 0:
             break
-        X = (o[None] + lam[idx, None] * dc[idx]).astype(f)
-        # the centre point x may lie outside the cube the decoder is defined on (the block's range is the union of its pixels' ranges): evaluate
-        # at c = x clamped into the cube -- no extrapolated value is trusted.  The rendered surface lies inside the cube (rays are clipped to
-        # it), the cube is convex and c is its nearest point to x, so |x - s|^2 >= cd^2 + |c - s|^2 >= cd^2 + max(f(c), 0)^2 for every surface
-        # point s: a valid distance bound at x (inside the cube cd is exactly 0 and the value is the decoder's)
+        m = idx.size
+        P = np.zeros((m, K_), f)
+        P[:, 0] = lam[idx]
+        qp = q[idx].copy()
+        for j in range(1, K_):
+            P[:, j] = (P[:, j - 1] + ((f(sigma) * qp).astype(f) * aprev[idx]).astype(f)).astype(f)
+            qp = (qp * q[idx]).astype(f)
+        X = (o[None, None] + P[:, :, None] * dc[idx][:, None, :]).astype(f)
         Xc = np.minimum(np.maximum(X, -f(bound)), f(bound)).astype(f)
         e = (X - Xc).astype(f)
-        cd = np.sqrt(((e[:, 0] * e[:, 0]).astype(f) + (e[:, 1] * e[:, 1]).astype(f)).astype(f) + (e[:, 2] * e[:, 2]).astype(f)).astype(f)
-        rows = np.concatenate([np.broadcast_to(latn, (idx.size, L)), Xc], 1).astype(f)
-        v = decoder_forward(layers, spec, rows)[:, 0].astype(f)
+        cd = np.sqrt(((e[..., 0] * e[..., 0]).astype(f) + (e[..., 1] * e[..., 1]).astype(f)).astype(f) + (e[..., 2] * e[..., 2]).astype(f)).astype(f)
+        rows = np.concatenate([np.broadcast_to(latn, (m * K_, L)), Xc.reshape(-1, 3)], 1).astype(f)
+        v = decoder_forward(layers, spec, rows)[:, 0].astype(f).reshape(m, K_)
         vp = np.maximum(v, f(0))
         v = np.where(cd > 0, np.sqrt(((cd * cd).astype(f) + (vp * vp).astype(f)).astype(f)).astype(f), v).astype(f)
-        evals += idx.size
-        free = (v - (lam[idx] * delta[idx]).astype(f)).astype(f)
-        go = free > f(eps)                                   # (NaN: stop)
-        adv = (lam[idx] + (free / (dn[idx] + delta[idx]).astype(f)).astype(f)).astype(f)
-        out = go & ~(adv < far_b[idx])
-        margin[idx] = np.minimum(margin[idx], np.abs(free - f(eps)))
-        margin[idx[go]] = np.minimum(margin[idx[go]], np.abs(adv - far_b[idx])[go])
-        start[idx[~go]] = lam[idx[~go]]
-        start[idx[out]] = -1.0
-        keep = go & ~out
-        lam[idx[keep]] = adv[keep]
-        active[idx] = keep
+        evals += m * K_
+        free = (v - (P * delta[idx, None]).astype(f)).astype(f)
+        with np.errstate(invalid="ignore"):
+            A = (free / (dn[idx] + delta[idx]).astype(f)[:, None]).astype(f)          # the advance each sample would allow
+        ADV = (P + A).astype(f)
+        done = np.zeros(m, bool)
+        lam_new, a_last, a_before = lam[idx].copy(), aprev[idx].copy(), aprev[idx].copy()
+        mg = np.full(m, np.inf)
+        for j in range(K_):
+            if j > 0:
+                gap = (P[:, j] - P[:, j - 1]).astype(f)
+                valid = (P[:, j] > P[:, j - 1]) & (gap <= A[:, j - 1])
+                mg = np.where(done, mg, np.minimum(mg, np.abs(gap - A[:, j - 1])))
+                done |= ~valid                                   # the prediction left the proven range: the pass ends at the previous sample
+            take = ~done
+            go = free[:, j] > f(eps)                             # (NaN: stop)
+            mg = np.where(take, np.minimum(mg, np.abs(free[:, j] - f(eps))), mg)
+            stop = take & ~go
+            start[idx[stop]] = P[stop, j]
+            out = take & go & ~(ADV[:, j] < far_b[idx])
+            mg = np.where(take & go, np.minimum(mg, np.abs(ADV[:, j] - far_b[idx])), mg)
+            start[idx[out]] = -1.0
+            adv_ok = take & go & ~out
+            a_before = np.where(adv_ok, a_last, a_before)
+            a_last = np.where(adv_ok, A[:, j], a_last)
+            lam_new = np.where(adv_ok, ADV[:, j], lam_new)
+            active[idx[stop | out]] = False
+            done |= stop | out
+        margin[idx] = np.minimum(margin[idx], mg)
+        keep = active[idx]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            qn = np.where(a_before > 0, np.minimum(np.maximum((a_last / a_before).astype(f), f(0.5)), f(1.5)), f(1.0)).astype(f)
+        lam[idx[keep]] = lam_new[keep]
+        aprev[idx[keep]] = a_last[keep]
+        q[idx[keep]] = qn[keep]
     start[active] = lam[active]
     return start, margin, evals
 
 
 def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, bound=1.0, near=1e-3, spec_from=None, spec_k=1, sigma=0.9,
-                 cone_block=None, cone_steps=10, image_wh=None):
+                 cone_block=None, cone_steps=10, image_wh=None, cone_spec_k=1):
     """March every ray: x = o + lam d, v = decoder(latn, x); |v| < eps -> hit at lam; else lam += v / |d|; lam >= far (exit of the cube
     [-bound, bound]^3) or NaN -> miss; out of steps -> miss (unresolved).
     Speculative passes (spec_k > 1, from pass index spec_from on): a pass evaluates spec_k samples of the ray at once, p_0 = lam and
@@ -878,7 +918,7 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
         pxy = np.asarray(pixels_xy, np.int64)
         bid = (pxy[:, 1] // BL) * nbx + pxy[:, 0] // BL
         ub, inv = np.unique(bid, return_inverse=True)
-        cstart, cmarg, cone_evals = cone_march(layers, spec, latn, pose, Kinv, image_wh, BL, ub, cone_steps, eps, bound, near)
+        cstart, cmarg, cone_evals = cone_march(layers, spec, latn, pose, Kinv, image_wh, BL, ub, cone_steps, eps, bound, near, cone_spec_k, sigma)
         cs = cstart[inv]
         cone_margin = cmarg[inv]
         cone_culled = active & (cs < 0)

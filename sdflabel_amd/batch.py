@@ -134,6 +134,16 @@ class BatchRenderer:
             self.reuse = bool(getattr(decoder, "prefilter_reuse", False))
             self.max_reuse = int(getattr(decoder, "prefilter_max_reuse", 16))
             self.lat_ref, self.age, self.reuse_flag = f(B, self.L), i(B), i(B)
+            # audit (r04): the guard sees the half pass only at the candidates; every step a rotating 1 / audit_stride slice of the NON-candidate
+            # rows is evaluated with the exact-f32 decoder as well, and a row that belongs to the band although it was never proposed counts a
+            # hard violation like the guard's (check_overflow raises).  decoder.prefilter_audit = False turns it off (the r03 behaviour).
+            self.audit = bool(getattr(decoder, "prefilter_audit", True))
+            self.audit_stride = int(getattr(decoder, "prefilter_audit_stride", 16))
+            if self.audit:
+                self.audit_cap = B * ((G + self.audit_stride - 1) // self.audit_stride)
+                self.audit_rows, self.audit_src, self.audit_sdf = f(self.audit_cap, NI), i(self.audit_cap), f(self.audit_cap)
+                self.audit_n, self.audit_phase, self.audit_dev = i(1), i(1), f(B)
+            self.fault = None           # tests: (flat grid rows int64 tensor, values) written over the half pass's output -- a planted half-pass error
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.p_cam, self.n_cam, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.fidx, self.fcnt, self.fslot = i(B, cap), i(B), i(B, cap)
@@ -223,6 +233,8 @@ class BatchRenderer:
             self.violations.zero_()
             self.max_dev.zero_()
             self.margin_dev.fill_(self.margin)
+            if self.audit:
+                self.audit_dev.zero_()
 
     def forward(self, yaw=None, trans=None, latent=None, mlp_events=None, events=None):
         """mlp_events: optional (start, end) torch.cuda.Event pair recorded around the decoder-forward launch (bench.py roofline).
@@ -254,12 +266,24 @@ class BatchRenderer:
                                          P(self.age), self.max_reuse, P(self.reuse_flag), st), "sdfr_prefilter_plan")
                 ck(L.sdfr_mlp_forward_f16_skip(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.reuse_flag), G, st),
                    "sdfr_mlp_forward_f16_skip")
+                if self.fault is not None:
+                    self.sdf.index_copy_(0, self.fault[0], self.fault[1])
                 ck(L.sdfr_band_select_skip(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.reuse_flag), P(self.cidx), cap, P(self.ccnt),
                                            P(self.cslot), P(self.scratch), st), "sdfr_band_select_skip")
             else:
                 ck(L.sdfr_mlp_forward_f16(self.handle.h, P(self.inputs), B * G, P(self.sdf), None, st), "sdfr_mlp_forward_f16")
+                if self.fault is not None:
+                    self.sdf.index_copy_(0, self.fault[0], self.fault[1])
                 ck(L.sdfr_band_select_margin(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.cidx), cap, P(self.ccnt), P(self.cslot),
                                              P(self.scratch), st), "sdfr_band_select_margin")
+            if self.audit:
+                ck(L.sdfr_prefilter_audit_select(P(self.inputs), P(self.cslot), G, self.NI, B, self.audit_stride, P(self.audit_phase), P(self.audit_rows),
+                                                 P(self.audit_src), P(self.audit_n), self.audit_cap, st), "sdfr_prefilter_audit_select")
+                ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 0, st),
+                   "sdfr_mlp_forward_counted")
+                ck(L.sdfr_prefilter_audit_check(P(self.sdf), P(self.audit_sdf), P(self.audit_src), P(self.audit_n), self.audit_cap, G, B, self.thr,
+                                                P(self.reuse_flag) if self.reuse else None, P(self.audit_dev), P(self.violations), P(self.audit_phase), st),
+                   "sdfr_prefilter_audit_check")
             # exact float32 sdf and Jacobian of the candidates (recomputing kernel, 16-row tiles), patched into the grid array
             ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.cidx), cap, P(self.ccnt), P(self.Jc), P(self.sdf_band), None, None,
                                    0, st), "sdfr_mlp_jacobian")
@@ -382,8 +406,12 @@ class BatchRenderer:
         if not self.prefilter:
             return None
         v = self.violations.sum(0).tolist()
-        return {"violations": int(v[0]), "hard_violations": int(v[1]), "max_deviation": float(self.max_dev.max()),
-                "margin": float(self.margin_dev.max())}
+        rep = {"violations": int(v[0]), "hard_violations": int(v[1]), "max_deviation": float(self.max_dev.max()),
+               "margin": float(self.margin_dev.max())}
+        if self.audit:
+            rep["audit"] = {"stride": self.audit_stride, "rows_last_step": int(self.audit_n[0]), "steps": int(self.audit_phase[0]),
+                            "max_deviation_at_non_candidates": float(self.audit_dev.max())}
+        return rep
 
     def check_overflow(self):
         """Raise if the last forward dropped surfels (the reference has no capacity: a truncated shape must not pass silently).  One sync."""

@@ -170,6 +170,87 @@ __global__ __launch_bounds__(1024) void sdfr_prefilter_guard_kernel(float* __res
     }
 }
 
+// ---- audit of the two-stage evaluation (r04) ------------------------------------------------------------------------------
+// The guard above sees the half pass's error only at the CANDIDATES.  A row outside them that the half pass misplaced by more than the margin
+// (so that it belongs to the band but was never proposed) is invisible to it.  The audit closes that: every step, the non-candidate rows of
+// ONE residue class g = phase (mod stride) -- a rotating 1/stride slice of the grid, every row once per `stride` steps -- are evaluated with
+// the exact float32 decoder (sdfr_mlp_forward_counted on the compact row list written here) and judged by sdfr_prefilter_audit_check:
+//   |exact| < thr on a non-candidate row  ->  a band row WAS excluded in this step: hard violation (violations[2b+1]), the result is refused
+//                                              like a candidate-side hard violation (BatchRenderer.check_overflow raises);
+//   |half - exact| (crops that ran the half pass this step)  ->  audit_dev[b] = the largest seen since the last reset, for the report.
+// Everything on the device: the phase is a device counter advanced by the check kernel (graph-capturable, no host state).
+__global__ __launch_bounds__(256) void sdfr_prefilter_audit_select_kernel(const float* __restrict__ inputs, const int32_t* __restrict__ cslot,
+                                                                         int64_t G, int NI, int stride, const int32_t* __restrict__ phase,
+                                                                         float* __restrict__ rows, int32_t* __restrict__ src,
+                                                                         int32_t* __restrict__ n_audit, int cap_rows) {
+    const int b = blockIdx.y;
+    const int ph = ((*phase) % stride + stride) % stride;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;          // k-th row of the residue class
+    const int64_t g = k * stride + ph;
+    const bool take = g < G && cslot[(int64_t)b * G + g] < 0;
+    const unsigned long long bal = __ballot(take);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && bal) base = atomicAdd(n_audit, __popcll(bal));
+    base = __shfl(base, 0, 64);
+    const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+    if (take && pos < cap_rows) {
+        const float* in = inputs + ((int64_t)b * G + g) * NI;
+        float* o = rows + (int64_t)pos * NI;
+        for (int c = 0; c < NI; ++c) o[c] = in[c];
+        src[pos] = (int)((int64_t)b * G + g);
+    }
+}
+
+__global__ __launch_bounds__(256) void sdfr_prefilter_audit_check_kernel(const float* __restrict__ sdf_grid, const float* __restrict__ sdf_exact,
+                                                                        const int32_t* __restrict__ src, const int32_t* __restrict__ n_audit,
+                                                                        int cap_rows, int64_t G, float thr, const int32_t* __restrict__ reused,
+                                                                        float* __restrict__ audit_dev, int32_t* __restrict__ violations,
+                                                                        int32_t* __restrict__ phase) {
+    const int n = min(*n_audit, cap_rows);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int r = src[i];
+        const int b = (int)(r / G);
+        const float ex = sdf_exact[i];
+        if (!(fabsf(ex) >= thr)) atomicAdd(&violations[2 * b + 1], 1);                 // a band row outside the candidates (or NaN): missed
+        if (!(reused && reused[b])) {
+            const float dev = fabsf(sdf_grid[r] - ex);                                  // (non-negative floats order like their bit patterns)
+            atomicMax(reinterpret_cast<int*>(audit_dev) + b, __float_as_int(dev));
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // (every block of the select kernel has read the phase: this launch follows it in stream order)
+        *phase = *phase + 1;
+    }
+}
+
+extern "C" int sdfr_prefilter_audit_select(const float* inputs, const int32_t* cslot, int64_t G, int n_inputs, int B, int stride, const int32_t* phase,
+                                           float* rows, int32_t* src, int32_t* n_audit, int cap_rows, void* stream) {
+    SDFR_REQUIRE(inputs && cslot && phase && rows && src && n_audit, "sdfr_prefilter_audit_select: NULL argument");
+    SDFR_REQUIRE(G > 0 && n_inputs > 0 && stride > 0 && cap_rows > 0, "sdfr_prefilter_audit_select: bad size");
+    if (B <= 0) return SDFR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    SDFR_HIP_CHECK(hipMemsetAsync(n_audit, 0, sizeof(int32_t), s));
+    const int per = sdfr_cdiv(G, stride);
+    hipLaunchKernelGGL(sdfr_prefilter_audit_select_kernel, dim3(sdfr_cdiv(per, 256), B), dim3(256), 0, s, inputs, cslot, G, n_inputs, stride, phase,
+                       rows, src, n_audit, cap_rows);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_prefilter_audit_check(const float* sdf_grid, const float* sdf_exact, const int32_t* src, const int32_t* n_audit, int cap_rows,
+                                          int64_t G, int B, float thr, const int32_t* reused, float* audit_dev, int32_t* violations,
+                                          int32_t* phase, void* stream) {
+    SDFR_REQUIRE(sdf_grid && sdf_exact && src && n_audit && audit_dev && violations && phase, "sdfr_prefilter_audit_check: NULL argument");
+    SDFR_REQUIRE(G > 0 && cap_rows > 0, "sdfr_prefilter_audit_check: bad size");
+    if (B <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_prefilter_audit_check_kernel, dim3(sdfr_cdiv(cap_rows, 256)), dim3(256), 0, (hipStream_t)stream, sdf_grid, sdf_exact, src,
+                       n_audit, cap_rows, G, thr, reused, audit_dev, violations, phase);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
 // Plan of the two-stage evaluation for this step, per crop (one thread each): may the candidate set of the last half pass be reused?
 // A row outside it had |half sdf| >= thr + margin at the latent z0 of that pass, so its exact |sdf| at the current latent z1 is at least
 // thr + margin - dev - lip * |z1 - z0|  (dev: the half pass's deviation, lip: Lipschitz constant of the decoder in the normalised latent,

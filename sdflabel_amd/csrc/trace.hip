@@ -149,10 +149,31 @@ __device__ __forceinline__ TraceRay cone_centre_ray(const float* __restrict__ P,
     return trace_ray(P, Ki, 0.5f * (float)(x0 + x1), 0.5f * (float)(y0 + y1));
 }
 
+// Speculative cone passes (r04): a pass evaluates K samples of a cone, p_0 = lam, p_j = p_{j-1} + sigma q^j a_prev (a_prev = the cone's previous
+// advance, q = the ratio of its last two advances clamped to [0.5, 1.5]); sample j counts only inside the range its predecessor proved free.
+// Rows of cone slot s: s * K + j.  The rotating counters hold ROW counts (K per listed cone).
+__device__ __forceinline__ void cone_positions(float lam, float aprev, float q, int K, float sigma, float* __restrict__ p) {
+    float pj = lam, qp = q;
+    for (int j = 0; j < K; ++j) {
+        if (j > 0) { pj = __fadd_rn(pj, __fmul_rn(__fmul_rn(sigma, qp), aprev)); qp = __fmul_rn(qp, q); }
+        p[j] = pj;
+    }
+}
+#define CONE_KMAX 8
+__device__ __forceinline__ int cone_append(bool keep, int32_t* __restrict__ counter, int K) {
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && bal) base = atomicAdd(counter, __popcll(bal) * K);
+    base = __shfl(base, 0, 64);
+    return base / K + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
 __global__ __launch_bounds__(256) void sdfr_trace_cone_setup_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
                                                                    const float* __restrict__ latn, int L, int W, int H, int BL, float bound,
-                                                                   float near, int32_t* __restrict__ counters, int32_t* __restrict__ ids,
-                                                                   float4* __restrict__ st, float* __restrict__ cone, float* __restrict__ inputs) {
+                                                                   float near, int K, float sigma, int32_t* __restrict__ counters,
+                                                                   int32_t* __restrict__ ids, float4* __restrict__ st, float2* __restrict__ aux,
+                                                                   float* __restrict__ cone, float* __restrict__ inputs) {
     const int b = blockIdx.y;
     const int nbx = (W + BL - 1) / BL, nby = (H + BL - 1) / BL, nblk = nbx * nby;
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -179,54 +200,82 @@ __global__ __launch_bounds__(256) void sdfr_trace_cone_setup_kernel(const float*
             }
         cone[(int64_t)b * nblk + k] = -1.f;                     // until the march says where the block's rays start
     }
-    const int slot = trace_append(keep, counters);
+    const int slot = cone_append(keep, counters, K);
     if (keep) {
+        const float a0 = __fmul_rn(0.1f, __fsub_rn(far_b, near_b));      // first guess of an advance: a tenth of the block's parameter range
         ids[slot] = b * nblk + k;
         st[slot] = make_float4(near_b, delta, far_b, sqrtf(rc.dx * rc.dx + rc.dy * rc.dy + rc.dz * rc.dz));
-        (void)cone_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, rc, near_b, bound);
+        aux[slot] = make_float2(a0, 1.f);
+        float p[CONE_KMAX];
+        cone_positions(near_b, a0, 1.f, K, sigma, p);
+        for (int j = 0; j < K; ++j)
+            (void)cone_write_row(inputs + ((int64_t)slot * K + j) * (L + 3), latn + (int64_t)b * L, L, rc, p[j], bound);
     }
 }
 
 __global__ __launch_bounds__(256) void sdfr_trace_cone_step_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
                                                                   const float* __restrict__ latn, int L, int W, int H, int BL, float eps,
-                                                                  float bound, const float* __restrict__ sdf, const int32_t* __restrict__ n_cur,
-                                                                  int32_t* __restrict__ n_next, int32_t* __restrict__ n_zero,
-                                                                  const int32_t* __restrict__ ids_in, const float4* __restrict__ st_in,
+                                                                  float bound, int K, float sigma, const float* __restrict__ sdf,
+                                                                  const int32_t* __restrict__ n_cur, int32_t* __restrict__ n_next,
+                                                                  int32_t* __restrict__ n_zero, const int32_t* __restrict__ ids_in,
+                                                                  const float4* __restrict__ st_in, const float2* __restrict__ aux_in,
                                                                   int32_t* __restrict__ ids_out, float4* __restrict__ st_out,
-                                                                  float* __restrict__ inputs, float* __restrict__ cone, int last,
-                                                                  unsigned long long* __restrict__ evals) {
+                                                                  float2* __restrict__ aux_out, float* __restrict__ inputs,
+                                                                  float* __restrict__ cone, int last, unsigned long long* __restrict__ evals) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    const int n = *n_cur;
+    const int nrows = *n_cur;
+    const int n = nrows / K;
     if (s == 0) *n_zero = 0;
-    if (s == 0 && evals) atomicAdd(evals, (unsigned long long)n);
+    if (s == 0 && evals) atomicAdd(evals, (unsigned long long)nrows);
     if (blockIdx.x * 256 >= n) return;
     bool keep = false;
     int id = 0;
     float4 st = make_float4(0.f, 0.f, 0.f, 1.f);
+    float2 ax = make_float2(0.f, 1.f);
     const int nbx = (W + BL - 1) / BL, nby = (H + BL - 1) / BL, nblk = nbx * nby;
     TraceRay rc = {};
     int b = 0;
     if (s < n) {
         id = ids_in[s];
         st = st_in[s];
+        ax = aux_in[s];
         b = id / nblk;
         int x0, y0, x1, y1;
         rc = cone_centre_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, id - b * nblk, nbx, BL, W, H, x0, y0, x1, y1);
-        const float v = cone_value(sdf[s], cone_clamp_dist(rc, st.x, bound));     // (the row held the point clamped into the cube)
-        const float free_ = v - __fmul_rn(st.x, st.y);
-        if (!(free_ > eps)) cone[id] = st.x;                       // the cone touches the tolerance band (or NaN): its rays take over here
-        else {
-            const float adv = st.x + free_ / (st.w + st.y);
-            if (!(adv < st.z)) cone[id] = -1.f;                    // past the cube for every ray of the block: culled
-            else if (last) cone[id] = adv;                         // out of cone passes: the rays start where the cone got to
-            else { keep = true; st.x = adv; }
+        float p[CONE_KMAX];
+        cone_positions(st.x, ax.x, ax.y, K, sigma, p);
+        const float den = __fadd_rn(st.w, st.y);
+        // walk the accepted prefix (oracle/sdf_oracle.py::cone_march)
+        float lam_new = st.x, a_last = ax.x, a_before = ax.x, a_prevj = 0.f;
+        bool done = false, alive = true;
+        for (int j = 0; j < K && !done; ++j) {
+            if (j > 0) {
+                const float gap = __fsub_rn(p[j], p[j - 1]);
+                if (!((p[j] > p[j - 1]) && (gap <= a_prevj))) break;       // the prediction left the range its predecessor proved free
+            }
+            const float v = cone_value(sdf[(int64_t)s * K + j], cone_clamp_dist(rc, p[j], bound));   // (the row held the point clamped into the cube)
+            const float free_ = __fsub_rn(v, __fmul_rn(p[j], st.y));
+            if (!(free_ > eps)) { cone[id] = p[j]; alive = false; done = true; break; }   // touches the tolerance band (or NaN): the rays take over here
+            const float a = free_ / den;
+            const float adv = __fadd_rn(p[j], a);
+            if (!(adv < st.z)) { cone[id] = -1.f; alive = false; done = true; break; }     // past the cube for every ray of the block: culled
+            a_before = a_last; a_last = a; lam_new = adv; a_prevj = a;
+        }
+        if (alive) {
+            const float qn = (a_before > 0.f) ? fminf(fmaxf(a_last / a_before, 0.5f), 1.5f) : 1.f;
+            if (last) cone[id] = lam_new;                          // out of cone passes: the rays start where the cone got to
+            else { keep = true; st.x = lam_new; ax = make_float2(a_last, qn); }
         }
     }
-    const int slot = trace_append(keep, n_next);
+    const int slot = cone_append(keep, n_next, K);
     if (keep) {
         ids_out[slot] = id;
         st_out[slot] = st;
-        (void)cone_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, rc, st.x, bound);
+        aux_out[slot] = ax;
+        float p[CONE_KMAX];
+        cone_positions(st.x, ax.x, ax.y, K, sigma, p);
+        for (int j = 0; j < K; ++j)
+            (void)cone_write_row(inputs + ((int64_t)slot * K + j) * (L + 3), latn + (int64_t)b * L, L, rc, p[j], bound);
     }
 }
 
@@ -504,25 +553,30 @@ extern "C" int sdfr_trace_setup(const float* pose, const float* Kinv, const floa
 // from, or -1 (no ray of the block can hit).  counters: device int32[8] (zeroed here; [0..2] rotating counts, [4..5] one uint64: decoder
 // evaluations), ids0/st0, ids1/st1: ping-pong cone lists (int32[n] / float[n][4], n = B * blocks), inputs float[n][L+3], sdf float[n].
 extern "C" int sdfr_trace_cone(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H,
-                               float bound, float near, float eps, int block, int cone_steps, int half, int32_t* counters, int32_t* ids0,
-                               float* st0, int32_t* ids1, float* st1, float* inputs, float* sdf, float* cone, void* stream) {
-    SDFR_REQUIRE(d && pose && Kinv && latn && counters && ids0 && st0 && ids1 && st1 && inputs && sdf && cone, "sdfr_trace_cone: NULL argument");
+                               float bound, float near, float eps, int block, int cone_steps, int spec_k, float sigma, int half,
+                               int32_t* counters, int32_t* ids0, float* st0, float* aux0, int32_t* ids1, float* st1, float* aux1, float* inputs,
+                               float* sdf, float* cone, void* stream) {
+    SDFR_REQUIRE(d && pose && Kinv && latn && counters && ids0 && st0 && aux0 && ids1 && st1 && aux1 && inputs && sdf && cone,
+                 "sdfr_trace_cone: NULL argument");
     SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0 && bound > 0.f && block >= 2 && cone_steps >= 1, "sdfr_trace_cone: bad size");
+    SDFR_REQUIRE(spec_k >= 1 && spec_k <= CONE_KMAX, "sdfr_trace_cone: spec_k = %d (1 ... %d samples per cone and pass)", spec_k, CONE_KMAX);
     SDFR_REQUIRE(d->n_inputs == L + 3, "sdfr_trace_cone: decoder with L + 3 = %d inputs expected, it has %d", L + 3, d->n_inputs);
     hipStream_t s = (hipStream_t)stream;
     const int nblk = sdfr_cdiv(W, block) * sdfr_cdiv(H, block);
     const int64_t n_max = (int64_t)B * nblk;
+    SDFR_REQUIRE(n_max * spec_k < (int64_t)1 << 31, "sdfr_trace_cone: too many cone rows");
     SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
     hipLaunchKernelGGL(sdfr_trace_cone_setup_kernel, dim3(sdfr_cdiv(nblk, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, W, H, block, bound, near,
-                       counters, ids0, reinterpret_cast<float4*>(st0), cone, inputs);
+                       spec_k, sigma, counters, ids0, reinterpret_cast<float4*>(st0), reinterpret_cast<float2*>(aux0), cone, inputs);
     unsigned long long* evals = reinterpret_cast<unsigned long long*>(counters + 4);
     for (int step = 0; step < cone_steps; ++step) {
-        const int rc = sdfr_mlp_forward_counted(d, inputs, n_max, counters + step % 3, sdf, half, stream);
+        const int rc = sdfr_mlp_forward_counted(d, inputs, n_max * spec_k, counters + step % 3, sdf, half, stream);
         if (rc != SDFR_OK) return rc;
         const int a = step & 1;
-        hipLaunchKernelGGL(sdfr_trace_cone_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, block, eps, bound, sdf,
-                           counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? ids1 : ids0,
-                           reinterpret_cast<const float4*>(a ? st1 : st0), a ? ids0 : ids1, reinterpret_cast<float4*>(a ? st0 : st1), inputs, cone,
+        hipLaunchKernelGGL(sdfr_trace_cone_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, block, eps, bound,
+                           spec_k, sigma, sdf, counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? ids1 : ids0,
+                           reinterpret_cast<const float4*>(a ? st1 : st0), reinterpret_cast<const float2*>(a ? aux1 : aux0), a ? ids0 : ids1,
+                           reinterpret_cast<float4*>(a ? st0 : st1), reinterpret_cast<float2*>(a ? aux0 : aux1), inputs, cone,
                            step == cone_steps - 1 ? 1 : 0, evals);
     }
     SDFR_LAUNCH_CHECK();

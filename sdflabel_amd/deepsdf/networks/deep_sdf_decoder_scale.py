@@ -118,20 +118,24 @@ def sdf_state_of(t):
     return None
 
 
-def mlp_jacobian(state, idx, n, use_masks=True, half=None):
+def mlp_jacobian(state, idx, n, use_masks=True, half=None, cnt_dev=None):
     """J (n, NI), sdf_sel (n,) for the rows idx[:n] of state.inputs.  With the masks the forward launch saved the Jacobian is a
     backward-only pass; otherwise the kernel recomputes the forward for the selected rows.  half: run the mask-fed backward with half
-    operands too (default: whatever the forward used; half=False keeps the float32 backward on top of a float16 forward)."""
+    operands too (default: whatever the forward used; half=False keeps the float32 backward on top of a float16 forward).
+    cnt_dev (device int32[1]): the row count is read on the device and `n` is only the capacity of the launch -- rows beyond the count are
+    not touched; returns the full (n, NI) / (n,) buffers (the caller slices once it knows the count)."""
     L = _lib.lib()
     J = torch.empty((max(n, 1), state.inputs.shape[1]), dtype=torch.float32, device=state.inputs.device)
     sel = torch.empty((max(n, 1),), dtype=torch.float32, device=state.inputs.device)
     if n > 0:
       with _lib.guard(state.inputs):
         um = use_masks and state.mask_ws is not None and state.sdf is not None
-        _lib.check(L.sdfr_mlp_jacobian(state.handle.h, _lib.ptr(state.inputs), state.G, 1, _lib.ptr(idx), n, None, _lib.ptr(J),
+        _lib.check(L.sdfr_mlp_jacobian(state.handle.h, _lib.ptr(state.inputs), state.G, 1, _lib.ptr(idx), n, _lib.ptr(cnt_dev), _lib.ptr(J),
                                        _lib.ptr(sel), _lib.ptr(state.sdf) if um else None, _lib.ptr(state.mask_ws) if um else None,
                                        (2 if (state.f16 if half is None else half) else 1) if state.f16 else 0, _lib.stream_ptr()),
                    "sdfr_mlp_jacobian")
+    if cnt_dev is not None:
+        return J, sel
     return J[:n], sel[:n]
 
 

@@ -71,9 +71,24 @@ class _SurfaceFn(torch.autograd.Function):
         return g_sdf, g_xyz, None, None, None, None, None, None, None, None, None
 
 
-def band_select(sdf_flat, threshold, want_slot=True):
+_PINNED = {}
+
+
+def _pinned_count(dev):
+    """one pinned host int32 per device for the asynchronous read of a device-side count"""
+    t = _PINNED.get(dev)
+    if t is None:
+        t = _PINNED[dev] = torch.empty((1,), dtype=torch.int32).pin_memory()
+    return t
+
+
+def band_select(sdf_flat, threshold, want_slot=True, queue=None):
     """(idx int32 (N,), N, slot int32 (G,)) -- ascending rows with |sdf| < threshold.  One host sync for N (the reference's
-    masked_select, grid.py:65, synchronises as well)."""
+    masked_select, grid.py:65, synchronises as well).
+    queue (r04): a callable queue(idx, cnt_dev) that enqueues device work consuming the selection with the count still ON THE DEVICE.  The
+    count then travels to a pinned host buffer asynchronously, an event marks the copy, `queue` runs, and the host waits for the EVENT only:
+    the GPU works on what `queue` enqueued while the host goes on with N (a plain .item() would have to come before those launches, and after
+    them it would wait for them too -- measured slower in r03).  Returns (idx, N, slot, whatever queue returned)."""
     L = _lib.lib()
     G = sdf_flat.shape[0]
     dev = sdf_flat.device
@@ -84,8 +99,16 @@ def band_select(sdf_flat, threshold, want_slot=True):
     with _lib.guard(sdf_flat):
         _lib.check(L.sdfr_band_select(_lib.ptr(sdf_flat), G, 1, float(threshold), _lib.ptr(idx), G, _lib.ptr(cnt), _lib.ptr(slot),
                                       _lib.ptr(scratch), _lib.stream_ptr()), "sdfr_band_select")
-    n = int(cnt.item())
-    return idx, n, slot
+    if queue is None:
+        n = int(cnt.item())
+        return idx, n, slot
+    host = _pinned_count(dev)
+    host.copy_(cnt, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    queued = queue(idx, cnt)
+    ev.synchronize()                                                   # the band count is on the host; the queued launches are still running
+    return idx, int(host[0]), slot, queued
 
 
 class Grid3D:
@@ -112,20 +135,26 @@ class Grid3D:
         fused = state is not None and state.G == self.points.shape[0] and state.sdf is not None
         # float32 values for the kernels: the decoder's own output when available (a half `pred_sdf_grid` is a rounded copy of it)
         sdf_c = state.sdf if fused else pred_sdf_grid.detach().float().contiguous().view(-1)
-        idx, n, slot = band_select(sdf_c, threshold)
-
         def narrow(ts):
             return ts if out_dtype == torch.float32 else tuple(t.to(out_dtype) for t in ts)
 
         if fused:
-            # fused path: Jacobian of the HIP decoder at the band rows only
-            J, _ = mlp_jacobian(state, idx, n)
-            J = J.contiguous()
+            # fused path: Jacobian of the HIP decoder at the band rows only -- enqueued BEHIND the band selection with the count still on the
+            # device and a capacity guessed from this grid's previous band (r04: the host then waits for the count alone, not for the Jacobian;
+            # a band that outgrew the guess is evaluated again at its exact size)
+            G_ = sdf_c.shape[0]
+            guess = min(G_, max(256, int(1.25 * getattr(self, "_last_band", G_ // 8)) + 64))
+            idx, n, slot, (J, _) = band_select(sdf_c, threshold, queue=lambda idx_, cnt_: mlp_jacobian(state, idx_, guess, cnt_dev=cnt_))
+            self._last_band = n
+            if n > guess:
+                J, _ = mlp_jacobian(state, idx, n)
+            J = J[:n].contiguous()
             state.idx, state.slot, state.J, state.cap = idx, slot, J, max(n, 1)
             state.band_token = getattr(state, "band_token", 0) + 1      # a second get_surface_points on the same state re-writes the cache
             NI = state.inputs.shape[1]
             xyz_src = state.inputs[:, NI - 3:]
             return narrow(_SurfaceFn.apply(pred_sdf_grid, self.points, sdf_c, xyz_src, NI, idx, n, J, NI, NI - 3, state))
+        idx, n, slot = band_select(sdf_c, threshold)
         # generic path: any differentiable SDF of self.points
         (g,) = torch.autograd.grad(pred_sdf_grid.sum(), self.points, retain_graph=True, allow_unused=True)
         if g is None:

@@ -51,13 +51,18 @@ class _TraceFn(torch.autograd.Function):
         return None, g[0].clone(), g[1].clone(), g[2].clone()
 
 
-def default_spec_from(rays_per_crop, half):
+def default_spec_from(rays_per_crop, half, cone=False):
     """first speculative pass of the default schedule.  Where the speculative passes pay depends on how many rays are still marching at that
     pass: K samples per ray cost K rows, and only once a pass is latency-bound (few tiles) are they free.  Measured optimum
-    (tools/sphere_time.py --scan, one crop): 128x128 rays 8, 256x256 10, 512x512 13-14 (float16) / 18 (float32, whose 64-row passes are
-    matrix-bound) -- a function of the crop's ray count alone, fixed at construction, so the pass index still decides."""
+    (tools/sphere_time.py --scan, one crop): without the cone phase 128x128 rays 8, 256x256 10, 512x512 13-14 (float16) / 18 (float32, whose
+    64-row passes are matrix-bound); behind the cone phase (r04: 60 % of the pixel tiles never start a ray, the others start next to the
+    surface) the float16 march pays earlier: 128x128 4 (3:7 1.26, 4:8 1.17, 5:9 1.20 ms), 256x256 6 (4:8 1.91, 5:9 1.84, 6:10 1.67, 10:13 1.71 ms),
+    512x512 8 (8:11 3.64, 10:13 3.67, 13:16 3.85 ms) -- a function of the crop's ray count alone, fixed at construction, so the pass index
+    still decides."""
     import math
     r = math.log2(max(int(rays_per_crop), 1) / 65536.0)
+    if cone and half:
+        return max(3, min(6 + round(r), 24))
     s = 10 + (round((1.5 if half else 4.0) * r) if r >= 0 else round(r))
     return max(4, min(s, 24))
 
@@ -65,7 +70,7 @@ def default_spec_from(rays_per_crop, half):
 class SphereTracer:
     def __init__(self, decoder, K, resolution_px, batch=1, steps=64, eps=2e-3, bound=1.0, near=1e-3, device="cuda", head_steps=None,
                  tail_rows=4096, spec_from=None, spec_k=None, sigma=0.9, spec_from2=None, spec_k2=None, polish=None,
-                 cone_block=None, cone_steps=10, uniform_tiles=True, points=False):
+                 cone_block=None, cone_steps=None, uniform_tiles=True, points=False, cone_spec_k=None):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise _lib.SdfrError("SphereTracer runs on the GPU only")
@@ -89,15 +94,18 @@ class SphereTracer:
             if self.half:
                 raise _lib.SdfrError("SphereTracer: the float16 march needs a 512-wide decoder without LayerNorm")
             self.spec_k, spec_k2 = 1, 1
+        cone_on = (4 if cone_block is None else int(cone_block)) > 0
+        spec_from_given = spec_from is not None
         if spec_from is None:
-            spec_from = default_spec_from(self.W * self.H, bool(self.half))   # (per crop, not per batch: a crop renders the same alone or in a batch)
+            spec_from = default_spec_from(self.W * self.H, bool(self.half), cone_on)   # (per crop, not per batch: a crop renders the same alone or in a batch)
         self.spec_from, self.sigma = int(spec_from), float(sigma)
         if self.spec_k not in (1, 4):
             raise ValueError("spec_k must be 1 or 4")
         # second level: from pass index spec_from2 on (default spec_from + 3) the looping kernel's survivors -- the creeping rays that end the
         # march, scattered over the tiles -- are re-packed 64 / spec_k2 to a tile and take spec_k2 samples per pass (default 16 with spec_k 4)
         self.spec_k2 = int(spec_k2) if spec_k2 is not None else (16 if self.spec_k == 4 else 1)
-        self.spec_from2 = int(spec_from2) if spec_from2 is not None else self.spec_from + 3
+        self.spec_from2 = int(spec_from2) if spec_from2 is not None else self.spec_from + (4 if (cone_on and self.half and not spec_from_given
+                                                                                                      and self.W * self.H <= 65536) else 3)
         if self.spec_k2 <= self.spec_k:
             self.spec_k2 = self.spec_k                                              # off
         elif self.spec_k2 not in (8, 16) or self.spec_from2 <= self.spec_from:
@@ -114,7 +122,18 @@ class SphereTracer:
         # cone_block pixel tile until the SDF falls below the cone's radius; tiles whose cone leaves the cube are culled, the others' rays start
         # where their cone stopped (csrc/trace.hip sdfr_trace_cone; 3.2x fewer decoder evaluations on the bench crop)
         self.cone_block = 4 if cone_block is None else int(cone_block)
-        self.cone_steps = int(cone_steps)
+        # speculative cone passes (r04): cone_spec_k samples per cone and pass (accepted while inside the range the previous sample proved free).
+        # A cone pass is one decoder pass of latency whatever its row count at one crop, so 4 samples x 4 passes (default) replace the 10
+        # sequential plain passes -- the same culling for 2x the (few) cone evaluations; cone_spec_k=1, cone_steps=10: the plain cone march
+        self.cone_spec_k = 4 if cone_spec_k is None else int(cone_spec_k)
+        if self.cone_spec_k < 1 or self.cone_spec_k > 8:
+            raise ValueError("cone_spec_k: 1 ... 8 samples per cone and pass")
+        # passes: a crop of up to 4096 cones (256x256 at 4x4 pixels) is one round of 64-row tiles even with 4 samples each -- every pass costs one
+        # decoder pass of latency, so 4 passes (1.70 ms per render against 2.03 with 10); a 512x512 crop's 16 k cones are matrix-bound, the extra
+        # passes cull more and start the rays closer to the surface (3.64 against 4.2 ms).  A function of the crop size, not of the batch.
+        cones = ((self.W + max(self.cone_block, 1) - 1) // max(self.cone_block, 1)) * ((self.H + max(self.cone_block, 1) - 1) // max(self.cone_block, 1))
+        self.cone_steps = int(cone_steps) if cone_steps is not None else ((4 if cones <= 4096 else 10) if self.cone_spec_k >= 4 else
+                                                                          (6 if self.cone_spec_k >= 2 else 10))
         # uniform_tiles: the cone passes of a float16 decoder use ONE product shape whatever the device-side count (sdfr_mlp_forward_counted
         # half | 2), like the per-ray march (32x32x16 products in its 128- and 64-row head tiles and in the looping kernel with spec_k = 4):
         # a crop's rays then see the same decoder bits alone and inside a batch -> BatchRefiner(render="trace") refines a crop bit-identically
@@ -149,8 +168,8 @@ class SphereTracer:
             nc = B * ((W + self.cone_block - 1) // self.cone_block) * ((H + self.cone_block - 1) // self.cone_block)
             self.cone = f(nc)                                                  # per pixel tile: start parameter or -1 (culled)
             self.cone_counters = i(_COUNTERS)
-            self.cone_ids, self.cone_st = [i(nc), i(nc)], [f(nc, 4), f(nc, 4)]
-            self.cone_inputs, self.cone_sdf = f(nc, self.NI), f(nc)
+            self.cone_ids, self.cone_st, self.cone_aux = [i(nc), i(nc)], [f(nc, 4), f(nc, 4)], [f(nc, 2), f(nc, 2)]
+            self.cone_inputs, self.cone_sdf = f(nc * self.cone_spec_k, self.NI), f(nc * self.cone_spec_k)
         self.hit_lam, self.hit_sdf, self.lam_s = f(n), f(n), f(n)
         self.hit_slot, self.idx = i(n), i(n)
         self.rows, self.J, self.f0 = f(n, self.NI), f(n, self.NI), f(n)
@@ -188,9 +207,10 @@ class SphereTracer:
                 events["march"][0].record()
             if self.cone_block:
                 ck(L.sdfr_trace_cone(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, self.eps,
-                                     self.cone_block, self.cone_steps, (self.half | 2) if (self.half and self.uniform_tiles) else self.half,
-                                     P(self.cone_counters), P(self.cone_ids[0]), P(self.cone_st[0]),
-                                     P(self.cone_ids[1]), P(self.cone_st[1]), P(self.cone_inputs), P(self.cone_sdf), P(self.cone), st),
+                                     self.cone_block, self.cone_steps, self.cone_spec_k, self.sigma,
+                                     (self.half | 2) if (self.half and self.uniform_tiles) else self.half,
+                                     P(self.cone_counters), P(self.cone_ids[0]), P(self.cone_st[0]), P(self.cone_aux[0]),
+                                     P(self.cone_ids[1]), P(self.cone_st[1]), P(self.cone_aux[1]), P(self.cone_inputs), P(self.cone_sdf), P(self.cone), st),
                    "sdfr_trace_cone")
             ck(L.sdfr_trace_setup(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, P(self.counters), P(self.pix[0]),
                                   P(self.lam[0]), P(self.far), P(self.inputs), P(self.cone) if self.cone_block else None, self.cone_block, st),

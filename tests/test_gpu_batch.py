@@ -613,6 +613,51 @@ def test_prefilter_guard_trips_grows_the_margin_and_raises(dec):
     assert br.prefilter_report()["violations"] == 0 and float(br.margin_dev.min()) == pytest.approx(br.margin)
 
 
+@pytest.mark.parametrize("reuse", [False, True])
+def test_prefilter_audit_catches_a_band_row_the_half_pass_misplaced(dec, reuse):
+    """the guard compares the half pass with the exact values at the CANDIDATES only; a band row that the half pass
+    misplaced by more than the margin is never proposed and stays invisible to it.  Plant exactly that -- the half pass's output of one true
+    band row of crop 1 overwritten with 0.5 ("far from the surface") -- and the rotating audit of the non-candidate rows (1/16 of the grid
+    per step, exact-f32) must count a hard violation for that crop within 16 steps; check_overflow() then refuses the result.  Crop 0 stays
+    quiet.  Without the audit (decoder.prefilter_audit = False, the r03 behaviour) the row silently drops out of the band."""
+    B, D, H, W = 2, 40, 32, 32
+    a = [T(np.array([0.6, -0.4], np.float32)), T(np.array([[0.0, 0.0, 3.5], [0.1, -0.05, 3.2]], np.float32)),
+         T(np.array([[0.3, -0.5, 0.8], [-0.2, 0.6, 0.4]], np.float32))]
+    outcomes = {}
+    for audit in (True, False):
+        dp, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter")
+        dp.prefilter_reuse, dp.prefilter_audit = reuse, audit
+        br = sdflabel_amd.BatchRenderer(dp.to(DEV), D, K_for(H, W), (W, H), B, device=DEV)
+        out = br.forward(*a)
+        n1 = int(out["n"][1])
+        g = int(br.idx[1, n1 // 2])                                    # a true band row of crop 1 (exact |sdf| < 0.03)
+        assert br.prefilter_report()["hard_violations"] == 0
+        if audit:
+            assert br.prefilter_report()["audit"]["rows_last_step"] > 0.9 * B * br.G / 16 - br.cap
+        br.fault = (torch.tensor([br.G + g], device=DEV), torch.tensor([0.5], device=DEV))
+        br.invalidate_shape()                                          # (candidate reuse: force a fresh half pass so that the fault enters the candidate selection)
+        caught = None
+        for step in range(16):
+            br.forward()
+            assert int(br.cnt[1]) == n1 - 1                            # the planted row is missing from the band in every step
+            if int(br.violations[1, 1]) > 0:
+                caught = step
+                break
+        outcomes[audit] = caught
+        assert int(br.violations[0].sum()) == 0                        # crop 0 is not affected
+        if audit:
+            assert caught is not None and caught < 16
+            with pytest.raises(sdflabel_amd.SdfrError, match="prefilter"):
+                br.check_overflow()
+            br.fault = None
+            br.forward(*a)                                             # new crops: clean state, and no fault -> quiet for a whole rotation
+            for _ in range(16):
+                br.forward()
+            assert br.prefilter_report()["hard_violations"] == 0 and int(br.cnt[1]) == n1
+            assert 0 < br.prefilter_report()["audit"]["max_deviation_at_non_candidates"] < br.margin
+    assert outcomes[False] is None                                     # the guard alone never sees it
+
+
 def test_prefilter_candidate_reuse_skips_the_half_pass_and_changes_nothing(dec):
     """decoder.prefilter_reuse: while the normalised latent has moved less than margin / (4 lip) since the last half pass, that pass and the
     candidate selection are skipped (decided per crop on the device).  The refinement must be bit-identical to the plain two-stage mode, most

@@ -92,7 +92,7 @@ def test_second_consumer_of_the_decoder_output_keeps_its_gradient(dec):
     seen = {}
     lat = torch.tensor([0.3, -0.5, 0.8], device=DEV, requires_grad=True)
     sdf, _ = dec(_inputs(grid, lat))
-    sdf.register_hook(lambda g: seen.setdefault("tag", getattr(g, "_sdfr_band_of", None)))
+    sdf.register_hook(lambda g: seen.update(tag=getattr(g, "_sdfr_band_of", None)))          # (returns None: the gradient passes unchanged)
     surf(sdf).backward()
     assert isinstance(seen["tag"], BandTag)
 

@@ -42,8 +42,10 @@ def oracle_layers():
 
 
 def _oracle_kw(H, W, half=False, steps=64):
-    sf = default_spec_from(H * W, half)
-    return dict(steps=steps, cone_block=4, cone_steps=10, spec_from=[(sf, 4), (sf + 3, 16)])
+    sf = default_spec_from(H * W, half, True)
+    cones = ((W + 3) // 4) * ((H + 3) // 4)
+    return dict(steps=steps, cone_block=4, cone_steps=4 if cones <= 4096 else 10, cone_spec_k=4,
+                spec_from=[(sf, 4), (sf + (4 if (half and H * W <= 65536) else 3), 16)])                                      # the tracer's defaults
 
 
 def _problem(name):

@@ -166,3 +166,6 @@ def test_sphere_tracer_default_schedule_is_a_function_of_the_crop_size_alone():
     assert [default_spec_from(n * n, True) for n in (64, 128, 256, 512)] == [6, 8, 10, 13]
     assert [default_spec_from(n * n, False) for n in (64, 128, 256, 512)] == [6, 8, 10, 18]
     assert default_spec_from(1, True) == 4 and default_spec_from(1 << 30, False) == 24
+    # behind the cone phase (r04 default) the float16 march starts its speculative passes earlier
+    assert [default_spec_from(n * n, True, True) for n in (64, 128, 256, 512)] == [3, 4, 6, 8]
+    assert [default_spec_from(n * n, False, True) for n in (128, 256)] == [8, 10]

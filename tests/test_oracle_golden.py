@@ -528,6 +528,11 @@ def test_sphere_trace_oracle_self_consistency():
         dd = np.abs(cn["depth"] - tr["depth"])[both]
         assert dd.max() < 1e-3 and np.quantile(dd, 0.98) < 1e-4
         assert cn["evals"] < 0.8 * tr["evals"] and cn["cone_evals"] < 0.3 * tr["evals"]        # (a 40x40 image: 100 tiles; 3x fewer at 256x256)
+        # speculative cone passes (r04): 4 samples per pass in 4 passes -- a valid, shorter-stepped cone march: no hit of plain tracing is lost,
+        # about the culling of the 10 plain passes
+        sp = O.sphere_trace(layers, spec, lat, O.render_pose(yaw, t), Kinv, px, cone_block=block, cone_steps=4, cone_spec_k=4, image_wh=(W, H))
+        assert not (sp["cone_culled"] & tr["hit"]).any() and (sp["hit"] != tr["hit"]).sum() <= 2
+        assert sp["cone_culled"].sum() > 0.8 * cn["cone_culled"].sum() and sp["cone_evals"] < 3 * cn["cone_evals"]
 
 
 def test_cone_march_stays_conservative_when_the_centre_ray_leaves_the_cube():

@@ -19,7 +19,7 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--spec", type=int, nargs="*", default=[1, 4], help="samples per ray and pass in the looping kernel")
 ap.add_argument("--scan", default="", help="'from:from2,from:from2,...' -- schedules to time instead of the built-in list")
 ap.add_argument("--cone", type=int, nargs="*", default=[0], help="cone_block values to time (0: no cone phase)")
-ap.add_argument("--cone-steps", type=int, default=10)
+ap.add_argument("--cone-steps", type=int, default=None, help="cone passes (default: the tracer's own, 4 with 4 samples per pass)")
 ap.add_argument("--only", default="", help="f32 | f16: one precision, default schedule only (profiling runs)")
 ap.add_argument("--kw", default="", help="JSON list of SphereTracer keyword dicts to time instead of the built-in schedules, e.g. '[{\"tail_rows\": 0}, {\"uniform_tiles\": false}]'")
 ap.add_argument("--reps", type=int, default=10)

@@ -18,7 +18,7 @@ ap.add_argument("--steps", type=int, default=64)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--spec", type=int, nargs="*", default=[1, 4], help="samples per ray and pass in the looping kernel")
 ap.add_argument("--scan", default="", help="'from:from2,from:from2,...' -- schedules to time instead of the built-in list")
-ap.add_argument("--cone", type=int, nargs="*", default=[0], help="cone_block values to time (0: no cone phase)")
+ap.add_argument("--cone", type=int, nargs="*", default=[-1], help="cone_block values to time (0: no cone phase; -1: the tracer's default, 4)")
 ap.add_argument("--cone-steps", type=int, default=None, help="cone passes (default: the tracer's own, 4 with 4 samples per pass)")
 ap.add_argument("--only", default="", help="f32 | f16: one precision, default schedule only (profiling runs)")
 ap.add_argument("--kw", default="", help="JSON list of SphereTracer keyword dicts to time instead of the built-in schedules, e.g. '[{\"tail_rows\": 0}, {\"uniform_tiles\": false}]'")
@@ -45,7 +45,7 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
         scheds += [dict(spec_k=4, spec_k2=1), dict(spec_k=4, spec_k2=8), dict(spec_k=4, spec_from2=14), dict(spec_k=4, spec_from2=18),
                    dict(spec_k=4, spec_from=10, spec_from2=14), dict(spec_k=4, spec_from=16, spec_from2=20), dict(spec_k=4, tail_rows=2048),
                    dict(spec_k=4, tail_rows=8192), dict(spec_k=1, head_steps=args.steps, tail_rows=0), dict(spec_k=4, polish="exact")]
-    for sch in [dict(dict(cone_block=c, cone_steps=args.cone_steps), **s_) for s_ in scheds for c in args.cone]:
+    for sch in [dict(dict(cone_block=(None if c < 0 else c), cone_steps=args.cone_steps), **s_) for s_ in scheds for c in args.cone]:
         tr = sdflabel_amd.SphereTracer(d, K_for(H, W), (W, H), B, steps=args.steps, device=dev, **sch)
         head, tail, spec_k, spec_from = tr.head_steps, tr.tail_rows, tr.spec_k, tr.spec_from
 

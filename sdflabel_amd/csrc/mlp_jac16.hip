@@ -56,11 +56,15 @@ void sdfr_launch_fwd_f16_512_tile16(const MlpParams& P, int64_t n, hipStream_t s
 #define SDFR_T16_NW SDFR_J16_NW
 #define SDFR_T16_PF SDFR_J16_PF
 #endif
+#ifndef SDFR_T64_PF
+#define SDFR_T64_PF 2          // weight-fragment ring of the 64-row half kernels (forward on 64-row tiles, looping tail): A/B with tools/ab_t64.sh
+#define SDFR_T64_PFB 2
+#endif
 void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n_rays, int spec_k, hipStream_t s) {
     static_assert(16 * SDFR_T16_FT * SDFR_T16_NW == 512, "padded width 512 = 16 * FT * NW");
     const dim3 grid(sdfr_cdiv(n_rays, P.t_rt));           // a tile = t_rt rays (16: K <= 4 samples per pass; 8: K <= 8; 4: K <= 16) on 64 rows
     if (spec_k > 1)
-        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 2, 8, 2, 4, 2>), grid, dim3(512), 0, s, P);
+        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 2, 8, SDFR_T64_PF, 4, SDFR_T64_PFB>), grid, dim3(512), 0, s, P);
     else
         hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_T16_FT, 1, SDFR_T16_NW, SDFR_T16_PF, 4>), grid, dim3(64 * SDFR_T16_NW), 0, s, P);
 }
@@ -69,5 +73,5 @@ void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n_rays, int spec_k, hi
 // march, when the active rays fill the chip once with 64-row tiles but only a fraction of it with 128-row tiles -- a step is then one pass of
 // a half-size tile (~60 us) instead of one pass of a full-size tile (~100 us).
 void sdfr_launch_fwd_f16_512_tile64(const MlpParams& P, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 2, 8, 2, 0, 2>), dim3(sdfr_cdiv(n, 64)), dim3(512), 0, s, P);
+    hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 2, 8, SDFR_T64_PF, 0, SDFR_T64_PFB>), dim3(sdfr_cdiv(n, 64)), dim3(512), 0, s, P);
 }

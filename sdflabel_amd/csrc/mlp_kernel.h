@@ -146,7 +146,12 @@ template <> struct Mma<h16, 32> {
     typedef f32x16 acc_t; typedef h16x8 vec_t;
     static constexpr int KV = 8, NSTEP = 1;
     static __device__ __forceinline__ acc_t step(const vec_t& a, const vec_t& b, acc_t c, int) {
+#ifdef SDFR_ABL_NOMFMA
+        c[0] += (float)a[0] * (float)b[0];       // ablation (timing only, wrong results): the loads stay live, the matrix pipe stays idle
+        return c;
+#else
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
     }
 };
 template <> struct Mma<h16, 16> {
@@ -711,8 +716,12 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #define SDFR_H_FAST_EPI 1
 #endif
         if constexpr (SDFR_H_FAST_EPI && HALF && !LN && !JAC) {
+#ifdef SDFR_ABL_NOEPI
+            if (acc[0][0][0] == 12345.f) epilogue_half_fast();  // ablation (timing only, wrong results): barriers stay, the epilogue's work goes
+#else
             if (inj_here) epilogue(std::true_type{});          // decoders with more than 8 input columns: generic injection
             else epilogue_half_fast();
+#endif
         }
         else if (inj_here) epilogue(std::true_type{});
         else epilogue(std::false_type{});

@@ -467,7 +467,7 @@ def main():
     # Three decoder arithmetics, labelled: exact float32 (the parity path, headline), float16 (the reference's shipped precision,
     # config_refine.ini:19; pinned to the reference's own float16 trajectory, golden G8h) and float32_prefilter + candidate reuse (exact
     # float32 on everything consumed downstream; guarded at run time); and the configs[4] shape (512x512 rays, float16 decoder).
-    def sharded_section(label, precision, reuse, size, total, workload):
+    def sharded_section(label, precision, reuse, size, total, workload, render="splat"):
         chunk = max(1, min(64, (total + world - 1) // world))
         Kc = K_for(size, size)
 
@@ -477,7 +477,7 @@ def main():
                 d2, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)
                 d2.prefilter_reuse = reuse
                 d2 = d2.to(dev)
-            rf = sdflabel_amd.BatchRefiner(d2, D, Kc, (size, size), chunk, lidar_cap=4096, device=dev)
+            rf = sdflabel_amd.BatchRefiner(d2, D, Kc, (size, size), chunk, lidar_cap=4096, device=dev, render=render)
             nocs1, lidar = synthetic_targets(dec, D, Kc, size, size, dev)      # targets from the exact-f32 rendering of the ground truth, all modes
             rf.set_crops(crop_params(list(range(chunk))), nocs1.expand(chunk, 3, size, size), [lidar] * chunk)
             rf.capture()
@@ -503,13 +503,15 @@ def main():
                "gathered_row": "yaw, trans(3), scale, latent(%d), weighted 2-D loss, weighted 3-D loss" % rf.L,
                "mean_weighted_losses_2d_3d_after": [float(table[:, -2].mean()), float(table[:, -1].mean())],
                "gathered_table_ok": ok, "scaling": "strong (total crops fixed): speed-up at N ranks = seconds(N=1) / seconds(N)"}
-        if getattr(rf.br, "prefilter", False):
+        if render != "splat":
+            out["renderer"] = "sphere tracer (BatchRefiner(render='trace'), surfel-semantics backward): not the reference's algorithm"
+        if rf.br is not None and getattr(rf.br, "prefilter", False):
             out["guard"] = rf.br.prefilter_report()
             out["candidate_reuse"] = bool(rf.br.reuse)
         del st, rf
         return out
 
-    sharded = sharded16 = sharded_pf = sharded_c4 = None
+    sharded = sharded16 = sharded_pf = sharded_c4 = sharded_tr = None
     if args.total_crops > 0 and not args.no_extras and CB == 1:
         wl = ("BASELINE configs[3]: %d crops of %dx%d rays sharded crop i -> rank i mod %d, chunks of %d through BatchRefiner (reference losses + "
               "solver, HIP-graph replay), one all_gather of the result rows")
@@ -518,6 +520,10 @@ def main():
                                     torch.float16, False, H, args.total_crops, wl)
         sharded_pf = sharded_section("float32_prefilter + candidate reuse: f16 pass proposes, exact f32 on everything consumed, run-time guard",
                                      "float32_prefilter", True, H, args.total_crops, wl)
+        # ... and the same flow with the sphere tracer as the loop's renderer (float16 decoder; an eighth of the crops: the traced iteration costs
+        # 4x the float16 splat path's)
+        sharded_tr = sharded_section("sphere tracer as the loop's renderer, float16 decoder", torch.float16, False, H, max(world, args.total_crops // 8), wl,
+                                     render="trace")
         if H == 256 and args.configs4_crops > 0:
             sharded_c4 = sharded_section("BASELINE configs[4] shape: 512x512 rays, float16 decoder on the f16 matrix cores", torch.float16, False, 512,
                                          args.configs4_crops, "BASELINE configs[4]: %d crops of %dx%d rays, float16 DeepSDF decoder, sharded crop i -> rank "
@@ -680,8 +686,10 @@ def main():
                 prm = [crop.yaw.detach().clone(), crop.trans.detach().clone().view(1, 3), crop.latent.detach().clone().view(1, -1)]
                 o3, o1 = torch.ones(1, 3, Hs, Ws, device=dev), torch.ones(1, 1, Hs, Ws, device=dev)
 
+                tr.yaw.copy_(prm[0].reshape(-1)); tr.trans.copy_(prm[1]); tr.latent.copy_(prm[2])      # inputs resident before the timed region
+
                 def tstep(ev=None):
-                    tr.render(*prm, events=ev)
+                    tr.render(events=ev)
                     tr.backward(g_color=o3, g_depth=o1, g_normals=o3)
 
                 for _ in range(3):
@@ -852,6 +860,7 @@ def main():
         line["refine_sharded_float16"] = sharded16
         line["refine_sharded_prefilter"] = sharded_pf
         line["refine_sharded_configs4"] = sharded_c4
+        line["refine_sharded_traced"] = sharded_tr
         line["pose_only"] = pose_only
         line["sphere_trace"] = sphere
         line["world_size"] = world

@@ -385,6 +385,10 @@ int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, in
                      int32_t* counters, int32_t* pix,
                      float* lam /* ray state float[n][4]: lam = next sample, rho = |sdf| of the previous sample, q = ratio of the last two radii, - */,
                      float* far, float* inputs, const float* cone, int cone_block, void* stream);
+/* ... which also zero-fills hit_lam / hit_sdf (float[B*W*H], both or neither NULL): no separate fills before a march */
+int sdfr_trace_setup2(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
+                      int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, const float* cone, int cone_block, float* hit_lam,
+                      float* hit_sdf, void* stream);
 /* Cone marching ahead of the per-ray march (optional): ONE ray through the centre of every block x block pixel tile stands for its pixels --
  * all pixel rays share origin and parametrisation, so the tile's rays at parameter lam lie within lam * delta of the centre ray's point
  * (delta = max |d_corner - d_centre|).  v = decoder(centre point): v - lam delta > eps -> nothing within the cone's cross-section, advance by
@@ -444,6 +448,34 @@ int64_t sdfr_trace_backward_ws_floats(int B, int W, int H);
 int sdfr_trace_backward(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
                         const float* J, const float* f0, const float* g_color, const float* g_depth, const float* g_normals, float* ws,
                         float* g_pose, float* g_latn, void* stream);
+
+/* Ragged extents for the sphere tracer (r04): every crop of the batch its own image size and intrinsics, as for the splat path's `_r` entry points.
+ * ext->wh: DEVICE int32[B][2] = (W_b, H_b); ext->pix_stride: pixels of a crop's slot in every per-pixel array (far, hit_lam, hit_sdf, hit_slot,
+ * pt_slot, lam_s: [B * pix_stride]; images [B][C][pix_stride]; global pixel id = b * pix_stride + y * W_b + x); ext->cone_cap: cone slots per crop
+ * (>= ceil(W_b / block) * ceil(H_b / block); cone float[B * cone_cap], the cone lists n = B * cone_cap).  The struct itself is read on the HOST at
+ * the call.  Same arithmetic per crop as the fixed-extent entry points: a crop traces bit-identically alone at its own size. */
+typedef struct sdfr_extents { const int32_t* wh; int pix_stride; int cone_cap; } sdfr_extents;
+int sdfr_trace_setup_r(const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext, float bound, float near,
+                       int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, const float* cone, int cone_block, float* hit_lam,
+                       float* hit_sdf, void* stream);
+int sdfr_trace_cone_r(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext,
+                      float bound, float near, float eps, int block, int cone_steps, int spec_k, float sigma, int half, int32_t* counters,
+                      int32_t* ids0, float* st0, float* aux0, int32_t* ids1, float* st1, float* aux1, float* inputs, float* sdf, float* cone,
+                      void* stream);
+int sdfr_trace_march_r(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext, float eps,
+                       int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2, float sigma, int half,
+                       int32_t* counters, int32_t* pix0, float* lam0, int32_t* pix1, float* lam1, int32_t* pix2, float* lam2, const float* far,
+                       float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam, float* hit_sdf, void* stream);
+int sdfr_trace_hits_r(const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext, const float* hit_lam,
+                      int32_t* n_hits, int32_t* hit_slot, int32_t* idx, float* rows, void* stream);
+int sdfr_trace_composite_r(const float* pose, const float* Kinv, int L, int B, const sdfr_extents* ext, const float* hit_lam, const int32_t* hit_slot,
+                           const float* J, const float* f0, float* color, float* mask, float* depth, float* normals, float* lam_s, void* stream);
+int sdfr_trace_points_r(const float* Kinv, int B, const sdfr_extents* ext, const int32_t* hit_slot, const float* lam_s, float* xyzf, int ecap,
+                        int32_t* ecnt, int32_t* pt_slot, void* stream);
+int sdfr_trace_refine_backward_r(const float* pose, const float* Kinv, int L, int B, const sdfr_extents* ext, const float* hit_lam,
+                                 const int32_t* hit_slot, const float* J, const float* f0, const float* g_color, const float* g_depth,
+                                 const float* g_normals, const float* g_xyzf, const int32_t* pt_slot, int ecap, int surfel, float* ws /* sdfr_trace_backward_ws_floats(B, pix_stride, 1) */,
+                                 float* g_pose, float* g_latn, void* stream);
 
 /* The sphere tracer as a backend of the refinement loop (pipelines/optimizer.py:110-146 reads rendering['color'] and points['xyzf'] from its
  * renderer).  sdfr_trace_points gives points['xyzf'] of a traced render: the camera-frame hit points p_cam = lam_s K^-1 [x, y, 1] of each crop's

@@ -19,6 +19,8 @@ _PROTOS = {
     "sdfr_mlp_forward_counted": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     "sdfr_trace_setup": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "sdfr_trace_setup2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "sdfr_trace_cone": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_int,
                                 c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
@@ -33,6 +35,20 @@ _PROTOS = {
     "sdfr_trace_backward_ws_floats": (c_int64, [c_int, c_int, c_int]),
     "sdfr_trace_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_trace_setup_r": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "sdfr_trace_cone_r": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_float, c_float, c_int, c_int, c_int,
+                                  c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+    "sdfr_trace_march_r": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_trace_hits_r": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_trace_composite_r": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
+    "sdfr_trace_points_r": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "sdfr_trace_refine_backward_r": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_trace_points": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "sdfr_trace_refine_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -116,6 +132,11 @@ EXPORTS = tuple(_PROTOS)
 
 class SdfrError(RuntimeError):
     pass
+
+
+class Extents(ctypes.Structure):
+    """sdfr_extents of include/sdfr.h (read on the host at the call; `wh` is a device pointer)"""
+    _fields_ = [("wh", c_void_p), ("pix_stride", c_int), ("cone_cap", c_int)]
 
 
 def lib():

@@ -98,6 +98,7 @@ struct MlpParams {
     float* t_hit_lam;            // per pixel: ray parameter of the hit (0: none)
     float* t_hit_sdf;            // per pixel: decoder value at the marched hit
     int t_W, t_H, t_steps;       // image size; passes left in the march's step budget
+    const int32_t* t_wh; int t_PS;  // ragged extents (r04): per-crop (W_b, H_b) on the device or NULL; pixel slot per crop (W H when dense)
     float t_eps, t_sigma;
     unsigned long long* t_evals; // += active rays per pass (ray evaluations of the march, for the roofline)
     int32_t* t_unresolved;       // += rays still active when the step budget ran out
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             const float pos = (j < k) ? pj : t_st.x;
             float* row = P.t_rows + ((int64_t)blockIdx.x * PT + j * RT + tid) * NI;
             if (with_latent) {
-                const int P_ = P.t_W * P.t_H;
+                const int P_ = P.t_PS;
                 const float* lz = P.t_latn + (int64_t)(t_gp / P_) * (NI - 3);
                 for (int c = 0; c < NI - 3; ++c) row[c] = lz[c];
             }
@@ -298,10 +299,11 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             t_gp = P.t_pix[s];
             t_st = P.t_lam[s];
             t_farl = P.t_far[t_gp];
-            const int P_ = P.t_W * P.t_H, b = t_gp / P_, px = t_gp - b * P_;
+            const int P_ = P.t_PS, b = t_gp / P_, px = t_gp - b * P_;
+            const int Wb = P.t_wh ? P.t_wh[2 * b] : P.t_W;
             const float* Pm = P.t_pose + (int64_t)b * 16;
             const float* Ki = P.t_Kinv + (int64_t)b * 9;
-            const float x = (float)(px % P.t_W), y = (float)(px / P.t_W);
+            const float x = (float)(px % Wb), y = (float)(px / Wb);
             const float rx = fmaf(Ki[1], y, Ki[0] * x) + Ki[2], ry = fmaf(Ki[4], y, Ki[3] * x) + Ki[5], rz = fmaf(Ki[7], y, Ki[6] * x) + Ki[8];
             t_dx = Pm[0] * rx + Pm[4] * ry + Pm[8] * rz;
             t_dy = Pm[1] * rx + Pm[5] * ry + Pm[9] * rz;

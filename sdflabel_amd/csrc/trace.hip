@@ -18,6 +18,15 @@
 #define SDFR_TRACE_COUNTERS 8
 struct TraceRay { float ox, oy, oz, dx, dy, dz; };
 
+// Image extents of the crops of a launch.  Dense: every crop W x H pixels, pixel slot PS = W H, cone slots ncap = its cone count.  Ragged (r04;
+// wh != NULL): crop b is W_b = wh[2b] x H_b = wh[2b+1] pixels inside a slot of PS pixels (global pixel id gp = b PS + y W_b + x) and owns ncap cone
+// slots -- every crop of a batch its own size and intrinsics, read on the device (the reference pipeline's crops: utils/refinement.py:586-609).
+struct TraceDims { const int32_t* wh; int W, H, PS, ncap; };
+__device__ __forceinline__ void trace_dims(const TraceDims& D, int b, int& W, int& H) {
+    W = D.W; H = D.H;
+    if (D.wh) { W = D.wh[2 * b]; H = D.wh[2 * b + 1]; }
+}
+
 __device__ __forceinline__ TraceRay trace_ray(const float* __restrict__ P, const float* __restrict__ Ki, float x, float y) {
     // pixel ray in the camera frame (same arithmetic as the splat's pixel_ray)
     const float rx = fmaf(Ki[1], y, Ki[0] * x) + Ki[2];
@@ -106,27 +115,33 @@ __device__ __forceinline__ bool trace_slab(const TraceRay& r, float bound, float
 // every pixel of every crop: slab test against the cube; rays that hit it enter the active list.  cone (optional, sdfr_trace_cone): per
 // cone_block x cone_block pixel block the parameter its cone march stopped at (the block's rays start there) or -1 (no ray of the block can hit)
 __global__ __launch_bounds__(256) void sdfr_trace_setup_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
-                                                              const float* __restrict__ latn, int L, int W, int H, float bound, float near,
+                                                              const float* __restrict__ latn, int L, const TraceDims D, float bound, float near,
                                                               int32_t* __restrict__ counters, int32_t* __restrict__ pix,
                                                               float4* __restrict__ lam, float* __restrict__ far, float* __restrict__ inputs,
-                                                              const float* __restrict__ cone, int cone_block) {
+                                                              const float* __restrict__ cone, int cone_block, float* __restrict__ hit_lam,
+                                                              float* __restrict__ hit_sdf) {
     const int b = blockIdx.y;
-    const int P_ = W * H;
+    const int P_ = D.PS;
+    int W, H;
+    trace_dims(D, b, W, H);
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool active = false;
     TraceRay r = {};
     float l0 = 0.f, l1 = 0.f;
-    if (p < P_) {
+    if (p < W * H) {
         const int x = p % W, y = p / W;
         r = trace_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, (float)x, (float)y);
         active = trace_slab(r, bound, near, l0, l1);
         if (cone && active) {
-            const int nbx = (W + cone_block - 1) / cone_block, nby = (H + cone_block - 1) / cone_block;
-            const float c = cone[(int64_t)b * nbx * nby + (y / cone_block) * nbx + x / cone_block];
+            const int nbx = (W + cone_block - 1) / cone_block;
+            const float c = cone[(int64_t)b * D.ncap + (y / cone_block) * nbx + x / cone_block];
             if (c < 0.f) active = false;
             else { l0 = fmaxf(l0, c); active = l0 < l1; }
         }
+    }
+    if (p < P_) {
         far[(int64_t)b * P_ + p] = active ? l1 : 0.f;
+        if (hit_lam) { hit_lam[(int64_t)b * P_ + p] = 0.f; hit_sdf[(int64_t)b * P_ + p] = 0.f; }     // (the march records hits here: no separate fills)
     }
     const int slot = trace_append(active, counters);
     if (active) {
@@ -170,11 +185,13 @@ __device__ __forceinline__ int cone_append(bool keep, int32_t* __restrict__ coun
 }
 
 __global__ __launch_bounds__(256) void sdfr_trace_cone_setup_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
-                                                                   const float* __restrict__ latn, int L, int W, int H, int BL, float bound,
+                                                                   const float* __restrict__ latn, int L, const TraceDims D, int BL, float bound,
                                                                    float near, int K, float sigma, int32_t* __restrict__ counters,
                                                                    int32_t* __restrict__ ids, float4* __restrict__ st, float2* __restrict__ aux,
                                                                    float* __restrict__ cone, float* __restrict__ inputs) {
     const int b = blockIdx.y;
+    int W, H;
+    trace_dims(D, b, W, H);
     const int nbx = (W + BL - 1) / BL, nby = (H + BL - 1) / BL, nblk = nbx * nby;
     const int k = blockIdx.x * 256 + threadIdx.x;
     bool keep = false;
@@ -198,12 +215,12 @@ __global__ __launch_bounds__(256) void sdfr_trace_cone_setup_kernel(const float*
                 float l0, l1;
                 if (trace_slab(rk, bound, near, l0, l1)) { near_b = fminf(near_b, l0); far_b = fmaxf(far_b, l1); keep = true; }
             }
-        cone[(int64_t)b * nblk + k] = -1.f;                     // until the march says where the block's rays start
+        cone[(int64_t)b * D.ncap + k] = -1.f;                   // until the march says where the block's rays start
     }
     const int slot = cone_append(keep, counters, K);
     if (keep) {
         const float a0 = __fmul_rn(0.1f, __fsub_rn(far_b, near_b));      // first guess of an advance: a tenth of the block's parameter range
-        ids[slot] = b * nblk + k;
+        ids[slot] = b * D.ncap + k;
         st[slot] = make_float4(near_b, delta, far_b, sqrtf(rc.dx * rc.dx + rc.dy * rc.dy + rc.dz * rc.dz));
         aux[slot] = make_float2(a0, 1.f);
         float p[CONE_KMAX];
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(256) void sdfr_trace_cone_setup_kernel(const float*
 }
 
 __global__ __launch_bounds__(256) void sdfr_trace_cone_step_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
-                                                                  const float* __restrict__ latn, int L, int W, int H, int BL, float eps,
+                                                                  const float* __restrict__ latn, int L, const TraceDims D, int BL, float eps,
                                                                   float bound, int K, float sigma, const float* __restrict__ sdf,
                                                                   const int32_t* __restrict__ n_cur, int32_t* __restrict__ n_next,
                                                                   int32_t* __restrict__ n_zero, const int32_t* __restrict__ ids_in,
@@ -232,16 +249,18 @@ __global__ __launch_bounds__(256) void sdfr_trace_cone_step_kernel(const float* 
     int id = 0;
     float4 st = make_float4(0.f, 0.f, 0.f, 1.f);
     float2 ax = make_float2(0.f, 1.f);
-    const int nbx = (W + BL - 1) / BL, nby = (H + BL - 1) / BL, nblk = nbx * nby;
     TraceRay rc = {};
     int b = 0;
     if (s < n) {
         id = ids_in[s];
         st = st_in[s];
         ax = aux_in[s];
-        b = id / nblk;
+        b = id / D.ncap;
+        int W, H;
+        trace_dims(D, b, W, H);
+        const int nbx = (W + BL - 1) / BL;
         int x0, y0, x1, y1;
-        rc = cone_centre_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, id - b * nblk, nbx, BL, W, H, x0, y0, x1, y1);
+        rc = cone_centre_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, id - b * D.ncap, nbx, BL, W, H, x0, y0, x1, y1);
         float p[CONE_KMAX];
         cone_positions(st.x, ax.x, ax.y, K, sigma, p);
         const float den = __fadd_rn(st.w, st.y);
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(256) void sdfr_trace_cone_step_kernel(const float* 
 
 // one march step of every active ray (count on the device): advance by the decoder's value, retire hits and exits, compact the survivors
 __global__ __launch_bounds__(256) void sdfr_trace_step_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
-                                                             const float* __restrict__ latn, int L, int W, int H, float eps,
+                                                             const float* __restrict__ latn, int L, const TraceDims D, float eps,
                                                              const float* __restrict__ sdf, const int32_t* __restrict__ n_cur,
                                                              int32_t* __restrict__ n_next, int32_t* __restrict__ n_zero,
                                                              const int32_t* __restrict__ pix_in, const float4* __restrict__ lam_in,
@@ -301,7 +320,9 @@ __global__ __launch_bounds__(256) void sdfr_trace_step_kernel(const float* __res
     TraceRay r = {};
     if (s < n) {
         gp = pix_in[s];
-        const int P_ = W * H, b = gp / P_, p = gp - b * P_;
+        const int P_ = D.PS, b = gp / P_, p = gp - b * P_;
+        int W, H;
+        trace_dims(D, b, W, H);
         r = trace_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, (float)(p % W), (float)(p / W));
         const float v = sdf[s];
         st = lam_in[s];
@@ -314,7 +335,7 @@ __global__ __launch_bounds__(256) void sdfr_trace_step_kernel(const float* __res
     }
     const int slot = trace_append(keep, n_next);
     if (keep) {
-        const int b = gp / (W * H);
+        const int b = gp / D.PS;
         pix_out[slot] = gp;
         lam_out[slot] = st;
         trace_write_row(inputs + (int64_t)slot * (L + 3), latn + (int64_t)b * L, L, r, st.x);
@@ -329,17 +350,19 @@ __global__ void sdfr_trace_leftover_kernel(const int32_t* __restrict__ n_cur, in
 // hit pixels -> compact list of decoder rows [latent, x0 = o + lam0 d] (ballot append; the order is irrelevant: everything downstream is
 // addressed per pixel through hit_slot) for the exact-f32 value + Jacobian pass (sdfr_mlp_jacobian with idx = identity, cnt = n_hits)
 __global__ __launch_bounds__(256) void sdfr_trace_hits_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv,
-                                                             const float* __restrict__ latn, int L, int W, int H,
+                                                             const float* __restrict__ latn, int L, const TraceDims D,
                                                              const float* __restrict__ hit_lam, int32_t* __restrict__ n_hits,
                                                              int32_t* __restrict__ hit_slot, int32_t* __restrict__ idx, float* __restrict__ rows) {
-    const int b = blockIdx.y, P_ = W * H;
+    const int b = blockIdx.y, P_ = D.PS;
+    int W, H;
+    trace_dims(D, b, W, H);
     const int p = blockIdx.x * 256 + threadIdx.x;
     bool hit = false;
     float lam = 0.f;
     TraceRay r = {};
     if (p < P_) {
         lam = hit_lam[(int64_t)b * P_ + p];
-        hit = lam > 0.f;
+        hit = lam > 0.f && p < W * H;
         if (hit) r = trace_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, (float)(p % W), (float)(p / W));
     }
     const int slot = trace_append(hit, n_hits);
@@ -370,12 +393,14 @@ __device__ __forceinline__ TraceHit trace_polish(const TraceRay& r, float lam0, 
 
 // images of the hits: depth = lam_s r_z, NOCS colour = (x_s (-1,1,1) + 1) / 2 (projection.py:53-55, rasterer.py:113-114), normals = (R n + 1) / 2, mask = 1;
 // zero elsewhere.  Layouts as the splat renderer's: color [B][3][H][W], mask / depth [B][1][H][W], normals [B][3][H][W].
-__global__ __launch_bounds__(256) void sdfr_trace_composite_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv, int L, int W, int H,
+__global__ __launch_bounds__(256) void sdfr_trace_composite_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv, int L, const TraceDims D,
                                                                   const float* __restrict__ hit_lam, const int32_t* __restrict__ hit_slot,
                                                                   const float* __restrict__ J, const float* __restrict__ f0,
                                                                   float* __restrict__ color, float* __restrict__ mask, float* __restrict__ depth,
                                                                   float* __restrict__ normals, float* __restrict__ lam_s) {
-    const int b = blockIdx.y, P_ = W * H;
+    const int b = blockIdx.y, P_ = D.PS;
+    int W, H;
+    trace_dims(D, b, W, H);
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P_) return;
     const int64_t gp = (int64_t)b * P_ + p;
@@ -410,15 +435,18 @@ __global__ __launch_bounds__(256) void sdfr_trace_composite_kernel(const float* 
 // in a FIXED order (block tree here, block partials in order in the second kernel): deterministic, batch independent.
 #define TRB_THREADS 256
 #define TRB_MAXL 8
-__global__ __launch_bounds__(TRB_THREADS) void sdfr_trace_backward_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv, int L, int W,
-                                                                         int H, const float* __restrict__ hit_lam,
+__global__ __launch_bounds__(TRB_THREADS) void sdfr_trace_backward_kernel(const float* __restrict__ pose, const float* __restrict__ Kinv, int L,
+                                                                         const TraceDims D, const float* __restrict__ hit_lam,
                                                                          const int32_t* __restrict__ hit_slot, const float* __restrict__ J,
                                                                          const float* __restrict__ f0, const float* __restrict__ g_color,
                                                                          const float* __restrict__ g_depth, const float* __restrict__ g_normals,
                                                                          const float* __restrict__ g_xyzf, const int32_t* __restrict__ pt_slot,
                                                                          int ecap, int surfel, float* __restrict__ partial) {
     constexpr int NV = 12 + TRB_MAXL;
-    const int b = blockIdx.y, P_ = W * H, tid = threadIdx.x;
+    const int b = blockIdx.y, P_ = D.PS, tid = threadIdx.x;
+    int W, H;
+    trace_dims(D, b, W, H);
+    (void)H;
     const int p = blockIdx.x * TRB_THREADS + tid;
     float v[NV];
 #pragma unroll
@@ -535,16 +563,56 @@ __global__ __launch_bounds__(256) void sdfr_trace_backward_sum_kernel(const floa
     if (tid >= 32 && tid < 36) g_pose[(int64_t)b * 16 + 12 + (tid - 32)] = 0.f;
 }
 
+// ---- extents of a call: dense (W, H) or ragged (sdfr_extents: per-crop sizes on the device) ---------------------------------------------------
+static inline TraceDims dense_dims(int W, int H, int cone_block) {
+    TraceDims D = {nullptr, W, H, W * H, cone_block > 0 ? sdfr_cdiv(W, cone_block) * sdfr_cdiv(H, cone_block) : 1};
+    return D;
+}
+static inline int ragged_dims(TraceDims& D, const sdfr_extents* e, const char* who) {
+    SDFR_REQUIRE(e && e->wh && e->pix_stride > 0 && e->cone_cap > 0, "%s: ragged extents need wh, pix_stride and cone_cap", who);
+    D.wh = e->wh; D.W = 0; D.H = 0; D.PS = e->pix_stride; D.ncap = e->cone_cap;
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_trace_setup2(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
+                                 int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, const float* cone, int cone_block,
+                                 float* hit_lam, float* hit_sdf, void* stream);
 extern "C" int sdfr_trace_setup(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
                                 int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, const float* cone, int cone_block,
                                 void* stream) {
+    return sdfr_trace_setup2(pose, Kinv, latn, L, B, W, H, bound, near, counters, pix, lam, far, inputs, cone, cone_block, nullptr, nullptr, stream);
+}
+
+// ... which also zero-fills the march's per-pixel hit records (hit_lam / hit_sdf float[B*W*H], both or neither): two launches fewer per render
+static int trace_setup_impl(const float* pose, const float* Kinv, const float* latn, int L, int B, const TraceDims& D, float bound, float near,
+                            int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, const float* cone, int cone_block,
+                            float* hit_lam, float* hit_sdf, void* stream);
+extern "C" int sdfr_trace_setup2(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound, float near,
+                                 int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, const float* cone, int cone_block,
+                                 float* hit_lam, float* hit_sdf, void* stream) {
+    SDFR_REQUIRE(W > 0 && H > 0, "sdfr_trace_setup: bad size");
+    return trace_setup_impl(pose, Kinv, latn, L, B, dense_dims(W, H, cone_block), bound, near, counters, pix, lam, far, inputs, cone, cone_block, hit_lam,
+                            hit_sdf, stream);
+}
+extern "C" int sdfr_trace_setup_r(const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext, float bound, float near,
+                                  int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, const float* cone, int cone_block,
+                                  float* hit_lam, float* hit_sdf, void* stream) {
+    TraceDims D;
+    int rc = ragged_dims(D, ext, "sdfr_trace_setup_r");
+    if (rc) return rc;
+    return trace_setup_impl(pose, Kinv, latn, L, B, D, bound, near, counters, pix, lam, far, inputs, cone, cone_block, hit_lam, hit_sdf, stream);
+}
+static int trace_setup_impl(const float* pose, const float* Kinv, const float* latn, int L, int B, const TraceDims& D, float bound, float near,
+                            int32_t* counters, int32_t* pix, float* lam, float* far, float* inputs, const float* cone, int cone_block,
+                            float* hit_lam, float* hit_sdf, void* stream) {
+    SDFR_REQUIRE((hit_lam == nullptr) == (hit_sdf == nullptr), "sdfr_trace_setup2: hit_lam and hit_sdf go together");
     SDFR_REQUIRE(pose && Kinv && latn && counters && pix && lam && far && inputs, "sdfr_trace_setup: NULL argument");
-    SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0 && bound > 0.f, "sdfr_trace_setup: bad size");
+    SDFR_REQUIRE(L >= 0 && B > 0 && bound > 0.f, "sdfr_trace_setup: bad size");
     SDFR_REQUIRE(!cone || cone_block >= 2, "sdfr_trace_setup: cone starts need their block size (>= 2), got %d", cone_block);
     hipStream_t s = (hipStream_t)stream;
     SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
-    hipLaunchKernelGGL(sdfr_trace_setup_kernel, dim3(sdfr_cdiv((int64_t)W * H, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, W, H, bound, near,
-                       counters, pix, reinterpret_cast<float4*>(lam), far, inputs, cone, cone_block);
+    hipLaunchKernelGGL(sdfr_trace_setup_kernel, dim3(sdfr_cdiv((int64_t)D.PS, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, D, bound, near,
+                       counters, pix, reinterpret_cast<float4*>(lam), far, inputs, cone, cone_block, hit_lam, hit_sdf);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -552,28 +620,50 @@ extern "C" int sdfr_trace_setup(const float* pose, const float* Kinv, const floa
 // Cone marching ahead of the per-ray march: cone float[B][ceil(W/block)*ceil(H/block)] receives per pixel block the parameter its rays start
 // from, or -1 (no ray of the block can hit).  counters: device int32[8] (zeroed here; [0..2] rotating counts, [4..5] one uint64: decoder
 // evaluations), ids0/st0, ids1/st1: ping-pong cone lists (int32[n] / float[n][4], n = B * blocks), inputs float[n][L+3], sdf float[n].
+static int trace_cone_impl(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, const TraceDims& D,
+                           float bound, float near, float eps, int block, int cone_steps, int spec_k, float sigma, int half,
+                           int32_t* counters, int32_t* ids0, float* st0, float* aux0, int32_t* ids1, float* st1, float* aux1, float* inputs,
+                           float* sdf, float* cone, void* stream);
 extern "C" int sdfr_trace_cone(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H,
                                float bound, float near, float eps, int block, int cone_steps, int spec_k, float sigma, int half,
                                int32_t* counters, int32_t* ids0, float* st0, float* aux0, int32_t* ids1, float* st1, float* aux1, float* inputs,
                                float* sdf, float* cone, void* stream) {
+    SDFR_REQUIRE(W > 0 && H > 0 && block >= 2, "sdfr_trace_cone: bad size");
+    return trace_cone_impl(d, pose, Kinv, latn, L, B, dense_dims(W, H, block), bound, near, eps, block, cone_steps, spec_k, sigma, half, counters, ids0, st0,
+                           aux0, ids1, st1, aux1, inputs, sdf, cone, stream);
+}
+extern "C" int sdfr_trace_cone_r(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext,
+                                 float bound, float near, float eps, int block, int cone_steps, int spec_k, float sigma, int half,
+                                 int32_t* counters, int32_t* ids0, float* st0, float* aux0, int32_t* ids1, float* st1, float* aux1, float* inputs,
+                                 float* sdf, float* cone, void* stream) {
+    TraceDims D;
+    int rc = ragged_dims(D, ext, "sdfr_trace_cone_r");
+    if (rc) return rc;
+    return trace_cone_impl(d, pose, Kinv, latn, L, B, D, bound, near, eps, block, cone_steps, spec_k, sigma, half, counters, ids0, st0, aux0, ids1, st1,
+                           aux1, inputs, sdf, cone, stream);
+}
+static int trace_cone_impl(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, const TraceDims& D,
+                           float bound, float near, float eps, int block, int cone_steps, int spec_k, float sigma, int half,
+                           int32_t* counters, int32_t* ids0, float* st0, float* aux0, int32_t* ids1, float* st1, float* aux1, float* inputs,
+                           float* sdf, float* cone, void* stream) {
     SDFR_REQUIRE(d && pose && Kinv && latn && counters && ids0 && st0 && aux0 && ids1 && st1 && aux1 && inputs && sdf && cone,
                  "sdfr_trace_cone: NULL argument");
-    SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0 && bound > 0.f && block >= 2 && cone_steps >= 1, "sdfr_trace_cone: bad size");
+    SDFR_REQUIRE(L >= 0 && B > 0 && bound > 0.f && block >= 2 && cone_steps >= 1, "sdfr_trace_cone: bad size");
     SDFR_REQUIRE(spec_k >= 1 && spec_k <= CONE_KMAX, "sdfr_trace_cone: spec_k = %d (1 ... %d samples per cone and pass)", spec_k, CONE_KMAX);
     SDFR_REQUIRE(d->n_inputs == L + 3, "sdfr_trace_cone: decoder with L + 3 = %d inputs expected, it has %d", L + 3, d->n_inputs);
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = sdfr_cdiv(W, block) * sdfr_cdiv(H, block);
+    const int nblk = D.ncap;
     const int64_t n_max = (int64_t)B * nblk;
     SDFR_REQUIRE(n_max * spec_k < (int64_t)1 << 31, "sdfr_trace_cone: too many cone rows");
     SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
-    hipLaunchKernelGGL(sdfr_trace_cone_setup_kernel, dim3(sdfr_cdiv(nblk, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, W, H, block, bound, near,
+    hipLaunchKernelGGL(sdfr_trace_cone_setup_kernel, dim3(sdfr_cdiv(nblk, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, D, block, bound, near,
                        spec_k, sigma, counters, ids0, reinterpret_cast<float4*>(st0), reinterpret_cast<float2*>(aux0), cone, inputs);
     unsigned long long* evals = reinterpret_cast<unsigned long long*>(counters + 4);
     for (int step = 0; step < cone_steps; ++step) {
         const int rc = sdfr_mlp_forward_counted(d, inputs, n_max * spec_k, counters + step % 3, sdf, half, stream);
         if (rc != SDFR_OK) return rc;
         const int a = step & 1;
-        hipLaunchKernelGGL(sdfr_trace_cone_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, block, eps, bound,
+        hipLaunchKernelGGL(sdfr_trace_cone_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, D, block, eps, bound,
                            spec_k, sigma, sdf, counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? ids1 : ids0,
                            reinterpret_cast<const float4*>(a ? st1 : st0), reinterpret_cast<const float2*>(a ? aux1 : aux0), a ? ids0 : ids1,
                            reinterpret_cast<float4*>(a ? st0 : st1), reinterpret_cast<float2*>(a ? aux0 : aux1), inputs, cone,
@@ -590,8 +680,8 @@ extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float
                  "sdfr_trace_step: NULL argument");
     SDFR_REQUIRE(step >= 0 && n_max >= 0, "sdfr_trace_step: bad size");
     if (n_max == 0) return SDFR_OK;
-    hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, pose, Kinv, latn, L, W, H, eps,
-                       sdf, counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, pix_in,
+    hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, pose, Kinv, latn, L,
+                       dense_dims(W, H, 0), eps, sdf, counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, pix_in,
                        reinterpret_cast<const float4*>(lam_in), pix_out, reinterpret_cast<float4*>(lam_out), far, inputs, hit_lam, hit_sdf, 0,
                        (unsigned long long*)nullptr);
     SDFR_LAUNCH_CHECK();
@@ -617,20 +707,45 @@ extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float
 // stage ends, its survivors are appended to a third list (pix2 / lam2, counters[7]) and a second launch marches them 64 / spec_k2 to a tile
 // with spec_k2 samples per pass: the 256x256 bench crop ends at pass 21 instead of 31 for 3 % more decoder evaluations.
 // tail_rows_buf: scratch float[tiles][16 spec_k][L + 3], tiles = ceil(n / 16), or ceil(n spec_k2 / 64) with the second level.
+static int trace_march_impl(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, const TraceDims& D,
+                            float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2,
+                            float sigma, int half, int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_,
+                            int32_t* pix2, float* lam2_, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
+                            float* hit_sdf, void* stream);
 extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H,
                                 float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2,
                                 float sigma, int half, int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_,
                                 int32_t* pix2, float* lam2_, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
                                 float* hit_sdf, void* stream) {
+    SDFR_REQUIRE(W > 0 && H > 0, "sdfr_trace_march: bad size");
+    return trace_march_impl(d, pose, Kinv, latn, L, B, dense_dims(W, H, 0), eps, steps, head_steps, tail_rows, spec_from, spec_k, spec_from2, spec_k2, sigma,
+                            half, counters, pix0, lam0_, pix1, lam1_, pix2, lam2_, far, inputs, sdf, tail_rows_buf, hit_lam, hit_sdf, stream);
+}
+extern "C" int sdfr_trace_march_r(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext,
+                                  float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2,
+                                  float sigma, int half, int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_,
+                                  int32_t* pix2, float* lam2_, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
+                                  float* hit_sdf, void* stream) {
+    TraceDims D;
+    int rc = ragged_dims(D, ext, "sdfr_trace_march_r");
+    if (rc) return rc;
+    return trace_march_impl(d, pose, Kinv, latn, L, B, D, eps, steps, head_steps, tail_rows, spec_from, spec_k, spec_from2, spec_k2, sigma, half, counters,
+                            pix0, lam0_, pix1, lam1_, pix2, lam2_, far, inputs, sdf, tail_rows_buf, hit_lam, hit_sdf, stream);
+}
+static int trace_march_impl(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, const TraceDims& D,
+                            float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2,
+                            float sigma, int half, int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_,
+                            int32_t* pix2, float* lam2_, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
+                            float* hit_sdf, void* stream) {
     SDFR_REQUIRE(d && pose && Kinv && latn && counters && pix0 && lam0_ && pix1 && lam1_ && far && inputs && sdf && tail_rows_buf && hit_lam &&
                      hit_sdf, "sdfr_trace_march: NULL argument");
     float4* lam0 = reinterpret_cast<float4*>(lam0_);
     float4* lam1 = reinterpret_cast<float4*>(lam1_);
     float4* lam2 = reinterpret_cast<float4*>(lam2_);
-    SDFR_REQUIRE(B > 0 && W > 0 && H > 0 && steps > 0 && head_steps >= 0 && tail_rows >= 0, "sdfr_trace_march: bad size");
+    SDFR_REQUIRE(B > 0 && steps > 0 && head_steps >= 0 && tail_rows >= 0, "sdfr_trace_march: bad size");
     SDFR_REQUIRE(spec_k == 1 || spec_k == 4, "sdfr_trace_march: spec_k = %d (1: plain tracing, 4: four samples per ray and pass)", spec_k);
     SDFR_REQUIRE(d->n_inputs == L + 3, "sdfr_trace_march: decoder with L + 3 = %d inputs expected, it has %d", L + 3, d->n_inputs);
-    const int64_t n_max = (int64_t)B * W * H;
+    const int64_t n_max = (int64_t)B * D.PS;
     SDFR_REQUIRE(n_max < (int64_t)1 << 31, "sdfr_trace_march: too many rays");
     hipStream_t s = (hipStream_t)stream;
     if (d->HP != 512 || d->has_ln) {
@@ -643,7 +758,7 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
             int rc = sdfr_mlp_forward_counted(d, inputs, n_max, counters + step % 3, sdf, 0, stream);
             if (rc != SDFR_OK) return rc;
             const int a = step & 1;
-            hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, eps, sdf,
+            hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, D, eps, sdf,
                                counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? pix1 : pix0,
                                a ? reinterpret_cast<float4*>(lam1_) : reinterpret_cast<float4*>(lam0_), a ? pix0 : pix1,
                                a ? reinterpret_cast<float4*>(lam0_) : reinterpret_cast<float4*>(lam1_), far, inputs, hit_lam, hit_sdf, 1, evals_);
@@ -667,7 +782,7 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
     unsigned long long* evals = reinterpret_cast<unsigned long long*>(counters + 4);
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.trace = nullptr;
-    P.t_far = far; P.t_pose = pose; P.t_Kinv = Kinv; P.t_latn = latn; P.t_hit_lam = hit_lam; P.t_hit_sdf = hit_sdf; P.t_W = W; P.t_H = H;
+    P.t_far = far; P.t_pose = pose; P.t_Kinv = Kinv; P.t_latn = latn; P.t_hit_lam = hit_lam; P.t_hit_sdf = hit_sdf; P.t_W = D.W; P.t_H = D.H; P.t_wh = D.wh; P.t_PS = D.PS;
     P.t_eps = eps; P.t_sigma = sigma; P.t_evals = evals; P.t_unresolved = counters + 3;
     P.t_spec_from = spec_from; P.t_spec_k = spec_k; P.t_spec_from2 = spec_from2; P.t_spec_k2 = spec_k2;
     auto launch_tail = [&](const MlpParams& T) {
@@ -703,7 +818,7 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
         } else sdfr_launch_fwd_f32_512(F, n_max, false, s);
         if (tail_rows > 0) tail(step, tail_rows);
         const int a = step & 1;
-        hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, W, H, eps, sdf,
+        hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, D, eps, sdf,
                            counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? pix1 : pix0, a ? lam1 : lam0,
                            a ? pix0 : pix1, a ? lam0 : lam1, far, inputs, hit_lam, hit_sdf, tail_rows > 0 ? tail_rows : 1, evals);
     }
@@ -728,25 +843,51 @@ extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const 
 
 
 // hit list + rows for the Jacobian pass.  n_hits = counters + 6 (zeroed by sdfr_trace_setup).
-extern "C" int sdfr_trace_hits(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, const float* hit_lam,
-                               int32_t* n_hits, int32_t* hit_slot, int32_t* idx, float* rows, void* stream) {
+static int trace_hits_impl(const float* pose, const float* Kinv, const float* latn, int L, int B, const TraceDims& D, const float* hit_lam,
+                           int32_t* n_hits, int32_t* hit_slot, int32_t* idx, float* rows, void* stream) {
     SDFR_REQUIRE(pose && Kinv && latn && hit_lam && n_hits && hit_slot && idx && rows, "sdfr_trace_hits: NULL argument");
-    SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0, "sdfr_trace_hits: bad size");
-    hipLaunchKernelGGL(sdfr_trace_hits_kernel, dim3(sdfr_cdiv((int64_t)W * H, 256), B), dim3(256), 0, (hipStream_t)stream, pose, Kinv, latn, L, W, H,
+    SDFR_REQUIRE(L >= 0 && B > 0, "sdfr_trace_hits: bad size");
+    hipLaunchKernelGGL(sdfr_trace_hits_kernel, dim3(sdfr_cdiv((int64_t)D.PS, 256), B), dim3(256), 0, (hipStream_t)stream, pose, Kinv, latn, L, D,
                        hit_lam, n_hits, hit_slot, idx, rows);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
+extern "C" int sdfr_trace_hits(const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, const float* hit_lam,
+                               int32_t* n_hits, int32_t* hit_slot, int32_t* idx, float* rows, void* stream) {
+    SDFR_REQUIRE(W > 0 && H > 0, "sdfr_trace_hits: bad size");
+    return trace_hits_impl(pose, Kinv, latn, L, B, dense_dims(W, H, 0), hit_lam, n_hits, hit_slot, idx, rows, stream);
+}
+extern "C" int sdfr_trace_hits_r(const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext, const float* hit_lam,
+                                 int32_t* n_hits, int32_t* hit_slot, int32_t* idx, float* rows, void* stream) {
+    TraceDims D;
+    int rc = ragged_dims(D, ext, "sdfr_trace_hits_r");
+    if (rc) return rc;
+    return trace_hits_impl(pose, Kinv, latn, L, B, D, hit_lam, n_hits, hit_slot, idx, rows, stream);
+}
 
-extern "C" int sdfr_trace_composite(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
-                                    const float* J, const float* f0, float* color, float* mask, float* depth, float* normals, float* lam_s,
-                                    void* stream) {
+static int trace_composite_impl(const float* pose, const float* Kinv, int L, int B, const TraceDims& D, const float* hit_lam, const int32_t* hit_slot,
+                                const float* J, const float* f0, float* color, float* mask, float* depth, float* normals, float* lam_s,
+                                void* stream) {
     SDFR_REQUIRE(pose && Kinv && hit_lam && hit_slot && J && f0 && color && mask && depth && normals, "sdfr_trace_composite: NULL argument");
-    SDFR_REQUIRE(L >= 0 && B > 0 && W > 0 && H > 0, "sdfr_trace_composite: bad size");
-    hipLaunchKernelGGL(sdfr_trace_composite_kernel, dim3(sdfr_cdiv((int64_t)W * H, 256), B), dim3(256), 0, (hipStream_t)stream, pose, Kinv, L, W, H,
+    SDFR_REQUIRE(L >= 0 && B > 0, "sdfr_trace_composite: bad size");
+    hipLaunchKernelGGL(sdfr_trace_composite_kernel, dim3(sdfr_cdiv((int64_t)D.PS, 256), B), dim3(256), 0, (hipStream_t)stream, pose, Kinv, L, D,
                        hit_lam, hit_slot, J, f0, color, mask, depth, normals, lam_s);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
+}
+extern "C" int sdfr_trace_composite(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
+                                    const float* J, const float* f0, float* color, float* mask, float* depth, float* normals, float* lam_s,
+                                    void* stream) {
+    SDFR_REQUIRE(W > 0 && H > 0, "sdfr_trace_composite: bad size");
+    return trace_composite_impl(pose, Kinv, L, B, dense_dims(W, H, 0), hit_lam, hit_slot, J, f0, color, mask, depth, normals, lam_s, stream);
+}
+extern "C" int sdfr_trace_composite_r(const float* pose, const float* Kinv, int L, int B, const sdfr_extents* ext, const float* hit_lam,
+                                      const int32_t* hit_slot, const float* J, const float* f0, float* color, float* mask, float* depth,
+                                      float* normals, float* lam_s, void* stream) {
+    TraceDims D;
+    int rc = ragged_dims(D, ext, "sdfr_trace_composite_r");
+    if (rc) return rc;
+    return trace_composite_impl(pose, Kinv, L, B, D, hit_lam, hit_slot, J, f0, color, mask, depth, normals, lam_s, stream);
 }
 
 extern "C" int64_t sdfr_trace_backward_ws_floats(int B, int W, int H) {
@@ -755,19 +896,37 @@ extern "C" int64_t sdfr_trace_backward_ws_floats(int B, int W, int H) {
 
 // image gradients (any of them may be NULL) -> g_pose [B][16] (row-major 4x4: rotation and translation entries) and g_latn [B][L] (gradient
 // w.r.t. the NORMALISED latent); sdfr_params_backward turns them into the gradients of yaw, trans and the latent.
-extern "C" int sdfr_trace_refine_backward(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam,
-                                          const int32_t* hit_slot, const float* J, const float* f0, const float* g_color, const float* g_depth,
-                                          const float* g_normals, const float* g_xyzf, const int32_t* pt_slot, int ecap, int surfel, float* ws,
-                                          float* g_pose, float* g_latn, void* stream) {
+static int trace_refine_backward_impl(const float* pose, const float* Kinv, int L, int B, const TraceDims& D, const float* hit_lam,
+                                      const int32_t* hit_slot, const float* J, const float* f0, const float* g_color, const float* g_depth,
+                                      const float* g_normals, const float* g_xyzf, const int32_t* pt_slot, int ecap, int surfel, float* ws,
+                                      float* g_pose, float* g_latn, void* stream) {
     SDFR_REQUIRE(pose && Kinv && hit_lam && hit_slot && J && f0 && ws && g_pose && g_latn, "sdfr_trace_refine_backward: NULL argument");
-    SDFR_REQUIRE(L >= 0 && L <= TRB_MAXL && B > 0 && W > 0 && H > 0, "sdfr_trace_refine_backward: latent size 0..%d", TRB_MAXL);
+    SDFR_REQUIRE(L >= 0 && L <= TRB_MAXL && B > 0, "sdfr_trace_refine_backward: latent size 0..%d", TRB_MAXL);
     SDFR_REQUIRE(!g_xyzf || (pt_slot && ecap > 0), "sdfr_trace_refine_backward: g_xyzf needs pt_slot and ecap (sdfr_trace_points)");
-    const int nblk = sdfr_cdiv((int64_t)W * H, TRB_THREADS);
-    hipLaunchKernelGGL(sdfr_trace_backward_kernel, dim3(nblk, B), dim3(TRB_THREADS), 0, (hipStream_t)stream, pose, Kinv, L, W, H, hit_lam, hit_slot,
+    const int nblk = sdfr_cdiv((int64_t)D.PS, TRB_THREADS);
+    hipLaunchKernelGGL(sdfr_trace_backward_kernel, dim3(nblk, B), dim3(TRB_THREADS), 0, (hipStream_t)stream, pose, Kinv, L, D, hit_lam, hit_slot,
                        J, f0, g_color, g_depth, g_normals, g_xyzf, pt_slot, ecap, surfel, ws);
     hipLaunchKernelGGL(sdfr_trace_backward_sum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ws, nblk, L, g_pose, g_latn);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
+}
+extern "C" int sdfr_trace_refine_backward(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam,
+                                          const int32_t* hit_slot, const float* J, const float* f0, const float* g_color, const float* g_depth,
+                                          const float* g_normals, const float* g_xyzf, const int32_t* pt_slot, int ecap, int surfel, float* ws,
+                                          float* g_pose, float* g_latn, void* stream) {
+    SDFR_REQUIRE(W > 0 && H > 0, "sdfr_trace_refine_backward: bad size");
+    return trace_refine_backward_impl(pose, Kinv, L, B, dense_dims(W, H, 0), hit_lam, hit_slot, J, f0, g_color, g_depth, g_normals, g_xyzf, pt_slot, ecap,
+                                      surfel, ws, g_pose, g_latn, stream);
+}
+extern "C" int sdfr_trace_refine_backward_r(const float* pose, const float* Kinv, int L, int B, const sdfr_extents* ext, const float* hit_lam,
+                                            const int32_t* hit_slot, const float* J, const float* f0, const float* g_color, const float* g_depth,
+                                            const float* g_normals, const float* g_xyzf, const int32_t* pt_slot, int ecap, int surfel, float* ws,
+                                            float* g_pose, float* g_latn, void* stream) {
+    TraceDims D;
+    int rc = ragged_dims(D, ext, "sdfr_trace_refine_backward_r");
+    if (rc) return rc;
+    return trace_refine_backward_impl(pose, Kinv, L, B, D, hit_lam, hit_slot, J, f0, g_color, g_depth, g_normals, g_xyzf, pt_slot, ecap, surfel, ws,
+                                      g_pose, g_latn, stream);
 }
 
 extern "C" int sdfr_trace_backward(const float* pose, const float* Kinv, int L, int B, int W, int H, const float* hit_lam, const int32_t* hit_slot,
@@ -782,11 +941,14 @@ extern "C" int sdfr_trace_backward(const float* pose, const float* Kinv, int L, 
 // sdfr_trace_hits) into xyzf [B][ecap][3]; ecnt [B] = the crop's TRUE hit count (callers compare against ecap; surplus rows are dropped);
 // pt_slot [B*W*H] = a pixel's row or -1.  One workgroup per crop: ballot + running offset.
 #define TRP_THREADS 1024
-__global__ __launch_bounds__(TRP_THREADS) void sdfr_trace_points_kernel(const float* __restrict__ Kinv, int W, int H,
+__global__ __launch_bounds__(TRP_THREADS) void sdfr_trace_points_kernel(const float* __restrict__ Kinv, const TraceDims D,
                                                                        const int32_t* __restrict__ hit_slot, const float* __restrict__ lam_s,
                                                                        float* __restrict__ xyzf, int ecap, int32_t* __restrict__ ecnt,
                                                                        int32_t* __restrict__ pt_slot) {
-    const int b = blockIdx.x, P_ = W * H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int W, H;
+    trace_dims(D, b, W, H);
+    const int P_ = W * H, PS = D.PS;
     const float* Ki = Kinv + (int64_t)b * 9;
     __shared__ int wcnt[TRP_THREADS / 64];
     __shared__ int base;
@@ -794,7 +956,7 @@ __global__ __launch_bounds__(TRP_THREADS) void sdfr_trace_points_kernel(const fl
     __syncthreads();
     for (int p0 = 0; p0 < P_; p0 += TRP_THREADS) {
         const int p = p0 + tid;
-        const int64_t gp = (int64_t)b * P_ + p;
+        const int64_t gp = (int64_t)b * PS + p;
         const bool hit = p < P_ && hit_slot[gp] >= 0;
         const unsigned long long bal = __ballot(hit);
         if (lane == 0) wcnt[wave] = __popcll(bal);
@@ -817,11 +979,25 @@ __global__ __launch_bounds__(TRP_THREADS) void sdfr_trace_points_kernel(const fl
     if (tid == 0) ecnt[b] = base;
 }
 
+static int trace_points_impl(const float* Kinv, int B, const TraceDims& D, const int32_t* hit_slot, const float* lam_s, float* xyzf, int ecap,
+                             int32_t* ecnt, int32_t* pt_slot, void* stream);
 extern "C" int sdfr_trace_points(const float* Kinv, int B, int W, int H, const int32_t* hit_slot, const float* lam_s, float* xyzf, int ecap,
                                  int32_t* ecnt, int32_t* pt_slot, void* stream) {
+    SDFR_REQUIRE(W > 0 && H > 0, "sdfr_trace_points: bad size");
+    return trace_points_impl(Kinv, B, dense_dims(W, H, 0), hit_slot, lam_s, xyzf, ecap, ecnt, pt_slot, stream);
+}
+extern "C" int sdfr_trace_points_r(const float* Kinv, int B, const sdfr_extents* ext, const int32_t* hit_slot, const float* lam_s, float* xyzf, int ecap,
+                                   int32_t* ecnt, int32_t* pt_slot, void* stream) {
+    TraceDims D;
+    int rc = ragged_dims(D, ext, "sdfr_trace_points_r");
+    if (rc) return rc;
+    return trace_points_impl(Kinv, B, D, hit_slot, lam_s, xyzf, ecap, ecnt, pt_slot, stream);
+}
+static int trace_points_impl(const float* Kinv, int B, const TraceDims& D, const int32_t* hit_slot, const float* lam_s, float* xyzf, int ecap,
+                             int32_t* ecnt, int32_t* pt_slot, void* stream) {
     SDFR_REQUIRE(Kinv && hit_slot && lam_s && xyzf && ecnt && pt_slot, "sdfr_trace_points: NULL argument");
-    SDFR_REQUIRE(B > 0 && W > 0 && H > 0 && ecap > 0, "sdfr_trace_points: bad size");
-    hipLaunchKernelGGL(sdfr_trace_points_kernel, dim3(B), dim3(TRP_THREADS), 0, (hipStream_t)stream, Kinv, W, H, hit_slot, lam_s, xyzf, ecap, ecnt,
+    SDFR_REQUIRE(B > 0 && ecap > 0, "sdfr_trace_points: bad size");
+    hipLaunchKernelGGL(sdfr_trace_points_kernel, dim3(B), dim3(TRP_THREADS), 0, (hipStream_t)stream, Kinv, D, hit_slot, lam_s, xyzf, ecap, ecnt,
                        pt_slot);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;

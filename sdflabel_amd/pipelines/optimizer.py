@@ -69,10 +69,10 @@ class Optimizer:
         dev = grid.points.device
         cap = max(1024, 1 << (max(n_lidar, 1) - 1).bit_length())      # lidar capacity, rounded up so that a refiner is reused across crops
         Kn = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32)
-        # splat renderer: ragged extents -- the refiner is keyed on a pixel CAPACITY (next power of two of the crop's area), not on the crop's
+        # ragged extents -- the refiner is keyed on a pixel CAPACITY (next power of two of the crop's area), not on the crop's
         # size or intrinsics, which reach the kernels as data (set_crops): the pipeline's crops all have their own (H, W) and K
-        # (utils/refinement.py:586-609), yet share one set of buffers and one captured graph.  Tracer backend: fixed extents.
-        ragged = self.render == 'splat'
+        # (utils/refinement.py:586-609), yet share one set of buffers and one captured graph -- with either renderer.
+        ragged = True
         H_, W_ = int(crop_size[0]), int(crop_size[1])
         pmax = max(1024, 1 << (max(H_ * W_, 1) - 1).bit_length())
         side = 4 * int(np.ceil(np.sqrt(pmax)))

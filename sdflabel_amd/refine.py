@@ -30,7 +30,7 @@ class BatchRefiner:
         trace_grad="surfel" (default): hits differentiate as material points, the autograd semantics of the reference's surfels -- the mode
         the loop converges with; "image": image-space implicit-function gradients at the fixed pixels (DESIGN.md 3.6 has the comparison).
         tracer_kwargs: SphereTracer options (steps, cone_block, polish, ...).
-        max_pixels / max_side (splat renderer; r04): ragged extents -- every crop of a batch its own image size (H_b, W_b) and intrinsics K_b,
+        max_pixels / max_side (both renderers; r04): ragged extents -- every crop of a batch its own image size (H_b, W_b) and intrinsics K_b,
         given to set_crops(); buffers are sized for max_pixels pixels per crop and the captured graph serves every crop set within the caps
         (the reference pipeline's crops all differ: utils/refinement.py:586-609, pipelines/refine_css.py:117-129).  crop_size is then the
         default extent.  A crop refines bit-identically to the same crop alone in a fixed-size refiner."""
@@ -48,7 +48,8 @@ class BatchRefiner:
         if render == "trace":
             from .renderer.sphere_tracer import SphereTracer
             self.br = None
-            self.tr = SphereTracer(decoder, K, (self.W, self.H), batch, device=device, points=True, **(tracer_kwargs or {}))
+            self.tr = SphereTracer(decoder, K, (self.W, self.H), batch, device=device, points=True, max_pixels=max_pixels, max_side=max_side,
+                                   **(tracer_kwargs or {}))
             dev, self.L, est_cap = self.tr.dev, self.tr.L, self.tr.ecap
         else:
             self.tr = None
@@ -73,8 +74,9 @@ class BatchRefiner:
         self.lidar_cap = int(lidar_cap)
         self.lidar = torch.zeros((B, self.lidar_cap, 3), dtype=torch.float32, device=dev)
         self.lcnt = torch.zeros((B,), dtype=torch.int32, device=dev)
-        self.ragged = br is not None and br.ragged
-        img_shape = (B, 3, br.PS) if self.ragged else (B, 3, self.H, self.W)
+        self.rd = br if br is not None else self.tr             # the renderer: BatchRenderer or SphereTracer (same extents interface)
+        self.ragged = bool(self.rd.ragged)
+        img_shape = (B, 3, self.rd.PS) if self.ragged else (B, 3, self.H, self.W)
         self.target = torch.zeros(img_shape, dtype=torch.float32, device=dev)
         self.loss2d = torch.zeros((B,), dtype=torch.float32, device=dev)
         self.loss3d = torch.zeros((B,), dtype=torch.float32, device=dev)
@@ -83,7 +85,7 @@ class BatchRefiner:
         self.npairs = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.stepped = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.g_color = torch.zeros(img_shape, dtype=torch.float32, device=dev)
-        self.l2_scratch = torch.zeros((3 * B * (br.tiles16_cap if self.ragged else ((self.W + 15) // 16) * ((self.H + 15) // 16)),), dtype=torch.float32, device=dev)
+        self.l2_scratch = torch.zeros((3 * B * (self.rd.tiles16_cap if self.ragged else ((self.W + 15) // 16) * ((self.H + 15) // 16)),), dtype=torch.float32, device=dev)
         self.l3_scratch = torch.zeros((3 * B * ((est_cap + 63) // 64),), dtype=torch.float32, device=dev)
         self.g_xyzf = torch.zeros((B, est_cap, 3), dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros((B, 4), dtype=torch.float32, device=dev)
@@ -109,7 +111,7 @@ class BatchRefiner:
         self.latent.copy_(t(params['latent']).reshape(B, self.L))
         if self.ragged:
             sizes = [(int(h), int(w)) for h, w in crop_sizes] if crop_sizes is not None else [(self.H, self.W)] * B
-            self.br.set_extents([(w, h) for h, w in sizes], K)
+            self.rd.set_extents([(w, h) for h, w in sizes], K)
             self.target.zero_()
             for b, (h, w) in enumerate(sizes):
                 pred = t(nocs_pred[b])
@@ -161,8 +163,12 @@ class BatchRefiner:
         """the same iteration with the sphere tracer as the loop's renderer (optimizer.py:110-123 -> rendering['color'], points['xyzf'])"""
         tr, B = self.tr, self.B
         out = tr.render()
-        ck(L.sdfr_loss_2d(P(out["color"]), P(self.target), B, self.H, self.W, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color),
-                          P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d")
+        if self.ragged:
+            ck(L.sdfr_loss_2d_r(P(out["color"]), P(self.target), B, P(tr.wh), tr.PS, tr.tiles16_cap, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color),
+                                P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d_r")
+        else:
+            ck(L.sdfr_loss_2d(P(out["color"]), P(self.target), B, self.H, self.W, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color),
+                              P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d")
         ck(L.sdfr_loss_3d(P(out["xyzf"]), P(tr.ecnt), tr.ecap, P(self.lidar), P(self.lcnt), self.lidar_cap, P(self.scale), 0.2, self.w3, B,
                           P(self.loss3d), P(self.g_xyzf), P(self.g_scale), P(self.npairs), P(self.l3_scratch), st), "sdfr_loss_3d")
         tr.backward(g_color=self.g_color, g_xyzf=self.g_xyzf, surfel=self.surfel)

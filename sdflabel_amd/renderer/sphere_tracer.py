@@ -70,12 +70,23 @@ def default_spec_from(rays_per_crop, half, cone=False):
 class SphereTracer:
     def __init__(self, decoder, K, resolution_px, batch=1, steps=64, eps=2e-3, bound=1.0, near=1e-3, device="cuda", head_steps=None,
                  tail_rows=4096, spec_from=None, spec_k=None, sigma=0.9, spec_from2=None, spec_k2=None, polish=None,
-                 cone_block=None, cone_steps=None, uniform_tiles=True, points=False, cone_spec_k=None):
+                 cone_block=None, cone_steps=None, uniform_tiles=True, points=False, cone_spec_k=None, max_pixels=None, max_side=None):
+        """max_pixels / max_side (r04, ragged extents): every crop of the batch its OWN image size (W_b H_b <= max_pixels, sides <= max_side, default
+        4 sqrt(max_pixels)) and intrinsics, set with set_extents(); all per-pixel arrays then hold slots of max_pixels pixels per crop ([B, C,
+        max_pixels] images: image(b, name) gives the (C, H_b, W_b) view) and the kernels read the extents on the device, so one tracer (and one captured
+        graph around it) serves any crop sizes within the caps.  The march schedule is then a function of the CAPACITY.  resolution_px: initial extents."""
         dev = torch.device(device)
         if dev.type != "cuda":
             raise _lib.SdfrError("SphereTracer runs on the GPU only")
         self.dev, self.B = dev, int(batch)
         self.W, self.H = int(resolution_px[0]), int(resolution_px[1])
+        self.ragged = max_pixels is not None
+        self.PS = int(max_pixels) if self.ragged else self.W * self.H                 # pixel slot per crop
+        if self.ragged:
+            import math
+            self.max_side = int(max_side) if max_side is not None else min(self.PS, 4 * int(math.ceil(math.sqrt(self.PS))))
+            if self.W * self.H > self.PS or max(self.W, self.H) > self.max_side:
+                raise _lib.SdfrError("resolution_px %dx%d exceeds max_pixels %d / max_side %d" % (self.W, self.H, self.PS, self.max_side))
         self.steps, self.eps, self.bound, self.near = int(steps), float(eps), float(bound), float(near)
         # the device-side gate (count < tail_rows) is checked in each of the first head_steps steps; afterwards the tail takes whatever is left
         self.head_steps = min(self.steps, 24) if head_steps is None else int(head_steps)
@@ -97,7 +108,7 @@ class SphereTracer:
         cone_on = (4 if cone_block is None else int(cone_block)) > 0
         spec_from_given = spec_from is not None
         if spec_from is None:
-            spec_from = default_spec_from(self.W * self.H, bool(self.half), cone_on)   # (per crop, not per batch: a crop renders the same alone or in a batch)
+            spec_from = default_spec_from(self.PS, bool(self.half), cone_on)   # (per crop, not per batch: a crop renders the same alone or in a batch)
         self.spec_from, self.sigma = int(spec_from), float(sigma)
         if self.spec_k not in (1, 4):
             raise ValueError("spec_k must be 1 or 4")
@@ -105,7 +116,7 @@ class SphereTracer:
         # march, scattered over the tiles -- are re-packed 64 / spec_k2 to a tile and take spec_k2 samples per pass (default 16 with spec_k 4)
         self.spec_k2 = int(spec_k2) if spec_k2 is not None else (16 if self.spec_k == 4 else 1)
         self.spec_from2 = int(spec_from2) if spec_from2 is not None else self.spec_from + (4 if (cone_on and self.half and not spec_from_given
-                                                                                                      and self.W * self.H <= 65536) else 3)
+                                                                                                      and self.PS <= 65536) else 3)
         if self.spec_k2 <= self.spec_k:
             self.spec_k2 = self.spec_k                                              # off
         elif self.spec_k2 not in (8, 16) or self.spec_from2 <= self.spec_from:
@@ -131,8 +142,14 @@ class SphereTracer:
         # passes: a crop of up to 4096 cones (256x256 at 4x4 pixels) is one round of 64-row tiles even with 4 samples each -- every pass costs one
         # decoder pass of latency, so 4 passes (1.70 ms per render against 2.03 with 10); a 512x512 crop's 16 k cones are matrix-bound, the extra
         # passes cull more and start the rays closer to the surface (3.64 against 4.2 ms).  A function of the crop size, not of the batch.
-        cones = ((self.W + max(self.cone_block, 1) - 1) // max(self.cone_block, 1)) * ((self.H + max(self.cone_block, 1) - 1) // max(self.cone_block, 1))
-        self.cone_steps = int(cone_steps) if cone_steps is not None else ((4 if cones <= 4096 else 10) if self.cone_spec_k >= 4 else
+        bl = max(self.cone_block, 1)
+        if self.ragged:                                                             # cone slots any admissible shape can need
+            cones = (self.PS + bl * bl - 1) // (bl * bl) + (2 * self.max_side + bl - 1) // bl + 2
+        else:
+            cones = ((self.W + bl - 1) // bl) * ((self.H + bl - 1) // bl)
+        self.cone_cap = cones
+        nominal = (self.PS + bl * bl - 1) // (bl * bl) if self.ragged else cones         # (the schedule is a function of the pixel capacity)
+        self.cone_steps = int(cone_steps) if cone_steps is not None else ((4 if nominal <= 4096 else 10) if self.cone_spec_k >= 4 else
                                                                           (6 if self.cone_spec_k >= 2 else 10))
         # uniform_tiles: the cone passes of a float16 decoder use ONE product shape whatever the device-side count (sdfr_mlp_forward_counted
         # half | 2), like the per-ray march (32x32x16 products in its 128- and 64-row head tiles and in the looping kernel with spec_k = 4):
@@ -154,7 +171,7 @@ class SphereTracer:
         self.K = K.contiguous().to(dev)
         self.Kinv = torch.linalg.inv(K.cpu().float()).contiguous().to(dev)
         B, H, W = self.B, self.H, self.W
-        n = B * H * W
+        n = B * self.PS
         f = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
         i = lambda *s: torch.zeros(s, dtype=torch.int32, device=dev)
         self.yaw, self.trans, self.latent = f(B), f(B, 3), f(B, self.L)
@@ -165,7 +182,7 @@ class SphereTracer:
         tiles = (n + 15) // 16 if self.spec_k2 == self.spec_k else (n * self.spec_k2 + 63) // 64
         self.tail_rows_buf = f(tiles, 16 * self.spec_k, self.NI)                   # operand rows of the looping kernel's tiles
         if self.cone_block:
-            nc = B * ((W + self.cone_block - 1) // self.cone_block) * ((H + self.cone_block - 1) // self.cone_block)
+            nc = B * self.cone_cap
             self.cone = f(nc)                                                  # per pixel tile: start parameter or -1 (culled)
             self.cone_counters = i(_COUNTERS)
             self.cone_ids, self.cone_st, self.cone_aux = [i(nc), i(nc)], [f(nc, 4), f(nc, 4)], [f(nc, 2), f(nc, 2)]
@@ -173,13 +190,21 @@ class SphereTracer:
         self.hit_lam, self.hit_sdf, self.lam_s = f(n), f(n), f(n)
         self.hit_slot, self.idx = i(n), i(n)
         self.rows, self.J, self.f0 = f(n, self.NI), f(n, self.NI), f(n)
-        self.color, self.mask, self.depth, self.normals = f(B, 3, H, W), f(B, 1, H, W), f(B, 1, H, W), f(B, 3, H, W)
-        self.ws = f(int(_lib.lib().sdfr_trace_backward_ws_floats(B, W, H)))
+        if self.ragged:
+            PS = self.PS
+            self.color, self.mask, self.depth, self.normals = f(B, 3, PS), f(B, 1, PS), f(B, 1, PS), f(B, 3, PS)
+            self.wh = torch.tensor([[W, H]] * B, dtype=torch.int32, device=dev)
+            self.sizes = [(W, H)] * B
+            self.tiles16_cap = (PS + 255) // 256 + (2 * self.max_side + 15) // 16 + 2          # (for sdfr_loss_2d_r on the traced image)
+            self.ext = _lib.Extents(self.wh.data_ptr(), PS, self.cone_cap)
+        else:
+            self.color, self.mask, self.depth, self.normals = f(B, 3, H, W), f(B, 1, H, W), f(B, 1, H, W), f(B, 3, H, W)
+        self.ws = f(int(_lib.lib().sdfr_trace_backward_ws_floats(B, self.PS, 1)))
         self.mask_ws = i(int(_lib.lib().sdfr_decoder_mask_words(self.handle.h, n))) if self.half_polish else None
         self.g_pose, self.g_latn = f(B, 16), f(B, self.L)
         self.g_yaw, self.g_trans, self.g_latent = f(B), f(B, 3), f(B, self.L)
         # points['xyzf'] of the refinement loop (optimizer.py:125): camera-frame hit points per crop in pixel order (sdfr_trace_points)
-        self.ecap = H * W
+        self.ecap = self.PS
         if points:
             self.xyzf, self.ecnt, self.pt_slot = f(B, self.ecap, 3), i(B), i(n)
         else:
@@ -202,9 +227,10 @@ class SphereTracer:
             ck(L.sdfr_params_forward(P(self.yaw), P(self.trans), P(self.latent), self.L, None, 1, B, None, P(self.pose), P(self.latnorm), st),
                "sdfr_params_forward")
             torch.div(self.latent, self.latnorm.unsqueeze(1), out=self.latn)                    # F.normalize (optimizer.py:96)
-            self.hit_lam.zero_(); self.hit_sdf.zero_()
             if "march" in events:
                 events["march"][0].record()
+            if self.ragged:
+                return self._render_ragged(L, P, ck, st, events)
             if self.cone_block:
                 ck(L.sdfr_trace_cone(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, self.eps,
                                      self.cone_block, self.cone_steps, self.cone_spec_k, self.sigma,
@@ -212,9 +238,9 @@ class SphereTracer:
                                      P(self.cone_counters), P(self.cone_ids[0]), P(self.cone_st[0]), P(self.cone_aux[0]),
                                      P(self.cone_ids[1]), P(self.cone_st[1]), P(self.cone_aux[1]), P(self.cone_inputs), P(self.cone_sdf), P(self.cone), st),
                    "sdfr_trace_cone")
-            ck(L.sdfr_trace_setup(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, P(self.counters), P(self.pix[0]),
-                                  P(self.lam[0]), P(self.far), P(self.inputs), P(self.cone) if self.cone_block else None, self.cone_block, st),
-               "sdfr_trace_setup")
+            ck(L.sdfr_trace_setup2(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.bound, self.near, P(self.counters), P(self.pix[0]),
+                                   P(self.lam[0]), P(self.far), P(self.inputs), P(self.cone) if self.cone_block else None, self.cone_block,
+                                   P(self.hit_lam), P(self.hit_sdf), st), "sdfr_trace_setup")
             ck(L.sdfr_trace_march(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.eps, self.steps,
                                   self.head_steps, self.march_tail_rows, self.spec_from, self.spec_k, self.spec_from2, self.spec_k2, self.sigma,
                                   self.half, P(self.counters), P(self.pix[0]), P(self.lam[0]), P(self.pix[1]), P(self.lam[1]), P(self.pix[2]),
@@ -246,6 +272,72 @@ class SphereTracer:
             out["xyzf"], out["nf"] = self.xyzf, self.ecnt
         return out
 
+    def _render_ragged(self, L, P, ck, st, events):
+        """render() with per-crop extents: the same launches through the `_r` entry points (include/sdfr.h sdfr_extents)"""
+        import ctypes
+        B, n = self.B, self.B * self.PS
+        E = ctypes.addressof(self.ext)
+        if self.cone_block:
+            ck(L.sdfr_trace_cone_r(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, E, self.bound, self.near, self.eps, self.cone_block,
+                                   self.cone_steps, self.cone_spec_k, self.sigma, (self.half | 2) if (self.half and self.uniform_tiles) else self.half,
+                                   P(self.cone_counters), P(self.cone_ids[0]), P(self.cone_st[0]), P(self.cone_aux[0]), P(self.cone_ids[1]),
+                                   P(self.cone_st[1]), P(self.cone_aux[1]), P(self.cone_inputs), P(self.cone_sdf), P(self.cone), st), "sdfr_trace_cone_r")
+        ck(L.sdfr_trace_setup_r(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, E, self.bound, self.near, P(self.counters), P(self.pix[0]),
+                                P(self.lam[0]), P(self.far), P(self.inputs), P(self.cone) if self.cone_block else None, self.cone_block, P(self.hit_lam),
+                                P(self.hit_sdf), st), "sdfr_trace_setup_r")
+        ck(L.sdfr_trace_march_r(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, E, self.eps, self.steps, self.head_steps,
+                                self.march_tail_rows, self.spec_from, self.spec_k, self.spec_from2, self.spec_k2, self.sigma, self.half, P(self.counters),
+                                P(self.pix[0]), P(self.lam[0]), P(self.pix[1]), P(self.lam[1]), P(self.pix[2]), P(self.lam[2]), P(self.far), P(self.inputs),
+                                P(self.sdf), P(self.tail_rows_buf), P(self.hit_lam), P(self.hit_sdf), st), "sdfr_trace_march_r")
+        if "march" in events:
+            events["march"][1].record()
+        n_hits = self.counters[6:7]
+        ck(L.sdfr_trace_hits_r(P(self.pose), P(self.Kinv), P(self.latn), self.L, B, E, P(self.hit_lam), P(n_hits), P(self.hit_slot), P(self.idx),
+                               P(self.rows), st), "sdfr_trace_hits_r")
+        if self.half_polish:
+            ck(L.sdfr_mlp_forward_f16_counted(self.handle.h, P(self.rows), n, P(n_hits), P(self.sdf), P(self.mask_ws), st), "sdfr_mlp_forward_f16_counted")
+            ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.rows), n, 1, P(self.idx), n, P(n_hits), P(self.J), P(self.f0), P(self.sdf), P(self.mask_ws),
+                                   2 | 16, st), "sdfr_mlp_jacobian")
+        else:
+            ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.rows), n, 1, P(self.idx), n, P(n_hits), P(self.J), P(self.f0), None, None,
+                                   16 if self.jac_rows32 else 0, st), "sdfr_mlp_jacobian")
+        ck(L.sdfr_trace_composite_r(P(self.pose), P(self.Kinv), self.L, B, E, P(self.hit_lam), P(self.hit_slot), P(self.J), P(self.f0), P(self.color),
+                                    P(self.mask), P(self.depth), P(self.normals), P(self.lam_s), st), "sdfr_trace_composite_r")
+        if self.xyzf is not None:
+            ck(L.sdfr_trace_points_r(P(self.Kinv), B, E, P(self.hit_slot), P(self.lam_s), P(self.xyzf), self.ecap, P(self.ecnt), P(self.pt_slot), st),
+               "sdfr_trace_points_r")
+        out = {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.normals}
+        if self.xyzf is not None:
+            out["xyzf"], out["nf"] = self.xyzf, self.ecnt
+        return out
+
+    def set_extents(self, sizes_wh, K=None):
+        """ragged mode: per-crop image sizes [(W_b, H_b)] * B and (optionally) intrinsics K (B,3,3) | (3,3); in place: a captured graph stays valid"""
+        if not self.ragged:
+            raise _lib.SdfrError("set_extents needs a SphereTracer built with max_pixels")
+        sizes = [(int(w), int(h)) for w, h in sizes_wh]
+        if len(sizes) != self.B:
+            raise _lib.SdfrError("set_extents: %d sizes for %d crops" % (len(sizes), self.B))
+        for w, h in sizes:
+            if w < 1 or h < 1 or w * h > self.PS or max(w, h) > self.max_side:
+                raise _lib.SdfrError("crop of %dx%d pixels exceeds max_pixels %d / max_side %d" % (w, h, self.PS, self.max_side))
+        self.sizes = sizes
+        self.wh.copy_(torch.tensor(sizes, dtype=torch.int32))
+        if K is not None:
+            K = torch.as_tensor(K, dtype=torch.float32).cpu()
+            if K.dim() == 2:
+                K = K.unsqueeze(0).expand(self.B, 3, 3)
+            self.K.copy_(K.contiguous())
+            self.Kinv.copy_(torch.linalg.inv(K.float()).contiguous())
+
+    def image(self, b, name="color"):
+        """(C, H_b, W_b) view of crop b's image `name` in 'color' | 'mask' | 'depth' | 'normals' (both layouts)"""
+        t = {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.normals}[name]
+        if not self.ragged:
+            return t[b]
+        w, h = self.sizes[b]
+        return t[b, :, :w * h].view(t.shape[1], h, w)
+
     def backward(self, g_color=None, g_depth=None, g_normals=None, state=None, g_xyzf=None, surfel=False):
         """gradients of the last render() w.r.t. yaw [B], trans [B,3], latent [B,L] (static buffers).  state: saved copies of the buffers of an
         earlier render (the autograd path).  g_xyzf [B, ecap, 3]: gradient w.r.t. the hit points (constructed with points=True).
@@ -268,9 +360,15 @@ class SphereTracer:
                 if self.xyzf is None:
                     raise _lib.SdfrError("SphereTracer: g_xyzf needs a tracer built with points=True")
                 g_xyzf = c(g_xyzf, self.xyzf.shape)
-            ck(L.sdfr_trace_refine_backward(P(S["pose"]), P(self.Kinv), self.L, B, W, H, P(S["hit_lam"]), P(S["hit_slot"]), P(S["J"]), P(S["f0"]),
-                                            P(g_color), P(g_depth), P(g_normals), P(g_xyzf), P(self.pt_slot), self.ecap, 1 if surfel else 0,
-                                            P(self.ws), P(self.g_pose), P(self.g_latn), st), "sdfr_trace_refine_backward")
+            if self.ragged:
+                import ctypes
+                ck(L.sdfr_trace_refine_backward_r(P(S["pose"]), P(self.Kinv), self.L, B, ctypes.addressof(self.ext), P(S["hit_lam"]), P(S["hit_slot"]),
+                                                  P(S["J"]), P(S["f0"]), P(g_color), P(g_depth), P(g_normals), P(g_xyzf), P(self.pt_slot), self.ecap,
+                                                  1 if surfel else 0, P(self.ws), P(self.g_pose), P(self.g_latn), st), "sdfr_trace_refine_backward_r")
+            else:
+                ck(L.sdfr_trace_refine_backward(P(S["pose"]), P(self.Kinv), self.L, B, W, H, P(S["hit_lam"]), P(S["hit_slot"]), P(S["J"]), P(S["f0"]),
+                                                P(g_color), P(g_depth), P(g_normals), P(g_xyzf), P(self.pt_slot), self.ecap, 1 if surfel else 0,
+                                                P(self.ws), P(self.g_pose), P(self.g_latn), st), "sdfr_trace_refine_backward")
             ck(L.sdfr_params_backward(P(S["yaw"]), P(S["latent"]), self.L, P(S["latnorm"]), P(self.g_pose), P(self.g_latn), B, P(self.g_yaw),
                                       P(self.g_trans), P(self.g_latent), st), "sdfr_params_backward")
         return self.g_yaw, self.g_trans, self.g_latent

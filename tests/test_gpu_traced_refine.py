@@ -189,9 +189,10 @@ def test_optimizer_mirror_with_the_tracer_backend(dec, dec16):
     grid = sdflabel_amd.Grid3D(40, DEV)
     opt = Optimizer(params, DEV, WEIGHTS, render="trace")
     out = opt.optimize(30, target[0], lidar, dec16, grid, torch.from_numpy(K), [H, W])
+    # (the Optimizer keys its refiners on a pixel capacity -- here 16384 for the 96x96 crop -- and the tracer's schedule is a function of that capacity)
     rf = sdflabel_amd.BatchRefiner(dec16, 40, K, (H, W), 1, lidar_cap=max(1024, 1 << (int(lidar.shape[0]) - 1).bit_length()), weights=WEIGHTS,
-                                   device=DEV, render="trace")
-    rf.set_crops({k: v[0:1] for k, v in par.items()}, target, [lidar])
+                                   device=DEV, render="trace", max_pixels=16384, max_side=512)
+    rf.set_crops({k: v[0:1] for k, v in par.items()}, target, [lidar], K=K, crop_sizes=[(H, W)])
     rf.capture()
     rf.optimize(30)
     rows = N(rf.results()[0])[0]
@@ -199,3 +200,56 @@ def test_optimizer_mirror_with_the_tracer_backend(dec, dec16):
     assert np.array_equal(got, rows), (got, rows)
     assert abs(got[0] - GT_YAW) < abs(float(par["yaw"][0]) - GT_YAW)
     clear_refiner_cache()
+
+
+def test_traced_refinement_with_ragged_extents_equals_each_crop_alone(dec, dec16):
+    """r04: the tracer backend takes per-crop image sizes and intrinsics as device data too.  Four crops of different sizes / aspects (with their own
+    targets and lidar clouds) refined in ONE ragged BatchRefiner(render='trace') equal, bit for bit, the same crops refined one at a time in a one-crop
+    refiner of the same capacity (= the same march schedule); the captured graph survives a new crop set; and the product-side Optimizer shares one
+    traced refiner across crop sizes."""
+    from tests.test_gpu_ragged import _synthetic_crop
+    shapes = [(96, 128), (120, 100), (64, 160), (128, 72)]                                            # (H_b, W_b)
+    Ks = [K_for(h, w) for h, w in shapes]
+    for K_, (h, w) in zip(Ks[1:], shapes[1:]):
+        K_[0, 2] += 0.2 * w                                                                          # principal points off the centre
+    targets, lidars = [], []
+    for (h, w), K_ in zip(shapes, Ks):
+        tg, ld = _synthetic_crop(dec, 40, h, w, K_)
+        targets.append(tg); lidars.append(ld)
+    B = len(shapes)
+    par = crop_params([3, 4, 5, 6])
+    for b, K_ in enumerate(Ks):                                                                      # keep the object in view of the shifted principal points
+        par["trans"][b, 0] += 0.0
+    lcap = 1 << (max(l.shape[0] for l in lidars) - 1).bit_length()
+    kw = dict(render="trace", max_pixels=16384, max_side=256, lidar_cap=lcap, weights=WEIGHTS, device=DEV)
+    rf = sdflabel_amd.BatchRefiner(dec16, 40, Ks[0], shapes[0], B, **kw)
+    rf.set_crops(par, targets, lidars, K=np.stack(Ks), crop_sizes=shapes)
+    rf.capture()
+    rf.optimize(20)
+    rows = N(rf.results()[0])
+    assert int(rf.stepped.min()) == 1 and int(rf.tr.ecnt.min()) > 500
+    one = sdflabel_amd.BatchRefiner(dec16, 40, Ks[0], shapes[0], 1, **kw)
+    one.capture()
+    for b in range(B):
+        one.set_crops({k: v[b:b + 1] for k, v in par.items()}, [targets[b]], [lidars[b]], K=Ks[b], crop_sizes=[shapes[b]])
+        one.optimize(20)
+        assert np.array_equal(N(one.results()[0])[0], rows[b]), (b, N(one.results()[0])[0], rows[b])
+        # and the images are the crop's own: hits only inside its H_b x W_b pixels
+        assert float(one.tr.mask[0, 0, shapes[b][0] * shapes[b][1]:].abs().sum()) == 0.0
+    rot = [2, 3, 0, 1]
+    rf.set_crops({k: v[rot] for k, v in par.items()}, [targets[i] for i in rot], [lidars[i] for i in rot], K=np.stack([Ks[i] for i in rot]),
+                 crop_sizes=[shapes[i] for i in rot])
+    rf.optimize(20)
+    assert rf.captures == 1 and np.array_equal(N(rf.results()[0]), rows[rot])
+    # yaw moved towards the ground truth on every crop
+    assert (np.abs(rows[:, 0] - GT_YAW) < np.abs(par["yaw"] - GT_YAW)).all()
+    # ragged against the dense tracer on one crop: the same image (the schedules differ -- capacity 16384 against 96 x 128 pixels --, so not the same bits)
+    tr_d = sdflabel_amd.SphereTracer(dec16, Ks[0], (shapes[0][1], shapes[0][0]), 1, device=DEV)
+    tr_r = sdflabel_amd.SphereTracer(dec16, Ks[0], (shapes[0][1], shapes[0][0]), 1, device=DEV, max_pixels=16384, max_side=256)
+    a = [torch.tensor(par["yaw"][0:1], device=DEV), torch.tensor(par["trans"][0:1], device=DEV), torch.tensor(par["latent"][0:1], device=DEV)]
+    od = {k: v.clone() for k, v in tr_d.render(*a).items()}
+    tr_r.render(*a)
+    md, mr = od["mask"][0] > 0, tr_r.image(0, "mask") > 0
+    assert int((md != mr).sum()) <= 5
+    both = (md & mr)
+    assert float(((od["depth"][0] - tr_r.image(0, "depth")).abs() * both).max()) < 5e-2 and float(torch.median((od["depth"][0] - tr_r.image(0, "depth")).abs()[both])) < 1e-4

@@ -400,7 +400,7 @@ def main():
     # point moved by the box corner; pipelines/refine_css.py:203-223 constructs an Optimizer per annotation).  32 KITTI-like boxes, one
     # Optimizer(...).optimize(60, ...) call per crop as the pipeline issues them; the time INCLUDES building the refiner (buffers + HIP-graph
     # capture), which ragged extents make a once-per-capacity cost: refiners_built / graph_captures should read 1 / 1 per rendering area.
-    def varied_crops(area):
+    def varied_crops(area, render="splat"):
         from sdflabel_amd.pipelines import optimizer as OP
         OP.clear_refiner_cache()
         OP.STATS["refiners_built"] = 0
@@ -437,7 +437,7 @@ def main():
             y0, t0_, l0 = starts[b]
             p = {"yaw": y0.copy(), "trans": (gts[b] + (t0_ - np.asarray([0.0, 0.0, 3.5], np.float32))).astype(np.float32), "scale": np.array([2.0], np.float32),
                  "latent": l0.copy()}
-            opt = OP.Optimizer(p, dev, {"2d": 0.3, "3d": 0.5})
+            opt = OP.Optimizer(p, dev, {"2d": 0.3, "3d": 0.5}, render=render)
             out = opt.optimize(iters, targets[b], lidars[b], d16, grid, torch.from_numpy(Ks[b]), list(shapes[b]))
             caps.add(id(opt._refiner))
             errs0.append(abs(float(y0[0]) - 0.6)); errs1.append(abs(float(out["yaw"][0]) - 0.6))
@@ -447,6 +447,7 @@ def main():
         res_ = {"value": n / dt_v, "unit": "crops/s", "crops": n, "iterations_per_crop": iters, "rendering_area": area, "seconds_incl_refiner_construction": dt_v,
                 "crop_sizes_h_w_min_max": [list(min(shapes)), list(max(shapes))], "distinct_crop_sizes": len(set(shapes)), "pixel_capacity": pmax,
                 "refiners_built": OP.STATS["refiners_built"], "graph_captures": captures, "distinct_refiners_used": len(caps),
+                "renderer": "surfel splat (the reference's algorithm)" if render == "splat" else "sphere tracer (Optimizer(..., render='trace'))",
                 "decoder_precision": "float16 (the reference's shipped precision)", "mean_abs_yaw_error_before_after": [float(np.mean(errs0)), float(np.mean(errs1))],
                 "call": "Optimizer(params, device, weights).optimize(60, nocs, lidar, dsdf, grid, K_b, [H_b, W_b]) per crop, as pipelines/refine_css.py:203-223"}
         OP.clear_refiner_cache()
@@ -455,11 +456,12 @@ def main():
     varied = None
     if rank == 0 and CB == 1 and not args.no_extras:
         varied = {}
-        for area in (32, 256):
+        for area, render in ((32, "splat"), (256, "splat"), (256, "trace")):
+            key = "rendering_area_%d" % area + ("" if render == "splat" else "_traced")
             try:
-                varied["rendering_area_%d" % area] = varied_crops(area)
+                varied[key] = varied_crops(area, render)
             except Exception as e:
-                varied["rendering_area_%d" % area] = {"error": repr(e)[:300]}
+                varied[key] = {"error": repr(e)[:300]}
 
     # ---- BASELINE configs[3]: `--total-crops` crops sharded over the ranks (crop i -> rank i mod N), refined for the reference's 60 iterations
     # in chunks of 64 by BatchRefiner, ONE all_gather of the per-crop result rows at the end (sdflabel_amd.parallel.refine_sharded).

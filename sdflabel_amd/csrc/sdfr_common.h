@@ -40,6 +40,12 @@ struct SdfrDeviceGuard {
 
 static inline int sdfr_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// zero `bytes` (a multiple of 4) of device memory on `stream` with a KERNEL.  Not hipMemsetAsync: a memset node inside a captured HIP graph
+// faulted on replay ("Memory access fault by GPU ... write access to a read-only page") as soon as any eager work -- a copy, an allocation --
+// ran between two replays of the graph (ROCm 7.2 on gfx950, found in r04 with the traced refiner: profiles/r04_notes.md section 7); every
+// entry point of this library may be captured, so none of them enqueues a memset.
+hipError_t sdfr_zero_async(void* p, size_t bytes, hipStream_t stream);
+
 // XCD-aware crop mapping of a (x = work item of a crop, y = crop) grid.  MI355X deals the workgroups of a launch round-robin to its 8 XCDs by
 // their linear index, and each XCD has its own L2: with the plain mapping the workgroups of ONE crop land on all eight and every L2 fetches
 // that crop's data (surfel arrays in the splat forward, pixel records in its backward) for itself.  Re-deal the indices so that crop 8g + x

@@ -97,7 +97,7 @@ static int band_select_impl(const float* sdf, int64_t G, int B, float thr, const
     SDFR_REQUIRE(G >= 0 && B >= 0 && cap >= 0, "sdfr_band_select: negative size");
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (G == 0) { SDFR_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int32_t) * B, s)); return SDFR_OK; }
+    if (G == 0) { SDFR_HIP_CHECK(sdfr_zero_async(cnt, sizeof(int32_t) * B, s)); return SDFR_OK; }
     dim3 grid(sdfr_cdiv(G, 256), B);
     hipLaunchKernelGGL(sdfr_band_count_kernel, grid, dim3(256), 0, s, sdf, G, thr, thr_extra, scratch, skip);
     SDFR_LAUNCH_CHECK();
@@ -231,7 +231,7 @@ extern "C" int sdfr_prefilter_audit_select(const float* inputs, const int32_t* c
     SDFR_REQUIRE(G > 0 && n_inputs > 0 && stride > 0 && cap_rows > 0, "sdfr_prefilter_audit_select: bad size");
     if (B <= 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
-    SDFR_HIP_CHECK(hipMemsetAsync(n_audit, 0, sizeof(int32_t), s));
+    SDFR_HIP_CHECK(sdfr_zero_async(n_audit, sizeof(int32_t), s));
     const int per = sdfr_cdiv(G, stride);
     hipLaunchKernelGGL(sdfr_prefilter_audit_select_kernel, dim3(sdfr_cdiv(per, 256), B), dim3(256), 0, s, inputs, cslot, G, n_inputs, stride, phase,
                        rows, src, n_audit, cap_rows);
@@ -384,8 +384,8 @@ extern "C" int sdfr_surface_project_bwd(const float* g_points, const float* g_no
     SDFR_REQUIRE(g_points && normals && idx && g_sdf, "sdfr_surface_project_bwd: NULL argument");
     if (B <= 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
-    SDFR_HIP_CHECK(hipMemsetAsync(g_sdf, 0, sizeof(float) * (size_t)B * G, s));
-    if (g_xyz) SDFR_HIP_CHECK(hipMemsetAsync(g_xyz, 0, sizeof(float) * (size_t)B * G * 3, s));
+    SDFR_HIP_CHECK(sdfr_zero_async(g_sdf, sizeof(float) * (size_t)B * G, s));
+    if (g_xyz) SDFR_HIP_CHECK(sdfr_zero_async(g_xyz, sizeof(float) * (size_t)B * G * 3, s));
     if (cap <= 0) return SDFR_OK;
     dim3 grid(sdfr_cdiv(cap, 256), B);
     hipLaunchKernelGGL(sdfr_surface_project_bwd_kernel, grid, dim3(256), 0, s, g_points, g_nocs, normals, G, idx, cap, cnt,
@@ -424,7 +424,7 @@ extern "C" int sdfr_sdf_input_grad(const float* g_sdf, const int32_t* slot, cons
     SDFR_REQUIRE(g_sdf && slot && J && g_inputs, "sdfr_sdf_input_grad: NULL argument");
     if (B <= 0 || G <= 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (n_uncached) SDFR_HIP_CHECK(hipMemsetAsync(n_uncached, 0, sizeof(int32_t), s));
+    if (n_uncached) SDFR_HIP_CHECK(sdfr_zero_async(n_uncached, sizeof(int32_t), s));
     dim3 grid(sdfr_cdiv(G, 256), B);
     hipLaunchKernelGGL(sdfr_sdf_input_grad_kernel, grid, dim3(256), 0, s, g_sdf, slot, J, n_inputs, G, cap, g_inputs, n_uncached);
     SDFR_LAUNCH_CHECK();

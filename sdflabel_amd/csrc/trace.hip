@@ -610,7 +610,7 @@ static int trace_setup_impl(const float* pose, const float* Kinv, const float* l
     SDFR_REQUIRE(L >= 0 && B > 0 && bound > 0.f, "sdfr_trace_setup: bad size");
     SDFR_REQUIRE(!cone || cone_block >= 2, "sdfr_trace_setup: cone starts need their block size (>= 2), got %d", cone_block);
     hipStream_t s = (hipStream_t)stream;
-    SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
+    SDFR_HIP_CHECK(sdfr_zero_async(counters, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
     hipLaunchKernelGGL(sdfr_trace_setup_kernel, dim3(sdfr_cdiv((int64_t)D.PS, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, D, bound, near,
                        counters, pix, reinterpret_cast<float4*>(lam), far, inputs, cone, cone_block, hit_lam, hit_sdf);
     SDFR_LAUNCH_CHECK();
@@ -655,7 +655,7 @@ static int trace_cone_impl(const sdfr_decoder* d, const float* pose, const float
     const int nblk = D.ncap;
     const int64_t n_max = (int64_t)B * nblk;
     SDFR_REQUIRE(n_max * spec_k < (int64_t)1 << 31, "sdfr_trace_cone: too many cone rows");
-    SDFR_HIP_CHECK(hipMemsetAsync(counters, 0, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
+    SDFR_HIP_CHECK(sdfr_zero_async(counters, SDFR_TRACE_COUNTERS * sizeof(int32_t), s));
     hipLaunchKernelGGL(sdfr_trace_cone_setup_kernel, dim3(sdfr_cdiv(nblk, 256), B), dim3(256), 0, s, pose, Kinv, latn, L, D, block, bound, near,
                        spec_k, sigma, counters, ids0, reinterpret_cast<float4*>(st0), reinterpret_cast<float2*>(aux0), cone, inputs);
     unsigned long long* evals = reinterpret_cast<unsigned long long*>(counters + 4);

@@ -254,3 +254,35 @@ def test_traced_refinement_with_ragged_extents_equals_each_crop_alone(dec, dec16
     assert int((md != mr).sum()) <= 5
     both = (md & mr)
     assert float(((od["depth"][0] - tr_r.image(0, "depth")).abs() * both).max()) < 5e-2 and float(torch.median((od["depth"][0] - tr_r.image(0, "depth")).abs()[both])) < 1e-4
+
+
+def test_captured_traced_refiner_survives_eager_work_between_replays(dec, dec16):
+    """r04 regression: with hipMemsetAsync zeroing the march counters, a captured traced iteration replayed fine until ANY eager work (a copy,
+    an allocation, a new crop set) ran between two replays -- the next replay then died with 'Memory access fault by GPU ... write access to a
+    read-only page' (200 x 300 crop; bench.py's chunked refine_sharded_traced and the Optimizer's second crop hit it).  The library zeroes with
+    a kernel now (csrc/sdfr_common.h sdfr_zero_async); this is the failing sequence, and its result equals uninterrupted replays."""
+    H, W = 200, 300
+    K = K_for(H, W)
+    nocs, lidar = synthetic_targets(dec, 40, K, H, W, DEV)
+    par = crop_params([2])
+
+    def run(interrupt):
+        rf = sdflabel_amd.BatchRefiner(dec16, 40, K, (H, W), 1, lidar_cap=1024, weights=WEIGHTS, device=DEV, render="trace")
+        rf.set_crops(par, nocs, [lidar[:1024]])
+        rf.capture()
+        rf.optimize(5)
+        if interrupt:
+            torch.cuda.synchronize()
+            rf.tr.stats(); rf.results()
+            junk = [torch.zeros(1 << 20, device=DEV) for _ in range(8)]
+            del junk
+            synthetic_targets(dec, 40, K, H, W, DEV)
+        rf.optimize(5)
+        if interrupt:                                            # ... and a new crop set through the same graph
+            rows = N(rf.results()[0])
+            rf.set_crops(par, nocs, [lidar[:1024]])
+            rf.optimize(10)
+            assert np.array_equal(N(rf.results()[0]), rows)
+        return N(rf.results()[0])
+
+    assert np.array_equal(run(True), run(False))

@@ -169,3 +169,14 @@ def test_sphere_tracer_default_schedule_is_a_function_of_the_crop_size_alone():
     # behind the cone phase (r04 default) the float16 march starts its speculative passes earlier
     assert [default_spec_from(n * n, True, True) for n in (64, 128, 256, 512)] == [3, 4, 6, 8]
     assert [default_spec_from(n * n, False, True) for n in (128, 256)] == [8, 10]
+
+
+def test_no_memset_nodes_in_the_library():
+    """every entry point may be captured into a HIP graph, and memset nodes faulted on replay (r04): the kernels' sources zero memory with
+    sdfr_zero_async only"""
+    import glob
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sdflabel_amd", "csrc")
+    for path in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")):
+        src = "\n".join(l.split("//")[0] for l in open(path).read().splitlines())
+        assert "hipMemset" not in src, path

@@ -712,6 +712,9 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                         t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
                         *reinterpret_cast<h16x4*>(act_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV)) = t;
                     }
+#ifdef SDFR_EPI_FENCE
+                    __builtin_amdgcn_sched_barrier(0);         // (A/B: one accumulator tile's reads at a time -- 512-register geometries)
+#endif
                 }
         };
 #ifndef SDFR_H_FAST_EPI
@@ -756,7 +759,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         // geometry, so that a row's value has the same bits whether a 128-, 64- or 16-row tile evaluated it (r04: the sphere tracer's
         // march picks the tile size by the device-side row count, and a crop must march the same alone and in a batch); float32: as many
         // slices as the workgroup has threads per point (unchanged bits).
-        constexpr int SL = HALF ? 4 : NT / PT;
+        constexpr int SL = HALF ? (NT / PT < 4 ? NT / PT : 4) : NT / PT;       // (fewer than 4 threads per point: A/B geometries only)
         static_assert(SL * PT <= NT, "last linear: one thread per (slice, point)");
         constexpr int KGS = KG / SL;
         const int sl = tid / PT, pt = tid - sl * PT;

@@ -23,5 +23,9 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 # the sphere march: HBM bytes and matrix-pipe counters (three --pmc passes)
 bash $R/tools/sphere_pmc.sh $TAG > $O/pmcsph_$TAG.log 2>&1
 cd $R
+# gpurun merges at most 64 MiB back: the raw per-launch traces (60 MB for the full run) are not read by tools/summarize_profile.py -- only the
+# *_kernel_stats.csv of the trace runs and the *_counter_collection.csv of the PMC passes are
+find $O -name "*_kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O -name "*_agent_info.csv" -delete
+du -sh $O
 cat $O/pytest_$TAG.log | tail -3; tail -c 600 $O/bench_$TAG.json; tail -3 $O/bench_$TAG.err
 f=$(find $O/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -24 "$f"

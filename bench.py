@@ -716,6 +716,7 @@ def main():
                                  "head_steps": tr.head_steps, "tail_rows": tr.tail_rows, "samples_per_ray_and_pass_in_the_looping_kernel": tr.spec_k,
                                  "speculative_from_pass": tr.spec_from if tr.spec_k > 1 else None,
                                  "second_level": {"samples": tr.spec_k2, "from_pass": tr.spec_from2} if tr.spec_k2 > tr.spec_k else None,
+                                 "speculation_levels_from_pass_samples": [list(l) for l in tr.levels], "q_max": tr.q_max,
                                  "hit_pass": "float16 (decoder)" if tr.half_polish else "float32",
                                  "cone_marching": {"tile_px": tr.cone_block, "passes": tr.cone_steps, "cone_evaluations": st3.get("cone_evaluations"),
                                                    "culled_tiles": st3.get("culled_tiles")} if tr.cone_block else None,

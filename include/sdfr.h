@@ -31,6 +31,8 @@ extern "C" {
 #define SDFR_E_UNSUPPORTED (-3)
 
 #define SDFR_MAX_LAYERS 16
+#define SDFR_TRACE_LEVELS 6     /* most speculation levels of a sphere-tracing march schedule (sdfr_trace_march) */
+#define SDFR_TRACE_COUNTERS 32  /* int32 device counters of a march / a cone march (zeroed by sdfr_trace_setup / sdfr_trace_cone) */
 
 int sdfr_version(void);
 const char* sdfr_last_error(void);
@@ -398,7 +400,7 @@ int sdfr_trace_setup2(const float* pose, const float* Kinv, const float* latn, i
  * spec_k (1 ... 8; r04): speculative cone passes -- a pass evaluates spec_k samples of a cone, p_0 = lam, p_j = p_{j-1} + sigma q^j a_prev
  * (a_prev = the cone's previous advance, q = ratio of its last two advances in [0.5, 1.5]); sample j counts only inside the range its
  * predecessor proved free, so the accepted prefix is a valid, shorter-stepped cone march (4 samples x 4 passes cull what 10 plain passes cull).
- * counters: device int32[8] (zeroed here; [0..2] rotating ROW counts, [4..5] one uint64 = decoder evaluations); ids0/st0/aux0, ids1/st1/aux1:
+ * counters: device int32[SDFR_TRACE_COUNTERS] (zeroed here; [0..2] rotating ROW counts, [4..5] one uint64 = decoder evaluations); ids0/st0/aux0, ids1/st1/aux1:
  * ping-pong cone lists (int32[n], float[n][4], float[n][2], n = B * tiles); inputs float[n * spec_k][L+3], sdf float[n * spec_k] scratch.
  * half | 2: see sdfr_mlp_forward_counted.  No host synchronisation. */
 int sdfr_trace_cone(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float bound,
@@ -411,24 +413,28 @@ int sdfr_trace_step(const float* pose, const float* Kinv, const float* latn, int
                     int32_t* counters, int step, int64_t n_max, const int32_t* pix_in, const float* lam_in, int32_t* pix_out, float* lam_out,
                     const float* far, float* inputs, float* hit_lam, float* hit_sdf, void* stream);
 
-/* The whole march in ONE call, no host synchronisation (counters: device int32[8], zeroed by sdfr_trace_setup -- [0..2] rotating active
- * counts, [3] rays unresolved when the step budget ran out, [4..5] one uint64 = decoder evaluations of the march, [6] hits, [7] rays handed to the looping kernel's second stage).  While the
- * device-side count is >= tail_rows a step is the decoder on the active rows + the step kernel; below it ONE launch of the decoder kernel in
- * its looping mode takes the remaining rays to termination (16-ray tiles, ray state in registers, no per-step launch, no compaction); the
- * gate is evaluated on the device in each of the first head_steps steps, then an unconditional tail launch takes what is left.
- * spec_k = 4: from pass index spec_from on a pass evaluates four samples per ray (p_0 = lam, p_j = p_{j-1} + sigma q^j rho / |d|) and accepts
- * the prefix in which every sample lies inside the previous one's safe sphere -- a valid sphere-tracing sequence, nothing skipped; the pass
- * index alone decides (head_steps is clamped to spec_from), so a ray's samples do not depend on the launch schedule.  spec_k = 1: plain.
+/* The whole march in ONE call, no host synchronisation (counters: device int32[SDFR_TRACE_COUNTERS], zeroed by sdfr_trace_setup -- [0..2]
+ * rotating active counts, [3] rays unresolved when the step budget ran out, [4..5] one uint64 = decoder evaluations of the march, [6] hits,
+ * [7 + i] rays handed from stage i of the looping kernel to stage i + 1, [16 + i] tile counter of stage i).  While the device-side count is
+ * >= tail_rows a step is the decoder on the active rows + the step kernel; below it ONE launch of the decoder kernel in its looping mode takes
+ * the remaining rays on (ray state in registers, no per-step launch, no compaction); the gate is evaluated on the device in each of the first
+ * head_steps steps, then an unconditional launch takes what is left (tail_rows = 0: the hand-over happens at pass index head_steps, whatever
+ * the count -- a crop then marches the same alone and inside a batch).
+ * levels: HOST array int32[n_levels][2] = (first pass index, samples per ray and pass), both ascending, samples 4 / 8 / 16 / 32 / 64,
+ * n_levels <= SDFR_TRACE_LEVELS: from pass index levels[i][0] on a pass evaluates levels[i][1] samples per ray (p_0 = lam, p_j = p_{j-1} +
+ * sigma q^j rho / |d|; q = ratio of the ray's last two radii clamped to [0.5, q_max], q_max >= 1) and accepts the prefix in which every sample
+ * lies inside the previous one's safe sphere -- a valid sphere-tracing sequence, nothing skipped; the pass index alone decides (head_steps is
+ * clamped to levels[0][0]), so a ray's samples do not depend on the launch schedule.  n_levels = 0: plain tracing.  Each level is one launch of
+ * the looping kernel: 64 / samples rays per 64-row tile, a pool of sdfr_trace_pool() persistent workgroups fetching tiles from a device counter,
+ * survivors appended to the next level's list -- fewer, equally long passes for the grazing rays that end a march.
  * Decoders with LayerNorm or a hidden width below 257 march with per-step launches of their own float32 forward kernels (plain tracing, no
  * looping kernel; half must be 0).
- * spec_k2 = 8 or 16 from pass index spec_from2 > spec_from on (off: spec_k2 <= spec_k): at that pass the looping kernel's survivors -- a few
- * hundred creeping rays scattered over the tiles -- are re-packed 64 / spec_k2 to a tile by a second launch (list pix2 / lam2, counters[7])
- * and take spec_k2 samples per pass: fewer, equally long passes for the rays that end the march.
- * pix0/lam0 (filled by sdfr_trace_setup) and pix1/lam1 are the ping-pong active lists (lam: ray state float[n][4]), pix2/lam2 the second
- * stage's list (same sizes; may be NULL when it is off), sdf float[B*W*H] scratch, tail_rows_buf float[tiles][16 * spec_k][L + 3] scratch of
- * the looping kernel with tiles = ceil(B*W*H / 16), or ceil(B*W*H * spec_k2 / 64) with the second level. */
+ * pix0/lam0 (filled by sdfr_trace_setup) and pix1/lam1 are the ping-pong active lists (lam: ray state float[n][4]), pix2/lam2 the hand-over
+ * list between levels (same sizes; may be NULL with fewer than two levels; pix0/lam0 is the other one), sdf float[B*W*H] scratch, tail_rows_buf
+ * float[sdfr_trace_pool()][64][L + 3] scratch of the looping kernel. */
+int sdfr_trace_pool(void);
 int sdfr_trace_march(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H, float eps,
-                     int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2, float sigma, int half,
+                     int steps, int head_steps, int tail_rows, const int32_t* levels, int n_levels, float q_max, float sigma, int half,
                      int32_t* counters, int32_t* pix0, float* lam0, int32_t* pix1, float* lam1, int32_t* pix2, float* lam2, const float* far,
                      float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam, float* hit_sdf, void* stream);
 /* hit pixels (hit_lam > 0) -> compact list: rows float[n][L+3] = [latn, o + lam d] for sdfr_mlp_jacobian (rows_per_crop = B*W*H, B = 1,
@@ -463,7 +469,7 @@ int sdfr_trace_cone_r(const sdfr_decoder* dec, const float* pose, const float* K
                       int32_t* ids0, float* st0, float* aux0, int32_t* ids1, float* st1, float* aux1, float* inputs, float* sdf, float* cone,
                       void* stream);
 int sdfr_trace_march_r(const sdfr_decoder* dec, const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext, float eps,
-                       int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2, float sigma, int half,
+                       int steps, int head_steps, int tail_rows, const int32_t* levels, int n_levels, float q_max, float sigma, int half,
                        int32_t* counters, int32_t* pix0, float* lam0, int32_t* pix1, float* lam1, int32_t* pix2, float* lam2, const float* far,
                        float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam, float* hit_sdf, void* stream);
 int sdfr_trace_hits_r(const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext, const float* hit_lam,

@@ -884,7 +884,7 @@ def cone_march(layers, spec, latn, pose, Kinv, image_wh, block, blocks, cone_ste
 
 
 def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, bound=1.0, near=1e-3, spec_from=None, spec_k=1, sigma=0.9,
-                 cone_block=None, cone_steps=10, image_wh=None, cone_spec_k=1):
+                 cone_block=None, cone_steps=10, image_wh=None, cone_spec_k=1, q_max=1.0):
     """March every ray: x = o + lam d, v = decoder(latn, x); |v| < eps -> hit at lam; else lam += v / |d|; lam >= far (exit of the cube
     [-bound, bound]^3) or NaN -> miss; out of steps -> miss (unresolved).
     Speculative passes (spec_k > 1, from pass index spec_from on): a pass evaluates spec_k samples of the ray at once, p_0 = lam and
@@ -932,10 +932,12 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
     margin = cone_margin.copy()
     n_steps = np.zeros(n, np.int32)
     evals = cone_evals
+    census = []                                                   # active rays at the start of every pass (schedule studies)
     for s in range(steps):
         idx = np.nonzero(active)[0]
         if idx.size == 0:
             break
+        census.append(int(idx.size))
         if isinstance(spec_from, (list, tuple)):                  # a schedule [(first pass index, samples per pass), ...], ascending
             k = 1
             for s_from, s_k in spec_from:
@@ -978,7 +980,7 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
         lam0[idx[ishit]] = pj[ishit]
         prev = np.where(J > 0, R[ar, np.maximum(J - 1, 0)], rho[idx]).astype(f)
         with np.errstate(divide="ignore", invalid="ignore"):
-            qn = np.where(prev > 0, np.minimum(np.maximum((rj / prev).astype(f), f(0.5)), f(1.0)), f(1.0)).astype(f)
+            qn = np.where(prev > 0, np.minimum(np.maximum((rj / prev).astype(f), f(0.5)), f(q_max)), f(1.0)).astype(f)
         l2 = (pj + (vj / dn[idx]).astype(f)).astype(f)
         keep = ~ishit & (l2 < l1[idx]) & ~np.isnan(vj)
         margin[idx[~ishit]] = np.minimum(margin[idx[~ishit]], np.abs(l1[idx[~ishit]] - l2[~ishit]))
@@ -988,7 +990,7 @@ def sphere_trace(layers, spec, latn, pose, Kinv, pixels_xy, steps=64, eps=2e-3, 
         active[idx] = keep
     unresolved = active.copy()
     out = {"hit": hit, "lam0": lam0, "unresolved": unresolved, "n_steps": n_steps, "evals": evals, "far": l1, "entered": l0 < l1, "cone_culled": cone_culled,
-           "cone_evals": cone_evals}
+           "cone_evals": cone_evals, "active_per_pass": census}
     hi_ = np.nonzero(hit)[0]
     x0 = (o[None] + lam0[hi_, None] * d[hi_]).astype(f)
     rows = np.concatenate([np.broadcast_to(latn, (hi_.size, L)), x0], 1).astype(f)

@@ -86,8 +86,11 @@ struct MlpParams {
     const int32_t* t_pix;        // active list: crop * W*H + pixel
     const float4* t_lam;         // active list: ray state (lam = next sample, rho = |sdf| of the previous accepted sample, q = ratio of the last two radii, -)
     int t_step0;                 // pass index of the kernel's first pass
-    int t_spec_from, t_spec_k;   // passes with index >= t_spec_from take t_spec_k samples per ray ...
-    int t_spec_from2, t_spec_k2; // ... and those with index >= t_spec_from2 (>= t_spec_from) t_spec_k2; the pass INDEX alone decides
+    int t_nlv;                   // speculation schedule: passes with index >= t_lv_from[i] take t_lv_k[i] samples per ray (levels ascending; before the
+    int t_lv_from[SDFR_TRACE_LEVELS], t_lv_k[SDFR_TRACE_LEVELS];   // first level: 1 sample); the pass INDEX alone decides, never a count
+    float t_qmax;                // upper clamp of the radius ratio q that spaces the speculative samples (lower clamp 0.5)
+    int32_t* t_tile_ctr;         // device counter (zeroed by sdfr_trace_setup) the workgroups of this launch fetch their tiles from: the grid is a
+                                 // bounded pool of persistent workgroups, each with ONE tile of scratch rows, whatever the ray count
     int t_stage;                 // passes this launch may run (<= t_steps)
     int32_t* t_next_cnt;         // next stage's active list (NULL: none): count, pixels, states
     int32_t* t_next_pix;
@@ -233,6 +236,21 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     const int NI = P.n_inputs;
 
     // ---- which rows does this tile hold ------------------------------------------------------------------
+    // MODE 4: a pool of persistent workgroups; each trip of this loop fetches one tile (t_rt rays) from the launch's device counter and marches
+    // it through the stage.  Every other mode: one trip, tile = blockIdx.x.
+    int* tile_slot = reinterpret_cast<int*>(gy) + 1;
+    do {
+    int tile = blockIdx.x;
+    if constexpr (TAIL) {
+        if (P.n_dev && P.n_dev_hi > 0 && (*P.n_dev < P.n_dev_lo || *P.n_dev >= P.n_dev_hi)) return;      // gated launch: nothing fetched
+        if (P.t_steps <= 0) return;
+        if (P.t_tile_ctr) {
+            __syncthreads();                                   // the previous tile's readers of the LDS state are through
+            if (tid == 0) tile_slot[0] = atomicAdd(P.t_tile_ctr, 1);
+            __syncthreads();
+            tile = tile_slot[0];
+        }
+    }
     int n_valid;
     if (JAC) {
         const int b = blockIdx.y;
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         }
     } else {
         // (MODE 4: a tile is t_rt RAYS of the active list -- n / n_dev count rays -- and PT operand rows of the tile's own scratch)
-        const int64_t r0 = (int64_t)blockIdx.x * (TAIL ? P.t_rt : PT);
+        const int64_t r0 = (int64_t)tile * (TAIL ? P.t_rt : PT);
         const int64_t n_rows = P.n_dev ? min(P.n, (int64_t)*P.n_dev) : P.n;          // sphere tracing: the active-ray count lives on the device
         if (r0 >= n_rows) return;
         if (P.n_dev && P.n_dev_hi > 0 && (*P.n_dev < P.n_dev_lo || *P.n_dev >= P.n_dev_hi)) return;
@@ -269,7 +287,11 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     const int KMAX = TAIL ? PT / RT : 1;                // most samples per ray and pass the tile has rows for
     // samples per ray of the pass with index s: the schedule, a function of s alone (clipped to what the tile can carry: the host picks t_rt so
     // that it never clips)
-    auto pass_k = [&](int s) { return min(KMAX, s >= P.t_spec_from2 ? P.t_spec_k2 : (s >= P.t_spec_from ? P.t_spec_k : 1)); };
+    auto pass_k = [&](int s) {
+        int k = 1;
+        for (int i = 0; i < P.t_nlv; ++i) k = (s >= P.t_lv_from[i]) ? P.t_lv_k[i] : k;
+        return min(KMAX, k);
+    };
     int t_gp = 0, t_left = 0, t_pass = 0;
     bool t_act = false;
     float4 t_st = make_float4(0.f, 0.f, 1.f, 0.f);
@@ -295,7 +317,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     if constexpr (TAIL) {
         t_left = min(P.t_steps, P.t_stage);
         if (tid < RT) {
-            const int64_t s = (int64_t)blockIdx.x * RT + (tid < n_valid ? tid : 0);        // lanes beyond the tile's rays mirror ray 0 (finite rows), inactive
+            const int64_t s = (int64_t)tile * RT + (tid < n_valid ? tid : 0);              // lanes beyond the tile's rays mirror ray 0 (finite rows), inactive
             t_gp = P.t_pix[s];
             t_st = P.t_lam[s];
             t_farl = P.t_far[t_gp];
@@ -829,7 +851,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                         P.t_hit_sdf[t_gp] = vj;
                         t_act = false;
                     } else {
-                        const float qn = (prev > 0.f) ? fminf(fmaxf(rj / prev, 0.5f), 1.f) : 1.f;
+                        const float qn = (prev > 0.f) ? fminf(fmaxf(rj / prev, 0.5f), P.t_qmax) : 1.f;
                         const float l2 = pj + vj / t_idn;
                         t_st.y = rj; t_st.z = qn;
                         if ((l2 < t_farl) && (vj == vj)) t_st.x = l2;
@@ -881,7 +903,8 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                 }
             }
         }
-        return;
+        if (!P.t_tile_ctr) return;                         // (one tile per workgroup: launches without a tile counter)
+        continue;                                          // the pool's next tile
     }
     if constexpr (JAC) {
     __syncthreads();
@@ -1114,6 +1137,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         }
     }
     }   // JAC
+    } while (TAIL);
 }
 
 

@@ -15,7 +15,6 @@
 #include "mlp_kernel.h"
 #include <float.h>
 
-#define SDFR_TRACE_COUNTERS 8
 struct TraceRay { float ox, oy, oz, dx, dy, dz; };
 
 // Image extents of the crops of a launch.  Dense: every crop W x H pixels, pixel slot PS = W H, cone slots ncap = its cone count.  Ragged (r04;
@@ -46,10 +45,10 @@ __device__ __forceinline__ TraceRay trace_ray(const float* __restrict__ P, const
 // One plain sample of a ray: st = (lam, rho, q, -), v = decoder value at lam, dn = |d|.  Returns 1 hit (st.x = the hit's lam), 0 keep marching
 // (st advanced), -1 miss (past the cube's far side, or NaN).  The K = 1 case of the march's step rule (oracle/sdf_oracle.py::sphere_trace);
 // the looping tail of the decoder kernel (mlp_kernel.h MODE 4) applies the same rule to the accepted prefix of its K samples.
-__device__ __forceinline__ int trace_advance(float4& st, float v, float dn, float eps, float far) {
+__device__ __forceinline__ int trace_advance(float4& st, float v, float dn, float eps, float far, float qmax) {
     const float r = fabsf(v);
     if (r < eps) return 1;
-    const float q = (st.y > 0.f) ? fminf(fmaxf(r / st.y, 0.5f), 1.f) : 1.f;
+    const float q = (st.y > 0.f) ? fminf(fmaxf(r / st.y, 0.5f), qmax) : 1.f;
     const float l2 = st.x + v / dn;
     st.y = r;
     st.z = q;
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(256) void sdfr_trace_step_kernel(const float* __res
                                                              int32_t* __restrict__ pix_out, float4* __restrict__ lam_out,
                                                              const float* __restrict__ far, float* __restrict__ inputs,
                                                              float* __restrict__ hit_lam, float* __restrict__ hit_sdf, int min_count,
-                                                             unsigned long long* __restrict__ evals) {
+                                                             unsigned long long* __restrict__ evals, float qmax) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     const int n = *n_cur;
     if (s == 0) *n_zero = 0;                     // the counter of the step after next (three counters rotate)
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(256) void sdfr_trace_step_kernel(const float* __res
         r = trace_ray(pose + (int64_t)b * 16, Kinv + (int64_t)b * 9, (float)(p % W), (float)(p / W));
         const float v = sdf[s];
         st = lam_in[s];
-        const int what = trace_advance(st, v, sqrtf(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz), eps, far[gp]);
+        const int what = trace_advance(st, v, sqrtf(r.dx * r.dx + r.dy * r.dy + r.dz * r.dz), eps, far[gp], qmax);
         if (what == 1) {                         // on the surface: retire as a hit
             hit_lam[gp] = st.x;
             hit_sdf[gp] = v;
@@ -683,7 +682,7 @@ extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float
     hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, pose, Kinv, latn, L,
                        dense_dims(W, H, 0), eps, sdf, counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, pix_in,
                        reinterpret_cast<const float4*>(lam_in), pix_out, reinterpret_cast<float4*>(lam_out), far, inputs, hit_lam, hit_sdf, 0,
-                       (unsigned long long*)nullptr);
+                       (unsigned long long*)nullptr, 1.f);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -697,43 +696,48 @@ extern "C" int sdfr_trace_step(const float* pose, const float* Kinv, const float
 // itself -- ONE launch of the decoder kernel in MODE 4 takes the remaining rays to termination: the workgroup loops over decoder pass ->
 // step rule -> hit / exit test for its 16 rays with the ray state in registers (no per-step launch, no compaction, no host read).  The gate
 // is evaluated on the device in every step of the head; after `head_steps` steps an unconditional tail launch takes whatever is left.
-// Speculative passes (spec_k = 4): from pass index spec_from on a pass evaluates FOUR samples per ray (64 operand rows per tile -- a 64-row
-// pass of the half kernel costs what a 16-row pass costs: both are paced by the weight stream through the CU) and accepts the prefix that
-// stays inside the previous samples' safe spheres; the rays creeping along a face at grazing incidence, which keep a march alive for dozens
-// of steps, advance four samples per pass.  The pass index alone decides (head_steps is clamped to spec_from), so a ray's sample sequence
-// does not depend on the launch schedule.
-// Second level (spec_k2 = 8 or 16 from pass spec_from2 > spec_from on; off with spec_k2 <= spec_k): what keeps the looping kernel alive is a few
-// hundred creeping rays scattered over the tiles -- the chip idles while each of them pays ~55 us per pass -- so at pass spec_from2 the first
-// stage ends, its survivors are appended to a third list (pix2 / lam2, counters[7]) and a second launch marches them 64 / spec_k2 to a tile
-// with spec_k2 samples per pass: the 256x256 bench crop ends at pass 21 instead of 31 for 3 % more decoder evaluations.
-// tail_rows_buf: scratch float[tiles][16 spec_k][L + 3], tiles = ceil(n / 16), or ceil(n spec_k2 / 64) with the second level.
+// Speculative passes: `levels` (host array int32[n_levels][2] = first pass index, samples per ray and pass; both ascending; samples 4, 8, 16, 32
+// or 64) is the march's schedule -- from pass index levels[i][0] on a pass evaluates levels[i][1] samples per ray (p_0 = lam, p_j = p_{j-1} +
+// sigma q^j rho / |d|, q = ratio of the ray's last two radii clamped to [0.5, q_max]) and accepts the prefix that stays inside the previous
+// samples' safe spheres.  A 64-row pass of the looping kernel costs what a 16-row pass costs (both are paced by the weight stream through the
+// CU), so the rows a tile carries are spent on ever fewer rays: 64 / k rays per tile at level k.  What keeps a march alive are the rays that
+// creep along the surface at grazing incidence and MISS (256x256 bench crop: every hit is found by pass 10, the last miss leaves the cube in
+// pass 15), and they advance k samples per pass.  The pass index alone decides (head_steps is clamped to the first level's pass), so a ray's
+// sample sequence does not depend on the launch schedule or on the batch.
+// Every level is one launch of the looping kernel (a STAGE): a pool of persistent workgroups fetches tiles from the stage's device counter
+// (counters[16 + stage]), marches each through the stage's passes and appends the survivors to the next stage's list (counters[7 + stage];
+// lists: pix2 / lam2 and pix0 / lam0 in turn -- the head's lists are free by then).  r04: up to SDFR_TRACE_LEVELS levels (r03: two, fixed
+// tiles-per-ray grids and a scratch tile per ray tile).
+// tail_rows_buf: scratch float[SDFR_TRACE_POOL][64][L + 3] (one tile of operand rows per pool workgroup).
+#define SDFR_TRACE_POOL 1024
+extern "C" int sdfr_trace_pool(void) { return SDFR_TRACE_POOL; }
 static int trace_march_impl(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, const TraceDims& D,
-                            float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2,
+                            float eps, int steps, int head_steps, int tail_rows, const int32_t* levels, int n_levels, float q_max,
                             float sigma, int half, int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_,
                             int32_t* pix2, float* lam2_, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
                             float* hit_sdf, void* stream);
 extern "C" int sdfr_trace_march(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, int W, int H,
-                                float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2,
+                                float eps, int steps, int head_steps, int tail_rows, const int32_t* levels, int n_levels, float q_max,
                                 float sigma, int half, int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_,
                                 int32_t* pix2, float* lam2_, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
                                 float* hit_sdf, void* stream) {
     SDFR_REQUIRE(W > 0 && H > 0, "sdfr_trace_march: bad size");
-    return trace_march_impl(d, pose, Kinv, latn, L, B, dense_dims(W, H, 0), eps, steps, head_steps, tail_rows, spec_from, spec_k, spec_from2, spec_k2, sigma,
+    return trace_march_impl(d, pose, Kinv, latn, L, B, dense_dims(W, H, 0), eps, steps, head_steps, tail_rows, levels, n_levels, q_max, sigma,
                             half, counters, pix0, lam0_, pix1, lam1_, pix2, lam2_, far, inputs, sdf, tail_rows_buf, hit_lam, hit_sdf, stream);
 }
 extern "C" int sdfr_trace_march_r(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, const sdfr_extents* ext,
-                                  float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2,
+                                  float eps, int steps, int head_steps, int tail_rows, const int32_t* levels, int n_levels, float q_max,
                                   float sigma, int half, int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_,
                                   int32_t* pix2, float* lam2_, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
                                   float* hit_sdf, void* stream) {
     TraceDims D;
     int rc = ragged_dims(D, ext, "sdfr_trace_march_r");
     if (rc) return rc;
-    return trace_march_impl(d, pose, Kinv, latn, L, B, D, eps, steps, head_steps, tail_rows, spec_from, spec_k, spec_from2, spec_k2, sigma, half, counters,
+    return trace_march_impl(d, pose, Kinv, latn, L, B, D, eps, steps, head_steps, tail_rows, levels, n_levels, q_max, sigma, half, counters,
                             pix0, lam0_, pix1, lam1_, pix2, lam2_, far, inputs, sdf, tail_rows_buf, hit_lam, hit_sdf, stream);
 }
 static int trace_march_impl(const sdfr_decoder* d, const float* pose, const float* Kinv, const float* latn, int L, int B, const TraceDims& D,
-                            float eps, int steps, int head_steps, int tail_rows, int spec_from, int spec_k, int spec_from2, int spec_k2,
+                            float eps, int steps, int head_steps, int tail_rows, const int32_t* levels, int n_levels, float q_max,
                             float sigma, int half, int32_t* counters, int32_t* pix0, float* lam0_, int32_t* pix1, float* lam1_,
                             int32_t* pix2, float* lam2_, const float* far, float* inputs, float* sdf, float* tail_rows_buf, float* hit_lam,
                             float* hit_sdf, void* stream) {
@@ -743,7 +747,15 @@ static int trace_march_impl(const sdfr_decoder* d, const float* pose, const floa
     float4* lam1 = reinterpret_cast<float4*>(lam1_);
     float4* lam2 = reinterpret_cast<float4*>(lam2_);
     SDFR_REQUIRE(B > 0 && steps > 0 && head_steps >= 0 && tail_rows >= 0, "sdfr_trace_march: bad size");
-    SDFR_REQUIRE(spec_k == 1 || spec_k == 4, "sdfr_trace_march: spec_k = %d (1: plain tracing, 4: four samples per ray and pass)", spec_k);
+    SDFR_REQUIRE(n_levels >= 0 && n_levels <= SDFR_TRACE_LEVELS && (n_levels == 0 || levels), "sdfr_trace_march: 0 ... %d speculation levels",
+                 SDFR_TRACE_LEVELS);
+    SDFR_REQUIRE(q_max >= 1.f && q_max <= 4.f, "sdfr_trace_march: q_max = %g (1 ... 4)", (double)q_max);
+    for (int i = 0; i < n_levels; ++i) {
+        const int k = levels[2 * i + 1];
+        SDFR_REQUIRE(k == 4 || k == 8 || k == 16 || k == 32 || k == 64, "sdfr_trace_march: level %d takes %d samples per pass (4, 8, 16, 32 or 64)", i, k);
+        SDFR_REQUIRE(levels[2 * i] >= 0 && (i == 0 || (levels[2 * i] > levels[2 * i - 2] && k > levels[2 * i - 1])),
+                     "sdfr_trace_march: levels must ascend in pass index and in samples");
+    }
     SDFR_REQUIRE(d->n_inputs == L + 3, "sdfr_trace_march: decoder with L + 3 = %d inputs expected, it has %d", L + 3, d->n_inputs);
     const int64_t n_max = (int64_t)B * D.PS;
     SDFR_REQUIRE(n_max < (int64_t)1 << 31, "sdfr_trace_march: too many rays");
@@ -751,7 +763,7 @@ static int trace_march_impl(const sdfr_decoder* d, const float* pose, const floa
     if (d->HP != 512 || d->has_ln) {
         // LayerNorm decoders and hidden widths below 257: the looping kernel (MODE 4) is built for the 512-wide weight-norm / plain decoders
         // only; these march with per-step launches of their own forward kernels (device-side count, float32, plain sphere tracing -- the
-        // oracle's arithmetic with spec_k = 1), all `steps` of them: correct, not tuned
+        // oracle's arithmetic without speculation), all `steps` of them: correct, not tuned
         SDFR_REQUIRE(!half, "sdfr_trace_march: half operands need a 512-wide decoder without LayerNorm");
         unsigned long long* evals_ = reinterpret_cast<unsigned long long*>(counters + 4);
         for (int step = 0; step < steps; ++step) {
@@ -761,44 +773,44 @@ static int trace_march_impl(const sdfr_decoder* d, const float* pose, const floa
             hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, D, eps, sdf,
                                counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? pix1 : pix0,
                                a ? reinterpret_cast<float4*>(lam1_) : reinterpret_cast<float4*>(lam0_), a ? pix0 : pix1,
-                               a ? reinterpret_cast<float4*>(lam0_) : reinterpret_cast<float4*>(lam1_), far, inputs, hit_lam, hit_sdf, 1, evals_);
+                               a ? reinterpret_cast<float4*>(lam0_) : reinterpret_cast<float4*>(lam1_), far, inputs, hit_lam, hit_sdf, 1, evals_, q_max);
         }
         hipLaunchKernelGGL(sdfr_trace_leftover_kernel, dim3(1), dim3(64), 0, s, counters + steps % 3, counters + 3);
         SDFR_LAUNCH_CHECK();
         return SDFR_OK;
     }
-    if (spec_k == 1) spec_from = 0x7fffffff;
-    if (spec_from < 0) spec_from = 0;
-    // second speculation level (spec_k2 = 8 or 16 samples per pass from pass spec_from2 >= spec_from on): a second stage of the looping kernel
-    // with 64 / spec_k2 rays per tile takes over the rays that are still marching then.  Off: spec_k2 <= spec_k.
-    const bool two = spec_k > 1 && spec_k2 > spec_k && spec_from2 < steps;
-    if (two) {
-        SDFR_REQUIRE(spec_k2 == 8 || spec_k2 == 16, "sdfr_trace_march: spec_k2 = %d (8 or 16 samples per ray and pass, or <= spec_k: off)", spec_k2);
-        SDFR_REQUIRE(pix2 && lam2, "sdfr_trace_march: the second speculation level needs its ray list (pix2, lam2)");
-        SDFR_REQUIRE(spec_from2 > spec_from, "sdfr_trace_march: spec_from2 = %d must lie behind spec_from = %d", spec_from2, spec_from);
-    } else { spec_from2 = 0x7fffffff; spec_k2 = spec_k; }
+    // levels that start inside the step budget
+    int nlv = 0;
+    while (nlv < n_levels && levels[2 * nlv] < steps) ++nlv;
+    const int spec_from = nlv > 0 ? levels[0] : 0x7fffffff;
+    const int spec_k = nlv > 0 ? 4 : 1;                          // which looping kernel: 64-row tiles (speculative schedules) or 16-row tiles (plain)
+    SDFR_REQUIRE(nlv <= 1 || (pix2 && lam2), "sdfr_trace_march: more than one speculation level needs the hand-over list (pix2, lam2)");
     if (head_steps > steps) head_steps = steps;
     if (head_steps > spec_from) head_steps = spec_from;          // speculative passes exist in the looping kernel only
     unsigned long long* evals = reinterpret_cast<unsigned long long*>(counters + 4);
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.trace = nullptr;
     P.t_far = far; P.t_pose = pose; P.t_Kinv = Kinv; P.t_latn = latn; P.t_hit_lam = hit_lam; P.t_hit_sdf = hit_sdf; P.t_W = D.W; P.t_H = D.H; P.t_wh = D.wh; P.t_PS = D.PS;
-    P.t_eps = eps; P.t_sigma = sigma; P.t_evals = evals; P.t_unresolved = counters + 3;
-    P.t_spec_from = spec_from; P.t_spec_k = spec_k; P.t_spec_from2 = spec_from2; P.t_spec_k2 = spec_k2;
+    P.t_eps = eps; P.t_sigma = sigma; P.t_qmax = q_max; P.t_evals = evals; P.t_unresolved = counters + 3;
+    P.t_nlv = nlv;
+    for (int i = 0; i < SDFR_TRACE_LEVELS; ++i) { P.t_lv_from[i] = i < nlv ? levels[2 * i] : 0x7fffffff; P.t_lv_k[i] = i < nlv ? levels[2 * i + 1] : 1; }
     auto launch_tail = [&](const MlpParams& T) {
-        // (a launch gated to counts below n_dev_hi needs workgroups for that many rays only: an empty 256-workgroup launch is cheaper to skip
-        // than an empty 4096-workgroup one, and the march enqueues one per head step)
+        // (a launch gated to counts below n_dev_hi needs workgroups for that many rays only; beyond SDFR_TRACE_POOL tiles the pool's workgroups
+        // fetch one tile after the other)
         const int64_t n_grid = n_max < (int64_t)T.n_dev_hi ? n_max : (int64_t)T.n_dev_hi;
-        if (half) sdfr_launch_tail_f16_512(T, n_grid, spec_k, s); else sdfr_launch_tail_f32_512(T, n_grid, spec_k, s);
+        const int64_t pool = (int64_t)SDFR_TRACE_POOL * T.t_rt;
+        if (half) sdfr_launch_tail_f16_512(T, n_grid < pool ? n_grid : pool, spec_k, s); else sdfr_launch_tail_f32_512(T, n_grid < pool ? n_grid : pool, spec_k, s);
     };
-    // first stage: 16 rays per tile, from pass `step` (whichever step the device-side count picks) to the end of the budget or to spec_from2
-    auto tail = [&](int step, int hi) {
+    // stage 0: from pass `step` (whichever step the device-side count picks, or the end of the head) to the second level's first pass or the end
+    // of the budget: 64 / levels[0][1] rays per tile (plain schedules: 16 rays on 16 rows)
+    auto stage0 = [&](int step, int hi) {
         MlpParams T = P;
-        T.inputs = tail_rows_buf; T.t_rows = tail_rows_buf; T.t_rt = 16;
+        T.inputs = tail_rows_buf; T.t_rows = tail_rows_buf; T.t_rt = nlv > 0 ? 64 / levels[1] : 16;
         T.n_dev = counters + step % 3; T.n_dev_lo = 1; T.n_dev_hi = hi;
         T.t_pix = (step & 1) ? pix1 : pix0; T.t_lam = (step & 1) ? lam1 : lam0; T.t_steps = steps - step; T.t_step0 = step;
         T.t_stage = T.t_steps; T.t_next_cnt = nullptr; T.t_next_pix = nullptr; T.t_next_lam = nullptr;
-        if (two && step < spec_from2) { T.t_stage = spec_from2 - step; T.t_next_cnt = counters + 7; T.t_next_pix = pix2; T.t_next_lam = lam2; }
+        T.t_tile_ctr = counters + 16;
+        if (nlv > 1 && step < levels[2]) { T.t_stage = levels[2] - step; T.t_next_cnt = counters + 7; T.t_next_pix = pix2; T.t_next_lam = lam2; }
         launch_tail(T);
     };
     for (int step = 0; step < head_steps; ++step) {
@@ -816,21 +828,26 @@ static int trace_march_impl(const sdfr_decoder* d, const float* pose, const floa
             }
             if (n_max >= F.n_dev_lo) sdfr_launch_fwd_f16_512(F, n_max, false, s);
         } else sdfr_launch_fwd_f32_512(F, n_max, false, s);
-        if (tail_rows > 0) tail(step, tail_rows);
+        if (tail_rows > 0) stage0(step, tail_rows);
         const int a = step & 1;
         hipLaunchKernelGGL(sdfr_trace_step_kernel, dim3(sdfr_cdiv(n_max, 256)), dim3(256), 0, s, pose, Kinv, latn, L, D, eps, sdf,
                            counters + step % 3, counters + (step + 1) % 3, counters + (step + 2) % 3, a ? pix1 : pix0, a ? lam1 : lam0,
-                           a ? pix0 : pix1, a ? lam0 : lam1, far, inputs, hit_lam, hit_sdf, tail_rows > 0 ? tail_rows : 1, evals);
+                           a ? pix0 : pix1, a ? lam0 : lam1, far, inputs, hit_lam, hit_sdf, tail_rows > 0 ? tail_rows : 1, evals, q_max);
     }
     if (head_steps < steps) {
-        tail(head_steps, 0x7fffffff);
-        if (two) {
-            // second stage: the survivors of the first (list pix2 / lam2, count in counters[7]), 64 / spec_k2 rays per tile, to the end
+        stage0(head_steps, 0x7fffffff);
+        // stages 1 ...: the survivors of the stage before (count in counters[6 + i]), 64 / k rays per tile, to the next level's first pass or the end
+        for (int i = 1; i < nlv; ++i) {
             MlpParams T = P;
-            T.inputs = tail_rows_buf; T.t_rows = tail_rows_buf; T.t_rt = 64 / spec_k2;
-            T.n_dev = counters + 7; T.n_dev_lo = 1; T.n_dev_hi = 0x7fffffff;
-            T.t_pix = pix2; T.t_lam = lam2; T.t_steps = steps - spec_from2; T.t_step0 = spec_from2;
+            T.inputs = tail_rows_buf; T.t_rows = tail_rows_buf; T.t_rt = 64 / levels[2 * i + 1];
+            T.n_dev = counters + 6 + i; T.n_dev_lo = 1; T.n_dev_hi = 0x7fffffff;
+            T.t_pix = (i & 1) ? pix2 : pix0; T.t_lam = (i & 1) ? lam2 : lam0; T.t_steps = steps - levels[2 * i]; T.t_step0 = levels[2 * i];
             T.t_stage = T.t_steps; T.t_next_cnt = nullptr; T.t_next_pix = nullptr; T.t_next_lam = nullptr;
+            T.t_tile_ctr = counters + 16 + i;
+            if (i + 1 < nlv) {
+                T.t_stage = levels[2 * i + 2] - levels[2 * i]; T.t_next_cnt = counters + 7 + i;
+                T.t_next_pix = (i & 1) ? pix0 : pix2; T.t_next_lam = (i & 1) ? lam0 : lam2;
+            }
             launch_tail(T);
         }
     } else {

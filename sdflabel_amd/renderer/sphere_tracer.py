@@ -29,7 +29,7 @@ import torch
 
 from .. import _lib
 
-_COUNTERS = 8
+_COUNTERS = 32                # include/sdfr.h SDFR_TRACE_COUNTERS
 
 
 class _TraceFn(torch.autograd.Function):
@@ -67,10 +67,25 @@ def default_spec_from(rays_per_crop, half, cone=False):
     return max(4, min(s, 24))
 
 
+def default_spec_levels(rays_per_crop, half, cone=False):
+    """the default speculation schedule [(first pass index, samples per ray and pass), ...] of a crop with `rays_per_crop` pixels: a function of
+    the crop's size only (never of the batch: a crop marches the same alone and inside a batch)"""
+    sf = default_spec_from(rays_per_crop, half, cone)
+    return [(sf, 4), (sf + (4 if (cone and half and rays_per_crop <= 65536) else 3), 16)]
+
+
+def default_q_max():
+    """upper clamp of the radius ratio q that spaces speculative samples (p_j = p_{j-1} + sigma q^j rho / |d|).  1.0 (r03) never guessed growing
+    radii, so the rays that LEAVE the surface -- the grazing misses that end every march -- crept out at their smallest step; 1.5: 5 % fewer
+    evaluations, 5-6 % less time at every size and batch (r04, profiles/r04_notes.md section 8); 2 and 3 measure the same (q rarely exceeds 1.5)"""
+    return 1.5
+
+
 class SphereTracer:
     def __init__(self, decoder, K, resolution_px, batch=1, steps=64, eps=2e-3, bound=1.0, near=1e-3, device="cuda", head_steps=None,
                  tail_rows=4096, spec_from=None, spec_k=None, sigma=0.9, spec_from2=None, spec_k2=None, polish=None,
-                 cone_block=None, cone_steps=None, uniform_tiles=True, points=False, cone_spec_k=None, max_pixels=None, max_side=None):
+                 cone_block=None, cone_steps=None, uniform_tiles=True, points=False, cone_spec_k=None, max_pixels=None, max_side=None,
+                 spec_levels=None, q_max=None):
         """max_pixels / max_side (r04, ragged extents): every crop of the batch its OWN image size (W_b H_b <= max_pixels, sides <= max_side, default
         4 sqrt(max_pixels)) and intrinsics, set with set_extents(); all per-pixel arrays then hold slots of max_pixels pixels per crop ([B, C,
         max_pixels] images: image(b, name) gives the (C, H_b, W_b) view) and the kernels read the extents on the device, so one tracer (and one captured
@@ -119,8 +134,36 @@ class SphereTracer:
                                                                                                       and self.PS <= 65536) else 3)
         if self.spec_k2 <= self.spec_k:
             self.spec_k2 = self.spec_k                                              # off
-        elif self.spec_k2 not in (8, 16) or self.spec_from2 <= self.spec_from:
-            raise ValueError("spec_k2 must be 8 or 16 (or <= spec_k: off), spec_from2 > spec_from")
+        elif self.spec_k2 not in (8, 16, 32, 64) or self.spec_from2 <= self.spec_from:
+            raise ValueError("spec_k2 must be 8, 16, 32 or 64 (or <= spec_k: off), spec_from2 > spec_from")
+        # The schedule the kernels get: levels [(first pass index, samples per ray and pass), ...], both ascending (include/sdfr.h sdfr_trace_march).
+        # spec_levels given: that list.  Otherwise the two levels above -- or, with nothing about the schedule given at all, the default of
+        # default_spec_levels(): four levels that spend the 64 rows of a tile on ever fewer rays (the march ends with a few hundred grazing
+        # MISSES; r04 census in profiles/r04_notes.md section 8).  q_max: upper clamp of the radius ratio that spaces the speculative samples.
+        legacy = spec_from_given or spec_k is not None or spec_k2 is not None or spec_from2 is not None
+        if spec_levels is not None:
+            self.levels = [(int(a), int(b)) for a, b in spec_levels]
+        elif self.spec_k == 1:
+            self.levels = []
+        elif legacy:
+            self.levels = [(self.spec_from, 4)] + ([(self.spec_from2, self.spec_k2)] if self.spec_k2 > self.spec_k else [])
+        else:
+            self.levels = default_spec_levels(self.PS, bool(self.half), cone_on)
+        if self.generic_march:
+            self.levels = []
+        for i, (a, b) in enumerate(self.levels):
+            if b not in (4, 8, 16, 32, 64) or a < 0 or (i and (a <= self.levels[i - 1][0] or b <= self.levels[i - 1][1])):
+                raise ValueError("spec_levels: (first pass, samples) ascending in both, samples 4 / 8 / 16 / 32 / 64")
+        if len(self.levels) > 6:
+            raise ValueError("at most 6 speculation levels")
+        self.q_max = float(q_max) if q_max is not None else (1.0 if (legacy or spec_levels is not None) else default_q_max())
+        if self.levels:                                                             # (reported by bench.py: the first two levels)
+            self.spec_k, self.spec_from = 4, self.levels[0][0]
+            self.spec_from2, self.spec_k2 = (self.levels[1] if len(self.levels) > 1 else (self.spec_from, self.spec_k))
+        else:
+            self.spec_k = self.spec_k2 = 1
+        import numpy as _np
+        self._levels_host = _np.ascontiguousarray(_np.asarray(self.levels, dtype=_np.int32).reshape(-1, 2))      # (kept alive: the C call reads it)
         # the hit pass (decoder value + input Jacobian at the marched points: Newton polish, normals, implicit-function gradients): "exact" =
         # float32 whatever the decoder's precision; "decoder" = in the decoder's own precision -- with a float16 decoder the half forward with
         # ReLU masks + the mask-fed half Jacobian (what the splat path does at float16: 0.1 ms instead of 1.25 ms for 18 k hits; the surface
@@ -179,8 +222,7 @@ class SphereTracer:
         self.counters = i(_COUNTERS)
         self.pix, self.lam = [i(n), i(n), i(n)], [f(n, 4), f(n, 4), f(n, 4)]   # active lists (ping, pong, second tail stage): pixel, ray state (lam, rho, q, -)
         self.far, self.inputs, self.sdf = f(n), f(n, self.NI), f(n)
-        tiles = (n + 15) // 16 if self.spec_k2 == self.spec_k else (n * self.spec_k2 + 63) // 64
-        self.tail_rows_buf = f(tiles, 16 * self.spec_k, self.NI)                   # operand rows of the looping kernel's tiles
+        self.tail_rows_buf = f(int(_lib.lib().sdfr_trace_pool()), 64 if self.levels else 16, self.NI)   # one tile of operand rows per pool workgroup
         if self.cone_block:
             nc = B * self.cone_cap
             self.cone = f(nc)                                                  # per pixel tile: start parameter or -1 (culled)
@@ -242,7 +284,7 @@ class SphereTracer:
                                    P(self.lam[0]), P(self.far), P(self.inputs), P(self.cone) if self.cone_block else None, self.cone_block,
                                    P(self.hit_lam), P(self.hit_sdf), st), "sdfr_trace_setup")
             ck(L.sdfr_trace_march(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, W, H, self.eps, self.steps,
-                                  self.head_steps, self.march_tail_rows, self.spec_from, self.spec_k, self.spec_from2, self.spec_k2, self.sigma,
+                                  self.head_steps, self.march_tail_rows, self._levels_host.ctypes.data, len(self.levels), self.q_max, self.sigma,
                                   self.half, P(self.counters), P(self.pix[0]), P(self.lam[0]), P(self.pix[1]), P(self.lam[1]), P(self.pix[2]),
                                   P(self.lam[2]), P(self.far), P(self.inputs), P(self.sdf),
                                   P(self.tail_rows_buf), P(self.hit_lam), P(self.hit_sdf), st), "sdfr_trace_march")
@@ -286,7 +328,7 @@ class SphereTracer:
                                 P(self.lam[0]), P(self.far), P(self.inputs), P(self.cone) if self.cone_block else None, self.cone_block, P(self.hit_lam),
                                 P(self.hit_sdf), st), "sdfr_trace_setup_r")
         ck(L.sdfr_trace_march_r(self.handle.h, P(self.pose), P(self.Kinv), P(self.latn), self.L, B, E, self.eps, self.steps, self.head_steps,
-                                self.march_tail_rows, self.spec_from, self.spec_k, self.spec_from2, self.spec_k2, self.sigma, self.half, P(self.counters),
+                                self.march_tail_rows, self._levels_host.ctypes.data, len(self.levels), self.q_max, self.sigma, self.half, P(self.counters),
                                 P(self.pix[0]), P(self.lam[0]), P(self.pix[1]), P(self.lam[1]), P(self.pix[2]), P(self.lam[2]), P(self.far), P(self.inputs),
                                 P(self.sdf), P(self.tail_rows_buf), P(self.hit_lam), P(self.hit_sdf), st), "sdfr_trace_march_r")
         if "march" in events:

@@ -104,9 +104,12 @@ def test_march_polish_images_and_gradients_against_the_oracle(dec, oracle_layers
         assert np.abs(got - want).max() < 1e-3 * max(1.0, np.abs(want).max()), (got, want)
 
 
-def test_march_against_the_oracle_on_the_second_decoder():
-    """the ellipsoid fit (curved surface, smooth normals; tools/fit_decoder.py --shape ellipsoid): default schedule with speculative passes,
-    hit set / depth / colour / normals against the oracle on every 2nd pixel"""
+@pytest.mark.parametrize("sched,q_max", [([(12, 4), (15, 16)], 1.0), ([(6, 4), (8, 8), (10, 16), (12, 32), (13, 64)], 1.5), ([(4, 8), (7, 64)], 3.0)])
+def test_march_against_the_oracle_on_the_second_decoder(sched, q_max):
+    """the ellipsoid fit (curved surface, smooth normals; tools/fit_decoder.py --shape ellipsoid): speculative schedules -- the r03 two-level
+    one, five levels up to 64 samples per ray and pass with the radius ratio clamped at 1.5 (r04: every level its own launch of the looping
+    kernel's workgroup pool, survivors handed from list to list), two coarse levels with q_max 3 -- hit set / depth / colour / normals against
+    the oracle marching the SAME schedule, on every 2nd pixel"""
     from sdflabel_amd.fixtures import ASSET_ELLIPSOID
     d, _ = sdflabel_amd.setup_dsdf(ASSET_ELLIPSOID + ".pt", precision=torch.float32)
     d = d.to(DEV)
@@ -114,18 +117,20 @@ def test_march_against_the_oracle_on_the_second_decoder():
     layers = O.decoder_layers_from_state(st, spec)
     H, W = 96, 96
     K = K_for(H, W)
-    tr = sdflabel_amd.SphereTracer(d, K, (W, H), 1, steps=64, device=DEV, spec_from=12, spec_k=4, spec_from2=15, spec_k2=16)
+    tr = sdflabel_amd.SphereTracer(d, K, (W, H), 1, steps=64, device=DEV, spec_levels=sched, q_max=q_max)
+    assert tr.levels == sched and tr.q_max == q_max
     out = tr.render(*_args())
+    assert tr.stats()["unresolved"] == 0
     ys, xs = np.meshgrid(np.arange(0, H, 2), np.arange(0, W, 2), indexing="ij")
     px = np.stack([xs.reshape(-1), ys.reshape(-1)], 1)
     lat = np.asarray(LAT[0], np.float32)
     latn = lat / np.sqrt((lat * lat).sum())
     ref = O.sphere_trace(layers, spec, latn, O.render_pose(YAW[0], TRANS[0]), np.linalg.inv(K).astype(np.float32), px, steps=64,
-                         spec_from=[(12, 4), (15, 16)], cone_block=4, cone_steps=tr.cone_steps, cone_spec_k=tr.cone_spec_k, image_wh=(W, H))
+                         spec_from=sched, q_max=q_max, cone_block=4, cone_steps=tr.cone_steps, cone_spec_k=tr.cone_spec_k, image_wh=(W, H))
     sel = (px[:, 1], px[:, 0])
     hit = N(out["mask"][0, 0])[sel] > 0
     safe = ref["margin"] > 1e-4
-    assert ref["hit"].sum() > 200 and safe.mean() > 0.95
+    assert ref["hit"].sum() > 200 and safe.mean() > 0.9                # (more speculative decisions, more rays with one of them near its threshold)
     assert np.array_equal(hit[safe], ref["hit"][safe])
     good = safe & ref["hit"] & hit & ref["ok"]
     assert good.sum() > 150

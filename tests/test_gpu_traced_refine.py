@@ -14,7 +14,7 @@ import torch
 import sdflabel_amd
 from oracle import sdf_oracle as O
 from sdflabel_amd.fixtures import GT_TRANS, GT_YAW, crop_params, synthetic_targets
-from sdflabel_amd.renderer.sphere_tracer import default_spec_from
+from sdflabel_amd.renderer.sphere_tracer import default_q_max, default_spec_from, default_spec_levels
 from tests._util import ASSET, K_for, fitted_state, gold
 from tests.test_gpu_parity import N
 
@@ -44,8 +44,8 @@ def oracle_layers():
 def _oracle_kw(H, W, half=False, steps=64):
     sf = default_spec_from(H * W, half, True)
     cones = ((W + 3) // 4) * ((H + 3) // 4)
-    return dict(steps=steps, cone_block=4, cone_steps=4 if cones <= 4096 else 10, cone_spec_k=4,
-                spec_from=[(sf, 4), (sf + (4 if (half and H * W <= 65536) else 3), 16)])                                      # the tracer's defaults
+    return dict(steps=steps, cone_block=4, cone_steps=4 if cones <= 4096 else 10, cone_spec_k=4, q_max=default_q_max(),
+                spec_from=default_spec_levels(H * W, half, True))                                                                 # the tracer's defaults
 
 
 def _problem(name):

@@ -169,6 +169,9 @@ def test_sphere_tracer_default_schedule_is_a_function_of_the_crop_size_alone():
     # behind the cone phase (r04 default) the float16 march starts its speculative passes earlier
     assert [default_spec_from(n * n, True, True) for n in (64, 128, 256, 512)] == [3, 4, 6, 8]
     assert [default_spec_from(n * n, False, True) for n in (128, 256)] == [8, 10]
+    from sdflabel_amd.renderer.sphere_tracer import default_q_max, default_spec_levels
+    assert default_spec_levels(256 * 256, True, True) == [(6, 4), (10, 16)] and default_spec_levels(512 * 512, True, True) == [(8, 4), (11, 16)]
+    assert default_spec_levels(256 * 256, False, False) == [(10, 4), (13, 16)] and default_q_max() == 1.5
 
 
 def test_no_memset_nodes_in_the_library():

@@ -517,6 +517,18 @@ def test_sphere_trace_oracle_self_consistency():
         assert dd.max() < 1e-3 and np.quantile(dd, 0.98) < 1e-4
     assert two["n_steps"].max() < one["n_steps"].max() < tr["n_steps"].max()
     assert two["evals"] < 1.2 * tr["evals"]
+    # r04: more levels (up to 64 samples per ray and pass) and a radius ratio that may GROW (q_max > 1: rays leaving the surface are guessed
+    # with growing steps): still the same surface, fewer passes again; the census lists the active rays per pass
+    many = O.sphere_trace(layers, spec, lat, O.render_pose(yaw, t), Kinv, px, spec_from=[(8, 4), (10, 8), (12, 16), (13, 64)], q_max=1.5)
+    grow = O.sphere_trace(layers, spec, lat, O.render_pose(yaw, t), Kinv, px, spec_from=[(10, 4), (14, 16)], q_max=1.5)
+    for sp in (many, grow):
+        assert sp["unresolved"].sum() == 0 and (sp["hit"] != tr["hit"]).sum() <= 3
+        both = sp["hit"] & tr["hit"] & sp["ok"] & tr["ok"]
+        dd = np.abs(sp["depth"] - tr["depth"])[both]
+        assert dd.max() < 1e-3 and np.quantile(dd, 0.98) < 1e-4
+    assert len(grow["active_per_pass"]) <= len(two["active_per_pass"]) and grow["evals"] <= two["evals"]
+    assert many["n_steps"].max() <= two["n_steps"].max() and many["active_per_pass"][0] == two["active_per_pass"][0]
+    assert all(a >= b for a, b in zip(many["active_per_pass"], many["active_per_pass"][1:]))
     # cone marching first (one ray per 4x4 / 8x8 pixel tile): no culled ray is a hit of plain tracing, the same surface, far fewer evaluations
     for block in (4, 8):
         cn = O.sphere_trace(layers, spec, lat, O.render_pose(yaw, t), Kinv, px, cone_block=block, cone_steps=10, image_wh=(W, H))

@@ -35,7 +35,9 @@ for prec in ((torch.float32, torch.float16) if not args.only else ((torch.float1
     d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
     d = d.to(dev)
     macs = d.handle(torch.device(dev)).macs
-    scheds = [dict(spec_k=k) for k in args.spec]                              # the defaults (spec_k 4: second level 16 from spec_from + 4)
+    scheds = [dict(spec_k=k) for k in args.spec]                              # (spec_k given: the r03 two-level schedule, q_max 1)
+    if args.only:
+        scheds = [dict()]                                                      # profiling runs: the tracer's own defaults
     if args.kw:
         import json
         scheds = json.loads(args.kw)

@@ -172,7 +172,9 @@ extern "C" int sdfr_mlp_forward_counted(const sdfr_decoder* d, const float* inpu
         // one product shape whatever the count (half | 2): 128-row tiles while they fill the chip, 64-row tiles of the SAME 32x32x16 products
         // below -- a row's value then has the same bits in every launch, so a crop marches identically alone and inside a batch (the 16-row
         // tiles below use 16x16x32 products, whose summation order differs)
-        const int mid = 64 * 256;
+        // (counts up to and INCLUDING 64 x 256 rows take the 64-row tiles: a launch bound of exactly that many rows -- the cone passes of a
+        // 256x256 crop: 4096 cones x 4 samples -- then needs no 128-row launch at all)
+        const int mid = 64 * 256 + 1;
         P.n_dev_lo = mid; P.n_dev_hi = 0x7fffffff;
         if (n_max >= mid) sdfr_launch_fwd_f16_512(P, n_max, false, s);
         P.n_dev_lo = 0; P.n_dev_hi = mid;

@@ -22,7 +22,7 @@ def _worker(rank, world, port, n_crops, q):
         mine = shard_crops(n_crops, rank, world)
         rows = torch.stack([_crop_result(i) for i in mine]) if mine else torch.zeros((0, 4))
         table = gather_crop_results(rows, n_crops)
-        q.put((rank, mine, table.clone()))
+        q.put((rank, mine, table.numpy().copy()))        # by value: a tensor travels as a file descriptor the exiting worker may close first
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -63,7 +63,7 @@ def test_gather_ranks_gloo(world, n_crops):
     ref = torch.stack([_crop_result(i) for i in range(n_crops)])
     for rank, mine, table in got:
         assert mine == list(range(rank, n_crops, world))
-        assert torch.equal(table, ref)
+        assert torch.equal(torch.from_numpy(table), ref)
 
 
 def test_single_process_passthrough():
@@ -119,7 +119,7 @@ def _sharded_worker(rank, world, port, n_crops, chunk, fail_rank, q):
             table = refine_sharded(rf, _params(n_crops), torch.zeros(1, 3, 4, 4), torch.zeros(5, 3), 7, rank, world)
         except RuntimeError as e:
             err = str(e)
-        q.put((rank, None if table is None else table.clone(), err, len(rf.calls)))
+        q.put((rank, None if table is None else table.numpy().copy(), err, len(rf.calls)))     # (by value, see above)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -140,7 +140,7 @@ def test_refine_sharded_chunks_pads_and_gathers_gloo(world, n_crops, chunk):
         assert p.exitcode == 0
     ref = _expected(n_crops, 7)
     for rank, table, err, calls in got:
-        assert err is None and torch.equal(table, ref), rank
+        assert err is None and torch.equal(torch.from_numpy(table), ref), rank
         mine = len(range(rank, n_crops, world))
         assert calls == (mine + chunk - 1) // chunk
 
@@ -158,7 +158,7 @@ def test_refine_sharded_local_failure_still_joins_the_collective_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got[1][1] is not None and "boom" in got[1][1]
-    t0 = got[0][0]
+    t0 = torch.from_numpy(got[0][0])
     assert got[0][1] is None and torch.equal(t0[0::2], _expected(6, 7)[0::2]) and bool(torch.isnan(t0[1::2]).all())
 
 

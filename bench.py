@@ -626,8 +626,9 @@ def main():
             out.update({"decoder_forward_ms_covers": "f16 grid pass + candidate selection + exact-f32 sdf and Jacobian of the candidates",
                         "candidates": int(b2.ccnt[0]), "prefilter_margin": b2.margin, "f16_pass_max_deviation_at_calibration": b2.f16_error,
                         "guard": b2.prefilter_report(), "candidate_reuse": bool(b2.reuse),
-                        "audited": bool(b2.audit), "audit_note": "every step a rotating 1/16 slice of the NON-candidate rows is evaluated with the exact-f32 "
-                        "decoder too; a band row the half pass never proposed counts a hard violation (r04)" if b2.audit else "audit off (the r03 behaviour): "
+                        "audited": bool(b2.audit), "audit_note": "every step a rotating 1/16 slice of the NON-candidate rows is evaluated a second time, with "
+                        "float32-grade values (the error-compensated split kernel: within 2.4e-7 of the exact-f32 one; decoder.prefilter_audit_arith = 'float32' "
+                        "takes the exact kernel); a band row the half pass never proposed counts a hard violation (r04)" if b2.audit else "audit off (the r03 behaviour): "
                         "the half pass is checked at the candidates only",
                         "lipschitz_latent_calibrated": getattr(b2, "lipschitz", None)})
         else:

@@ -89,6 +89,8 @@ int sdfr_mlp_forward_f16_counted(const sdfr_decoder* dec, const float* inputs, i
  * rounding).  Same replaced interface as sdfr_mlp_forward (deep_sdf_decoder_scale.py:78-107); mask_ws has the layout
  * sdfr_mlp_forward writes (pass mask_from_f16 = 0 to sdfr_mlp_jacobian).  Requires |hidden activation| < 65504. */
 int sdfr_mlp_forward_split(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream);
+/* ... over the first *n_dev rows (device int32, clamped to n_max; rows beyond are not touched): the audit rows of the two-stage evaluation */
+int sdfr_mlp_forward_split_counted(const sdfr_decoder* dec, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf, void* stream);
 /* size (in uint32 words) of the mask workspace for n rows */
 int64_t sdfr_decoder_mask_words(const sdfr_decoder* dec, int64_t n);
 

@@ -76,6 +76,7 @@ _PROTOS = {
     "sdfr_mlp_forward_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "sdfr_mlp_forward_f16_counted": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_mlp_forward_split": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sdfr_mlp_forward_split_counted": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "sdfr_decoder_mask_words": (c_int64, [c_void_p, c_int64]),
     "sdfr_mlp_jacobian": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_int, c_void_p]),

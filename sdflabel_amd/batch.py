@@ -139,6 +139,10 @@ class BatchRenderer:
             # hard violation like the guard's (check_overflow raises).  decoder.prefilter_audit = False turns it off (the r03 behaviour).
             self.audit = bool(getattr(decoder, "prefilter_audit", True))
             self.audit_stride = int(getattr(decoder, "prefilter_audit_stride", 16))
+            # arithmetic of the audit's reference values: "split" (default) = float32-grade values from error-compensated f16 matrix products
+            # (sdfr_mlp_forward_split: within 2.4e-7 of the exact-f32 kernel, 2.5x its speed -- the audit compares against a margin of ~1e-3);
+            # "float32" = the exact-f32 kernel (r04's first version: 6.6 ms of a 21.6 ms step at 64 crops; split: see profiles/r04_notes.md section 9)
+            self.audit_split = str(getattr(decoder, "prefilter_audit_arith", "split")) == "split" and self.handle.hp == 512 and not self.handle.has_ln
             if self.audit:
                 self.audit_cap = B * ((G + self.audit_stride - 1) // self.audit_stride)
                 self.audit_rows, self.audit_src, self.audit_sdf = f(self.audit_cap, NI), i(self.audit_cap), f(self.audit_cap)
@@ -279,8 +283,12 @@ class BatchRenderer:
             if self.audit:
                 ck(L.sdfr_prefilter_audit_select(P(self.inputs), P(self.cslot), G, self.NI, B, self.audit_stride, P(self.audit_phase), P(self.audit_rows),
                                                  P(self.audit_src), P(self.audit_n), self.audit_cap, st), "sdfr_prefilter_audit_select")
-                ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 0, st),
-                   "sdfr_mlp_forward_counted")
+                if self.audit_split:
+                    ck(L.sdfr_mlp_forward_split_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), st),
+                       "sdfr_mlp_forward_split_counted")
+                else:
+                    ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 0, st),
+                       "sdfr_mlp_forward_counted")
                 ck(L.sdfr_prefilter_audit_check(P(self.sdf), P(self.audit_sdf), P(self.audit_src), P(self.audit_n), self.audit_cap, G, B, self.thr,
                                                 P(self.reuse_flag) if self.reuse else None, P(self.audit_dev), P(self.violations), P(self.audit_phase), st),
                    "sdfr_prefilter_audit_check")
@@ -410,6 +418,7 @@ class BatchRenderer:
                "margin": float(self.margin_dev.max())}
         if self.audit:
             rep["audit"] = {"stride": self.audit_stride, "rows_last_step": int(self.audit_n[0]), "steps": int(self.audit_phase[0]),
+                            "reference_values": "float32_split (error-compensated f16 MFMAs)" if self.audit_split else "float32",
                             "max_deviation_at_non_candidates": float(self.audit_dev.max())}
         return rep
 

@@ -258,6 +258,21 @@ extern "C" int sdfr_mlp_forward_split(const sdfr_decoder* d, const float* inputs
     return SDFR_OK;
 }
 
+// ... over the first *n_dev rows only (device count, clamped to n_max): float32-grade values of a row list whose length lives on the device
+// (the audit of the two-stage evaluation, csrc/surface.hip)
+extern "C" int sdfr_mlp_forward_split_counted(const sdfr_decoder* d, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf,
+                                              void* stream) {
+    SDFR_REQUIRE(d && inputs && sdf && n_dev, "sdfr_mlp_forward_split_counted: NULL argument");
+    SDFR_REQUIRE(n_max >= 0 && n_max < (int64_t)1 << 31, "sdfr_mlp_forward_split_counted: n_max=%lld out of range", (long long)n_max);
+    SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_split_counted: built for 512-wide decoders without LayerNorm");
+    if (n_max == 0) return SDFR_OK;
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.n_dev = n_dev; P.n_dev_lo = 0; P.n_dev_hi = 0; P.trace = nullptr;
+    sdfr_launch_fwd_split_512(P, n_max, false, (hipStream_t)stream);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
 extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int64_t rows_per_crop, int B,
                                  const int32_t* idx, int cap, const int32_t* cnt, float* J, float* sdf_sel,
                                  const float* sdf_full, const uint32_t* mask_ws, int mask_from_f16, void* stream) {

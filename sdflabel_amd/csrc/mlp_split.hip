@@ -47,7 +47,9 @@ __global__ __launch_bounds__(64 * NW, 1) void sdfr_mlp_split_kernel(const MlpPar
     const int lp = lane % MS, lg = lane / MS;
     const int NI = P.n_inputs;
     const int64_t r0 = (int64_t)blockIdx.x * PT;
-    const int n_valid = (int)min((int64_t)PT, P.n - r0);
+    const int64_t n_rows = P.n_dev ? min(P.n, (int64_t)*P.n_dev) : P.n;       // (optional device-side row count: sdfr_mlp_forward_split_counted)
+    if (r0 >= n_rows) return;
+    const int n_valid = (int)min((int64_t)PT, n_rows - r0);
     auto row_of = [&](int pt) { return r0 + (pt < n_valid ? pt : 0); };
     auto elem = [&](int k, int pt) { return (((k / KV) * 2) * PT + pt) * KV + (k % KV); };      // hi element; lo is PT * KV further
 

@@ -613,21 +613,23 @@ def test_prefilter_guard_trips_grows_the_margin_and_raises(dec):
     assert br.prefilter_report()["violations"] == 0 and float(br.margin_dev.min()) == pytest.approx(br.margin)
 
 
-@pytest.mark.parametrize("reuse", [False, True])
-def test_prefilter_audit_catches_a_band_row_the_half_pass_misplaced(dec, reuse):
+@pytest.mark.parametrize("reuse,arith", [(False, "split"), (True, "split"), (False, "float32")])
+def test_prefilter_audit_catches_a_band_row_the_half_pass_misplaced(dec, reuse, arith):
     """the guard compares the half pass with the exact values at the CANDIDATES only; a band row that the half pass
     misplaced by more than the margin is never proposed and stays invisible to it.  Plant exactly that -- the half pass's output of one true
     band row of crop 1 overwritten with 0.5 ("far from the surface") -- and the rotating audit of the non-candidate rows (1/16 of the grid
-    per step, exact-f32) must count a hard violation for that crop within 16 steps; check_overflow() then refuses the result.  Crop 0 stays
-    quiet.  Without the audit (decoder.prefilter_audit = False, the r03 behaviour) the row silently drops out of the band."""
+    per step; reference values from the float32-grade split kernel -- the default -- or the exact-f32 kernel) must count a hard violation for
+    that crop within 16 steps; check_overflow() then refuses the result.  Crop 0 stays quiet.  Without the audit (decoder.prefilter_audit =
+    False, the r03 behaviour) the row silently drops out of the band."""
     B, D, H, W = 2, 40, 32, 32
     a = [T(np.array([0.6, -0.4], np.float32)), T(np.array([[0.0, 0.0, 3.5], [0.1, -0.05, 3.2]], np.float32)),
          T(np.array([[0.3, -0.5, 0.8], [-0.2, 0.6, 0.4]], np.float32))]
     outcomes = {}
     for audit in (True, False):
         dp, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter")
-        dp.prefilter_reuse, dp.prefilter_audit = reuse, audit
+        dp.prefilter_reuse, dp.prefilter_audit, dp.prefilter_audit_arith = reuse, audit, arith
         br = sdflabel_amd.BatchRenderer(dp.to(DEV), D, K_for(H, W), (W, H), B, device=DEV)
+        assert not audit or br.audit_split == (arith == "split")
         out = br.forward(*a)
         n1 = int(out["n"][1])
         g = int(br.idx[1, n1 // 2])                                    # a true band row of crop 1 (exact |sdf| < 0.03)

@@ -163,3 +163,64 @@ def test_optimizer_mirror_shares_one_refiner_across_crop_sizes(dec):
     assert np.abs(ends[0] - za["traj"][-1]).max() < 5e-4
     assert np.array_equal(ends[0], ends[2])                                            # the refiner carries nothing over from the crop in between
     OP.clear_refiner_cache()
+
+
+def test_degenerate_extents_in_one_ragged_batch(dec):
+    """edge cases of the extents: a 1x1 crop, one-pixel-wide strips in both directions, a crop that fills the pixel capacity exactly and a tiny odd one,
+    side by side in one batch -- splat path: every image and gradient bit-identical to the same crop rendered alone at its own fixed size; tracer:
+    identical to the same crop alone in a ragged tracer of the same capacity, no hit outside a crop's own pixels; nothing reads or writes out of bounds
+    (the box would fault) and every value is finite."""
+    D = 40
+    sizes = [(1, 1), (1, 64), (64, 1), (64, 64), (3, 5), (7, 2)]                     # (W_b, H_b)
+    B, PS = len(sizes), 64 * 64
+    Ks = []
+    for w, h in sizes:
+        K_ = K_for(max(h, 8), max(w, 8))                                              # a focal length that keeps the object in a tiny crop's view
+        K_[0, 2], K_[1, 2] = w / 2.0, h / 2.0
+        Ks.append(K_)
+    Ks = np.stack(Ks)
+    yaw = T(np.linspace(0.2, 0.9, B).astype(np.float32))
+    trans = T(np.tile(np.array([[0.0, 0.0, 3.5]], np.float32), (B, 1)))
+    lat = T(np.tile(np.array([[0.3, -0.5, 0.8]], np.float32), (B, 1)))
+    br = sdflabel_amd.BatchRenderer(dec, D, Ks[0], sizes[0], B, device=DEV, max_pixels=PS, max_side=64)
+    br.set_extents(sizes, Ks)
+    out = br.forward(yaw, trans, lat)
+    g_img = {k: torch.zeros_like(out[k]) for k in ("color", "mask", "depth", "normals")}
+    for b, (w, h) in enumerate(sizes):
+        for k in g_img:
+            g_img[k][b, :, :w * h] = T(pattern_weights((g_img[k].shape[1], w * h), SALT[k]))
+    g = [t.clone() for t in br.backward(g_color=g_img["color"], g_mask=g_img["mask"], g_depth=g_img["depth"], g_normals=g_img["normals"])]
+    covered = 0
+    for b, (w, h) in enumerate(sizes):
+        one = sdflabel_amd.BatchRenderer(dec, D, Ks[b], (w, h), 1, device=DEV)
+        o1 = one.forward(yaw[b:b + 1], trans[b:b + 1], lat[b:b + 1])
+        for k in g_img:
+            img = br.image(b, k)
+            assert img.shape[1:] == (h, w) and bool(torch.isfinite(img).all()) and torch.equal(o1[k][0], img), (b, k)
+            assert float(out[k][b, :, w * h:].abs().sum()) == 0.0, (b, k)             # nothing beyond the crop's own pixels
+        g1 = one.backward(**{"g_" + k: g_img[k][b:b + 1, :, :w * h].reshape(1, -1, h, w) for k in g_img})
+        for x, y in zip(g1, g):
+            assert bool(torch.isfinite(y[b]).all()) and torch.equal(x[0], y[b]), b
+        covered += int((br.image(b, "mask") > 0).sum())
+    assert covered > 1000                                                             # (the 64x64 crop sees the object; the strips may or may not)
+    # the sphere tracer on the same extents
+    d16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    d16 = d16.to(DEV)
+    tr = sdflabel_amd.SphereTracer(d16, Ks[0], sizes[0], B, device=DEV, max_pixels=PS, max_side=64, points=True)
+    tr.set_extents(sizes, Ks)
+    ot = {k: v.clone() for k, v in tr.render(yaw, trans, lat).items()}
+    gt = [t.clone() for t in tr.backward(g_color=g_img["color"], g_depth=g_img["depth"], g_normals=g_img["normals"])]
+    assert tr.stats()["unresolved"] == 0
+    one = sdflabel_amd.SphereTracer(d16, Ks[0], sizes[0], 1, device=DEV, max_pixels=PS, max_side=64, points=True)
+    for b, (w, h) in enumerate(sizes):
+        one.set_extents([sizes[b]], Ks[b])
+        o1 = one.render(yaw[b:b + 1], trans[b:b + 1], lat[b:b + 1])
+        for k in ("color", "mask", "depth", "normals"):
+            assert bool(torch.isfinite(ot[k][b]).all()) and torch.equal(o1[k][0], ot[k][b]), (b, k)
+            assert float(ot[k][b, :, w * h:].abs().sum()) == 0.0, (b, k)
+        nf = int(ot["nf"][b])
+        assert int(o1["nf"][0]) == nf and torch.equal(o1["xyzf"][0, :nf], ot["xyzf"][b, :nf])       # (rows beyond the count are not written)
+        g1 = one.backward(g_color=g_img["color"][b:b + 1], g_depth=g_img["depth"][b:b + 1], g_normals=g_img["normals"][b:b + 1])
+        for x, y in zip(g1, gt):
+            assert bool(torch.isfinite(y[b]).all()) and torch.equal(x[0], y[b]), b
+    assert int(ot["nf"][3]) > 500

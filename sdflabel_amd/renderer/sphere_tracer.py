@@ -13,9 +13,11 @@ Everything is a HIP kernel behind the C ABI (csrc/trace.hip, csrc/mlp_kernel.h M
   sdfr_trace_setup      pixel rays in object space (o = -R^T t, d = R^T K^-1 [x, y, 1]) clipped against the cube [-1, 1]^3 -> active list
   sdfr_trace_march      while the device-side active count is >= tail_rows: decoder on the active rows (MFMA) + advance / retire / ballot
                         compaction per step; below it ONE launch of the decoder kernel in its looping mode marches the remaining rays to
-                        termination (16-ray tiles, no per-step launch); from pass `spec_from` on with `spec_k` = 4 samples per ray and pass
-                        (accepted while each lies inside the previous one's safe sphere: the creeping grazing rays advance 4 samples a
-                        pass), from pass `spec_from2` on the survivors re-packed 4 to a tile with `spec_k2` = 16 samples per pass
+                        termination (no per-step launch).  Speculation schedule `spec_levels` = [(first pass, samples per ray and pass), ...]
+                        (default two levels: 4 samples from a pass index that depends on the crop size, 16 samples four passes later;
+                        samples are accepted while each lies inside the previous one's safe sphere, spaced by the ray's radius ratio clamped
+                        to [0.5, q_max]): every level is one launch with 64 / samples rays per tile, run by a pool of persistent workgroups;
+                        the survivors of a level are re-packed for the next
   sdfr_trace_hits       hit pixels -> compact rows [latent, x0]
   hit pass              decoder value and input Jacobian at the hits (Newton polish, normals, d sdf / d latent): polish="decoder" in the
                         decoder's precision (float16: sdfr_mlp_forward_f16_counted with ReLU masks + the mask-fed half Jacobian),
@@ -25,6 +27,7 @@ Everything is a HIP kernel behind the C ABI (csrc/trace.hip, csrc/mlp_kernel.h M
                         hit set (silhouette changes carry no gradient, as in the splat path), fixed-order sums; sdfr_params_backward
                         maps them to yaw / trans / latent.
 """
+import numpy as np
 import torch
 
 from .. import _lib
@@ -162,8 +165,7 @@ class SphereTracer:
             self.spec_from2, self.spec_k2 = (self.levels[1] if len(self.levels) > 1 else (self.spec_from, self.spec_k))
         else:
             self.spec_k = self.spec_k2 = 1
-        import numpy as _np
-        self._levels_host = _np.ascontiguousarray(_np.asarray(self.levels, dtype=_np.int32).reshape(-1, 2))      # (kept alive: the C call reads it)
+        self._levels_host = np.ascontiguousarray(np.asarray(self.levels, dtype=np.int32).reshape(-1, 2))      # (kept alive: the C call reads it)
         # the hit pass (decoder value + input Jacobian at the marched points: Newton polish, normals, implicit-function gradients): "exact" =
         # float32 whatever the decoder's precision; "decoder" = in the decoder's own precision -- with a float16 decoder the half forward with
         # ReLU masks + the mask-fed half Jacobian (what the splat path does at float16: 0.1 ms instead of 1.25 ms for 18 k hits; the surface

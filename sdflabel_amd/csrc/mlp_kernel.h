@@ -217,15 +217,25 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     // layers which re-inject input columns (latent_in / xyz_in_all) find them in the operand at a fixed place and no epilogue has to patch
     // them in (the generic per-element injection path cost the one wave that ran it 12 k cycles per layer, everybody else waiting)
     constexpr int KGX = KG + ((HALF && !JAC) ? 4 : 0);
-    __shared__ float4 lds4[KGX * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4 + LN_F4];
-    vec_t* act = reinterpret_cast<vec_t*>(lds4);                  // [KG][PT] 16-byte vectors: act[k/KV][point][k%KV]
+    // Two operand tiles in turn where LDS has the room (half forward modes on tiles of up to 64 rows: 2 x 70 KB): a layer's epilogue writes the
+    // NEXT operand into the other tile, so no wave has to wait until every wave has finished READING the current one -- one barrier per layer
+    // instead of two.  These tiles are the sphere tracer's passes, each a chain of 8 latency-bound layers (r04, profiles/r04_notes.md section 8).
+#ifndef SDFR_ACT_DBUF
+#define SDFR_ACT_DBUF 1
+#endif
+    constexpr bool DBUF = SDFR_ACT_DBUF && HALF && !JAC && !LN && !SAVE && (2 * KGX * PT * 16 <= 144 * 1024);
+    constexpr int ACT4 = (DBUF ? 2 : 1) * KGX * PT;
+    __shared__ float4 lds4[ACT4 + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4 + LN_F4];
+    vec_t* act = reinterpret_cast<vec_t*>(lds4);                  // [KG][PT] 16-byte vectors: act[k/KV][point][k%KV] -- the operand the products read
     ET* act_e = reinterpret_cast<ET*>(lds4);
-    float* red = reinterpret_cast<float*>(lds4 + KGX * PT);        // [NT]
-    int* rows = reinterpret_cast<int*>(lds4 + KGX * PT + NT / 4);  // [PT] source row of each point (128 ints max)
-    float* gy = reinterpret_cast<float*>(lds4 + KGX * PT + NT / 4 + 32);   // [PT] d out / d y_last
-    int* slots = reinterpret_cast<int*>(lds4 + KGX * PT + NT / 4 + 32 + (PT + 3) / 4);   // [PT] J slot or -1
-    uint32_t* masks = reinterpret_cast<uint32_t*>(lds4 + KGX * PT + NT / 4 + 32 + (PT + 3) / 4 * 2);
-    float* lnred = reinterpret_cast<float*>(lds4 + KGX * PT + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4);   // [NW][PT]
+    vec_t* actw = DBUF ? act + KGX * PT : act;                    // ... and the one the epilogue writes (the same without the second tile)
+    ET* actw_e = reinterpret_cast<ET*>(actw);
+    float* red = reinterpret_cast<float*>(lds4 + ACT4);            // [NT]
+    int* rows = reinterpret_cast<int*>(lds4 + ACT4 + NT / 4);      // [PT] source row of each point (128 ints max)
+    float* gy = reinterpret_cast<float*>(lds4 + ACT4 + NT / 4 + 32);   // [PT] d out / d y_last
+    int* slots = reinterpret_cast<int*>(lds4 + ACT4 + NT / 4 + 32 + (PT + 3) / 4);   // [PT] J slot or -1
+    uint32_t* masks = reinterpret_cast<uint32_t*>(lds4 + ACT4 + NT / 4 + 32 + (PT + 3) / 4 * 2);
+    float* lnred = reinterpret_cast<float*>(lds4 + ACT4 + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4);   // [NW][PT]
     float* lnrstd = lnred + NW * PT;                                                                                   // [layers][PT]
 
     const int tid = threadIdx.x;
@@ -364,6 +374,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                 const int pt = e / (4 * KV), k = e - pt * (4 * KV);
                 const float v = (P.kinj && k < NI) ? P.inputs[(int64_t)rows[pt] * NI + k] : 0.f;
                 act_e[((KG + k / KV) * PT + pt) * KV + (k % KV)] = (ET)v;
+                if (DBUF) actw_e[((KG + k / KV) * PT + pt) * KV + (k % KV)] = (ET)v;       // (the tile's input rows sit behind BOTH operand tiles)
             }
         }
     };
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         for (int f = 0; f < FT; ++f)
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) b4s[f][rg] = *reinterpret_cast<const float4*>(bias + feat0(f, rg));
-        __syncthreads();                                  // every wave is done reading act
+        if (!DBUF) __syncthreads();                       // every wave is done reading act (two operand tiles: the epilogue writes the other one)
         SDFR_STAMP(l, 2);
         uint32_t mw[MW];
 #pragma unroll
@@ -693,7 +704,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                                     if (j0 + i >= inj_lo && j0 + i < inj_hi) v[i] = src[j0 + i];
                             }
                         }
-                        store4(act_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV), v);
+                        store4(actw_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV), v);
                     }
                 }
         };
@@ -732,7 +743,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                         hi = __builtin_elementwise_max(hi, z);
                         h16x4 t;
                         t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
-                        *reinterpret_cast<h16x4*>(act_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV)) = t;
+                        *reinterpret_cast<h16x4*>(actw_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV)) = t;
                     }
 #ifdef SDFR_EPI_FENCE
                     __builtin_amdgcn_sched_barrier(0);         // (A/B: one accumulator tile's reads at a time -- 512-register geometries)
@@ -766,6 +777,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         }
         SDFR_STAMP(l, 3);
         __syncthreads();
+        if (DBUF) { vec_t* t_ = act; act = actw; actw = t_; ET* e_ = act_e; act_e = actw_e; actw_e = e_; }       // the next layer reads what this one wrote
         SDFR_STAMP(l, 4);
     }
 

@@ -166,7 +166,7 @@ extern "C" int sdfr_mlp_forward_counted(const sdfr_decoder* d, const float* inpu
     SDFR_REQUIRE(!half || (d->HP == 512 && !d->has_ln), "sdfr_mlp_forward_counted: half operands need a 512-wide decoder without LayerNorm");
     if (n_max == 0) return SDFR_OK;
     MlpParams P = d->proto;
-    P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.n_dev = n_dev; P.trace = nullptr;
+    P.inputs = inputs; P.n = n_max; P.sdf = sdf; P.maskbuf = nullptr; P.n_dev = n_dev; P.trace = g_trace;      // (cycle stamps: trace builds only)
     hipStream_t s = (hipStream_t)stream;
     if (half & 2) {
         // one product shape whatever the count (half | 2): 128-row tiles while they fill the chip, 64-row tiles of the SAME 32x32x16 products

@@ -425,6 +425,33 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #ifndef SDFR_STRAIGHT_KLOOP
 #define SDFR_STRAIGHT_KLOOP 1
 #endif
+#ifndef SDFR_UNROLLED_KLOOP
+#define SDFR_UNROLLED_KLOOP 0
+#endif
+        constexpr int NKT_FULL = HP / KT;                 // K tiles of a full-width layer (32 with half operands, 64 with float32)
+        if (SDFR_UNROLLED_KLOOP && HALF && FULL && nkt == NKT_FULL && NKT_FULL % PF == 0) {
+            // The same loop with a compile-time trip count, fully unrolled: in straight-line code the compiler's s_waitcnt counts are exact for
+            // EVERY stage.  In the rolled loop it merges the wait states over the back edge and drains the weight ring to its newest stage at
+            // the top of every iteration (vmcnt(2) where vmcnt(6) was due with a ring of 4: profiles/r04_notes.md section 10) -- which is why
+            // deeper weight rings never paid before.
+#pragma unroll
+            for (int t = 0; t < NKT_FULL; t += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    if (t + u + PF - 1 < NKT_FULL) load_a(t + u + PF - 1, a[(u + PF - 1) % PF]);
+                    if (t + u + PFB - 1 < NKT_FULL) load_b(t + u + PFB - 1, b[(u + PFB - 1) % PFB]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks = 0; ks < M::NSTEP; ++ks)
+#pragma unroll
+                        for (int f = 0; f < FT; ++f)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) acc[f][p] = M::step(a[u][f], b[u % PFB][p], acc[f][p], ks);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            return;
+        }
         if (SDFR_STRAIGHT_KLOOP && FULL && nkt % PF == 0) {
             // The common case (every 512-wide layer): a K loop WITHOUT branches.  Prefetch indices are clamped instead of guarded (the
             // tail re-reads the last tile into ring slots nobody consumes), so the body is one basic block and the compiler's s_waitcnt

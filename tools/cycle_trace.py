@@ -15,7 +15,12 @@ inp = torch.cat([lat.expand(grid.points.size(0), -1), grid.points.detach()], 1).
 out = torch.empty(inp.shape[0], device=dev)
 L = _lib.lib()
 mws = torch.empty(int(L.sdfr_decoder_mask_words(h, inp.shape[0])), dtype=torch.int32, device=dev)
-fn = {"f16": L.sdfr_mlp_forward_f16, "f32": L.sdfr_mlp_forward, "split": L.sdfr_mlp_forward_split}[which]
+fn = {"f16": L.sdfr_mlp_forward_f16, "f32": L.sdfr_mlp_forward, "split": L.sdfr_mlp_forward_split}.get(which)
+if which == "t64":
+    # the 64-row half forward of the sphere tracer's march (sdfr_mlp_forward_counted, half | 2, on 16 000 rows: one round of 250 tiles)
+    inp = inp[:16000].contiguous()
+    cnt = torch.tensor([16000], dtype=torch.int32, device=dev)
+    fn = lambda h_, i_, n_, o_, m_, s_: L.sdfr_mlp_forward_counted(h_, i_, n_, _lib.ptr(cnt), o_, 3, s_)
 trace = torch.zeros(2 * 16 * 5, dtype=torch.int64, device=dev)
 for _ in range(3):
     _lib.check(fn(h, _lib.ptr(inp), inp.shape[0], _lib.ptr(out), _lib.ptr(mws), _lib.stream_ptr()), "fwd")

@@ -422,3 +422,27 @@ def test_half_hit_pass_tile_geometries_agree():
     assert float(torch.quantile(dj, 0.99)) < 3e-2 * scale and float(dj.median()) < 1e-3 * scale and float(dj.mean()) < 3e-3 * scale and float(dj.max()) < 0.3 * scale, \
         (float(torch.quantile(dj, 0.99)), float(dj.mean()), float(dj.max()), scale)
     assert float((fx[:n_hits] - f64_).abs().max()) < 5e-3
+
+
+def test_half_march_on_every_tile_geometry_renders_the_same_surface():
+    """the float16 march through its other kernels -- plain tracing (spec_k = 1: the looping kernel on 16-row tiles), non-uniform tiles
+    (uniform_tiles=False: 16-row tiles of 16x16x32 products for thin cone passes, count-driven hand-over) -- against the default schedule (64- and
+    128-row tiles of 32x32x16 products): the same hit set up to a few silhouette rays and the same depths to half precision.  (Late r04: the tiles
+    of up to 64 rows keep two operand tiles in LDS -- every geometry of the half forward goes through here.)"""
+    H, W = 96, 128
+    d16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    d16 = d16.to(DEV)
+    ref = sdflabel_amd.SphereTracer(d16, K_for(H, W), (W, H), 1, steps=64, device=DEV)
+    a = {k: v.clone() for k, v in ref.render(*_args()).items()}
+    assert ref.stats()["unresolved"] == 0 and int((a["mask"] > 0).sum()) > 2000
+    for kw in (dict(spec_k=1), dict(uniform_tiles=False), dict(spec_k=1, cone_block=0), dict(spec_levels=[(3, 8), (6, 32)], q_max=2.0)):
+        tr = sdflabel_amd.SphereTracer(d16, K_for(H, W), (W, H), 1, steps=64, device=DEV, **kw)
+        b = tr.render(*_args())
+        assert tr.stats()["unresolved"] <= 2, (kw, tr.stats())
+        flips = a["mask"] != b["mask"]
+        assert int(flips.sum()) <= 6, (kw, int(flips.sum()))
+        both = (a["mask"] > 0) & (b["mask"] > 0)
+        dd = (a["depth"] - b["depth"]).abs()[both]
+        assert float(dd.median()) < 1e-4 and float(torch.quantile(dd, 0.98)) < 5e-3, (kw, float(dd.median()), float(torch.quantile(dd, 0.98)))
+        dc = (a["color"] - b["color"]).abs().amax(1, keepdim=True)[both]
+        assert float(dc.median()) < 1e-4, (kw, float(dc.median()))

@@ -1,0 +1,276 @@
+// Micro-benchmark / prototype (NOT part of libsdfr_hip.so): a chain of NL full-width half layers  y = relu(W x + b), W [512][512] f16,
+// f32 accumulate, evaluated by a REGISTER-RESIDENT kernel -- the design DESIGN.md section 8 (2a) argues for:
+//   * 4 waves per workgroup (one per SIMD, 512 registers each), every wave owns 32 points and ALL 512 features: 16 accumulator tiles of
+//     v_mfma_f32_32x32x16_f16 (256 accumulator registers);
+//   * a point's activations never leave its wave: after bias + ReLU + f32->f16 the accumulator tile of features 32f .. 32f+31 becomes the
+//     B fragments of the next layer's k tiles 2f and 2f+1 by one exchange between lanes p and p+32 (lane (p,g) of a tile holds features
+//     8i + 4g + j; the B fragment of lane (p,g) wants features 8g .. 8g+7 of a 16-feature k tile);
+//   * the weights are the only shared operand: every stage (16 k x 512 features = 16 KiB) is staged ONCE per CU into an LDS ring by
+//     global_load_lds_dwordx4 (each wave a quarter), published by a counted s_waitcnt vmcnt + one s_barrier per stage, and read by all four
+//     waves as A fragments; the ring streams across layer boundaries.
+// No LDS round trip of activations, no barrier between layers.  Checked here against a naive kernel on the first 256 points.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/rr_mlp tools/micro/rr_mlp.hip && /tmp/rr_mlp [points = 512000] [layers = 8]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define HP 512            // layer width (features = k)
+#define KT 16             // k per stage (one 32x32x16 MFMA k tile)
+#define NKT (HP / KT)     // 32 stages per layer
+#define FTILES (HP / 32)  // 16 feature tiles per wave
+#ifndef RING
+#define RING 8            // LDS ring slots of 16 KiB (NKT % RING == 0); RING - 2 stages are in flight while one is consumed
+#endif
+#ifndef INPLACE_A
+#define INPLACE_A 0
+#endif
+#ifndef PERMLANE_SWAP
+#define PERMLANE_SWAP 1
+#endif
+#define STAGE_VEC (2 * HP)  // 16-byte vectors per stage: [lane group g][feature]
+
+// weight image: Wimg[l][t][g][f] = 8 halves W[l][f][16 t + 8 g .. + 7]   (A fragment of lane (f % 32, g) of feature tile f / 32)
+// bias image: [l][HP] float
+
+#ifndef GLDS_ASM
+#define GLDS_ASM 0
+#endif
+__device__ __forceinline__ void glds16(const void* g, void* lds) {
+#if GLDS_ASM
+    // (the builtin makes hipcc drain the LDS read queue -- s_waitcnt lgkmcnt(0) -- at every M0 write that follows a DMA; in asm the wave-uniform
+    // LDS base goes to M0 by hand and the compiler sees neither the DMA nor the M0 write)
+    const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory", "m0");
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+#endif
+}
+
+template <int NL_MAX>
+__global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict__ Wimg, const float* __restrict__ bias, const h16x8* __restrict__ x,
+                                                        h16x8* __restrict__ out, int n_points, int NL) {
+    __shared__ h16x8 ring[RING * STAGE_VEC];              // 64 KiB
+    __shared__ float lbias[NL_MAX * HP];                  // 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31, g = lane >> 5;
+    const int64_t pt = (int64_t)blockIdx.x * 128 + wave * 32 + p;
+    const int total = NL * NKT;                           // stages of the whole chain
+
+    // this wave's quarter of a stage: vectors [wave * 256 + i * 64 + lane], i = 0 .. 3.  Stages beyond the last are clamped to it: the load then
+    // refills a slot nobody reads any more, and the loop body needs no branch (one basic block per layer: the compiler's own waits stay exact)
+    auto issue = [&](int S) {
+#ifdef ABL_NO_DMA
+        if (S >= RING - 1) return;                          // ablation (timing only, wrong results): the ring is filled once and never refilled
+#endif
+        const int Sc = S < total ? S : total - 1;
+        const h16x8* src = Wimg + (int64_t)Sc * STAGE_VEC + wave * 256 + lane;
+        h16x8* dst = ring + (S % RING) * STAGE_VEC + wave * 256;              // wave-uniform base; the hardware adds lane * 16
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(src + i * 64, dst + i * 64);
+    };
+#pragma unroll
+    for (int S = 0; S < RING - 1; ++S) issue(S);
+    for (int e = tid; e < NL * HP; e += 256) lbias[e] = bias[e];
+
+    // layer-0 operand: B fragment of k tile t = x[pt][16 t + 8 g .. + 7]
+    h16x8 B[NKT];
+    const bool live = pt < n_points;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) B[t] = live ? x[pt * (HP / 8) + 2 * t + g] : (h16x8)(h16)0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the x loads; also lands the first RING - 1 stages -- once)
+    __syncthreads();
+
+    const h16x8* lds0 = ring + g * HP + p;
+#if INPLACE_A
+    // (variant, measured slower: 1047 against 1112 TFLOP/s) ONE buffer of a whole stage, refilled in place, the barrier at the stage boundary
+    h16x8 A[FTILES];
+#pragma unroll
+    for (int f = 0; f < FTILES; ++f) A[f] = lds0[f * 32];
+#else
+    // A fragments: two half-stage buffers of 8 feature tiles; half 0 of stage 0 is read here, every later half under the other half's products
+    h16x8 A0[8], A1[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) A0[f] = lds0[f * 32];
+#endif
+
+    for (int l = 0; l < NL; ++l) {
+        f32x16 acc[FTILES];
+#pragma unroll
+        for (int f = 0; f < FTILES; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            const int S = l * NKT + t;
+            const h16x8* slot = lds0 + (t % RING) * STAGE_VEC;                 // (NKT % RING == 0: the slot of a stage depends on t alone)
+            const h16x8* next = lds0 + ((t + 1) % RING) * STAGE_VEC;
+#if INPLACE_A
+            (void)slot;
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING - 3) * 4) : "memory");
+            issue(S + RING - 1);
+#pragma unroll
+            for (int f = 0; f < FTILES; ++f) {
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[f], B[t], acc[f], 0, 0, 0);
+                A[f] = next[f * 32];
+            }
+#pragma unroll
+            for (int f = 0; f < FTILES; ++f) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#else
+            // feature tiles 0 .. 7 of stage S (fragments read during the previous half) while tiles 8 .. 15 are read
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A1[f] = slot[(8 + f) * 32];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[f], B[t], acc[f], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < 8; ++f) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            // stage S + 1 has landed (this wave's quarter: all but the RING - 3 younger stages' loads are done), then everybody's; every wave has
+            // also finished the products of stage S - 1, so that stage's slot is free: refill it with stage S + RING - 1
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING - 3) * 4) : "memory");
+            issue(S + RING - 1);
+            // feature tiles 8 .. 15 of stage S while tiles 0 .. 7 of stage S + 1 are read
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A0[f] = next[f * 32];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) acc[8 + f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[f], B[t], acc[8 + f], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < 8; ++f) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
+#endif
+        }
+        // epilogue in registers: bias + ReLU + pack; accumulator tile f -> B fragments of k tiles 2f, 2f + 1
+        const float* bl = lbias + l * HP;
+#pragma unroll
+        for (int f = 0; f < FTILES; ++f) {
+            uint32_t P[4][2];                               // [i][pair]: features 32 f + 8 i + 4 g + {0,1}, {2,3} as packed halves
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bl + 32 * f + 8 * i + 4 * g);
+                f32x2 lo = {acc[f][4 * i + 0] + b4.x, acc[f][4 * i + 1] + b4.y}, hi = {acc[f][4 * i + 2] + b4.z, acc[f][4 * i + 3] + b4.w};
+                h16x2 l2 = __builtin_convertvector(lo, h16x2), h2 = __builtin_convertvector(hi, h16x2);
+                const h16x2 z = {(h16)0, (h16)0};
+                l2 = __builtin_elementwise_max(l2, z);
+                h2 = __builtin_elementwise_max(h2, z);
+                P[i][0] = *reinterpret_cast<uint32_t*>(&l2);
+                P[i][1] = *reinterpret_cast<uint32_t*>(&h2);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                   // k tile 2 f + h: features 16 h + 8 g .. + 7 = (i = 2h, both groups) for g = 0, (i = 2h + 1, both groups) for g = 1
+                uint32_t w[4];
+#if PERMLANE_SWAP
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    // v_permlane32_swap X, Y: lanes 32..63 of X <-> lanes 0..31 of Y.  With X = (i = 2h) and Y = (i = 2h + 1): afterwards X holds
+                    // features 8g + 0..3 and Y features 8g + 4..7 of the k tile in BOTH lane groups -- the exchange without LDS and without a wait
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 r = __builtin_amdgcn_permlane32_swap(P[2 * h][q], P[2 * h + 1][q], false, false);
+                    w[q] = r[0];
+                    w[2 + q] = r[1];
+                }
+#else
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    // lane (p,0) keeps (i = 2h, g = 0) and needs (i = 2h, g = 1); lane (p,1) keeps (i = 2h + 1, g = 1) and needs (i = 2h + 1, g = 0):
+                    // each sends what the other needs (v_permlane32_swap does the same without the crossbar; ds_bpermute here for clarity)
+                    const uint32_t send = g ? P[2 * h][q] : P[2 * h + 1][q];
+                    const uint32_t recv = (uint32_t)__shfl_xor((int)send, 32, 64);
+                    w[q] = g ? recv : P[2 * h][q];          // features 8 g + 0 .. 3
+                    w[2 + q] = g ? P[2 * h + 1][q] : recv;  // features 8 g + 4 .. 7
+                }
+#endif
+                uint32_t* dst = reinterpret_cast<uint32_t*>(&B[2 * f + h]);
+                dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clamped refills of the last stages: nothing may land in LDS after the workgroup has gone)
+    if (live) {
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) out[pt * (HP / 8) + 2 * t + g] = B[t];
+    }
+}
+
+// naive reference: one thread per (point, feature) and layer
+__global__ void ref_layer(const h16* __restrict__ W, const float* __restrict__ b, const h16* __restrict__ xin, h16* __restrict__ xout, int n) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x, pt = blockIdx.y;
+    if (f >= HP || pt >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < HP; ++k) s += (float)W[(size_t)f * HP + k] * (float)xin[(size_t)pt * HP + k];
+    s += b[f];
+    xout[(size_t)pt * HP + f] = (h16)(s > 0.f ? s : 0.f);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 512000;
+    const int NL = argc > 2 ? atoi(argv[2]) : 8;
+    if (NL < 1 || NL > 8 || n < 256) { printf("layers 1 .. 8, points >= 256\n"); return 1; }
+    std::vector<h16> W((size_t)NL * HP * HP), X((size_t)n * HP);
+    std::vector<float> Bv((size_t)NL * HP);
+    uint32_t s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto& w : W) w = (h16)(rnd() * 0.125f);            // |W x| stays O(1) over 8 layers
+    for (auto& b : Bv) b = rnd() * 0.2f;
+    for (auto& x : X) x = (h16)(rnd() * 2.0f);
+    std::vector<h16> Wimg(W.size());
+    for (int l = 0; l < NL; ++l)
+        for (int t = 0; t < NKT; ++t)
+            for (int g = 0; g < 2; ++g)
+                for (int f = 0; f < HP; ++f)
+                    for (int j = 0; j < 8; ++j)
+                        Wimg[((((size_t)l * NKT + t) * 2 + g) * HP + f) * 8 + j] = W[((size_t)l * HP + f) * HP + 16 * t + 8 * g + j];
+    h16 *dW, *dWimg, *dX, *dOut, *dR0, *dR1;
+    float* dB;
+    CK(hipMalloc(&dW, W.size() * 2)); CK(hipMalloc(&dWimg, W.size() * 2)); CK(hipMalloc(&dX, X.size() * 2)); CK(hipMalloc(&dOut, X.size() * 2));
+    CK(hipMalloc(&dR0, 256 * HP * 2)); CK(hipMalloc(&dR1, 256 * HP * 2)); CK(hipMalloc(&dB, Bv.size() * 4));
+    CK(hipMemcpy(dW, W.data(), W.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dWimg, Wimg.data(), W.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dX, X.data(), X.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, Bv.data(), Bv.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dOut, 0, X.size() * 2));
+    const int grid = (n + 127) / 128;
+    auto launch = [&]() {
+        hipLaunchKernelGGL(rr_mlp_kernel<8>, dim3(grid), dim3(256), 0, 0, (const h16x8*)dWimg, dB, (const h16x8*)dX, (h16x8*)dOut, n, NL);
+    };
+    launch();
+    CK(hipDeviceSynchronize());
+    // reference on the first 256 points
+    CK(hipMemcpy(dR0, dX, 256 * HP * 2, hipMemcpyDeviceToDevice));
+    for (int l = 0; l < NL; ++l) {
+        hipLaunchKernelGGL(ref_layer, dim3(HP / 256, 256), dim3(256), 0, 0, dW + (size_t)l * HP * HP, dB + l * HP, dR0, dR1, 256);
+        std::swap(dR0, dR1);
+    }
+    CK(hipDeviceSynchronize());
+    std::vector<h16> got(256 * HP), want(256 * HP), last((size_t)128 * HP);
+    CK(hipMemcpy(got.data(), dOut, got.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(want.data(), dR0, want.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(last.data(), dOut + (size_t)(n - 128) * HP, last.size() * 2, hipMemcpyDeviceToHost));
+    double maxd = 0, maxv = 0, sum = 0; int nz = 0;
+    for (size_t i = 0; i < got.size(); ++i) {
+        const double a = (double)got[i], b = (double)want[i];
+        maxd = fmax(maxd, fabs(a - b)); maxv = fmax(maxv, fabs(b)); sum += b; nz += b != 0.0;
+    }
+    double lsum = 0; for (auto v : last) lsum += (double)v;
+    printf("check on 256 points x %d features after %d layers: max |rr - naive| = %.4g (max |value| %.4g, %d non-zero, sum %.6g); last 128 points sum %.6g\n",
+           HP, NL, maxd, maxv, nz, sum, lsum);
+    const bool ok = maxd <= 2e-2 * fmax(1.0, maxv) && nz > 1000;
+    printf(ok ? "CHECK OK\n" : "CHECK FAILED\n");
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 5; ++i) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); best = fminf(best, ms / 5);
+    }
+    const double flop = 2.0 * (double)n * NL * HP * HP;
+    printf("%d points, %d layers of 512 x 512: %.4f ms per launch = %.0f TFLOP/s = %.1f %% of 2.5 PFLOP/s  (%.1f us per 64 000 points)\n", n, NL, best,
+           flop / (best * 1e-3) / 1e12, 100.0 * flop / (best * 1e-3) / 2.5e15, best * 1e3 * 64000.0 / n);
+    return ok ? 0 : 2;
+}

@@ -30,6 +30,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef RING
 #define RING 8            // LDS ring slots of 16 KiB (NKT % RING == 0); RING - 2 stages are in flight while one is consumed
 #endif
+#ifndef GLDS_IMM
+#define GLDS_IMM 0
+#endif
 #ifndef INPLACE_A
 #define INPLACE_A 0
 #endif
@@ -75,8 +78,18 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
         const int Sc = S < total ? S : total - 1;
         const h16x8* src = Wimg + (int64_t)Sc * STAGE_VEC + wave * 256 + lane;
         h16x8* dst = ring + (S % RING) * STAGE_VEC + wave * 256;              // wave-uniform base; the hardware adds lane * 16
+#if GLDS_IMM
+        // one M0 value per stage: the instruction's immediate offset moves the global AND the LDS address of the other three quarters-of-a-quarter
+        const __attribute__((address_space(1))) void* gs = (const __attribute__((address_space(1))) void*)src;
+        __attribute__((address_space(3))) void* ls = (__attribute__((address_space(3))) void*)dst;
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 3072, 0);
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(src + i * 64, dst + i * 64);
+#endif
     };
 #pragma unroll
     for (int S = 0; S < RING - 1; ++S) issue(S);

@@ -30,6 +30,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef RING
 #define RING 8            // LDS ring slots of 16 KiB (NKT % RING == 0); RING - 2 stages are in flight while one is consumed
 #endif
+#ifndef DMA_TOP
+#define DMA_TOP 0
+#endif
 #ifndef GLDS_IMM
 #define GLDS_IMM 0
 #endif
@@ -139,6 +142,11 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
 #pragma unroll
             for (int f = 0; f < FTILES; ++f) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
 #else
+#if DMA_TOP
+            // refill at the TOP of the stage, where the compiler's drain of the LDS read queue (it comes with every M0 write after a DMA) only waits
+            // for fragments this half needs anyway: the slot of stage S - 2 is free since the barrier in the middle of stage S - 1
+            issue(S + RING - 2);                            // (S = 0 re-issues the prologue's last stage into its own slot: harmless, and no branch)
+#endif
             // feature tiles 0 .. 7 of stage S (fragments read during the previous half) while tiles 8 .. 15 are read
 #pragma unroll
             for (int f = 0; f < 8; ++f) A1[f] = slot[(8 + f) * 32];
@@ -149,7 +157,9 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
             // stage S + 1 has landed (this wave's quarter: all but the RING - 3 younger stages' loads are done), then everybody's; every wave has
             // also finished the products of stage S - 1, so that stage's slot is free: refill it with stage S + RING - 1
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING - 3) * 4) : "memory");
+#if !DMA_TOP
             issue(S + RING - 1);
+#endif
             // feature tiles 8 .. 15 of stage S while tiles 0 .. 7 of stage S + 1 are read
 #pragma unroll
             for (int f = 0; f < 8; ++f) A0[f] = next[f * 32];

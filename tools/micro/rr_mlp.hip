@@ -30,6 +30,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef RING
 #define RING 8            // LDS ring slots of 16 KiB (NKT % RING == 0); RING - 2 stages are in flight while one is consumed
 #endif
+#ifndef BARRIER_BUILTIN
+#define BARRIER_BUILTIN 0
+#endif
 #ifndef DMA_TOP
 #define DMA_TOP 0
 #endif
@@ -42,7 +45,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef PERMLANE_SWAP
 #define PERMLANE_SWAP 1
 #endif
-#define STAGE_VEC (2 * HP)  // 16-byte vectors per stage: [lane group g][feature]
+#ifndef KSUB
+#define KSUB 1            // k tiles (of 16) per ring stage: one barrier, one DMA batch and one drain of the LDS read queue per KSUB * 512 matrix cycles
+#endif
+#define TILE_VEC (2 * HP)             // 16-byte vectors per k tile: [lane group g][feature]
+#define STAGE_VEC (KSUB * TILE_VEC)   // ... per ring stage
 
 // weight image: Wimg[l][t][g][f] = 8 halves W[l][f][16 t + 8 g .. + 7]   (A fragment of lane (f % 32, g) of feature tile f / 32)
 // bias image: [l][HP] float
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 31, g = lane >> 5;
     const int64_t pt = (int64_t)blockIdx.x * 128 + wave * 32 + p;
-    const int total = NL * NKT;                           // stages of the whole chain
+    const int total = NL * NKT / KSUB;                    // ring stages of the whole chain
 
     // this wave's quarter of a stage: vectors [wave * 256 + i * 64 + lane], i = 0 .. 3.  Stages beyond the last are clamped to it: the load then
     // refills a slot nobody reads any more, and the loop body needs no branch (one basic block per layer: the compiler's own waits stay exact)
@@ -79,8 +86,8 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
         if (S >= RING - 1) return;                          // ablation (timing only, wrong results): the ring is filled once and never refilled
 #endif
         const int Sc = S < total ? S : total - 1;
-        const h16x8* src = Wimg + (int64_t)Sc * STAGE_VEC + wave * 256 + lane;
-        h16x8* dst = ring + (S % RING) * STAGE_VEC + wave * 256;              // wave-uniform base; the hardware adds lane * 16
+        const h16x8* src = Wimg + (int64_t)Sc * STAGE_VEC + wave * (256 * KSUB) + lane;
+        h16x8* dst = ring + (S % RING) * STAGE_VEC + wave * (256 * KSUB);     // wave-uniform base; the hardware adds lane * 16
 #if GLDS_IMM
         // one M0 value per stage: the instruction's immediate offset moves the global AND the LDS address of the other three quarters-of-a-quarter
         const __attribute__((address_space(1))) void* gs = (const __attribute__((address_space(1))) void*)src;
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
         __builtin_amdgcn_global_load_lds(gs, ls, 16, 3072, 0);
 #else
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(src + i * 64, dst + i * 64);
+        for (int i = 0; i < 4 * KSUB; ++i) glds16(src + i * 64, dst + i * 64);
 #endif
     };
 #pragma unroll
@@ -125,11 +132,14 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
         for (int f = 0; f < FTILES; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+        static_assert((NKT / KSUB) % RING == 0 && NKT % KSUB == 0, "the ring slot of a k tile must depend on the tile's index in the layer alone");
+        static_assert(KSUB == 1 || (!INPLACE_A && !DMA_TOP), "the variants exist for one k tile per stage only");
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
-            const int S = l * NKT + t;
-            const h16x8* slot = lds0 + (t % RING) * STAGE_VEC;                 // (NKT % RING == 0: the slot of a stage depends on t alone)
-            const h16x8* next = lds0 + ((t + 1) % RING) * STAGE_VEC;
+            const int S = l * (NKT / KSUB) + t / KSUB;                          // ring stage of k tile t
+            const h16x8* slot = lds0 + ((t / KSUB) % RING) * STAGE_VEC + (t % KSUB) * TILE_VEC;
+            const int tn = (t + 1) % NKT;                                       // (the first k tile of the next layer sits in ring slot 0 again)
+            const h16x8* next = lds0 + ((tn / KSUB) % RING) * STAGE_VEC + (tn % KSUB) * TILE_VEC;
 #if INPLACE_A
             (void)slot;
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING - 3) * 4) : "memory");
@@ -156,11 +166,24 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
             for (int f = 0; f < 8; ++f) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
             // stage S + 1 has landed (this wave's quarter: all but the RING - 3 younger stages' loads are done), then everybody's; every wave has
             // also finished the products of stage S - 1, so that stage's slot is free: refill it with stage S + RING - 1
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING - 3) * 4) : "memory");
-#if !DMA_TOP
-            issue(S + RING - 1);
+            if (t % KSUB == KSUB - 1) {                     // (compile-time: t is an unrolled index) the stage's last k tile: publish the next stage
+#if BARRIER_BUILTIN
+                {   // (variant: the compiler's own builtins instead of inline asm -- it can then count the LDS reads across the barrier)
+                    constexpr int N = (RING - 3) * 4 * KSUB;
+                    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+                    __builtin_amdgcn_s_barrier();
+#if BARRIER_BUILTIN == 1
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // (2: without the fence -- the check decides whether that is safe)
 #endif
-            // feature tiles 8 .. 15 of stage S while tiles 0 .. 7 of stage S + 1 are read
+                }
+#else
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RING - 3) * 4 * KSUB) : "memory");
+#endif
+#if !DMA_TOP
+                issue(S + RING - 1);
+#endif
+            }
+            // feature tiles 8 .. 15 of k tile t while tiles 0 .. 7 of k tile t + 1 are read
 #pragma unroll
             for (int f = 0; f < 8; ++f) A0[f] = next[f * 32];
 #pragma unroll

@@ -68,6 +68,30 @@ __device__ __forceinline__ void glds16(const void* g, void* lds) {
 #endif
 }
 
+#ifndef ASM_KLOOP
+#define ASM_KLOOP 0
+#endif
+#if ASM_KLOOP
+// One half k tile in inline asm: 8 products on fragments u0..u7 (read by the PREVIOUS block) while 8 fragments n0..n7 are read for the NEXT block.
+// The LDS reads are invisible to the compiler, so none of its s_waitcnt lgkmcnt(0) drains appear; the waits are counted by hand: before product f the
+// reads still allowed in flight are u(f+1)..u7 and n0..nf = 8, whatever f (older compiler-issued LDS operations only make the wait stricter: the
+// queue is in order).  OFF = byte offset of the block's first fragment from `ad` (fragments 512 B apart).  s_nop: the hazard recogniser does not see
+// the MFMAs either (accumulator written by v_accvgpr_write before / read by v_accvgpr_read after the block).
+#define RR_STEP(F, OFFB)                                                        \
+    "ds_read_b128 %[n" #F "], %[ad] offset:" #OFFB "\n\t"                      \
+    "s_waitcnt lgkmcnt(8)\n\t"                                                  \
+    "v_mfma_f32_32x32x16_f16 %[c" #F "], %[u" #F "], %[b], %[c" #F "]\n\t"
+#define RR_HALF(ACC, U, N, BFRAG, AD, O0, O1, O2, O3, O4, O5, O6, O7)                                                                  \
+    asm volatile("s_nop 7\n\t" RR_STEP(0, O0) RR_STEP(1, O1) RR_STEP(2, O2) RR_STEP(3, O3) RR_STEP(4, O4) RR_STEP(5, O5) RR_STEP(6, O6) RR_STEP(7, O7) \
+                 "s_nop 7\n\ts_nop 7"                                                                                                    \
+                 : [c0] "+a"(ACC[0]), [c1] "+a"(ACC[1]), [c2] "+a"(ACC[2]), [c3] "+a"(ACC[3]), [c4] "+a"(ACC[4]), [c5] "+a"(ACC[5]),      \
+                   [c6] "+a"(ACC[6]), [c7] "+a"(ACC[7]), [n0] "=&v"(N[0]), [n1] "=&v"(N[1]), [n2] "=&v"(N[2]), [n3] "=&v"(N[3]),          \
+                   [n4] "=&v"(N[4]), [n5] "=&v"(N[5]), [n6] "=&v"(N[6]), [n7] "=&v"(N[7])                                                 \
+                 : [u0] "v"(U[0]), [u1] "v"(U[1]), [u2] "v"(U[2]), [u3] "v"(U[3]), [u4] "v"(U[4]), [u5] "v"(U[5]), [u6] "v"(U[6]),         \
+                   [u7] "v"(U[7]), [b] "v"(BFRAG), [ad] "v"(AD)                                                                           \
+                 : "memory")
+#endif
+
 template <int NL_MAX>
 __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict__ Wimg, const float* __restrict__ bias, const h16x8* __restrict__ x,
                                                         h16x8* __restrict__ out, int n_points, int NL) {
@@ -122,8 +146,17 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
 #else
     // A fragments: two half-stage buffers of 8 feature tiles; half 0 of stage 0 is read here, every later half under the other half's products
     h16x8 A0[8], A1[8];
+#if ASM_KLOOP
+    const uint32_t lds_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(ring + g * HP + p);     // LDS byte address of this lane's fragment column
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:512\n\tds_read_b128 %2, %8 offset:1024\n\tds_read_b128 %3, %8 offset:1536\n\t"
+                 "ds_read_b128 %4, %8 offset:2048\n\tds_read_b128 %5, %8 offset:2560\n\tds_read_b128 %6, %8 offset:3072\n\tds_read_b128 %7, %8 offset:3584"
+                 : "=&v"(A0[0]), "=&v"(A0[1]), "=&v"(A0[2]), "=&v"(A0[3]), "=&v"(A0[4]), "=&v"(A0[5]), "=&v"(A0[6]), "=&v"(A0[7])
+                 : "v"(lds_b)
+                 : "memory");
+#else
 #pragma unroll
     for (int f = 0; f < 8; ++f) A0[f] = lds0[f * 32];
+#endif
 #endif
 
     for (int l = 0; l < NL; ++l) {
@@ -158,12 +191,18 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
             issue(S + RING - 2);                            // (S = 0 re-issues the prologue's last stage into its own slot: harmless, and no branch)
 #endif
             // feature tiles 0 .. 7 of stage S (fragments read during the previous half) while tiles 8 .. 15 are read
+#if ASM_KLOOP
+            const uint32_t ad_cur = lds_b + (uint32_t)((((t / KSUB) % RING) * STAGE_VEC + (t % KSUB) * TILE_VEC) * 16);
+            const uint32_t ad_nxt = lds_b + (uint32_t)((((tn / KSUB) % RING) * STAGE_VEC + (tn % KSUB) * TILE_VEC) * 16);
+            RR_HALF((acc + 0), A0, A1, B[t], ad_cur, 4096, 4608, 5120, 5632, 6144, 6656, 7168, 7680);
+#else
 #pragma unroll
             for (int f = 0; f < 8; ++f) A1[f] = slot[(8 + f) * 32];
 #pragma unroll
             for (int f = 0; f < 8; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[f], B[t], acc[f], 0, 0, 0);
 #pragma unroll
             for (int f = 0; f < 8; ++f) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#endif
             // stage S + 1 has landed (this wave's quarter: all but the RING - 3 younger stages' loads are done), then everybody's; every wave has
             // also finished the products of stage S - 1, so that stage's slot is free: refill it with stage S + RING - 1
             if (t % KSUB == KSUB - 1) {                     // (compile-time: t is an unrolled index) the stage's last k tile: publish the next stage
@@ -184,12 +223,16 @@ __global__ __launch_bounds__(256, 1) void rr_mlp_kernel(const h16x8* __restrict_
 #endif
             }
             // feature tiles 8 .. 15 of k tile t while tiles 0 .. 7 of k tile t + 1 are read
+#if ASM_KLOOP
+            RR_HALF((acc + 8), A1, A0, B[t], ad_nxt, 0, 512, 1024, 1536, 2048, 2560, 3072, 3584);
+#else
 #pragma unroll
             for (int f = 0; f < 8; ++f) A0[f] = next[f * 32];
 #pragma unroll
             for (int f = 0; f < 8; ++f) acc[8 + f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[f], B[t], acc[8 + f], 0, 0, 0);
 #pragma unroll
             for (int f = 0; f < 8; ++f) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
+#endif
 #endif
         }
         // epilogue in registers: bias + ReLU + pack; accumulator tile f -> B fragments of k tiles 2f, 2f + 1

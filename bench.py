@@ -136,13 +136,96 @@ def cpu_baseline():
             "seconds_per_crop_iteration_samples": samples,
             "by_threads": {str(k): {"rays_per_s": v[0], "seconds_per_crop_iteration": v[1]} for k, v in out.items()},
             "host_cores": ncpu,
-            "sample": "1 full crop-iteration (fwd+bwd to yaw/trans/latent) of the bench workload (synthetic crop 0's start, the GPU step's input), all %dx%d rays, D=%d, N=%d surfels, dense "
-                      "N x P formulation as the reference, torch CPU ops + autograd (oracle/torch_cpu_port.py); 1 warm-up + 3 timed "
-                      "iterations on %d threads, value = their median; one more timed iteration on %d threads in by_threads" % (H, W, D, n_surf, t8, t32)}
+            "sample": "one full crop-iteration (fwd+bwd) of the bench workload: all %dx%d rays, D=%d, N=%d surfels, the reference's dense N x P "
+                      "algorithm as torch-CPU ops (oracle/torch_cpu_port.py); median of 3 on %d threads (+1 on %d threads in the extras)" % (H, W, D, n_surf, t8, t32)}
+
+
+# ---- the printed line -------------------------------------------------------------------------------------------------------------------
+# The driver parses the LAST stdout line.  It carries the contract keys and nothing else; every other section of a run lives in
+# bench_extras.json.  tests/test_host_cpu.py pins the key set and the 4 KB bound.
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config", "roofline", "cpu_baseline", "refine", "extras")
+CONFIG_KEYS = ("workload", "crops_per_gpu", "rays_per_crop", "grid_points", "surfels", "front_facing", "march_steps", "parallelism")
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "flops_per_launch", "avg_launch_ms")
+CPU_KEYS = ("value", "unit", "cores", "kind", "host_cores", "sample")
+LINE_MAX_BYTES = 4096
+
+
+# a full-size record (the sections of the r04 run, abridged) for the line tests and --line-check
+CANNED_LINE = {
+    "metric": "rendered rays/sec (fwd+bwd)", "value": 34243950.123456, "unit": "rays/s", "n_gpus": 1, "rccl_ranks": 1, "steps": 250, "warmup": 10,
+    "ms_per_step": 1.9137984, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+    "config": {"workload": "BASELINE configs[1]: one 256x256 crop per GPU, DeepSDF 8x512 on a 40^3 grid, fwd+bwd to yaw/trans/latent", "crops_per_gpu": 1,
+               "rays_per_crop": 65536, "grid_points": 64000, "surfels": 2751, "front_facing": 763, "march_steps": None, "parallelism": "crop-parallel x1"},
+    "roofline": {"kernel": "sdfr_mlp_kernel<float,32,2,2,8,2,1,2> (fused decoder forward)", "bound": "mfma", "achieved": 137.0297, "peak": 157.3,
+                 "unit": "TFLOP/s", "frac": 0.871136, "traffic": 271958400.0, "flops_per_launch": 2.349466e11, "avg_launch_ms": 1.714567,
+                 "timing": "x" * 300, "traffic_source": "y" * 300},
+    "cpu_baseline": {"value": 6137.024, "unit": "rays/s", "cores": 8, "kind": "port", "host_cores": 256, "sample": "z" * 900,
+                     "by_threads": {"8": {}, "32": {}}, "seconds_per_crop_iteration_samples": [10.6, 10.7, 10.8]},
+    "refine_sharded": {"crops_per_s": 9.508298, "total_crops": 1024, "iterations_per_crop": 60, "workload": "w" * 400},
+    "refine_sharded_float16": {"crops_per_s": 71.89664, "total_crops": 1024, "iterations_per_crop": 60},
+    "sphere_trace": {"f16_64_steps": {"note": "n" * 5000}}, "dropin_api": {"launches": {"k": list(range(500))}}, "per_rank_ms_per_step": [1.9] * 8,
+}
+
+
+def _short(v, n):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+
+
+def _num(v):
+    # 7 significant digits are plenty for a printed rate; keeps the line small
+    return float("%.7g" % v) if isinstance(v, float) else v
+
+
+def compact_line(full, extras_path=None):
+    """The one JSON line bench.py prints: the contract keys of `full` (the dict with every section of the run), strings bounded, < 4 KB."""
+    out = {}
+    for k in LINE_KEYS:
+        if k in ("config", "roofline", "cpu_baseline", "refine", "extras"):
+            continue
+        out[k] = _num(full.get(k))
+    cfg = full.get("config") or {}
+    out["config"] = {k: _short(cfg.get(k), 200) for k in CONFIG_KEYS if k in cfg}
+    rf = full.get("roofline") or {}
+    out["roofline"] = {k: _num(_short(rf.get(k), 120)) for k in ROOFLINE_KEYS if k in rf}
+    cb = full.get("cpu_baseline")
+    out["cpu_baseline"] = {k: _num(_short(cb.get(k), 240)) for k in CPU_KEYS if k in cb} if isinstance(cb, dict) else None
+    # the metric's second half ("refine-demo crops/sec"): the sharded 60-iteration refinement, exact f32 and the reference's shipped f16
+    ref = {}
+    for key, name in (("refine_sharded", "f32"), ("refine_sharded_float16", "f16")):
+        sec = full.get(key)
+        if isinstance(sec, dict) and "crops_per_s" in sec:
+            ref[name + "_crops_per_s"] = _num(float(sec["crops_per_s"]))
+            ref["total_crops"] = sec.get("total_crops")
+            ref["iterations_per_crop"] = sec.get("iterations_per_crop")
+    out["refine"] = ref or None
+    out["extras"] = extras_path
+    line = json.dumps(out)
+    if len(line.encode()) >= LINE_MAX_BYTES:
+        raise RuntimeError("bench line of %d bytes: the driver's parser needs < %d" % (len(line.encode()), LINE_MAX_BYTES))
+    return line
+
+
+def write_extras(full, path=None):
+    """Every section of the run as indented JSON next to bench.py (and under gpurun_out/ when that directory exists: it is what a gpurun call
+    merges back).  Returns the repo-relative path written, or None when the directory is read-only (the line is printed regardless)."""
+    path = path or os.path.join(ROOT, "bench_extras.json")
+    written = None
+    for p in (path, os.path.join(ROOT, "gpurun_out", "bench_extras.json")):
+        if p != path and not os.path.isdir(os.path.dirname(p)):
+            continue
+        try:
+            with open(p, "w") as f:
+                json.dump(full, f, indent=1)
+            written = written or os.path.relpath(p, ROOT)
+        except OSError:
+            pass
+    return written
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--extras", default=None, help="where the full record of the run is written (default: bench_extras.json next to bench.py)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=250)
     ap.add_argument("--warmup", type=int, default=10)
@@ -154,6 +237,8 @@ def main():
                     "refinement length, configs/config_refine.ini:15)")
     ap.add_argument("--configs4-crops", type=int, default=256, help="crops of the configs[4]-shaped sharded section (512x512 rays, float16 decoder)")
     ap.add_argument("--no-extras", action="store_true", help="only the headline loop (+ cpu_baseline): skip the informational sections")
+    ap.add_argument("--line-check", action="store_true", help="with --launch-check: print the compact bench line (canned sections, no "
+                    "measurement) instead of the launch report")
     ap.add_argument("--launch-check", action="store_true", help="only bring up the N ranks, all_gather their ranks and print one JSON line "
                     "(plumbing check of the self-launcher; falls back to gloo on a machine without GPUs)")
     args = ap.parse_args()
@@ -212,7 +297,11 @@ def main():
             got = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(got, t)
             ranks = [int(g.item()) for g in got]
-        if rank == 0:
+        if rank == 0 and args.line_check:
+            # the compact line as a real run assembles it, with no measurement in it (value null): what the gloo test parses
+            print(compact_line(dict(CANNED_LINE, n_gpus=world, rccl_ranks=rccl_ranks, value=None, ms_per_step=None, data="none (--line-check)"),
+                               None), flush=True)
+        elif rank == 0:
             print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": rccl_ranks, "backend": backend, "rccl_version": rccl_version,
                               "launcher": launcher, "ranks": ranks, "devices": torch.cuda.device_count() if has_gpu else 0}), flush=True)
         if dist is not None:
@@ -259,6 +348,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # informational sections run in a one-rank job only: under --gpus N > 1 the command is the headline + the configs[3] sharded refinement in
+    # f32 and f16 (the strong-scaling figure), so that an 8-rank run stays well under 300 s
+    extras = (not args.no_extras) and world == 1
 
     def ev_pair():
         return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -272,8 +364,15 @@ def main():
     for i in range(args.steps):
         step()
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local)
     gc.enable()
+    per_rank_ms = [dt_local / args.steps * 1e3]
+    if dist is not None:                       # every rank's own step time (extras file only; the line's ms_per_step is their maximum)
+        t_ = torch.tensor([per_rank_ms[0]], device=dev, dtype=torch.float64)
+        got = [torch.zeros_like(t_) for _ in range(world)]
+        dist.all_gather(got, t_)
+        per_rank_ms = [float(g.item()) for g in got]
     assert not br.overflow()
     n_surf, n_front = int(br.cnt[0]), int(br.fcnt[0])
     loss = br.color[0].sum() + br.mask[0].sum() + br.nimg[0].sum() + br.xyzf[0].sum()
@@ -351,7 +450,7 @@ def main():
         rf.set_crops(p0, nocs_t, [lidar] * CB)               # restart from the initial parameters
         return rf, p0["yaw"].to(dev).clone()
 
-    res, err = timed_section(refine_setup, lambda st: st[0].optimize(iters)) if not args.no_extras else (None, "skipped (--no-extras)")
+    res, err = timed_section(refine_setup, lambda st: st[0].optimize(iters)) if extras else (None, "skipped (--no-extras or world > 1)")
     if res is None:
         refine = {"error": err}
     else:
@@ -378,7 +477,7 @@ def main():
         rf.set_crops(p0, nocs_t, [lidar] * CB)
         return rf, p0["yaw"].to(dev).clone(), p0["trans"].to(dev).clone()
 
-    res, err = timed_section(traced_setup, lambda st: st[0].optimize(iters)) if not args.no_extras else (None, "skipped (--no-extras)")
+    res, err = timed_section(traced_setup, lambda st: st[0].optimize(iters)) if extras else (None, "skipped (--no-extras or world > 1)")
     if res is None:
         refine_traced = {"error": err}
     else:
@@ -454,7 +553,7 @@ def main():
         return res_
 
     varied = None
-    if rank == 0 and CB == 1 and not args.no_extras:
+    if rank == 0 and CB == 1 and extras:
         varied = {}
         for area, render in ((32, "splat"), (256, "splat"), (256, "trace")):
             key = "rendering_area_%d" % area + ("" if render == "splat" else "_traced")
@@ -520,13 +619,14 @@ def main():
         sharded = sharded_section("exact float32 decoder (parity path)", torch.float32, False, H, args.total_crops, wl)
         sharded16 = sharded_section("float16 decoder = the reference's shipped precision (config_refine.ini:19), f32 everything else",
                                     torch.float16, False, H, args.total_crops, wl)
-        sharded_pf = sharded_section("float32_prefilter + candidate reuse: f16 pass proposes, exact f32 on everything consumed, run-time guard",
-                                     "float32_prefilter", True, H, args.total_crops, wl)
-        # ... and the same flow with the sphere tracer as the loop's renderer (float16 decoder; an eighth of the crops: the traced iteration costs
-        # 4x the float16 splat path's)
-        sharded_tr = sharded_section("sphere tracer as the loop's renderer, float16 decoder", torch.float16, False, H, max(world, args.total_crops // 8), wl,
-                                     render="trace")
-        if H == 256 and args.configs4_crops > 0:
+        if world == 1:
+            sharded_pf = sharded_section("float32_prefilter + candidate reuse: f16 pass proposes, exact f32 on everything consumed, run-time guard",
+                                         "float32_prefilter", True, H, args.total_crops, wl)
+            # ... and the same flow with the sphere tracer as the loop's renderer (float16 decoder; an eighth of the crops: the traced iteration
+            # costs 4x the float16 splat path's)
+            sharded_tr = sharded_section("sphere tracer as the loop's renderer, float16 decoder", torch.float16, False, H, max(world, args.total_crops // 8),
+                                         wl, render="trace")
+        if H == 256 and args.configs4_crops > 0 and world == 1:
             sharded_c4 = sharded_section("BASELINE configs[4] shape: 512x512 rays, float16 decoder on the f16 matrix cores", torch.float16, False, 512,
                                          args.configs4_crops, "BASELINE configs[4]: %d crops of %dx%d rays, float16 DeepSDF decoder, sharded crop i -> rank "
                                          "i mod %d, chunks of %d through BatchRefiner, one all_gather")
@@ -552,7 +652,7 @@ def main():
             b2.replay_step()
 
     pose_only = None
-    if not args.no_extras:
+    if extras:
         res, err = timed_section(pose_only_setup, pose_only_run)
         if res is None:
             pose_only = {"error": err}
@@ -567,7 +667,7 @@ def main():
 
     # ---- the splat pair at 64 crops per launch (BASELINE configs[2] shape), for roofline_splat (rank 0 only, a few steps)
     splat64 = None
-    if rank == 0 and CB == 1 and H == 256 and not args.no_extras:
+    if rank == 0 and CB == 1 and H == 256 and extras:
         try:
             b64 = sdflabel_amd.BatchRenderer(dec, D, K_for(H, W), (W, H), 64, device=dev)
             p64 = {k: torch.from_numpy(v).to(dev) for k, v in crop_params(list(range(64))).items()}
@@ -642,13 +742,13 @@ def main():
         return out
 
     f16 = split = prefilter = None
-    if not args.no_extras:
+    if extras:
         f16 = alt_decoder(torch.float16, "f16 decoder / f32 rest")
         split = alt_decoder("float32_split", "f32 results from error-compensated f16 operand pairs (3 f16 MFMAs per product) / f32 rest")
     #   float32_prefilter  a float16 pass over the grid proposes candidates |sdf| < 0.03 + margin; band membership, sdf and Jacobian of the
     #                  band come from the exact-f32 kernels run on the candidates only (decoder_forward_ms spans both passes incl. the Jacobian)
     prefilter_reuse = None
-    if not args.no_extras:
+    if extras:
         prefilter = alt_decoder("float32_prefilter", "exact f32 on the band candidates chosen by an f16 pass over the grid / f32 rest")
         #   ... and with the candidate set reused while the latent has moved less than margin / (4 lip) since the last f16 pass (here the latent
         #   does not move at all between the bench's steps, as under the 3e-5 learning rate of the refinement: the pass runs every 17th step)
@@ -669,7 +769,7 @@ def main():
     # roofline_march: decoder evaluations of the march (counted on the device, speculative samples included) x 2 M FLOP / march time (events around sdfr_trace_march) against the MFMA
     # peak of the march's operand type; step_kernel_hbm: algorithmic bytes of the advance / compaction kernel per ray-step.
     sphere = None
-    if rank == 0 and CB == 1 and not args.no_extras:
+    if rank == 0 and CB == 1 and extras:
         sphere = {}
         # (label, decoder precision, step budget, samples per pass (None: default schedule), hit pass, cone tile (None: default 4; 0: off), crop edge)
         for label, prec, steps, spec_k, polish, cone, size in (
@@ -792,7 +892,7 @@ def main():
         return out
 
     dropin = None
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and extras:
         grid = sdflabel_amd.Grid3D(D, dev)
         renderer = sdflabel_amd.Rasterer(torch.from_numpy(K_for(H, W)), (W, H)).to(dev)
         for _ in range(30):                                  # (host-bound loop: allocator, Python and the clocks settle over the first iterations)
@@ -819,8 +919,8 @@ def main():
             "rccl_version": rccl_version, "launcher": launcher, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: single" if (CB == 1 and H == 256) else ("BASELINE configs[4]-style: %d" % CB if H == 512 else "BASELINE configs[2]-style: %d" % CB)) + " %dx%d crop per GPU, DeepSDF 8x512 decoder on a 40^3 grid, " % (H, W) +
-                                   "fwd+bwd to yaw/trans/latent (BatchRenderer, B=%d), decoder re-evaluated every step" % CB,
+            "config": {"workload": ("BASELINE configs[1]: one" if (CB == 1 and H == 256) else ("BASELINE configs[4]-style: %d" % CB if H == 512 else "BASELINE configs[2]-style: %d" % CB)) +
+                                   " %dx%d crop(s) per GPU, DeepSDF 8x512 on a 40^3 grid, fwd+bwd to yaw/trans/latent, decoder re-evaluated every step" % (H, W),
                        "crops_per_gpu": CB, "rays_per_crop": H * W, "grid_points": G, "surfels": int(n_surf),
                        "front_facing": int(n_front), "march_steps": None, "parallelism": "crop-parallel x%d" % world},
         }
@@ -874,7 +974,11 @@ def main():
         line["prefilter_reuse_decoder"] = prefilter_reuse
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        line["per_rank_ms_per_step"] = per_rank_ms
+        # everything measured goes to bench_extras.json (and one copy under gpurun_out/ when that scratch directory exists); stdout carries
+        # ONE compact line with the contract keys only (a 24 KB line could not be parsed by the driver)
+        extras_path = write_extras(line, args.extras)
+        print(compact_line(line, extras_path), flush=True)
     if dist is not None:
         dist.barrier()                 # rank 0 has rank-0-only sections behind it (sphere tracing, drop-in census): leave together
         dist.destroy_process_group()

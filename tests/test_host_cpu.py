@@ -183,3 +183,55 @@ def test_no_memset_nodes_in_the_library():
     for path in glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")):
         src = "\n".join(l.split("//")[0] for l in open(path).read().splitlines())
         assert "hipMemset" not in src, path
+
+
+# ---- r05: the printed bench line (a 24 KB line could not be parsed by the driver) -----------------------------------------------
+
+def _bench_module():
+    import importlib
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def test_bench_line_is_compact_and_round_trips():
+    import json
+    B = _bench_module()
+    line = B.compact_line(B.CANNED_LINE, "bench_extras.json")
+    assert "\n" not in line and len(line.encode()) < 4096
+    d = json.loads(line)
+    assert d["value"] == pytest.approx(B.CANNED_LINE["value"], rel=1e-6) and d["n_gpus"] == 1 and d["higher_is_better"] is True
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] == pytest.approx(0.871136)
+    assert d["cpu_baseline"]["cores"] == 8 and d["cpu_baseline"]["kind"] == "port" and len(d["cpu_baseline"]["sample"]) <= 240
+    assert d["refine"] == {"f32_crops_per_s": pytest.approx(9.508298), "f16_crops_per_s": pytest.approx(71.89664), "total_crops": 1024,
+                           "iterations_per_crop": 60}
+    assert d["extras"] == "bench_extras.json"
+
+
+def test_bench_line_key_set_is_pinned():
+    """a new section belongs in bench_extras.json, not on the line: adding a top-level key fails here first"""
+    import json
+    B = _bench_module()
+    d = json.loads(B.compact_line(dict(B.CANNED_LINE, a_new_section={"x": 1}), None))
+    assert tuple(d.keys()) == ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "refine", "extras") == B.LINE_KEYS
+    assert set(d["roofline"]) <= set(B.ROOFLINE_KEYS) and set(d["config"]) <= set(B.CONFIG_KEYS) and set(d["cpu_baseline"]) <= set(B.CPU_KEYS)
+    # a multi-rank run has no cpu_baseline (rank 0 at N = 1 only): null, not missing
+    assert json.loads(B.compact_line({k: v for k, v in B.CANNED_LINE.items() if k != "cpu_baseline"}, None))["cpu_baseline"] is None
+
+
+def test_bench_line_refuses_to_grow_past_the_bound():
+    B = _bench_module()
+    fat = dict(B.CANNED_LINE, config=dict(B.CANNED_LINE["config"], **{k: "q" * 199 for k in B.CONFIG_KEYS}),
+               roofline={k: "r" * 119 for k in B.ROOFLINE_KEYS}, cpu_baseline={k: "s" * 239 for k in B.CPU_KEYS}, metric="m" * 3000)
+    with pytest.raises(RuntimeError, match="bench line"):
+        B.compact_line(fat, None)
+
+
+def test_bench_extras_file_holds_every_section(tmp_path):
+    import json
+    B = _bench_module()
+    p = str(tmp_path / "extras.json")
+    B.write_extras(B.CANNED_LINE, p)
+    assert json.load(open(p)).keys() == B.CANNED_LINE.keys()

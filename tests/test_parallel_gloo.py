@@ -189,6 +189,18 @@ def test_bench_self_launches_two_ranks_when_started_without_a_launcher():
     assert line["launcher"].startswith("self")
 
 
+def test_bench_line_of_a_two_rank_job_is_compact_and_carries_the_rank_count():
+    """`--launch-check --line-check`: two gloo ranks, rank 0 prints the line a real run prints (canned sections): parseable, < 4 KB, rccl_ranks 2"""
+    import json
+    r = _bench("--gpus", "2", "--launch-check", "--line-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints, and one line only"
+    assert len(lines[0].encode()) < 4096
+    line = json.loads(lines[0])
+    assert line["rccl_ranks"] == 2 and line["n_gpus"] == 2 and line["metric"].startswith("rendered rays/sec") and "roofline" in line
+
+
 def test_bench_refuses_more_ranks_than_gpus_instead_of_measuring_one():
     if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
         pytest.skip("this node has 8 GPUs")

@@ -34,7 +34,14 @@ extern "C" {
 #define SDFR_TRACE_LEVELS 6     /* most speculation levels of a sphere-tracing march schedule (sdfr_trace_march) */
 #define SDFR_TRACE_COUNTERS 32  /* int32 device counters of a march / a cone march (zeroed by sdfr_trace_setup / sdfr_trace_cone) */
 
+#define SDFR_VERSION 300        /* what sdfr_version() of the library this header belongs to returns; a binding compares the two */
+
+/* ABI version: bumped whenever an exported signature or a buffer size changes (300: the r04 argument lists of sdfr_trace_march /
+ * sdfr_trace_cone and the 32-word SDFR_TRACE_COUNTERS).  A caller built against another header must refuse the library. */
 int sdfr_version(void);
+/* 0 for the product library.  Bit 0: built with SDFR_EXPERIMENT (kernel geometry / option A/B build of tools/ab_variant.sh);
+ * bit 1: a timing-only ablation is compiled in and results are wrong by construction.  Bindings refuse a non-zero value. */
+int sdfr_build_flags(void);
 const char* sdfr_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -9,11 +9,13 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDFR_LIB") or os.path.join(_HERE, "lib", "libsdfr_hip.so")     # SDFR_LIB: A/B builds (tools/ab_build.sh)
 
+ABI_VERSION = 300          # include/sdfr.h SDFR_VERSION
 _lib = None
 
 # name -> (restype, argtypes); mirrors include/sdfr.h one to one
 _PROTOS = {
     "sdfr_version": (c_int, []),
+    "sdfr_build_flags": (c_int, []),
     "sdfr_last_error": (c_char_p, []),
     "sdfr_debug_set_trace": (c_int, [c_void_p]),
     "sdfr_mlp_forward_counted": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
@@ -153,6 +155,13 @@ def lib():
             fn = getattr(h, name)
             fn.restype = res
             fn.argtypes = args
+        if h.sdfr_version() != ABI_VERSION:
+            raise SdfrError("%s reports ABI version %d, this binding is written against %d (include/sdfr.h SDFR_VERSION): rebuild the library"
+                            % (LIB_PATH, h.sdfr_version(), ABI_VERSION))
+        flags = h.sdfr_build_flags()
+        if flags and os.environ.get("SDFR_ALLOW_AB") != "1":
+            raise SdfrError("%s is an experiment build (sdfr_build_flags() = %d%s): the product refuses it; set SDFR_ALLOW_AB=1 for A/B timing runs"
+                            % (LIB_PATH, flags, ", results wrong by construction" if flags & 2 else ""))
         _lib = h
     return _lib
 

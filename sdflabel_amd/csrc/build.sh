@@ -6,8 +6,24 @@ OUT="${SDFR_OUT:-$HERE/../lib}"
 mkdir -p "$OUT" "$HERE/obj"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+# Product builds take NO compile-time options from the environment.  The per-TU define hooks (kernel geometry A/B, timing-only ablations) exist
+# only for tools/ab_variant.sh, which sets SDFR_AB=1: such a library is compiled with -DSDFR_EXPERIMENT, reports it through sdfr_build_flags()
+# and is refused by sdflabel_amd/_lib.py unless SDFR_ALLOW_AB=1.
+if [ "${SDFR_AB:-0}" = "1" ]; then
+  ALLDEFS="$SDFR_FWD_DEFS $SDFR_F16_DEFS $SDFR_SPLIT_DEFS $SDFR_J16_DEFS $SDFR_JAC_DEFS $SDFR_LOSS_DEFS"
+  COMMON="$COMMON -DSDFR_EXPERIMENT=1"
+else
+  for v in SDFR_FWD_DEFS SDFR_F16_DEFS SDFR_SPLIT_DEFS SDFR_J16_DEFS SDFR_JAC_DEFS SDFR_LOSS_DEFS; do
+    [ -n "${!v}" ] && echo "build.sh: ignoring $v (set SDFR_AB=1 for an experiment build)" >&2
+  done
+  SDFR_FWD_DEFS=; SDFR_F16_DEFS=; SDFR_SPLIT_DEFS=; SDFR_J16_DEFS=; SDFR_JAC_DEFS=; SDFR_LOSS_DEFS=; ALLDEFS=
+  if [ -n "$SDFR_OUT$SDFR_LIBNAME" ]; then echo "build.sh: SDFR_OUT / SDFR_LIBNAME need SDFR_AB=1" >&2; exit 2; fi
+fi
+if [ "${SDFR_BUILD_DRYRUN:-0}" = "1" ]; then      # (tests/test_host_cpu.py: what WOULD be passed to the compiler)
+  echo "defs:[$(echo $ALLDEFS $SDFR_FWD_DEFS $SDFR_F16_DEFS $SDFR_SPLIT_DEFS $SDFR_J16_DEFS $SDFR_JAC_DEFS $SDFR_LOSS_DEFS)] common:[$COMMON]"; exit 0
+fi
 # the MLP uses MFMA + explicit fmaf; the geometric kernels keep separate roundings like the reference's ATen ops
-$HIPCC $COMMON -c "$HERE/common.hip"  -o "$HERE/obj/common.o" &
+$HIPCC $COMMON $ALLDEFS -c "$HERE/common.hip"  -o "$HERE/obj/common.o" &
 $HIPCC $COMMON -c "$HERE/mlp.hip"     -o "$HERE/obj/mlp.o" &
 $HIPCC $COMMON $SDFR_FWD_DEFS -c "$HERE/mlp_fwd32.hip" -o "$HERE/obj/mlp_fwd32.o" &
 $HIPCC $COMMON $SDFR_F16_DEFS -c "$HERE/mlp_fwd16.hip" -o "$HERE/obj/mlp_fwd16.o" &

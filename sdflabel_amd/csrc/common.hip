@@ -25,4 +25,19 @@ hipError_t sdfr_zero_async(void* p, size_t bytes, hipStream_t stream) {
 }
 
 extern "C" const char* sdfr_last_error(void) { return g_err; }
-extern "C" int sdfr_version(void) { return 200; }
+// 300: r05 -- sdfr_trace_march / sdfr_trace_cone took their r04 argument lists (levels array, q_max, spec_k, sigma, aux lists) and
+// SDFR_TRACE_COUNTERS grew from 8 to 32 words under version 200; a caller built against that header must not bind this library silently
+extern "C" int sdfr_version(void) { return SDFR_VERSION; }
+
+// bit 0: experiment build (SDFR_EXPERIMENT: some kernel geometry or option differs from the product's); bit 1: a timing-only ablation is
+// compiled in (results are WRONG by construction).  The product library returns 0; sdflabel_amd/_lib.py refuses anything else.
+extern "C" int sdfr_build_flags(void) {
+    int f = 0;
+#ifdef SDFR_EXPERIMENT
+    f |= 1;
+#if defined(SDFR_ABL_NOMFMA) || defined(SDFR_ABL_NOEPI) || defined(SDFR_PIN_WEIGHTS)
+    f |= 2;
+#endif
+#endif
+    return f;
+}

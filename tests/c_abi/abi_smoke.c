@@ -93,6 +93,10 @@ int main(void) {
     if (!(worstJ < 2e-3)) return 1;          /* a ReLU kink inside the 2e-5 stencil would show up here; none with this seed */
     CK(sdfr_decoder_destroy(dec));
     hipFree(dx); hipFree(dy); hipFree(dJ); hipFree(dsel); hipFree(didx);
+    if (sdfr_version() != SDFR_VERSION || sdfr_build_flags() != 0) {     /* what any binding checks before its first call */
+        printf("library version %d / build flags %d, header SDFR_VERSION %d\n", sdfr_version(), sdfr_build_flags(), SDFR_VERSION);
+        return 1;
+    }
     printf("C ABI smoke: OK (library version %d)\n", sdfr_version());
     return 0;
 }

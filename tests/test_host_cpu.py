@@ -235,3 +235,50 @@ def test_bench_extras_file_holds_every_section(tmp_path):
     p = str(tmp_path / "extras.json")
     B.write_extras(B.CANNED_LINE, p)
     assert json.load(open(p)).keys() == B.CANNED_LINE.keys()
+
+
+# ---- r05: the build is locked and the ABI version is checked ------------------------------------------------
+
+def test_in_tree_library_is_a_product_build_of_this_header():
+    h = sdflabel_amd.lib()
+    assert h.sdfr_build_flags() == 0
+    hdr = open(os.path.join(ROOT, "include", "sdfr.h")).read()
+    assert int(re.search(r"#define SDFR_VERSION (\d+)", hdr).group(1)) == h.sdfr_version() == _lib.ABI_VERSION
+
+
+def test_build_script_ignores_define_hooks_unless_asked_for_an_experiment_build():
+    import subprocess
+    sh = os.path.join(ROOT, "sdflabel_amd", "csrc", "build.sh")
+    env = dict(os.environ, SDFR_BUILD_DRYRUN="1", SDFR_F16_DEFS="-DSDFR_ABL_NOMFMA", SDFR_FWD_DEFS="-DSDFR_FWD_PF=3")
+    env.pop("SDFR_AB", None)
+    r = subprocess.run(["bash", sh], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "defs:[]" in r.stdout and "SDFR_EXPERIMENT" not in r.stdout and "ignoring SDFR_F16_DEFS" in r.stderr
+    r = subprocess.run(["bash", sh], capture_output=True, text=True, env=dict(env, SDFR_AB="1"))
+    assert r.returncode == 0 and "-DSDFR_ABL_NOMFMA" in r.stdout and "-DSDFR_EXPERIMENT=1" in r.stdout
+    # a product build cannot be redirected either
+    r = subprocess.run(["bash", sh], capture_output=True, text=True, env=dict(env, SDFR_LIBNAME="libx.so"))
+    assert r.returncode == 2
+
+
+def test_binding_refuses_an_experiment_library_and_a_foreign_abi(monkeypatch):
+    class Fake:
+        def __init__(self, version, flags):
+            self._v, self._f = version, flags
+
+        def __getattr__(self, name):
+            if name == "sdfr_version":
+                return lambda: self._v
+            if name == "sdfr_build_flags":
+                return lambda: self._f
+            return type("F", (), {"restype": None, "argtypes": None})()
+
+    import ctypes
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(ctypes, "CDLL", lambda p: Fake(_lib.ABI_VERSION, 1))
+    monkeypatch.delenv("SDFR_ALLOW_AB", raising=False)
+    with pytest.raises(_lib.SdfrError, match="experiment build"):
+        _lib.lib()
+    monkeypatch.setattr(ctypes, "CDLL", lambda p: Fake(200, 0))
+    with pytest.raises(_lib.SdfrError, match="ABI version 200"):
+        _lib.lib()
+    monkeypatch.setattr(_lib, "_lib", None)

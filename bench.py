@@ -577,6 +577,7 @@ def main():
             if precision is not torch.float32:
                 d2, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)
                 d2.prefilter_reuse = reuse
+                d2.candidate_reuse = reuse                     # (float16 mode: candidate rows only while the proven bound holds, r05)
                 d2 = d2.to(dev)
             rf = sdflabel_amd.BatchRefiner(d2, D, Kc, (size, size), chunk, lidar_cap=4096, device=dev, render=render)
             nocs1, lidar = synthetic_targets(dec, D, Kc, size, size, dev)      # targets from the exact-f32 rendering of the ground truth, all modes
@@ -606,19 +607,26 @@ def main():
                "gathered_table_ok": ok, "scaling": "strong (total crops fixed): speed-up at N ranks = seconds(N=1) / seconds(N)"}
         if render != "splat":
             out["renderer"] = "sphere tracer (BatchRefiner(render='trace'), surfel-semantics backward): not the reference's algorithm"
-        if rf.br is not None and getattr(rf.br, "prefilter", False):
+        if rf.br is not None and getattr(rf.br, "guarded", False):
             out["guard"] = rf.br.prefilter_report()
             out["candidate_reuse"] = bool(rf.br.reuse)
+            out["lipschitz_bound_latent"] = rf.br.lipschitz
+            out["margin"] = rf.br.margin
+            out["candidates_per_crop_last_chunk_mean_max"] = [float(rf.br.ccnt.float().mean()), int(rf.br.ccnt.max())]
+            out["full_grid_passes_per_crop_last_chunk_mean"] = float(rf.br.n_full.float().mean())
         del st, rf
         return out
 
-    sharded = sharded16 = sharded_pf = sharded_c4 = sharded_tr = None
+    sharded = sharded16 = sharded16_full = sharded_pf = sharded_c4 = sharded_tr = None
     if args.total_crops > 0 and not args.no_extras and CB == 1:
         wl = ("BASELINE configs[3]: %d crops of %dx%d rays sharded crop i -> rank i mod %d, chunks of %d through BatchRefiner (reference losses + "
               "solver, HIP-graph replay), one all_gather of the result rows")
         sharded = sharded_section("exact float32 decoder (parity path)", torch.float32, False, H, args.total_crops, wl)
-        sharded16 = sharded_section("float16 decoder = the reference's shipped precision (config_refine.ini:19), f32 everything else",
-                                    torch.float16, False, H, args.total_crops, wl)
+        sharded16 = sharded_section("float16 decoder = the reference's shipped precision (config_refine.ini:19), f32 everything else; candidate reuse: "
+                                    "the half decoder runs on the band candidates alone while a proven Lipschitz bound keeps them valid (bit-identical "
+                                    "to the full-grid evaluation, audited)", torch.float16, True, H, args.total_crops, wl)
+        if world == 1:
+            sharded16_full = sharded_section("float16 decoder, every grid row every iteration (the r04 figure)", torch.float16, False, H, args.total_crops, wl)
         if world == 1:
             sharded_pf = sharded_section("float32_prefilter + candidate reuse: f16 pass proposes, exact f32 on everything consumed, run-time guard",
                                          "float32_prefilter", True, H, args.total_crops, wl)
@@ -627,7 +635,7 @@ def main():
             sharded_tr = sharded_section("sphere tracer as the loop's renderer, float16 decoder", torch.float16, False, H, max(world, args.total_crops // 8),
                                          wl, render="trace")
         if H == 256 and args.configs4_crops > 0 and world == 1:
-            sharded_c4 = sharded_section("BASELINE configs[4] shape: 512x512 rays, float16 decoder on the f16 matrix cores", torch.float16, False, 512,
+            sharded_c4 = sharded_section("BASELINE configs[4] shape: 512x512 rays, float16 decoder on the f16 matrix cores, candidate reuse", torch.float16, True, 512,
                                          args.configs4_crops, "BASELINE configs[4]: %d crops of %dx%d rays, float16 DeepSDF decoder, sharded crop i -> rank "
                                          "i mod %d, chunks of %d through BatchRefiner, one all_gather")
 
@@ -962,6 +970,7 @@ def main():
         line["optimizer_mirror_varied_crops"] = varied
         line["refine_sharded"] = sharded
         line["refine_sharded_float16"] = sharded16
+        line["refine_sharded_float16_full_grid"] = sharded16_full
         line["refine_sharded_prefilter"] = sharded_pf
         line["refine_sharded_configs4"] = sharded_c4
         line["refine_sharded_traced"] = sharded_tr

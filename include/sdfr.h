@@ -164,9 +164,9 @@ int sdfr_prefilter_guard(float* sdf_grid, const float* sdf_exact, const int32_t*
  * most max_reuse steps in a row (lip: Lipschitz constant of the decoder in the normalised latent; inputs: the decoder input rows, whose
  * first L columns hold it; lat_ref float[B][L], age int32[B]: state, zero-initialised).  The half pass, the candidate selection and the
  * guard then take the flags: flagged crops are skipped (sdfr_mlp_forward_f16_skip, sdfr_band_select_skip) / patched but not judged
- * (sdfr_prefilter_guard2). */
+ * (sdfr_prefilter_guard2).  n_full int32[B] (may be NULL; r05): += 1 for every crop that is NOT flagged, i.e. runs its full-grid pass. */
 int sdfr_prefilter_plan(const float* inputs, int64_t G, int n_inputs, int L, int B, float lip, const float* margin, const float* max_dev,
-                        float* lat_ref, int32_t* age, int max_reuse, int32_t* reuse, void* stream);
+                        float* lat_ref, int32_t* age, int max_reuse, int32_t* reuse, int32_t* n_full, void* stream);
 int sdfr_mlp_forward_f16_skip(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, const int32_t* skip, int64_t rows_per_crop,
                               void* stream);
 int sdfr_band_select_skip(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, const int32_t* skip, int32_t* idx, int cap,
@@ -188,6 +188,27 @@ int sdfr_prefilter_audit_select(const float* inputs, const int32_t* cslot, int64
 int sdfr_prefilter_audit_check(const float* sdf_grid, const float* sdf_exact, const int32_t* src, const int32_t* n_audit, int cap_rows,
                                int64_t G, int B, float thr, const int32_t* reused, float* audit_dev, int32_t* violations, int32_t* phase,
                                void* stream);
+
+/* Candidate reuse of the float16 decoder mode (r05; the reference's shipped precision, configs/config_refine.ini:19, re-evaluates all G grid
+ * rows every iteration of pipelines/optimizer.py:96-104 although the latent moves by ~1e-6 per iteration).  The band is taken from the
+ * candidate rows (|half sdf| < thr + margin at the crop's last full-grid pass) alone:
+ *   sdfr_candidate_rows      rows[b][s][:] = inputs[b*G + cidx[b][s]][:] for s < ccnt[b] (ragged [B][stride] array, stride a multiple of 128;
+ *                            the rows up to the next multiple of 128 are filled with a finite row)
+ *   sdfr_mlp_forward_f16_ragged   the half decoder on crop b's first cnt[b] rows of such an array (whole 128-row tiles), masks saved: every
+ *                            row gets the bits sdfr_mlp_forward_f16 gives it in a full-grid launch
+ *   sdfr_scatter_values      writes them into the grid array; sdfr_band_select there returns the band (rows outside the candidates keep
+ *                            their values of the last full pass, >= thr + margin in magnitude)
+ *   sdfr_candidate_band_map  pos[b][e] = cslot[b*G + idx[b][e]]: the band rows' positions in the candidate array, for the mask-fed half
+ *                            Jacobian (sdfr_mlp_jacobian(dec, rows, stride, B, pos, ...)); a band row that is no candidate counts a hard
+ *                            violation (violations[2b+1], may be NULL)
+ * sdfr_prefilter_plan (with a proven Lipschitz bound as `lip`) decides per crop when a full pass is due; the audit re-evaluates a rotating
+ * slice of the other rows with the same kernel. */
+int sdfr_candidate_rows(const float* inputs, int64_t G, int n_inputs, int B, const int32_t* cidx, int stride, const int32_t* ccnt, float* rows,
+                        void* stream);
+int sdfr_mlp_forward_f16_ragged(const sdfr_decoder* dec, const float* inputs, int B, int64_t rows_per_crop, const int32_t* cnt, float* sdf,
+                                uint32_t* mask_ws, void* stream);
+int sdfr_candidate_band_map(const int32_t* idx, int cap, const int32_t* cnt, const int32_t* cslot, int64_t G, int B, int stride, int32_t* pos,
+                            int32_t* violations, void* stream);
 
 /* g_inputs[r][:] = g_sdf[r] * J[slot[r]][:]  for rows with slot[r] >= 0, else 0   (DeepSDF backward through the
  * cached band Jacobian).  n_uncached (device int32, may be NULL) receives the number of rows with g_sdf != 0 and

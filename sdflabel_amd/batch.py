@@ -130,7 +130,11 @@ class BatchRenderer:
             # safety factor 4 -- a calibrated ESTIMATE, not a proven Lipschitz bound.  On reused steps the half pass does not run, so the guard
             # has nothing to compare and an underestimated constant could let a band row slip out of the candidate set unnoticed: reuse is an
             # approximation by design (opt-in; bit-identical to the plain two-stage mode in every test and in the 1024-crop bench run).
-            self.lipschitz = 4.0 * lip
+            # r05: the constant the plan kernel uses is the PROVEN bound (Decoder.latent_lipschitz_bound: spectral norms of the effective
+            # weights along the latent's paths; r02-r04 used 4x the sampled finite difference, kept below as a diagnostic only -- the bound is
+            # ~100x it on the shipped decoder, and the latent moves ~1e-6 per iteration, so reuse still covers most steps)
+            self.lipschitz_sampled = lip
+            self.lipschitz = float(decoder.latent_lipschitz_bound())
             self.reuse = bool(getattr(decoder, "prefilter_reuse", False))
             self.max_reuse = int(getattr(decoder, "prefilter_max_reuse", 16))
             self.lat_ref, self.age, self.reuse_flag = f(B, self.L), i(B), i(B)
@@ -148,6 +152,49 @@ class BatchRenderer:
                 self.audit_rows, self.audit_src, self.audit_sdf = f(self.audit_cap, NI), i(self.audit_cap), f(self.audit_cap)
                 self.audit_n, self.audit_phase, self.audit_dev = i(1), i(1), f(B)
             self.fault = None           # tests: (flat grid rows int64 tensor, values) written over the half pass's output -- a planted half-pass error
+        # float16 candidate reuse (r05, opt-in: decoder.candidate_reuse = True): the half decoder runs over the whole grid only when a crop's
+        # candidate set (|sdf| < threshold + margin at that pass) may have gone stale; every other step evaluates the candidates alone, with the
+        # same kernel, so band, values and Jacobian have the bits of the full-grid evaluation (csrc/surface.hip).  "May have
+        # gone stale" is decided per crop on the device (sdfr_prefilter_plan) from a PROVEN bound: a row outside the candidates had
+        # |h(z0)| >= thr + margin, and |h(z1) - h(z0)| <= lip |z1 - z0| + 2 e16, lip = Decoder.latent_lipschitz_bound() (product of the
+        # spectral norms of the effective weights along the latent's paths: cannot be low), e16 = the half kernel's deviation from the exact
+        # decoder (calibrated below; the margin is at least 4 e16).  Reuse while lip |z1 - z0| <= margin / 4.  On top, every step a rotating
+        # 1 / audit_stride slice of the rows outside the candidates is evaluated too: one of them inside the band is a hard violation.
+        self.creuse = self.f16 and bool(getattr(decoder, "candidate_reuse", False)) and self.handle.hp == 512 and not self.handle.has_ln
+        if self.creuse:
+            Lh = _lib.lib()
+            self.cstride = (cap + 127) // 128 * 128
+            cs = self.cstride
+            self.cidx, self.ccnt, self.cslot, self.cpos = i(B, cs), i(B), i(B * G), i(B, cap)
+            self.crow, self.csdf = f(B * cs, NI), f(B * cs)
+            self.cmask = i(int(Lh.sdfr_decoder_mask_words(self.handle.h, B * cs)))
+            gen = torch.Generator().manual_seed(0)
+            s32, s16 = f(G), f(G)
+            worst = 0.0
+            for _ in range(4):
+                lat = torch.nn.functional.normalize(torch.randn(self.L, generator=gen), dim=0).to(dev)
+                inp = torch.cat([lat.expand(G, -1), self.grid], 1).contiguous()
+                _lib.check(Lh.sdfr_mlp_forward(self.handle.h, _lib.ptr(inp), G, _lib.ptr(s32), None, _lib.stream_ptr()), "sdfr_mlp_forward")
+                _lib.check(Lh.sdfr_mlp_forward_f16(self.handle.h, _lib.ptr(inp), G, _lib.ptr(s16), None, _lib.stream_ptr()), "sdfr_mlp_forward_f16")
+                worst = max(worst, float((s32 - s16).abs().max()))
+            self.f16_error = worst
+            self.margin = max(self.margin, 4.0 * worst)
+            self.margin_dev = torch.full((B,), self.margin, dtype=torch.float32, device=dev)
+            self.max_dev = f(B)                 # (stays 0: this mode has no second arithmetic to deviate from; the plan kernel reads it)
+            self.violations = i(B, 2)
+            self.lipschitz = float(decoder.latent_lipschitz_bound())
+            self.reuse = True
+            self.max_reuse = int(getattr(decoder, "candidate_max_reuse", 16))
+            self.lat_ref, self.age, self.reuse_flag = f(B, self.L), i(B), i(B)
+            self.audit = bool(getattr(decoder, "candidate_audit", True))
+            self.audit_stride = int(getattr(decoder, "candidate_audit_stride", 16))
+            if self.audit:
+                self.audit_cap = B * ((G + self.audit_stride - 1) // self.audit_stride)
+                self.audit_rows, self.audit_src, self.audit_sdf = f(self.audit_cap, NI), i(self.audit_cap), f(self.audit_cap)
+                self.audit_n, self.audit_phase, self.audit_dev = i(1), i(1), f(B)
+            self.fault = None                   # tests: (flat grid rows, values) written over the full pass's output
+        self.guarded = self.prefilter or self.creuse        # modes with device-side guard state (violations / margin / age)
+        self.n_full = i(B) if self.guarded else None        # full-grid half passes per crop since reset_guard() (counted by the plan kernel)
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.p_cam, self.n_cam, self.attr = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
         self.fidx, self.fcnt, self.fslot = i(B, cap), i(B), i(B, cap)
@@ -224,17 +271,18 @@ class BatchRenderer:
     def invalidate_shape(self):
         """call after changing self.latent in place (freeze_shape mode): the next forward() re-evaluates decoder, band and Jacobian"""
         self._shape_valid = False
-        if self.prefilter:
-            self.age.zero_()                     # the next step runs the half pass
+        if self.guarded:
+            self.age.zero_()                     # the next step runs the half pass over the whole grid
 
     def reset_guard(self):
         """float32_prefilter: new crops start with clean guard state -- the violation counters, the last deviation and the per-crop margin
         (back to the calibrated one) belong to the crops that were refined before, and a hard violation there must not make
         check_overflow() refuse every later, unrelated crop (refiners are cached and reused across Optimizer objects).  Called by
         set_params() and BatchRefiner.set_crops(); all in place, so a captured graph stays valid."""
-        if self.prefilter:
-            self.age.zero_()                     # new crops: the next step runs the half pass
+        if self.guarded:
+            self.age.zero_()                     # new crops: the next step runs the half pass over the whole grid
             self.violations.zero_()
+            self.n_full.zero_()
             self.max_dev.zero_()
             self.margin_dev.fill_(self.margin)
             if self.audit:
@@ -267,7 +315,7 @@ class BatchRenderer:
         elif self.prefilter:
             if self.reuse:
                 ck(L.sdfr_prefilter_plan(P(self.inputs), G, self.NI, self.L, B, self.lipschitz, P(self.margin_dev), P(self.max_dev), P(self.lat_ref),
-                                         P(self.age), self.max_reuse, P(self.reuse_flag), st), "sdfr_prefilter_plan")
+                                         P(self.age), self.max_reuse, P(self.reuse_flag), P(self.n_full), st), "sdfr_prefilter_plan")
                 ck(L.sdfr_mlp_forward_f16_skip(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.reuse_flag), G, st),
                    "sdfr_mlp_forward_f16_skip")
                 if self.fault is not None:
@@ -302,6 +350,41 @@ class BatchRenderer:
             ck(L.sdfr_gather_rows(P(self.J), P(self.Jc), self.NI, P(self.idx), P(self.cslot), G, B, cap, cap, P(self.cnt), st), "sdfr_gather_rows")
             if mlp_events is not None:
                 mlp_events[1].record()
+        elif self.creuse:
+            cs = self.cstride
+            ck(L.sdfr_prefilter_plan(P(self.inputs), G, self.NI, self.L, B, self.lipschitz, P(self.margin_dev), P(self.max_dev), P(self.lat_ref),
+                                     P(self.age), self.max_reuse, P(self.reuse_flag), P(self.n_full), st), "sdfr_prefilter_plan")
+            # full-grid pass of the crops whose candidate set is due (no masks: the Jacobian takes them from the candidate pass below)
+            ck(L.sdfr_mlp_forward_f16_skip(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.reuse_flag), G, st), "sdfr_mlp_forward_f16_skip")
+            if self.fault is not None:
+                self.sdf.index_copy_(0, self.fault[0], self.fault[1])
+            ck(L.sdfr_band_select_skip(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.reuse_flag), P(self.cidx), cs, P(self.ccnt),
+                                       P(self.cslot), P(self.scratch), st), "sdfr_band_select_skip")
+            # every crop: the candidates through the same half kernel (values + masks), written into the grid array
+            ck(L.sdfr_candidate_rows(P(self.inputs), G, self.NI, B, P(self.cidx), cs, P(self.ccnt), P(self.crow), st), "sdfr_candidate_rows")
+            ck(L.sdfr_mlp_forward_f16_ragged(self.handle.h, P(self.crow), B, cs, P(self.ccnt), P(self.csdf), P(self.cmask), st),
+               "sdfr_mlp_forward_f16_ragged")
+            ck(L.sdfr_scatter_values(P(self.sdf), P(self.csdf), P(self.cidx), G, B, cs, P(self.ccnt), st), "sdfr_scatter_values")
+            if self.audit:
+                ck(L.sdfr_prefilter_audit_select(P(self.inputs), P(self.cslot), G, self.NI, B, self.audit_stride, P(self.audit_phase), P(self.audit_rows),
+                                                 P(self.audit_src), P(self.audit_n), self.audit_cap, st), "sdfr_prefilter_audit_select")
+                # half | 2: 128- / 64-row tiles of the same 32x32x16 products -- the bits of the full-grid launch
+                ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 3, st),
+                   "sdfr_mlp_forward_counted")
+                ck(L.sdfr_prefilter_audit_check(P(self.sdf), P(self.audit_sdf), P(self.audit_src), P(self.audit_n), self.audit_cap, G, B, self.thr,
+                                                P(self.reuse_flag), P(self.audit_dev), P(self.violations), P(self.audit_phase), st),
+                   "sdfr_prefilter_audit_check")
+            if mlp_events is not None:
+                mlp_events[1].record()
+            ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
+            ck(L.sdfr_candidate_band_map(P(self.idx), cap, P(self.cnt), P(self.cslot), G, B, cs, P(self.cpos), P(self.violations), st),
+               "sdfr_candidate_band_map")
+            if "jacobian" in events:
+                events["jacobian"][0].record()
+            ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.crow), cs, B, P(self.cpos), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.csdf),
+                                   P(self.cmask), 2, st), "sdfr_mlp_jacobian")
+            if "jacobian" in events:
+                events["jacobian"][1].record()
         else:
             fwd = L.sdfr_mlp_forward_f16 if self.f16 else (L.sdfr_mlp_forward_split if self.split else L.sdfr_mlp_forward)
             ck(fwd(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.mask_ws), st), "sdfr_mlp_forward")
@@ -405,29 +488,37 @@ class BatchRenderer:
         over = (self.cnt > self.cap).any()
         if self.prefilter:
             over = over | (self.ccnt > self.cap).any()
+        if self.creuse:
+            over = over | (self.ccnt > self.cstride).any()
         return bool(over.item())
 
     def prefilter_report(self):
         """float32_prefilter only: {'violations': soft count, 'hard_violations': steps in which the half pass deviated by more than the
         margin at a candidate (a band row may have been missed), 'max_deviation': last step's, 'margin': current per-crop maximum}.
         One synchronisation."""
-        if not self.prefilter:
+        if not self.guarded:
             return None
         v = self.violations.sum(0).tolist()
         rep = {"violations": int(v[0]), "hard_violations": int(v[1]), "max_deviation": float(self.max_dev.max()),
                "margin": float(self.margin_dev.max())}
         if self.audit:
             rep["audit"] = {"stride": self.audit_stride, "rows_last_step": int(self.audit_n[0]), "steps": int(self.audit_phase[0]),
-                            "reference_values": "float32_split (error-compensated f16 MFMAs)" if self.audit_split else "float32",
+                            "reference_values": "float16 (the mode's own kernel)" if self.creuse else
+                            ("float32_split (error-compensated f16 MFMAs)" if self.audit_split else "float32"),
                             "max_deviation_at_non_candidates": float(self.audit_dev.max())}
         return rep
 
     def check_overflow(self):
         """Raise if the last forward dropped surfels (the reference has no capacity: a truncated shape must not pass silently).  One sync."""
         if self.overflow():
-            worst = int(self.cnt.max()) if not self.prefilter else max(int(self.cnt.max()), int(self.ccnt.max()))
+            worst = int(self.cnt.max()) if not self.guarded else max(int(self.cnt.max()), int(self.ccnt.max()))
             raise _lib.SdfrError("a crop's band holds %d surfels but BatchRenderer was built with cap=%d: rebuild it with a larger `cap` "
                                  "(default max(256, G/8))" % (worst, self.cap))
+        if self.creuse and int(self.violations[:, 1].sum()) > 0:
+            hard = int(self.violations[:, 1].sum())
+            self.violations[:, 1].zero_()
+            raise _lib.SdfrError("float16 candidate reuse: %d row(s) outside the candidate set were found inside the band (audit / band map): the "
+                                 "band of those steps was incomplete; use decoder.candidate_reuse = False or a larger decoder.prefilter_margin" % hard)
         if self.prefilter and int(self.violations[:, 1].sum()) > 0:
             hard, worst_dev = int(self.violations[:, 1].sum()), float(self.max_dev.max())
             self.violations[:, 1].zero_()        # reported once: the renderer stays usable for the next crops (the grown margins remain)

@@ -74,6 +74,8 @@ struct MlpParams {
     uint32_t* maskbuf;      // MODE 1 (write) / MODE 3 (read): ReLU masks [tile64][layer][word][thread]
     const int32_t* skip;         // forward: optional per-crop flags (skip_rows rows per crop): workgroups whose rows all belong to flagged crops exit
     int64_t skip_rows;
+    const int32_t* crop_cnt;     // forward: optional per-crop row counts of a [B][crop_rows] row array (crop_rows a multiple of the tile): tiles that
+    int64_t crop_rows;           // start at or beyond their crop's count exit (candidate rows of the float16 reuse mode, r05)
     const int32_t* n_dev;        // forward: optional device-side row count (rows >= *n_dev are not evaluated; n is the launch bound)
     int n_dev_lo, n_dev_hi;      // with n_dev and n_dev_hi > 0: the launch runs only while n_dev_lo <= *n_dev < n_dev_hi (two tile geometries of one step)
     unsigned long long* trace;   // builds with -DSDFR_MLP_TRACE: cycle stamps of workgroup 0 (sdfr_debug_set_trace), else unused
@@ -281,6 +283,10 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         if (r0 >= n_rows) return;
         if (P.n_dev && P.n_dev_hi > 0 && (*P.n_dev < P.n_dev_lo || *P.n_dev >= P.n_dev_hi)) return;
         if (TAIL && P.t_steps <= 0) return;
+        if (P.crop_cnt) {                           // ragged [B][crop_rows] row array: nothing to do beyond the crop's own count
+            const int64_t c = r0 / P.crop_rows;
+            if (r0 - c * P.crop_rows >= (int64_t)P.crop_cnt[c]) return;
+        }
         if (P.skip) {                               // two-stage evaluation: crops that reuse their candidate set skip the half pass
             // a tile is dropped only when EVERY crop it spans is flagged (rows_per_crop need not be a multiple of the tile: a tile may span
             // two or more crops); in a surviving tile the rows of flagged crops are computed but not stored (see the store of P.sdf)

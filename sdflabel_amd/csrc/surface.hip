@@ -259,7 +259,7 @@ extern "C" int sdfr_prefilter_audit_check(const float* sdf_grid, const float* sd
 // crop b (sdfr_mlp_forward_f16_skip, sdfr_band_select_skip); otherwise lat_ref[b] = the current normalised latent.
 __global__ void sdfr_prefilter_plan_kernel(const float* __restrict__ inputs, int64_t G, int NI, int L, int B, float lip,
                                            const float* __restrict__ margin, const float* __restrict__ max_dev, float* __restrict__ lat_ref,
-                                           int32_t* __restrict__ age, int max_reuse, int32_t* __restrict__ reuse) {
+                                           int32_t* __restrict__ age, int max_reuse, int32_t* __restrict__ reuse, int32_t* __restrict__ n_full) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float* z = inputs + (int64_t)b * G * NI;             // the latent columns of the crop's first input row
@@ -268,15 +268,19 @@ __global__ void sdfr_prefilter_plan_kernel(const float* __restrict__ inputs, int
     const bool ok = age[b] > 0 && age[b] <= max_reuse && lip * sqrtf(d2) <= 0.25f * margin[b] && max_dev[b] <= 0.5f * margin[b];
     reuse[b] = ok ? 1 : 0;
     if (ok) age[b] += 1;
-    else { age[b] = 1; for (int c = 0; c < L; ++c) lat_ref[b * L + c] = z[c]; }
+    else {
+        age[b] = 1;
+        for (int c = 0; c < L; ++c) lat_ref[b * L + c] = z[c];
+        if (n_full) n_full[b] += 1;                            // full-grid passes of this crop since the caller zeroed the counter
+    }
 }
 
 extern "C" int sdfr_prefilter_plan(const float* inputs, int64_t G, int n_inputs, int L, int B, float lip, const float* margin,
-                                   const float* max_dev, float* lat_ref, int32_t* age, int max_reuse, int32_t* reuse, void* stream) {
+                                   const float* max_dev, float* lat_ref, int32_t* age, int max_reuse, int32_t* reuse, int32_t* n_full, void* stream) {
     SDFR_REQUIRE(inputs && margin && max_dev && lat_ref && age && reuse && G > 0 && L >= 0 && n_inputs >= L, "sdfr_prefilter_plan: bad argument");
     if (B <= 0) return SDFR_OK;
     hipLaunchKernelGGL(sdfr_prefilter_plan_kernel, dim3(sdfr_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, inputs, G, n_inputs, L, B, lip, margin,
-                       max_dev, lat_ref, age, max_reuse, reuse);
+                       max_dev, lat_ref, age, max_reuse, reuse, n_full);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -295,6 +299,65 @@ extern "C" int sdfr_prefilter_guard2(float* sdf_grid, const float* sdf_exact, co
     if (B <= 0 || cap <= 0) return SDFR_OK;
     hipLaunchKernelGGL(sdfr_prefilter_guard_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, sdf_grid, sdf_exact, idx, G, cap, cnt, margin,
                        max_dev, violations, reused);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// ---- float16 candidate reuse (r05) ------------------------------------------------------------------------------------------------------
+// The float16 decoder mode evaluates the whole grid every iteration although only the latent moves, and by ~1e-6 per iteration
+// (pipelines/optimizer.py:34-38: lr 3e-5).  With decoder.candidate_reuse the band comes from the CANDIDATE rows (|half sdf| < thr + margin at
+// the last full pass) alone: their input rows are gathered into a ragged [B][stride] array (sdfr_candidate_rows), evaluated with the SAME
+// half kernel (sdfr_mlp_forward_f16_ragged: same bits per row as the full-grid launch), scattered back into the grid array
+// (sdfr_scatter_values) and band-selected there as ever; sdfr_candidate_band_map turns the band's grid rows into positions of the candidate
+// array, where the mask-fed half Jacobian finds its masks.  Valid while no row outside the candidates can have entered the band:
+// sdfr_prefilter_plan with a PROVEN Lipschitz bound of the decoder in the latent (Decoder.latent_lipschitz_bound) decides per crop on the
+// device, and the rotating audit (sdfr_prefilter_audit_*) re-evaluates 1 / stride of the other rows every step with the same kernel.
+__global__ __launch_bounds__(256) void sdfr_candidate_rows_kernel(const float* __restrict__ inputs, int64_t G, int NI, const int32_t* __restrict__ cidx,
+                                                                 int stride, const int32_t* __restrict__ ccnt, float* __restrict__ rows) {
+    const int b = blockIdx.y;
+    const int n = sdfr_count(ccnt, b, stride);
+    const int n_pad = min(stride, (n + 127) / 128 * 128);              // the last 128-row tile is computed whole: finite rows up to its end
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int s = (int)(t / NI), c = (int)(t - (int64_t)s * NI);
+    if (s >= n_pad) return;
+    const int64_t g = s < n ? (int64_t)cidx[(int64_t)b * stride + s] : 0;   // padding rows: the crop's grid row 0
+    rows[((int64_t)b * stride + s) * NI + c] = inputs[((int64_t)b * G + g) * NI + c];
+}
+
+extern "C" int sdfr_candidate_rows(const float* inputs, int64_t G, int n_inputs, int B, const int32_t* cidx, int stride, const int32_t* ccnt,
+                                   float* rows, void* stream) {
+    SDFR_REQUIRE(inputs && cidx && ccnt && rows && G > 0 && n_inputs > 0, "sdfr_candidate_rows: bad argument");
+    SDFR_REQUIRE(stride >= 0 && stride % 128 == 0, "sdfr_candidate_rows: stride %d is not a multiple of 128", stride);
+    if (B <= 0 || stride == 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_candidate_rows_kernel, dim3(sdfr_cdiv((int64_t)stride * n_inputs, 256), B), dim3(256), 0, (hipStream_t)stream, inputs, G,
+                       n_inputs, cidx, stride, ccnt, rows);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// pos[b][e] = cslot[b*G + idx[b][e]] for e < cnt[b]: the band rows' positions in their crop's candidate array.  A band row that is no
+// candidate (cannot happen while the candidate set is valid: its stale grid value is >= thr + margin) maps to position 0 and counts a hard
+// violation (violations[2b+1]), which check_overflow() refuses.
+__global__ __launch_bounds__(256) void sdfr_candidate_band_map_kernel(const int32_t* __restrict__ idx, int cap, const int32_t* __restrict__ cnt,
+                                                                     const int32_t* __restrict__ cslot, int64_t G, int stride,
+                                                                     int32_t* __restrict__ pos, int32_t* __restrict__ violations) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= sdfr_count(cnt, b, cap)) return;
+    int sl = cslot[(int64_t)b * G + idx[(int64_t)b * cap + e]];
+    if (sl < 0 || sl >= stride) {
+        sl = 0;
+        if (violations) atomicAdd(&violations[2 * b + 1], 1);
+    }
+    pos[(int64_t)b * cap + e] = sl;
+}
+
+extern "C" int sdfr_candidate_band_map(const int32_t* idx, int cap, const int32_t* cnt, const int32_t* cslot, int64_t G, int B, int stride,
+                                       int32_t* pos, int32_t* violations, void* stream) {
+    SDFR_REQUIRE(idx && cslot && pos && G > 0, "sdfr_candidate_band_map: bad argument");
+    if (B <= 0 || cap <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_candidate_band_map_kernel, dim3(sdfr_cdiv(cap, 256), B), dim3(256), 0, (hipStream_t)stream, idx, cap, cnt, cslot, G, stride,
+                       pos, violations);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

@@ -295,6 +295,30 @@ class Decoder(nn.Module):
                 inj.append((0, 0))
         return inj
 
+    def latent_lipschitz_bound(self):
+        """A PROVEN upper bound of || d sdf / d latent ||_2 over all inputs: the change of the decoder output per unit (Euclidean) change of the
+        latent columns of an input row, x fixed.  ReLU, tanh (and eval-mode dropout) are 1-Lipschitz, so along the layers the bound d_l of the
+        activation vector's change obeys  d_0 = ||W_0[:, latent columns]||_2,  d_l = ||W_l[:, activations]||_2 d_{l-1} + ||W_l[:, re-injected
+        latent columns]||_2  (deep_sdf_decoder_scale.py:90-93: x = cat(x, input)), with the spectral norms of the EFFECTIVE (weight-norm
+        folded) weights in float64.  532 on the shipped 8x512 decoder -- loose (a sampled finite difference reads ~1.3) but it cannot be low,
+        which is what the candidate reuse of BatchRenderer needs.  LayerNorm decoders: inf (the normalisation is not Lipschitz)."""
+        if any(getattr(self, "bn" + str(l), None) is not None for l in range(self.num_layers - 1)):
+            return float("inf")
+        Ls = self.latent_size
+        d = 0.0
+        for l, ((W, _), (inj_n, inj_off)) in enumerate(zip(self.effective_layers(), self._inject_table())):
+            W = np.asarray(W, np.float64)
+            if l == 0:
+                d = float(np.linalg.norm(W[:, :Ls], 2))
+                continue
+            prev = W.shape[1] - inj_n
+            t = float(np.linalg.norm(W[:, :prev], 2)) * d
+            nlat = max(0, min(Ls, inj_off + inj_n) - inj_off) if inj_n > 0 else 0      # re-injected input columns that are latent columns
+            if nlat > 0:
+                t += float(np.linalg.norm(W[:, prev:prev + nlat], 2))
+            d = t
+        return d * (1.0 + 1e-9)
+
     def _params_two_levels(self):
         """this module's parameters by direct dictionary access (lin*, bn* and the Linear layers of scale_net: two levels) -- what
         self.parameters() yields, without its recursive named_modules walk (40 us per forward); None if the tree is deeper than that"""

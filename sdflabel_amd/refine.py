@@ -184,7 +184,7 @@ class BatchRefiner:
         s.wait_stream(torch.cuda.current_stream(self.dev))
         snap = (self.params.clone(), self.adam_m.clone(), self.adam_v.clone(), self.adam_t.clone())
         br = self.br
-        guard = (br.violations.clone(), br.margin_dev.clone(), br.max_dev.clone()) if (br is not None and br.prefilter) else None
+        guard = (br.violations.clone(), br.margin_dev.clone(), br.max_dev.clone()) if (br is not None and br.guarded) else None
         with torch.cuda.stream(s):
             self.iteration()
         torch.cuda.current_stream(self.dev).wait_stream(s)

@@ -814,7 +814,7 @@ def test_prefilter_reuse_when_a_tile_of_the_half_pass_spans_two_crops(dec):
     mode (the skip test used to look at the tile's first and last rows only)"""
     D, H, W, B = 20, 48, 48, 5
     K, p0, target, lidar = _refine_problem(dec, D, H, W, B)
-    rows = []
+    rows, mixed = [], 0
     for reuse in (False, True):
         dp, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision="float32_prefilter")
         dp.prefilter_reuse = reuse
@@ -830,10 +830,15 @@ def test_prefilter_reuse_when_a_tile_of_the_half_pass_spans_two_crops(dec):
                     rf.latent[1] += torch.tensor([0.4, -0.3, 0.2], device=DEV)
                     rf.latent[3] -= torch.tensor([0.2, 0.3, -0.4], device=DEV)
             rf.iteration()
-            if reuse and it in (4, 9):
-                assert N(rf.br.reuse_flag).tolist() == [1, 0, 1, 0, 1]
+            if reuse:
+                flags = N(rf.br.reuse_flag).tolist()
+                mixed += 0 < sum(flags) < B
+                if it in (4, 9):
+                    # (r05: with the proven Lipschitz bound a neighbour may be due for a full pass of its own at the same step)
+                    assert flags[1] == 0 and flags[3] == 0, flags
         rows.append(N(rf.results()[0]))
         assert rf.br.prefilter_report()["hard_violations"] == 0
+    assert mixed >= 2                                          # steps in which reusing and non-reusing crops shared tiles of the half pass
     assert np.array_equal(rows[0], rows[1])
 
 

@@ -1,0 +1,179 @@
+"""r05: candidate reuse of the float16 decoder mode -- the reference's shipped precision (configs/config_refine.ini:19) --
+must change NOTHING: band index lists, decoder values, Jacobians and every image bit-identical to the full-grid float16 evaluation, iteration
+by iteration, while most iterations evaluate the candidate rows only."""
+import numpy as np
+import pytest
+import torch
+
+import sdflabel_amd
+from sdflabel_amd import _lib
+from tests._util import ASSET, K_for
+from tests.test_gpu_parity import N, T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _dec16(reuse, **attrs):
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    d.candidate_reuse = reuse
+    for k, v in attrs.items():
+        setattr(d, k, v)
+    return d.to(DEV)
+
+
+def _problem(D, H, W, B):
+    from sdflabel_amd.fixtures import crop_params, synthetic_targets
+    d32, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
+    K = K_for(H, W)
+    nocs1, lidar = synthetic_targets(d32.to(DEV), D, K, H, W, DEV)
+    return K, crop_params(list(range(B))), nocs1.expand(B, 3, H, W), lidar
+
+
+def _same_step(a, b):
+    """every array the rest of the step consumes, bit for bit (ragged arrays up to each crop's count)"""
+    assert torch.equal(a.cnt, b.cnt) and torch.equal(a.fcnt, b.fcnt)
+    live = torch.arange(a.cap, device=DEV).view(1, -1) < a.cnt.view(-1, 1)
+    assert torch.equal(a.idx[live], b.idx[live]), "band index lists differ"
+    assert torch.equal(a.sdf_band[live], b.sdf_band[live]) and torch.equal(a.J[live], b.J[live])
+    for name in ("color", "mask", "depth", "nimg", "xyzf", "points", "normals"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for name in ("g_yaw", "g_trans", "g_latent"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+@pytest.mark.parametrize("B,H,W,iters", [(64, 256, 256, 60), (3, 64, 48, 40)])
+def test_float16_candidate_reuse_is_bit_identical_to_the_full_grid_evaluation(B, H, W, iters):
+    D = 40
+    K, p0, target, lidar = _problem(D, H, W, B)
+    plain = sdflabel_amd.BatchRefiner(_dec16(False), D, K, (H, W), B, lidar_cap=4096, device=DEV)
+    reuse = sdflabel_amd.BatchRefiner(_dec16(True), D, K, (H, W), B, lidar_cap=4096, device=DEV)
+    assert reuse.br.creuse and not plain.br.creuse and reuse.br.lipschitz > 100.0        # the proven bound, not the sampled constant
+    assert reuse.br.margin >= 4.0 * reuse.br.f16_error > 0
+    plain.set_crops(p0, target, [lidar] * B)
+    reuse.set_crops(p0, target, [lidar] * B)
+    reused = 0
+    for it in range(iters):
+        plain.iteration()
+        reuse.iteration()
+        _same_step(plain.br, reuse.br)
+        flags = int(reuse.br.reuse_flag.sum())
+        assert it > 0 or flags == 0                                      # a crop's first step is a full pass
+        reused += flags
+    assert torch.equal(plain.results()[0], reuse.results()[0])
+    rep = reuse.br.prefilter_report()
+    assert rep["hard_violations"] == 0 and rep["violations"] == 0
+    # the audit's values at rows OUTSIDE the candidates, on steps with a full pass, are compared with that pass's: the same kernel arithmetic
+    # in another launch shape -> exactly equal
+    assert rep["audit"]["max_deviation_at_non_candidates"] == 0.0
+    # most steps evaluate the candidates alone: the first step of a crop, every (max_reuse + 1)-th and the steps after the latent has moved
+    # by margin / (4 lip) run the full grid
+    assert reused >= 0.75 * (iters - 1) * B, (reused, iters, B)
+    # ... and the candidates are a small part of the grid
+    assert 0 < int(reuse.br.ccnt.max()) <= reuse.br.cstride < reuse.br.G // 4
+
+
+def test_float16_candidate_reuse_replayed_from_a_hip_graph_and_in_chunks():
+    """the plan is a device-side decision: a captured iteration replays it; set_crops() on a cached refiner starts from a full pass"""
+    D, H, W, B = 40, 64, 64, 4
+    K, p0, target, lidar = _problem(D, H, W, 2 * B)
+    first = {k: v[:B] for k, v in p0.items()}
+    second = {k: v[B:] for k, v in p0.items()}
+    rows = []
+    for reuse in (False, True):
+        rf = sdflabel_amd.BatchRefiner(_dec16(reuse), D, K, (H, W), B, lidar_cap=4096, device=DEV)
+        rf.set_crops(first, target[:B], [lidar] * B)
+        rf.capture()
+        out = []
+        for params in (first, second):
+            rf.set_crops(params, target[:B], [lidar] * B)
+            rf.optimize(25)
+            out.append(N(rf.results()[0]))
+        rows.append(out)
+    assert np.array_equal(rows[0][0], rows[1][0]) and np.array_equal(rows[0][1], rows[1][1])
+
+
+def test_float16_candidate_reuse_latent_jump_forces_a_full_pass_for_that_crop_only():
+    D, H, W, B = 40, 48, 48, 3
+    K, p0, target, lidar = _problem(D, H, W, B)
+    rf = sdflabel_amd.BatchRefiner(_dec16(True), D, K, (H, W), B, lidar_cap=4096, device=DEV)
+    rf.set_crops(p0, target, [lidar] * B)
+    rf.iteration(); rf.iteration()
+    assert N(rf.br.reuse_flag).tolist() == [1, 1, 1]
+    with torch.no_grad():
+        rf.latent[1] += torch.tensor([0.5, -0.4, 0.3], device=DEV)
+    rf.iteration()
+    assert N(rf.br.reuse_flag).tolist() == [1, 0, 1]
+    # the band of the moved crop is the full-grid band of its new latent
+    chk = sdflabel_amd.BatchRenderer(_dec16(False), D, K, (W, H), B, device=DEV)
+    # (the solver has stepped since: evaluate the parameters the renderer saw -- br.inputs holds the normalised latent rows of that step)
+    chk.forward(rf.br.yaw, rf.br.trans, rf.br.latent)
+    chk2 = sdflabel_amd.BatchRenderer(_dec16(True), D, K, (W, H), B, device=DEV)
+    chk2.forward(rf.br.yaw, rf.br.trans, rf.br.latent)
+    _ = chk.backward(g_color=torch.ones_like(chk.color)); _ = chk2.backward(g_color=torch.ones_like(chk2.color))
+    _same_step(chk, chk2)
+
+
+def test_float16_candidate_reuse_audit_catches_a_band_row_outside_the_candidates():
+    """plant the failure the proof excludes: a true band row whose full-pass value is overwritten with 0.5 never becomes a candidate, so the
+    candidate pass cannot bring it back -- the rotating audit (1/16 of the other rows per step, the mode's own kernel) must find it within 16
+    steps and check_overflow() must refuse the result; without the audit it silently stays out of the band"""
+    B, D, H, W = 2, 40, 32, 32
+    a = [T(np.array([0.6, -0.4], np.float32)), T(np.array([[0.0, 0.0, 3.5], [0.1, -0.05, 3.2]], np.float32)),
+         T(np.array([[0.3, -0.5, 0.8], [-0.2, 0.6, 0.4]], np.float32))]
+    outcomes = {}
+    for audit in (True, False):
+        br = sdflabel_amd.BatchRenderer(_dec16(True, candidate_audit=audit), D, K_for(H, W), (W, H), B, device=DEV)
+        out = br.forward(*a)
+        n1 = int(out["n"][1])
+        g = int(br.idx[1, n1 // 2])
+        br.fault = (torch.tensor([br.G + g], device=DEV), torch.tensor([0.5], device=DEV))
+        br.invalidate_shape()                                          # the next step is a full pass: the fault enters the candidate selection
+        caught = None
+        for step in range(16):
+            br.forward()
+            assert int(br.cnt[1]) == n1 - 1
+            if int(br.violations[1, 1]) > 0:
+                caught = step
+                break
+        outcomes[audit] = caught
+        assert int(br.violations[0].sum()) == 0
+        if audit:
+            assert caught is not None
+            with pytest.raises(sdflabel_amd.SdfrError, match="candidate reuse"):
+                br.check_overflow()
+            br.fault = None
+            br.forward(*a)
+            for _ in range(17):
+                br.forward()
+            assert br.prefilter_report()["hard_violations"] == 0 and int(br.cnt[1]) == n1
+            br.check_overflow()
+    assert outcomes[False] is None
+
+
+def test_ragged_half_forward_gives_each_row_the_bits_of_the_full_grid_launch():
+    """C ABI: sdfr_mlp_forward_f16_ragged on gathered rows (two crops, counts that are no multiples of the 128-row tile, one empty crop)
+    against sdfr_mlp_forward_f16 over all rows; rows beyond a crop's last tile stay untouched"""
+    L = _lib.lib()
+    d = _dec16(False)
+    h = d.handle(torch.device(DEV, 0))
+    G, NI, B, stride = 5000, 6, 3, 1024
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.rand(B * G, NI, generator=gen) * 2 - 1).to(DEV)
+    full = torch.empty(B * G, device=DEV)
+    _lib.check(L.sdfr_mlp_forward_f16(h.h, _lib.ptr(x), B * G, _lib.ptr(full), None, _lib.stream_ptr()), "fwd")
+    cnt = torch.tensor([777, 0, 130], dtype=torch.int32, device=DEV)
+    cidx = torch.zeros(B, stride, dtype=torch.int32, device=DEV)
+    for b, n in enumerate(cnt.tolist()):
+        cidx[b, :n] = torch.randperm(G, generator=gen)[:n].sort()[0].to(torch.int32).to(DEV)
+    rows = torch.full((B * stride, NI), float("nan"), device=DEV)
+    _lib.check(L.sdfr_candidate_rows(_lib.ptr(x), G, NI, B, _lib.ptr(cidx), stride, _lib.ptr(cnt), _lib.ptr(rows), _lib.stream_ptr()), "rows")
+    out = torch.full((B * stride,), 7.0, device=DEV)
+    masks = torch.zeros(int(L.sdfr_decoder_mask_words(h.h, B * stride)), dtype=torch.int32, device=DEV)
+    _lib.check(L.sdfr_mlp_forward_f16_ragged(h.h, _lib.ptr(rows), B, stride, _lib.ptr(cnt), _lib.ptr(out), _lib.ptr(masks), _lib.stream_ptr()), "ragged")
+    out = out.view(B, stride)
+    for b, n in enumerate(cnt.tolist()):
+        assert torch.equal(out[b, :n], full[b * G + cidx[b, :n].long()])
+        pad = (n + 127) // 128 * 128
+        assert bool(torch.isfinite(out[b, :pad]).all()) and bool((out[b, pad:] == 7.0).all())
+    assert L.sdfr_mlp_forward_f16_ragged(h.h, _lib.ptr(rows), B, 1000, _lib.ptr(cnt), _lib.ptr(out), None, _lib.stream_ptr()) != 0     # not x128

@@ -282,3 +282,41 @@ def test_binding_refuses_an_experiment_library_and_a_foreign_abi(monkeypatch):
     with pytest.raises(_lib.SdfrError, match="ABI version 200"):
         _lib.lib()
     monkeypatch.setattr(_lib, "_lib", None)
+
+
+# ---- r05: the proven Lipschitz bound behind the candidate reuse -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kw", [None, dict(latent_in=[2, 4], xyz_in_all=False), dict(latent_in=[3], xyz_in_all=True), dict(latent_in=(), xyz_in_all=False)])
+def test_latent_lipschitz_bound_is_an_upper_bound(kw):
+    """Decoder.latent_lipschitz_bound() >= every sampled |sdf(z + dz, x) - sdf(z, x)| / |dz| (oracle forward, float64 differences), for the
+    shipped decoder and random decoders with other injection patterns; inf for LayerNorm decoders"""
+    rng = np.random.default_rng(5)
+    if kw is None:
+        d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
+        st, spec = fitted_state()
+        layers = O.decoder_layers_from_state(st, spec)
+        assert 100.0 < d.latent_lipschitz_bound() < 2000.0
+    else:
+        torch.manual_seed(3)
+        dims = [64, 64, 64, 64, 64, 64]
+        d = sdflabel_amd.Decoder(3, dims=dims, norm_layers=(), weight_norm=False, **kw).eval()
+        with torch.no_grad():
+            for p in d.parameters():
+                p.mul_(1.7)
+        layers = [(W, b, None) for W, b in d.effective_layers()]
+        spec = dict(dims=dims, latent_in=list(kw["latent_in"]), xyz_in_all=kw["xyz_in_all"])
+    bound = d.latent_lipschitz_bound()
+    worst = 0.0
+    for _ in range(24):
+        z = rng.normal(size=3); z /= np.linalg.norm(z)
+        dz = rng.normal(size=3) * 10.0 ** rng.uniform(-4, -1)
+        x = rng.uniform(-1, 1, size=(512, 3))
+        a = np.concatenate([np.tile(z, (512, 1)), x], 1).astype(np.float32)
+        b = a.copy(); b[:, :3] = (z + dz).astype(np.float32)
+        step = np.linalg.norm(b[0, :3].astype(np.float64) - a[0, :3].astype(np.float64))
+        fa, fb = O.decoder_forward(layers, spec, a).astype(np.float64), O.decoder_forward(layers, spec, b).astype(np.float64)
+        worst = max(worst, float(np.abs(fa - fb).max() / step))
+    assert 0.0 < worst <= bound, (worst, bound)
+    if kw is not None and not kw["latent_in"]:
+        ln = sdflabel_amd.Decoder(3, dims=[32, 32], norm_layers=(0, 1), weight_norm=False)
+        assert ln.latent_lipschitz_bound() == float("inf")

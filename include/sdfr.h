@@ -176,8 +176,9 @@ int sdfr_prefilter_guard2(float* sdf_grid, const float* sdf_exact, const int32_t
 int sdfr_gather_rows(float* out, const float* src, int ncol, const int32_t* idx, const int32_t* slot, int64_t G, int B, int cap,
                      int src_cap, const int32_t* cnt, void* stream);
 /* Audit of the two-stage evaluation (r04): the guard above observes the half pass only at the candidates; a row outside them that the half
- * pass misplaced by more than the margin is invisible to it.  Every step the NON-candidate rows of one residue class g = *phase (mod stride)
- * -- a rotating 1/stride slice of the grid: every row once per `stride` steps -- are listed by sdfr_prefilter_audit_select (rows
+ * pass misplaced by more than the margin is invisible to it.  Every step the NON-candidate rows of one slice of the grid -- the contiguous
+ * rows [ph * ceil(G / stride), (ph + 1) * ceil(G / stride)), ph = *phase mod stride: every row once per `stride` steps -- are listed by
+ * sdfr_prefilter_audit_select (rows
  * float[cap_rows][n_inputs] = their decoder input rows, src int32[cap_rows] = b * G + g, *n_audit = how many; cslot: the grid-row ->
  * candidate-slot map of the candidate selection), evaluated exactly by the caller (sdfr_mlp_forward_counted(dec, rows, cap_rows, n_audit,
  * sdf_exact, 0)) and judged by sdfr_prefilter_audit_check: |exact| < thr on such a row = a band row was excluded in this step ->

@@ -184,10 +184,12 @@ class BatchRenderer:
             self.violations = i(B, 2)
             self.lipschitz = float(decoder.latent_lipschitz_bound())
             self.reuse = True
-            self.max_reuse = int(getattr(decoder, "candidate_max_reuse", 16))
+            # (the bound is proven, so no full pass is forced for safety's sake inside a 60-iteration refinement, configs/config_refine.ini:15;
+            # measured at 64 crops per launch: max_reuse 16 -> 64 and audit stride 16 -> 32 take a refinement iteration from 4.5 to 3.5 ms)
+            self.max_reuse = int(getattr(decoder, "candidate_max_reuse", 64))
             self.lat_ref, self.age, self.reuse_flag = f(B, self.L), i(B), i(B)
             self.audit = bool(getattr(decoder, "candidate_audit", True))
-            self.audit_stride = int(getattr(decoder, "candidate_audit_stride", 16))
+            self.audit_stride = int(getattr(decoder, "candidate_audit_stride", 32))
             if self.audit:
                 self.audit_cap = B * ((G + self.audit_stride - 1) // self.audit_stride)
                 self.audit_rows, self.audit_src, self.audit_sdf = f(self.audit_cap, NI), i(self.audit_cap), f(self.audit_cap)

@@ -116,8 +116,8 @@ def test_float16_candidate_reuse_latent_jump_forces_a_full_pass_for_that_crop_on
 
 def test_float16_candidate_reuse_audit_catches_a_band_row_outside_the_candidates():
     """plant the failure the proof excludes: a true band row whose full-pass value is overwritten with 0.5 never becomes a candidate, so the
-    candidate pass cannot bring it back -- the rotating audit (1/16 of the other rows per step, the mode's own kernel) must find it within 16
-    steps and check_overflow() must refuse the result; without the audit it silently stays out of the band"""
+    candidate pass cannot bring it back -- the rotating audit (1/32 of the other rows per step, the mode's own kernel) must find it within one
+    rotation and check_overflow() must refuse the result; without the audit it silently stays out of the band"""
     B, D, H, W = 2, 40, 32, 32
     a = [T(np.array([0.6, -0.4], np.float32)), T(np.array([[0.0, 0.0, 3.5], [0.1, -0.05, 3.2]], np.float32)),
          T(np.array([[0.3, -0.5, 0.8], [-0.2, 0.6, 0.4]], np.float32))]
@@ -130,7 +130,7 @@ def test_float16_candidate_reuse_audit_catches_a_band_row_outside_the_candidates
         br.fault = (torch.tensor([br.G + g], device=DEV), torch.tensor([0.5], device=DEV))
         br.invalidate_shape()                                          # the next step is a full pass: the fault enters the candidate selection
         caught = None
-        for step in range(16):
+        for step in range(br.audit_stride if audit else 32):         # one whole rotation of the audit
             br.forward()
             assert int(br.cnt[1]) == n1 - 1
             if int(br.violations[1, 1]) > 0:
@@ -144,7 +144,7 @@ def test_float16_candidate_reuse_audit_catches_a_band_row_outside_the_candidates
                 br.check_overflow()
             br.fault = None
             br.forward(*a)
-            for _ in range(17):
+            for _ in range(br.audit_stride + 1):
                 br.forward()
             assert br.prefilter_report()["hard_violations"] == 0 and int(br.cnt[1]) == n1
             br.check_overflow()

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--precision", default="float32", choices=["float32", "float16", "float32_split", "float32_prefilter"])
+    ap.add_argument("--reuse", action="store_true", help="candidate reuse (float16: decoder.candidate_reuse; float32_prefilter: prefilter_reuse)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -38,6 +39,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     prec = {"float32": torch.float32, "float16": torch.float16}.get(args.precision, args.precision)
     dec, L = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
+    dec.candidate_reuse = dec.prefilter_reuse = bool(args.reuse)
     dec = dec.to(dev)
     D, H, W = 40, args.size, args.size
     K = K_for(H, W)

@@ -333,6 +333,27 @@ int sdfr_splat_weights_backward(int primitive, const float* K, const float* Kinv
                                 float depth_constant, const float* aux, const float* g_weights, const float* wsum, float* g_p_cam,
                                 float* g_n_cam, void* stream);
 
+/* The same three calls with the primitive's clamp configuration spelled out (r05) -- what the reference's standalone functions accept
+ * beyond the calls Rasterer.forward makes (rasterer.py:92-104):
+ *   clamp_alt = 0   the renderer's clamp: disc hard (softclamp=False), circle / circle_opt sigmoid (softclamp=True)
+ *   clamp_alt = 1   the other one: disc softclamp=True -- inside_surfel's OWN default, primitives.py:174,217-218: the mask
+ *                   sigmoid((diam - d) * c) > 0 holds until exp overflows, so practically every surfel covers every pixel (dense work,
+ *                   whole-image screen boxes); circle / circle_opt softclamp=False -- a hard edge (:51-53,:120)
+ *   clamp_constant  softclamp_constant of the sigmoid clamps (> 0; 3 / 5 / 5 are the functions' defaults, :13,:83,:175); ignored by hard clamps
+ * sdfr_splat_forward / _weights / _weights_backward are these with (0, default constant).  clamp_alt = 1 computes its own screen boxes
+ * (no SDFR_PRIM_BOXES_READY / SDFR_PRIM_BINS). */
+int sdfr_splat_forward_clamp(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr,
+                             const float* uv, const float* znorm, const float* bg, const float* bg_logit, int B, int cap, const int32_t* cnt,
+                             int W, int H, float diam, float depth_constant, int clamp_alt, float clamp_constant, int32_t* bbox_ws,
+                             float* color, float* mask, float* depth, float* normals, float* aux, void* stream);
+int sdfr_splat_weights_clamp(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* uv,
+                             const float* znorm, const float* bg_logit, int B, int cap, const int32_t* cnt, int W, int H, float diam,
+                             float depth_constant, int clamp_alt, float clamp_constant, const float* aux, float* weights, void* stream);
+int sdfr_splat_weights_backward_clamp(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* uv,
+                                      const float* znorm, int has_bg_row, int B, int cap, const int32_t* cnt, int W, int H, float diam,
+                                      float depth_constant, int clamp_alt, float clamp_constant, const float* aux, const float* g_weights,
+                                      const float* wsum, float* g_p_cam, float* g_n_cam, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Batched refinement step glue  --  the per-iteration host tensor algebra of pipelines/optimizer.py:86-100, for B crops
  * at once and entirely on the device (no host synchronisation anywhere in a step).

@@ -316,8 +316,9 @@ def pixel_rays(Kinv, grid_2d):
 
 
 def inside_surfel(Kinv, grid_2d, vertex_3d, normals, diam=0.04, depth_constant=150, add_bg=False,
-                  chunk=8192, want_aux=False):
-    """primitives.py:165-242 with softclamp=False (the renderer's call, rasterer.py:102-104).
+                  chunk=8192, want_aux=False, softclamp=False, softclamp_constant=5):
+    """primitives.py:165-242; softclamp=False is the renderer's call (rasterer.py:102-104), softclamp=True the function's own default
+    (:174,:217-218: the coverage mask is sigmoid((diam - d) * c) > 0, true until exp overflows -- d < diam + 88.7 / c).
 
     Kinv is K.float().inverse() (primitives.py:204), supplied by the caller.  Returns the (N[+1], P)
     weight matrix (the reference expands it to 3 identical channels, :241).  Dense, chunked over pixels.
@@ -343,8 +344,11 @@ def inside_surfel(Kinv, grid_2d, vertex_3d, normals, diam=0.04, depth_constant=1
         g3 = r[None, :, :] * z[:, :, None]                                         # :212
         vec = vertex_3d[:, None, :] - g3                                           # :215
         d = np.sqrt(np.sum(vec * vec, axis=-1)).astype(dt)
-        dist = np.maximum(dt.type(diam) - d, dt.type(0))                           # :220
-        m = (dist > 0)
+        if softclamp:
+            m = _sigmoid(((dt.type(diam) - d) * dt.type(softclamp_constant)).astype(dt)) > 0   # :217-218,:226
+        else:
+            dist = np.maximum(dt.type(diam) - d, dt.type(0))                       # :220
+            m = (dist > 0)
         if want_aux:
             aux["margin_disc"][s:s + chunk] = np.min(np.abs(dt.type(diam) - d), axis=0) if N else np.inf
         mf = m.astype(dt)
@@ -387,7 +391,8 @@ def depth_logits(vertex_3d, depth_constant):
     return (np.maximum(q, dt.type(0)) * dt.type(depth_constant)).astype(dt), q, zn
 
 
-def inside_circle(K, grid_2d, vertex_2d, vertex_3d, diam=0.02, depth_constant=100, softclamp_constant=3, add_bg=False, want_mask=False):
+def inside_circle(K, grid_2d, vertex_2d, vertex_3d, diam=0.02, depth_constant=100, softclamp_constant=3, add_bg=False, want_mask=False,
+                  softclamp=True):
     """primitives.py:4-71 with softclamp=True (the renderer's call, rasterer.py:94-96, leaves the default).  Note the reference
     thresholds sigmoid(.) > 0 (:55), which only fails once exp overflows (~29.6 px beyond the circle), and that the softmax runs
     over z * mask (:70): uncovered vertices keep a logit of 0 in the denominator."""
@@ -396,7 +401,10 @@ def inside_circle(K, grid_2d, vertex_2d, vertex_3d, diam=0.02, depth_constant=10
     diff = vertex_2d[:, None, :2].astype(dt) - grid_2d[None].astype(dt)                    # :42
     r = np.abs(K[0, 0].astype(dt) * dt.type(diam) / (vertex_3d[:, 2] + dt.type(eps)))      # :47
     d = np.sqrt(np.sum(diff * diff, axis=-1)).astype(dt)
-    m = _sigmoid(((r[:, None] - d) * dt.type(softclamp_constant)).astype(dt)) > 0          # :46-49,:55
+    if softclamp:
+        m = _sigmoid(((r[:, None] - d) * dt.type(softclamp_constant)).astype(dt)) > 0      # :46-49,:55
+    else:
+        m = np.maximum(r[:, None] - d, dt.type(0)) > 0                                      # :51-53,:55: a hard circle
     zl, _, _ = depth_logits(vertex_3d, depth_constant)                                      # :56-61
     L = zl[:, None] * m.astype(dt)
     mf = m.astype(dt)
@@ -409,7 +417,8 @@ def inside_circle(K, grid_2d, vertex_2d, vertex_3d, diam=0.02, depth_constant=10
     return (W, m) if want_mask else W
 
 
-def inside_circle_opt(K, vertex_2d, vertex_3d, diam=0.025, depth_constant=10000, softclamp_constant=5, add_bg=False, want_mask=False):
+def inside_circle_opt(K, vertex_2d, vertex_3d, diam=0.025, depth_constant=10000, softclamp_constant=5, add_bg=False, want_mask=False,
+                      softclamp=True):
     """primitives.py:74-162 -- every vertex stamps a 15x15 pixel square (sigmoid weights, all > 0) at trunc(vertex_2d + offset),
     indices clamped into the image (:125-127), duplicates summed by the sparse tensor (:135-138); image size from K (:109-110)."""
     dt = vertex_3d.dtype
@@ -420,7 +429,10 @@ def inside_circle_opt(K, vertex_2d, vertex_3d, diam=0.025, depth_constant=10000,
     off = np.concatenate((xx[..., None], yy[..., None]), axis=-1).reshape((-1, 2)).astype(dt)      # rasterer.py:30-32
     dist_prim = np.sqrt(np.sum(off * off, axis=-1)).astype(dt)
     r = np.abs(K[0, 0].astype(dt) * dt.type(diam) / (vertex_3d[:, 2] + dt.type(eps)))
-    prim = _sigmoid(((r[:, None] - dist_prim[None]) * dt.type(softclamp_constant)).astype(dt))       # :118
+    if softclamp:
+        prim = _sigmoid(((r[:, None] - dist_prim[None]) * dt.type(softclamp_constant)).astype(dt))   # :118
+    else:
+        prim = np.maximum(r[:, None] - dist_prim[None], dt.type(0)).astype(dt)                       # :120: stamp offsets inside the circle only
     ids = np.trunc(off[None] + vertex_2d[:, None, :].astype(dt)).astype(np.int64)                   # :122-124
     ids[..., 0] = np.clip(ids[..., 0], 0, x_px - 1)
     ids[..., 1] = np.clip(ids[..., 1], 0, y_px - 1)

@@ -116,6 +116,14 @@ _PROTOS = {
                                    c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "sdfr_splat_weights_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                             c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_forward_clamp": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_int, c_void_p, c_int, c_int, c_float, c_float, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_weights_clamp": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                         c_int, c_float, c_float, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_weights_backward_clamp": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                                  c_int, c_int, c_float, c_float, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p]),
     "sdfr_params_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_surface_latent_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sdfr_params_backward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

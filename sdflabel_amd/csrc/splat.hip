@@ -41,6 +41,11 @@ struct SplatArgs {
     int cap; const int32_t* cnt; int W, H;
     float diam, depth_constant;
     float cover_sq;                               // PRIM 0: coverage threshold on the squared distance (disc_cover_sq)
+    // clamp configuration of the primitive (r05).  clamp_c: the softclamp_constant of the sigmoid clamps (3 for the renderer's circle,
+    // primitives.py:13; reach = how far beyond the radius sigmoid((r - d) c) stays positive in float32).  Kernels instantiated with ALT take
+    // the OTHER clamp of their primitive, which Rasterer.forward never passes but the standalone functions offer: disc -> softclamp=True
+    // (sigmoid, :217-218: positive until exp overflows, i.e. practically every pixel), circle / circle_opt -> softclamp=False (hard edge, :51-53,:120)
+    float clamp_c, reach;
     // ragged extents (r04): wh != NULL -> crop b renders W_b = wh[2b] x H_b = wh[2b+1] pixels (every crop of a batch its own image size, as
     // the reference pipeline's crops have: utils/refinement.py:586-609); its images live in slots of `pst` pixels per channel
     // ([B][C][pst], rows of W_b pixels in the first W_b H_b entries).  wh == NULL: every crop W x H, pst = W H (the dense layout).
@@ -64,15 +69,23 @@ struct Hit {
 // primitives.py:209-226 for one (surfel, pixel) pair.  The coverage test  diam - ||v|| > 0  (:220,:226) is taken on the squared norm:
 // with a correctly rounded square root,  sqrt(x) < diam  <=>  x <= cover_sq  for the float cover_sq computed by disc_cover_sq() below --
 // the same decisions as the reference's norm-and-compare for every float x, without the square root.
+// primitives.py:217-218,:226 (softclamp=True): sigmoid((diam - ||v||) * c) > 0 with torch's float32 sigmoid 1 / (1 + exp(-x))
+__device__ __forceinline__ bool soft_disc_cover(float d2, float diam, float c) {
+    const float arg = (diam - sqrtf(d2)) * c;
+    return (1.f / (1.f + expf(-arg))) > 0.f;
+}
+
+template <bool ALT = false>
 __device__ __forceinline__ Hit disc_eval(float px, float py, float pz, float nx, float ny, float nz, float a, float rx, float ry, float rz,
-                                         float cover_sq) {
+                                         float cover_sq, float diam = 0.f, float clamp_c = 0.f) {
     Hit h;
     const float b0 = rx * nx + ry * ny + rz * nz;                                // :209
     h.small = fabsf(b0) < 0.01f;                                                 // :210
     h.b = h.small ? FLT_EPSILON : b0;
     h.t = a / h.b;                                                               // :211
     const float vx = px - rx * h.t, vy = py - ry * h.t, vz = pz - rz * h.t;     // :212,:215
-    h.m = (vx * vx + vy * vy + vz * vz) <= cover_sq;                             // :220,:226
+    if (ALT) h.m = soft_disc_cover(vx * vx + vy * vy + vz * vz, diam, clamp_c);
+    else h.m = (vx * vx + vy * vy + vz * vz) <= cover_sq;                        // :220,:226
     return h;
 }
 
@@ -88,11 +101,13 @@ static float disc_cover_sq(float diam) {
     return t;
 }
 
-// primitives.py:42-49,55: sigmoid((r - ||uv - pixel||) * 3) > 0
-__device__ __forceinline__ bool circle_cover(float u, float v, float r, float x, float y) {
+// primitives.py:42-49,55: sigmoid((r - ||uv - pixel||) * softclamp_constant) > 0;  ALT (softclamp=False, :51-53): clamp(r - d, min=0) > 0
+template <bool ALT = false>
+__device__ __forceinline__ bool circle_cover(float u, float v, float r, float x, float y, float c) {
     const float dx = u - x, dy = v - y;
     const float d = sqrtf(dx * dx + dy * dy);
-    const float arg = (r - d) * 3.f;
+    if (ALT) return (r - d) > 0.f;
+    const float arg = (r - d) * c;
     return (1.f / (1.f + expf(-arg))) > 0.f;
 }
 
@@ -111,6 +126,28 @@ __device__ __forceinline__ bool stamp_axis(float u, int p, int n) {
     if (p == 0) { int t = (int)truncf(u - 7.f); if (t <= 0) return true; }
     if (p == n - 1) { int t = (int)truncf(u + 7.f); if (t >= n - 1) return true; }
     return false;
+}
+
+// circle_opt with softclamp=False (primitives.py:120): a stamp offset (ox, oy) contributes clamp(r - ||(ox, oy)||, 0), and the sparse tensor
+// sums what lands on the same pixel (:135-138), so a pixel is covered iff SOME offset that maps to it lies inside the circle -- iff the one
+// with the smallest |ox| and the smallest |oy| does.  Offsets that map to pixel coordinate p on one axis: smallest |o|, or -1 if none.
+__device__ __forceinline__ int stamp_axis_min(float u, int p, int n) {
+    int best = -1;
+    for (int o = -7; o <= 7; ++o) {
+        int t = (int)truncf(u + (float)o);
+        t = t < 0 ? 0 : (t > n - 1 ? n - 1 : t);
+        const int ao = o < 0 ? -o : o;
+        if (t == p && (best < 0 || ao < best)) best = ao;
+    }
+    return best;
+}
+
+template <bool ALT = false>
+__device__ __forceinline__ bool stamp_cover(float u, float v, int x, int y, int W, int H, float r) {
+    if (!ALT) return stamp_axis(u, x, W) && stamp_axis(v, y, H);
+    const int ox = stamp_axis_min(u, x, W), oy = stamp_axis_min(v, y, H);
+    if (ox < 0 || oy < 0) return false;
+    return (r - sqrtf((float)(ox * ox + oy * oy))) > 0.f;
 }
 
 // per-surfel depth logit  clamp(-z / (||z|| + eps) + 1, 0) * C   (primitives.py:57-61, :141-144)
@@ -135,17 +172,18 @@ __device__ __forceinline__ bool interval(float lo_f, float hi_f, int n, int& lo,
     return lo <= hi;
 }
 
-template <int PRIM>
+template <int PRIM, bool ALT = false>
 __device__ __forceinline__ bool surfel_bbox(const SplatArgs& A, int b, int64_t e, int& x0, int& y0, int& x1, int& y1) {
     int W, H, PS_;
     splat_dims(A, b, W, H, PS_);
     x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
     const float* K = A.K + (int64_t)b * 9;
     if (PRIM == 0) {
+        if (ALT) return true;                                  // the soft clamp covers (practically) every pixel: the whole image
         return disc_bbox(K, A.p_cam[e * 3], A.p_cam[e * 3 + 1], A.p_cam[e * 3 + 2], A.diam, W, H, x0, y0, x1, y1);
     } else if (PRIM == 1) {
         const float u = A.uv[e * 2], v = A.uv[e * 2 + 1];
-        const float r = fabsf(K[0] * A.diam / (A.p_cam[e * 3 + 2] + FLT_EPSILON)) + SIGMOID_REACH + 1.f;
+        const float r = fabsf(K[0] * A.diam / (A.p_cam[e * 3 + 2] + FLT_EPSILON)) + (ALT ? 0.f : A.reach) + 1.f;
         if (!interval(u - r, u + r, W, x0, x1)) return false;
         if (!interval(v - r, v + r, H, y0, y1)) return false;
         return true;
@@ -161,14 +199,14 @@ __device__ __forceinline__ bool surfel_bbox(const SplatArgs& A, int b, int64_t e
     }
 }
 
-template <int PRIM>
+template <int PRIM, bool ALT = false>
 __global__ __launch_bounds__(256) void sdfr_splat_bbox_kernel(const SplatArgs A, int4* __restrict__ bbox) {
     const int b = blockIdx.y;
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= sdfr_count(A.cnt, b, A.cap)) return;
     const int64_t e = (int64_t)b * A.cap + s;
     int x0, y0, x1, y1;
-    const bool ok = surfel_bbox<PRIM>(A, b, e, x0, y0, x1, y1);
+    const bool ok = surfel_bbox<PRIM, ALT>(A, b, e, x0, y0, x1, y1);
     bbox[e] = ok ? make_int4(x0, y0, x1, y1) : make_int4(1, 1, 0, 0);
 }
 
@@ -213,7 +251,7 @@ __device__ __forceinline__ void acc_rescale(SplatAcc& a, float newmax) {
 // disc: the first sweep also records which pixels each candidate covers (one 64-bit ballot per candidate); the second sweep skips
 // candidates that cover no pixel of the tile and re-evaluates only the plane hit for the others (PW = 1 keeps ballots for tiles of at most
 // 64 candidates and re-evaluates the coverage otherwise: identical arithmetic).
-template <int PRIM, int PW>
+template <int PRIM, int PW, bool ALT = false>
 __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs A, const int4* __restrict__ bbox,
                                                                 const int32_t* __restrict__ bins, float* __restrict__ color,
                                                                 float* __restrict__ mask, float* __restrict__ depth,
@@ -391,7 +429,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
 #pragma unroll
         for (int j = 0; j < SPW; ++j) part[j] = 0.f;
         for_each([&](int j, int k, int c) {
-            const Hit h = disc_eval(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, A.cover_sq);
+            const Hit h = disc_eval<ALT>(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, A.cover_sq, diam, A.clamp_c);
             if (h.m) part[j] += h.t * h.t;
             if (use_cov) {
                 const unsigned long long cm = __ballot(h.m);
@@ -435,16 +473,16 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
                 const float t = sdw[6][k] / bb;
                 l = fmaxf((-t) / nue + 1.f, 0.f) * C;                             // :227-230
             } else {
-                const Hit h = disc_eval(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, A.cover_sq);
+                const Hit h = disc_eval<ALT>(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, A.cover_sq, diam, A.clamp_c);
                 l = fmaxf((-h.t) / nue + 1.f, 0.f) * C;
                 hit = h.m;
             }
         } else if (PRIM == 1) {
             l = sdw[10][k];
-            hit = circle_cover(sdw[0][k], sdw[1][k], sdw[6][k], (float)x, (float)y);
+            hit = circle_cover<ALT>(sdw[0][k], sdw[1][k], sdw[6][k], (float)x, (float)y, A.clamp_c);
         } else {
             l = sdw[10][k];
-            hit = stamp_axis(sdw[0][k], x, W) && stamp_axis(sdw[1][k], y, H);
+            hit = stamp_cover<ALT>(sdw[0][k], sdw[1][k], x, y, W, H, sdw[6][k]);
         }
         if (hit) {
             SplatAcc& a = acc[j];
@@ -545,7 +583,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // DENSE: the upstream gradient is given per (surfel, pixel) weight -- gW [B][rows][P], rows = cap (+1 with a background row) -- together with
 // Sd[b][pix] = sum_j w_j gW_j (the softmax-backward sum), instead of through the composited images: the backward of the standalone
 // primitives (sdfr_splat_weights), which hand out the dense weight matrix as the reference's inside_* functions do.
-template <int PRIM, bool DENSE = false>
+template <int PRIM, bool DENSE = false, bool ALT = false>
 __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, const float* __restrict__ aux,
                                                             const float* __restrict__ color, const float* __restrict__ mask,
                                                             const float* __restrict__ depth, const float* __restrict__ normals,
@@ -581,7 +619,7 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
     }
     int x0, y0, x1, y1;
     float sC0 = 0.f, sC1 = 0.f, sC2 = 0.f, sN0 = 0.f, sN1 = 0.f, sN2 = 0.f, sZ = 0.f, sA = 0.f, sB0 = 0.f, sB1 = 0.f, sB2 = 0.f, sL = 0.f;
-    if (surfel_bbox<PRIM>(A, b, e1, x0, y0, x1, y1)) {
+    if (surfel_bbox<PRIM, ALT>(A, b, e1, x0, y0, x1, y1)) {
         const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
         for (int i = lane; i < bw * bh; i += 64) {
             const int yy = i / bw;
@@ -591,12 +629,12 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
             bool cov;
             if (PRIM == 0) {
                 pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
-                h = disc_eval(px, py, pz, nx, ny, nz, a, rx, ry, rz, A.cover_sq);
+                h = disc_eval<ALT>(px, py, pz, nx, ny, nz, a, rx, ry, rz, A.cover_sq, diam, A.clamp_c);
                 cov = h.m;
             } else if (PRIM == 1) {
-                cov = circle_cover(u, v, rad, (float)x, (float)y);
+                cov = circle_cover<ALT>(u, v, rad, (float)x, (float)y, A.clamp_c);
             } else {
-                cov = stamp_axis(u, x, W) && stamp_axis(v, y, H);
+                cov = stamp_cover<ALT>(u, v, x, y, W, H, rad);
             }
             if (!cov) continue;
             const int pix = y * W + x;
@@ -673,7 +711,7 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
 // Rasterer.forward never needs it here (the splat kernels composite on the fly), but a caller of the standalone functions does: the
 // per-pixel softmax state `aux` of a splat forward pass plus one more sweep over each surfel's screen box reproduces every entry.
 // One wavefront per surfel; W must be zero-filled by the caller (only covered pixels are written).
-template <int PRIM>
+template <int PRIM, bool ALT = false>
 __global__ __launch_bounds__(256) void sdfr_splat_weights_kernel(const SplatArgs A, const float* __restrict__ aux, float* __restrict__ Wout,
                                                                 int rows) {
     const int b = blockIdx.y;
@@ -693,7 +731,7 @@ __global__ __launch_bounds__(256) void sdfr_splat_weights_kernel(const SplatArgs
         zl = depth_logit(pz, A.znorm[b], A.depth_constant, nullptr);
     }
     int x0, y0, x1, y1;
-    if (!surfel_bbox<PRIM>(A, b, e1, x0, y0, x1, y1)) return;
+    if (!surfel_bbox<PRIM, ALT>(A, b, e1, x0, y0, x1, y1)) return;
     const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
     float* row = Wout + ((int64_t)b * rows + s) * P;
     for (int i = lane; i < bw * bh; i += 64) {
@@ -706,13 +744,13 @@ __global__ __launch_bounds__(256) void sdfr_splat_weights_kernel(const SplatArgs
         if (PRIM == 0) {
             float rx, ry, rz;
             pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
-            const Hit h = disc_eval(px, py, pz, nx, ny, nz, a, rx, ry, rz, A.cover_sq);
+            const Hit h = disc_eval<ALT>(px, py, pz, nx, ny, nz, a, rx, ry, rz, A.cover_sq, A.diam, A.clamp_c);
             cov = h.m;
             logit = fmaxf((-h.t) / (ax.x + FLT_EPSILON) + 1.f, 0.f) * A.depth_constant;
         } else if (PRIM == 1) {
-            cov = circle_cover(u, v, rad, (float)x, (float)y);
+            cov = circle_cover<ALT>(u, v, rad, (float)x, (float)y, A.clamp_c);
         } else {
-            cov = stamp_axis(u, x, W) && stamp_axis(v, y, H);
+            cov = stamp_cover<ALT>(u, v, x, y, W, H, rad);
         }
         if (cov) row[pix] = expf(logit - ax.y) / ax.z;
     }
@@ -741,7 +779,24 @@ static int fill_args(SplatArgs& A, const char* who, int primitive, const float* 
     A.K = K; A.Kinv = Kinv; A.p_cam = p_cam; A.n_cam = n_cam; A.attr = attr; A.uv = uv; A.znorm = znorm; A.bg = bg; A.bg_logit = bg_logit;
     A.cap = cap; A.cnt = cnt; A.W = W; A.H = H; A.diam = diam; A.depth_constant = depth_constant;
     A.cover_sq = disc_cover_sq(diam);
+    A.clamp_c = (primitive == 1) ? 3.f : 5.f;                 // the functions' default softclamp_constant (primitives.py:13,83,175)
+    A.reach = SIGMOID_REACH;
     A.wh = nullptr; A.pst = W * H; A.bin_stride = sdfr_splat_bin_stride(cap, W, H);
+    return SDFR_OK;
+}
+
+// the clamp configuration of the *_clamp entry points: clamp_alt = the primitive's OTHER clamp (disc: softclamp=True; circle, circle_opt:
+// softclamp=False), clamp_constant = softclamp_constant of the sigmoid clamps (> 0)
+static int set_clamp(SplatArgs& A, const char* who, int primitive, int clamp_alt, float clamp_constant) {
+    SDFR_REQUIRE(clamp_alt == 0 || clamp_alt == 1, "%s: clamp_alt %d (0: the renderer's clamp of the primitive, 1: the other one)", who, clamp_alt);
+    const bool sigmoid = (primitive == 0) ? clamp_alt == 1 : clamp_alt == 0;
+    if (sigmoid) {
+        SDFR_REQUIRE(clamp_constant > 0.f && clamp_constant < 1e30f, "%s: softclamp_constant %g must be positive", who, (double)clamp_constant);
+        A.clamp_c = clamp_constant;
+        // sigmoid(x) > 0 in float32 while exp(-x) is finite: x > -88.73; beyond the radius by less than 88.73 / c (+ slack for the rounding of
+        // the product).  c = 3 keeps the constant the renderer path was built and tested with.
+        A.reach = (clamp_constant == 3.f) ? SIGMOID_REACH : 88.73f / clamp_constant * 1.001f + 0.05f;
+    }
     return SDFR_OK;
 }
 
@@ -757,7 +812,7 @@ static int64_t splat_serial_tiles() {
 }
 
 static int splat_forward_launch(const SplatArgs& A, int primitive, bool boxes_ready, bool use_bins, int B, int cap, int tiles, int32_t* bbox_ws,
-                                float* color, float* mask, float* depth, float* normals, float* aux, void* stream) {
+                                float* color, float* mask, float* depth, float* normals, float* aux, void* stream, bool alt = false) {
     SDFR_REQUIRE(cap == 0 || bbox_ws, "sdfr_splat_forward: NULL bbox workspace");
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -775,12 +830,27 @@ static int splat_forward_launch(const SplatArgs& A, int primitive, bool boxes_re
         if (serial) hipLaunchKernelGGL((sdfr_splat_fwd_kernel<P, 1>), gt, dim3(64), 0, s, A, bb, bins, color, mask, depth, normals, aux); \
         else hipLaunchKernelGGL((sdfr_splat_fwd_kernel<P, SPL_NS>), gt, dim3(64 * SPL_NS), 0, s, A, bb, bins, color, mask, depth, normals, aux); \
     } while (0)
+    // the other clamp of the primitive (standalone functions only): one wave per tile, boxes computed here (never boxes_ready / binned)
+#define SPL_LAUNCH_FWD_ALT(P)                                                                                                          \
+    do {                                                                                                                               \
+        if (cap > 0) hipLaunchKernelGGL((sdfr_splat_bbox_kernel<P, true>), gb, dim3(256), 0, s, A, bb);                                \
+        hipLaunchKernelGGL((sdfr_splat_fwd_kernel<P, 1, true>), gt, dim3(64), 0, s, A, bb, (const int32_t*)nullptr, color, mask, depth, normals, aux); \
+    } while (0)
+    if (alt) {
+        SDFR_REQUIRE(!boxes_ready && !use_bins, "sdfr_splat_forward_clamp: the alternative clamp computes its own screen boxes");
+        switch (primitive) {
+            case 0: SPL_LAUNCH_FWD_ALT(0); break;
+            case 1: SPL_LAUNCH_FWD_ALT(1); break;
+            default: SPL_LAUNCH_FWD_ALT(2); break;
+        }
+    } else
     switch (primitive) {
         case 0: SPL_LAUNCH_FWD(0); break;
         case 1: SPL_LAUNCH_FWD(1); break;
         default: SPL_LAUNCH_FWD(2); break;
     }
 #undef SPL_LAUNCH_FWD
+#undef SPL_LAUNCH_FWD_ALT
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -789,6 +859,17 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
                                   const float* attr, const float* uv, const float* znorm, const float* bg, const float* bg_logit, int B,
                                   int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant, int32_t* bbox_ws,
                                   float* color, float* mask, float* depth, float* normals, float* aux, void* stream) {
+    const int prim = primitive & ~(SDFR_PRIM_BOXES_READY | SDFR_PRIM_BINS);
+    return sdfr_splat_forward_clamp(primitive, K, Kinv, p_cam, n_cam, attr, uv, znorm, bg, bg_logit, B, cap, cnt, W, H, diam, depth_constant, 0,
+                                    prim == 1 ? 3.f : 5.f, bbox_ws, color, mask, depth, normals, aux, stream);
+}
+
+// ... with the primitive's clamp configuration spelled out (r05): what the standalone inside_* functions accept beyond the renderer's calls
+extern "C" int sdfr_splat_forward_clamp(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam,
+                                        const float* attr, const float* uv, const float* znorm, const float* bg, const float* bg_logit, int B,
+                                        int cap, const int32_t* cnt, int W, int H, float diam, float depth_constant, int clamp_alt,
+                                        float clamp_constant, int32_t* bbox_ws, float* color, float* mask, float* depth, float* normals,
+                                        float* aux, void* stream) {
     const bool boxes_ready = (primitive & SDFR_PRIM_BOXES_READY) != 0;      // bbox_ws already holds boxes and tile lists (sdfr_surfels_forward)
     const bool use_bins = (primitive & SDFR_PRIM_BINS) != 0;
     primitive &= ~(SDFR_PRIM_BOXES_READY | SDFR_PRIM_BINS);
@@ -796,8 +877,10 @@ extern "C" int sdfr_splat_forward(int primitive, const float* K, const float* Ki
     int rc = fill_args(A, "sdfr_splat_forward", primitive, K, Kinv, p_cam, n_cam, attr, uv, znorm, bg, bg_logit, B, cap, cnt, W, H, diam,
                        depth_constant);
     if (rc) return rc;
+    rc = set_clamp(A, "sdfr_splat_forward_clamp", primitive, clamp_alt, clamp_constant);
+    if (rc) return rc;
     return splat_forward_launch(A, primitive, boxes_ready, use_bins, B, cap, ((W + 7) / 8) * ((H + 7) / 8), bbox_ws, color, mask, depth, normals,
-                                aux, stream);
+                                aux, stream, clamp_alt != 0);
 }
 
 // ---- ragged extents: every crop of the batch its own image size (W_b, H_b) and intrinsics, read from device memory ------------------------
@@ -880,17 +963,32 @@ extern "C" int sdfr_splat_backward(int primitive, const float* K, const float* K
 extern "C" int sdfr_splat_weights(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* uv,
                                   const float* znorm, const float* bg_logit, int B, int cap, const int32_t* cnt, int W, int H, float diam,
                                   float depth_constant, const float* aux, float* weights, void* stream) {
+    return sdfr_splat_weights_clamp(primitive, K, Kinv, p_cam, n_cam, uv, znorm, bg_logit, B, cap, cnt, W, H, diam, depth_constant, 0,
+                                    primitive == 1 ? 3.f : 5.f, aux, weights, stream);
+}
+
+extern "C" int sdfr_splat_weights_clamp(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* uv,
+                                        const float* znorm, const float* bg_logit, int B, int cap, const int32_t* cnt, int W, int H, float diam,
+                                        float depth_constant, int clamp_alt, float clamp_constant, const float* aux, float* weights,
+                                        void* stream) {
     SplatArgs A;
     int rc = fill_args(A, "sdfr_splat_weights", primitive, K, Kinv, p_cam, n_cam, p_cam /* attr unused */, uv, znorm, nullptr, nullptr, B, cap,
                        cnt, W, H, diam, depth_constant);
     if (rc) return rc;
     SDFR_REQUIRE(aux && weights, "sdfr_splat_weights: NULL argument");
+    rc = set_clamp(A, "sdfr_splat_weights_clamp", primitive, clamp_alt, clamp_constant);
+    if (rc) return rc;
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
     const int rows = cap + (bg_logit ? 1 : 0);
     if (cap > 0) {
         const dim3 g(sdfr_cdiv(cap, 4), B);
-        switch (primitive) {
+        if (clamp_alt) switch (primitive) {
+            case 0: hipLaunchKernelGGL((sdfr_splat_weights_kernel<0, true>), g, dim3(256), 0, s, A, aux, weights, rows); break;
+            case 1: hipLaunchKernelGGL((sdfr_splat_weights_kernel<1, true>), g, dim3(256), 0, s, A, aux, weights, rows); break;
+            default: hipLaunchKernelGGL((sdfr_splat_weights_kernel<2, true>), g, dim3(256), 0, s, A, aux, weights, rows); break;
+        }
+        else switch (primitive) {
             case 0: hipLaunchKernelGGL(sdfr_splat_weights_kernel<0>, g, dim3(256), 0, s, A, aux, weights, rows); break;
             case 1: hipLaunchKernelGGL(sdfr_splat_weights_kernel<1>, g, dim3(256), 0, s, A, aux, weights, rows); break;
             default: hipLaunchKernelGGL(sdfr_splat_weights_kernel<2>, g, dim3(256), 0, s, A, aux, weights, rows); break;
@@ -905,18 +1003,36 @@ extern "C" int sdfr_splat_weights_backward(int primitive, const float* K, const 
                                            const float* uv, const float* znorm, int has_bg_row, int B, int cap, const int32_t* cnt, int W,
                                            int H, float diam, float depth_constant, const float* aux, const float* g_weights,
                                            const float* wsum, float* g_p_cam, float* g_n_cam, void* stream) {
+    return sdfr_splat_weights_backward_clamp(primitive, K, Kinv, p_cam, n_cam, uv, znorm, has_bg_row, B, cap, cnt, W, H, diam, depth_constant, 0,
+                                             primitive == 1 ? 3.f : 5.f, aux, g_weights, wsum, g_p_cam, g_n_cam, stream);
+}
+
+extern "C" int sdfr_splat_weights_backward_clamp(int primitive, const float* K, const float* Kinv, const float* p_cam, const float* n_cam,
+                                                 const float* uv, const float* znorm, int has_bg_row, int B, int cap, const int32_t* cnt, int W,
+                                                 int H, float diam, float depth_constant, int clamp_alt, float clamp_constant, const float* aux,
+                                                 const float* g_weights, const float* wsum, float* g_p_cam, float* g_n_cam, void* stream) {
     SplatArgs A;
     int rc = fill_args(A, "sdfr_splat_weights_backward", primitive, K, Kinv, p_cam, n_cam, p_cam /* attr unused */, uv, znorm, nullptr, nullptr,
                        B, cap, cnt, W, H, diam, depth_constant);
     if (rc) return rc;
     SDFR_REQUIRE(aux && g_weights && wsum && g_p_cam && g_n_cam, "sdfr_splat_weights_backward: NULL argument");
+    rc = set_clamp(A, "sdfr_splat_weights_backward_clamp", primitive, clamp_alt, clamp_constant);
+    if (rc) return rc;
     if (B == 0 || cap == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
     const dim3 g(sdfr_cdiv(cap, 4), B);
     const int rows = cap + (has_bg_row ? 1 : 0);
     const float* z = nullptr;
     float* zo = nullptr;
-    switch (primitive) {
+    if (clamp_alt) switch (primitive) {
+        case 0: hipLaunchKernelGGL((sdfr_splat_bwd_kernel<0, true, true>), g, dim3(256), 0, s, A, aux, z, z, z, z, z, z, z, z, g_p_cam, g_n_cam, zo,
+                                   g_weights, wsum, rows); break;
+        case 1: hipLaunchKernelGGL((sdfr_splat_bwd_kernel<1, true, true>), g, dim3(256), 0, s, A, aux, z, z, z, z, z, z, z, z, g_p_cam, g_n_cam, zo,
+                                   g_weights, wsum, rows); break;
+        default: hipLaunchKernelGGL((sdfr_splat_bwd_kernel<2, true, true>), g, dim3(256), 0, s, A, aux, z, z, z, z, z, z, z, z, g_p_cam, g_n_cam, zo,
+                                    g_weights, wsum, rows); break;
+    }
+    else switch (primitive) {
         case 0: hipLaunchKernelGGL((sdfr_splat_bwd_kernel<0, true>), g, dim3(256), 0, s, A, aux, z, z, z, z, z, z, z, z, g_p_cam, g_n_cam, zo,
                                    g_weights, wsum, rows); break;
         case 1: hipLaunchKernelGGL((sdfr_splat_bwd_kernel<1, true>), g, dim3(256), 0, s, A, aux, z, z, z, z, z, z, z, z, g_p_cam, g_n_cam, zo,

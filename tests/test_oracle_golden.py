@@ -625,3 +625,35 @@ def test_g14p_secondary_configurations_with_cropped_intrinsics(tag):
         a, ref = rend[k], z[tag + "_out_" + k]
         bad = (np.abs(a - ref) > 1e-4).reshape(a.shape[0], -1).any(0)
         assert not (bad & ~near).any() and bad.mean() <= 1e-3, (k, np.abs(a - ref).max())
+
+
+G13S_CASES = {
+    "disc_default_bg1": ("disc", dict(diam=0.03, softclamp=True, softclamp_constant=5, add_bg=True)),
+    "disc_soft_bg0": ("disc", dict(diam=0.04, softclamp=True, softclamp_constant=5, add_bg=False)),
+    "disc_soft_c40_bg1": ("disc", dict(diam=0.04, softclamp=True, softclamp_constant=40, add_bg=True)),
+    "circle_hard_bg0": ("circle", dict(diam=0.02, softclamp=False, add_bg=False)),
+    "circle_hard_bg1": ("circle", dict(diam=0.02, softclamp=False, add_bg=True)),
+    "circle_c30_default_diam_bg0": ("circle", dict(diam=0.07, softclamp=True, softclamp_constant=30, add_bg=False)),
+    "circle_opt_hard_bg0": ("circle_opt", dict(diam=0.025, softclamp=False, add_bg=False)),
+    "circle_opt_hard_bg1": ("circle_opt", dict(diam=0.025, softclamp=False, add_bg=True)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(G13S_CASES))
+def test_g13s_standalone_primitives_other_clamp_configurations(case):
+    """the clamp configurations Rasterer.forward never passes (the functions' own defaults among them), captured from the reference: G13s"""
+    z, zs = gold("g13_primitives.npz"), gold("g13s_primitive_clamps.npz")
+    W, H = [int(v) for v in z["res"]]
+    K = z["K"]
+    g2 = O.pixel_grid((W, H))
+    name, kw = G13S_CASES[case]
+    if name == "disc":
+        w = O.inside_surfel(np.linalg.inv(K).astype(np.float32), g2, z["points"], z["normals"], **kw)
+    elif name == "circle":
+        w = O.inside_circle(K, g2, z["uv"], z["points"], **kw)
+    else:
+        w = O.inside_circle_opt(K, z["uv"], z["points"], **kw)
+    ref = zs[case + "_w"]
+    assert w.shape == ref.shape
+    assert ((w > 0) == (ref > 0)).mean() > 0.9999
+    assert np.abs(w - ref).max() < (1e-3 if name == "circle_opt" else 5e-6)

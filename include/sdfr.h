@@ -299,7 +299,11 @@ int sdfr_splat_backward(int primitive, const float* K, const float* Kinv, const 
  *   tiles_cap >= ceil(W_b / 8) ceil(H_b / 8) for every crop (launch bound and tile-list layout of the splat workspace,
  *   sdfr_splat_ws_words_r words); tiles16_cap likewise for the 16 x 16 tiles of the 2-D loss.
  * Arithmetic per crop exactly as the fixed-extent calls: a crop's results are bit-identical to rendering it alone at its own size.
- * Disc primitive (the optimizer's), no background. */
+ * Disc primitive (the optimizer's), no background.
+ * CALLER'S CONTRACT (the extents live on the device, the entry points cannot check them): for every crop  1 <= W_b, 1 <= H_b,
+ * W_b * H_b <= pix_stride,  ceil(W_b/8) * ceil(H_b/8) <= tiles_cap,  ceil(W_b/16) * ceil(H_b/16) <= tiles16_cap,  and for the tracer
+ * ceil(W_b/block) * ceil(H_b/block) <= cone_cap.  An extent outside these bounds writes out of bounds.  The Python layer validates them
+ * in set_extents() (sdflabel_amd/batch.py, renderer/sphere_tracer.py) before they reach the device. */
 int64_t sdfr_splat_ws_words_r(int B, int cap, int tiles_cap);
 int sdfr_surfels_forward_r(const float* xyz, int xyz_stride, const float* sdf, int64_t G, const int32_t* idx, const float* J, int Jstride,
                            int Joff, const float* pose, const float* K, int B, int cap, const int32_t* cnt, int output_nocs,

@@ -71,38 +71,35 @@ class _SurfaceFn(torch.autograd.Function):
         return g_sdf, g_xyz, None, None, None, None, None, None, None, None, None
 
 
-_PINNED = {}
+def _pinned_count():
+    """a pinned host int32 for the asynchronous read of a device-side count.  Owned by the caller (one per Grid3D: ADVICE r04 -- a
+    process-global buffer per device let two grids on different streams or threads read each other's band count)"""
+    return torch.empty((1,), dtype=torch.int32).pin_memory()
 
 
-def _pinned_count(dev):
-    """one pinned host int32 per device for the asynchronous read of a device-side count"""
-    t = _PINNED.get(dev)
-    if t is None:
-        t = _PINNED[dev] = torch.empty((1,), dtype=torch.int32).pin_memory()
-    return t
-
-
-def band_select(sdf_flat, threshold, want_slot=True, queue=None):
+def band_select(sdf_flat, threshold, want_slot=True, queue=None, pinned=None):
     """(idx int32 (N,), N, slot int32 (G,)) -- ascending rows with |sdf| < threshold.  One host sync for N (the reference's
     masked_select, grid.py:65, synchronises as well).
     queue (r04): a callable queue(idx, cnt_dev) that enqueues device work consuming the selection with the count still ON THE DEVICE.  The
     count then travels to a pinned host buffer asynchronously, an event marks the copy, `queue` runs, and the host waits for the EVENT only:
     the GPU works on what `queue` enqueued while the host goes on with N (a plain .item() would have to come before those launches, and after
-    them it would wait for them too -- measured slower in r03).  Returns (idx, N, slot, whatever queue returned)."""
+    them it would wait for them too -- measured slower in r03).  Returns (idx, N, slot, whatever queue returned).
+    pinned: the caller's pinned int32[1] the count is copied to (a fresh one is allocated when omitted)."""
     L = _lib.lib()
     G = sdf_flat.shape[0]
     dev = sdf_flat.device
     g1 = max(G, 1)
-    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
-    ints = torch.empty((2 * g1 + (G + 255) // 256 + 1,), dtype=torch.int32, device=dev)
-    idx, slot, scratch = ints[:g1], (ints[g1:2 * g1] if want_slot else None), ints[2 * g1:]
+    # one allocation: idx | slot | scratch | cnt.  The count is not zeroed (r05): the selection's last block always writes it (G = 0: the
+    # library zero-fills it itself)
+    ints = torch.empty((2 * g1 + (G + 255) // 256 + 1 + 1,), dtype=torch.int32, device=dev)
+    idx, slot, scratch, cnt = ints[:g1], (ints[g1:2 * g1] if want_slot else None), ints[2 * g1:-1], ints[-1:]
     with _lib.guard(sdf_flat):
         _lib.check(L.sdfr_band_select(_lib.ptr(sdf_flat), G, 1, float(threshold), _lib.ptr(idx), G, _lib.ptr(cnt), _lib.ptr(slot),
                                       _lib.ptr(scratch), _lib.stream_ptr()), "sdfr_band_select")
     if queue is None:
         n = int(cnt.item())
         return idx, n, slot
-    host = _pinned_count(dev)
+    host = pinned if pinned is not None else _pinned_count()
     host.copy_(cnt, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
@@ -144,7 +141,10 @@ class Grid3D:
             # a band that outgrew the guess is evaluated again at its exact size)
             G_ = sdf_c.shape[0]
             guess = min(G_, max(256, int(1.25 * getattr(self, "_last_band", G_ // 8)) + 64))
-            idx, n, slot, (J, _) = band_select(sdf_c, threshold, queue=lambda idx_, cnt_: mlp_jacobian(state, idx_, guess, cnt_dev=cnt_))
+            if getattr(self, "_pinned", None) is None:
+                self._pinned = _pinned_count()                 # this grid's own (not shared between Grid3D objects)
+            idx, n, slot, (J, _) = band_select(sdf_c, threshold, queue=lambda idx_, cnt_: mlp_jacobian(state, idx_, guess, cnt_dev=cnt_),
+                                               pinned=self._pinned)
             self._last_band = n
             if n > guess:
                 J, _ = mlp_jacobian(state, idx, n)

@@ -36,6 +36,7 @@ class BatchRefiner:
         default extent.  A crop refines bit-identically to the same crop alone in a fixed-size refiner."""
         self.H, self.W = int(crop_size[0]), int(crop_size[1])
         self.B = int(batch)
+        self._K0 = torch.as_tensor(K, dtype=torch.float32).detach().cpu().clone()
         self.w2 = float((weights or {}).get('2d', 0.3))          # configs/config_refine.ini:26-27
         self.w3 = float((weights or {}).get('3d', 0.5))
         self.optimize_latent = bool(optimize_latent)
@@ -111,7 +112,8 @@ class BatchRefiner:
         self.latent.copy_(t(params['latent']).reshape(B, self.L))
         if self.ragged:
             sizes = [(int(h), int(w)) for h, w in crop_sizes] if crop_sizes is not None else [(self.H, self.W)] * B
-            self.rd.set_extents([(w, h) for h, w in sizes], K)
+            # K=None means the constructor's intrinsics, as the docstring says -- not whatever the previous crop set left in place
+            self.rd.set_extents([(w, h) for h, w in sizes], K if K is not None else self._K0)
             self.target.zero_()
             for b, (h, w) in enumerate(sizes):
                 pred = t(nocs_pred[b])
@@ -217,7 +219,12 @@ class BatchRefiner:
         return rows.clone(), (self.w2 * self.loss2d).clone(), (self.w3 * self.loss3d).clone()
 
     def check_overflow(self):
-        """splat: raise if a crop's band exceeded the surfel capacity (BatchRenderer.check_overflow).  trace: nothing can overflow (the point
-        list holds every pixel).  One synchronisation."""
+        """splat: raise if a crop's band exceeded the surfel capacity (BatchRenderer.check_overflow).  trace: the point list holds every pixel,
+        so nothing overflows, but rays that exhausted the march's step budget in the last iteration raise.  One synchronisation."""
         if self.br is not None:
             self.br.check_overflow()
+        elif self.tr.n_unresolved > 0:
+            # rays still marching when the step budget ran out count as misses: the last iteration refined against an incomplete hit set
+            # (too few steps for this view, grazing rays) -- the traced counterpart of a truncated band (ADVICE r04)
+            raise _lib.SdfrError("sphere tracer: %d ray(s) were unresolved after %d steps in the last iteration (treated as misses): raise "
+                                 "tracer_kwargs['steps']" % (self.tr.n_unresolved, self.tr.steps))

@@ -166,6 +166,20 @@ class _RasterFn(torch.autograd.Function):
         return (g_points[:n], g_normals[:n], None if nocs_mode else g_colors[:n], g_pose, None) + (None,) * 11
 
 
+_PLACEHOLDERS = {}
+
+
+def _placeholder(dev, slot):
+    """the 0-d zero tensor standing in for an image that was not asked for: one per (device, output slot), made once (r05: a fresh
+    new_zeros(()) per call was a fill launch per iteration); non-differentiable and never written, so sharing it across calls is safe, and
+    distinct per slot"""
+    key = (dev.type, dev.index, slot)
+    t = _PLACEHOLDERS.get(key)
+    if t is None:
+        t = _PLACEHOLDERS[key] = torch.zeros((), dtype=torch.float32, device=dev)
+    return t
+
+
 class _RasterDiscFn(torch.autograd.Function):
     """The optimizer's configuration (pipelines/optimizer.py:110-123: rot='dcm', primitives='disc', bg=None, output_nocs=True) with the fused
     kernels of the batched path: ONE projection launch writes the camera-frame surfels, the composited attribute (c + 1) / 2, the front-facing
@@ -189,7 +203,8 @@ class _RasterDiscFn(torch.autograd.Function):
             pose_c = pose.detach().contiguous().float()
             slab = torch.empty((5, m, 3), **f32)                      # p_cam, n_cam, attr, xyzf, rgbf
             p_cam, n_cam, attr, xyzf, rgbf = slab[0], slab[1], slab[2], slab[3], slab[4]
-            ints = torch.zeros((2 * m + 1,), dtype=torch.int32, device=dev)     # fidx | fslot | fcnt (zeroed: one fill)
+            # fidx | fslot | fcnt -- not zeroed (r05): with n > 0 the projection kernel writes fcnt and every fslot[s < n]; with n = 0 none is read
+            ints = torch.empty((2 * m + 1,), dtype=torch.int32, device=dev)
             fidx, fslot, fcnt = ints[:m], ints[m:2 * m], ints[2 * m:]
             imgs = torch.empty((8, H, W), **f32)                      # color(3) | mask | depth | normals(3)
             color, mask, depth, nimg = imgs[0:3], imgs[3:4], imgs[4:5], imgs[5:8]
@@ -212,7 +227,7 @@ class _RasterDiscFn(torch.autograd.Function):
         ctx.cfg = (n, nf, W, H, int(nocs_mode), want_mask, want_depth, want_normals)
         # (images that were not asked for: DISTINCT placeholder tensors, marked non-differentiable -- the same object in several output slots
         #  would make autograd route a gradient for any of them to the last duplicate)
-        zm, zd, zn = (None if want_mask else color.new_zeros(())), (None if want_depth else color.new_zeros(())), (None if want_normals else color.new_zeros(()))
+        zm, zd, zn = (None if want_mask else _placeholder(dev, 0)), (None if want_depth else _placeholder(dev, 1)), (None if want_normals else _placeholder(dev, 2))
         outs = (color, mask if want_mask else zm, depth if want_depth else zd, nimg if want_normals else zn, p_cam[:n], n_cam[:n], attr[:n],
                 xyzf[:nf], rgbf[:nf])
         ctx.mark_non_differentiable(outs[5], *[z for z in (zm, zd, zn) if z is not None])

@@ -433,7 +433,14 @@ class SphereTracer:
             cc = self.cone_counters.cpu().numpy()
             out["cone_evaluations"] = int(cc[4:6].view("uint64")[0])
             out["ray_evaluations"] += out["cone_evaluations"]                   # (decoder evaluations of the render: cones + rays)
-            out["culled_tiles"] = int((self.cone < 0).sum())
+            cone = self.cone.view(self.B, self.cone_cap)
+            if self.ragged:
+                # each crop's OWN tiles only: slots beyond ceil(W_b / block) * ceil(H_b / block) keep values of earlier extents
+                cb = self.cone_block
+                own = torch.tensor([((w + cb - 1) // cb) * ((h + cb - 1) // cb) for w, h in self.sizes], device=cone.device).view(-1, 1)
+                out["culled_tiles"] = int(((cone < 0) & (torch.arange(self.cone_cap, device=cone.device).view(1, -1) < own)).sum())
+            else:
+                out["culled_tiles"] = int((cone < 0).sum())
         return out
 
     @property

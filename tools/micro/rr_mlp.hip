@@ -307,9 +307,10 @@ int main(int argc, char** argv) {
     std::vector<float> Bv((size_t)NL * HP);
     uint32_t s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
-    for (auto& w : W) w = (h16)(rnd() * 0.125f);            // |W x| stays O(1) over 8 layers
-    for (auto& b : Bv) b = rnd() * 0.2f;
-    for (auto& x : X) x = (h16)(rnd() * 2.0f);
+    const float amp = argc > 3 ? (float)atof(argv[3]) : 1.f;    // 0: all-zero operands (what the matrix pipes' data-dependent power draw costs: timing only)
+    for (auto& w : W) w = (h16)(rnd() * 0.125f * amp);      // |W x| stays O(1) over 8 layers
+    for (auto& b : Bv) b = rnd() * 0.2f * amp;
+    for (auto& x : X) x = (h16)(rnd() * 2.0f * amp);
     std::vector<h16> Wimg(W.size());
     for (int l = 0; l < NL; ++l)
         for (int t = 0; t < NKT; ++t)
@@ -348,15 +349,15 @@ int main(int argc, char** argv) {
     double lsum = 0; for (auto v : last) lsum += (double)v;
     printf("check on 256 points x %d features after %d layers: max |rr - naive| = %.4g (max |value| %.4g, %d non-zero, sum %.6g); last 128 points sum %.6g\n",
            HP, NL, maxd, maxv, nz, sum, lsum);
-    const bool ok = maxd <= 2e-2 * fmax(1.0, maxv) && nz > 1000;
+    const bool ok = maxd <= 2e-2 * fmax(1.0, maxv) && (nz > 1000 || amp == 0.f);
     printf(ok ? "CHECK OK\n" : "CHECK FAILED\n");
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
-        hipEventRecord(e0);
+        (void)hipEventRecord(e0);
         for (int i = 0; i < 5; ++i) launch();
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1); best = fminf(best, ms / 5);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = fminf(best, ms / 5);
     }
     const double flop = 2.0 * (double)n * NL * HP * HP;
     printf("%d points, %d layers of 512 x 512: %.4f ms per launch = %.0f TFLOP/s = %.1f %% of 2.5 PFLOP/s  (%.1f us per 64 000 points)\n", n, NL, best,

@@ -31,7 +31,7 @@ _DEPTH_CONSTANT = 150.0
 
 class BatchRenderer:
     def __init__(self, decoder, density, K, resolution_px, batch, cap=None, device="cuda", threshold=0.03, output_nocs=True,
-                 max_pixels=None, max_side=None):
+                 max_pixels=None, max_side=None, candidate_reuse=None):
         """max_pixels (r04, ragged extents): every crop of the batch may have its OWN image size (W_b, H_b) with W_b H_b <= max_pixels and
         W_b, H_b <= max_side (default 4 sqrt(max_pixels)), and its own intrinsics -- what the reference pipeline's crops look like
         (utils/refinement.py:586-609).  Images then live in slots of max_pixels pixels per channel ([B, C, max_pixels]; image(b, name) gives
@@ -160,7 +160,8 @@ class BatchRenderer:
         # spectral norms of the effective weights along the latent's paths: cannot be low), e16 = the half kernel's deviation from the exact
         # decoder (calibrated below; the margin is at least 4 e16).  Reuse while lip |z1 - z0| <= margin / 4.  On top, every step a rotating
         # 1 / audit_stride slice of the rows outside the candidates is evaluated too: one of them inside the band is a hard violation.
-        self.creuse = self.f16 and bool(getattr(decoder, "candidate_reuse", False)) and self.handle.hp == 512 and not self.handle.has_ln
+        want_reuse = bool(getattr(decoder, "candidate_reuse", False)) if candidate_reuse is None else bool(candidate_reuse)
+        self.creuse = self.f16 and want_reuse and self.handle.hp == 512 and not self.handle.has_ln
         if self.creuse:
             Lh = _lib.lib()
             self.cstride = (cap + 127) // 128 * 128

@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             constexpr int TPP = NT / PT;
             constexpr int PMIN = (HP == 512) ? (HALF ? 32 : 16) : 1;
             constexpr int PARTS = (TPP < PMIN) ? PMIN : TPP, PPT = PARTS / TPP, JS = HP / PARTS;
-            static_assert(NT % PT == 0 && HP % PARTS == 0 && PARTS % TPP == 0 && 8 * PT <= NT && PARTS * 8 * PT * 4 <= KG * PT * 16,
+            static_assert(NT % PT == 0 && HP % PARTS == 0 && PARTS % TPP == 0 && PARTS * 8 * PT * 4 <= KG * PT * 16,
                           "first-layer reduction scratch fits the operand tile");
             const int pt = tid % PT, t0 = tid / PT;
             const float4* W0 = P.Wf + L.off_f;                   // forward image of layer 0: W0[(k/4)*HP + j] = W[j][k..k+3]
@@ -1148,8 +1148,8 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #pragma unroll
                 for (int k = 0; k < 8; ++k) scr[((t0 * PPT + q) * 8 + k) * PT + pt] = s8[q][k];
             __syncthreads();
-            if (tid < 8 * PT) {
-                const int k = tid / PT, q = tid % PT;
+            for (int e = tid; e < 8 * PT; e += NT) {           // (one trip while 8 PT <= NT; 128-row tiles of 512 threads: two)
+                const int k = e / PT, q = e % PT;
                 float t = 0.f;
                 for (int r = 0; r < PARTS; ++r) t += scr[(r * 8 + k) * PT + q];
                 if (k < NI && k < L.in_dim && slots[q] >= 0) atomicAdd(P.J + (int64_t)slots[q] * NI + k, t);

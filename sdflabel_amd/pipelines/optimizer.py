@@ -43,9 +43,13 @@ def get_opt_params(params, device):
 
 
 class Optimizer:
-    def __init__(self, params, device, weights, rot='dcm', render='splat', trace_grad='surfel', tracer_kwargs=None):
+    def __init__(self, params, device, weights, rot='dcm', render='splat', trace_grad='surfel', tracer_kwargs=None, candidate_reuse=True):
         """render='trace' (extension): the loop's renderer is the sphere tracer instead of the reference's surfel splat -- same losses, same
-        solver, same call (BatchRefiner(render='trace')); not the reference's algorithm, so no parity claim goes with it."""
+        solver, same call (BatchRefiner(render='trace')); not the reference's algorithm, so no parity claim goes with it.
+        candidate_reuse (float16 decoders, the reference's shipped precision; r05): the half decoder runs on the band candidates alone while a
+        proven Lipschitz bound keeps the candidate set valid -- the same bits as evaluating the whole grid every iteration (GPU tests), audited
+        at run time; False evaluates all G rows every iteration as the reference does."""
+        self.candidate_reuse = bool(candidate_reuse)
         if render not in ('splat', 'trace'):
             raise ValueError("render must be 'splat' or 'trace'")
         self.render, self.trace_grad, self.tracer_kwargs = render, trace_grad, dict(tracer_kwargs or {})
@@ -81,7 +85,7 @@ class Optimizer:
         shape_key = (pmax,) if ragged else (H_, W_, Kn.tobytes())
         key = (id(dsdf), D, shape_key, cap, str(dev), dsdf._param_key(dev),
                float(self.weights.get('2d', 0.3)), float(self.weights.get('3d', 0.5)), getattr(dsdf, 'mlp_precision', None), bool(optimize_latent),
-               self.render, self.trace_grad, tuple(sorted(self.tracer_kwargs.items())))
+               self.render, self.trace_grad, tuple(sorted(self.tracer_kwargs.items())), self.candidate_reuse)
         if self._key != key:
             hit = _REFINERS.get(key)
             if hit is not None and hit[0]() is dsdf:
@@ -89,7 +93,7 @@ class Optimizer:
             else:
                 rf = BatchRefiner(dsdf, D, Kn, crop_size, 1, lidar_cap=cap, weights=self.weights, device=dev, optimize_latent=optimize_latent,
                                   render=self.render, trace_grad=self.trace_grad, tracer_kwargs=self.tracer_kwargs,
-                                  max_pixels=pmax if ragged else None, max_side=side if ragged else None)
+                                  max_pixels=pmax if ragged else None, max_side=side if ragged else None, candidate_reuse=self.candidate_reuse)
                 STATS["refiners_built"] += 1
                 while len(_REFINERS) >= _REFINERS_MAX:
                     _REFINERS.pop(next(iter(_REFINERS)))

@@ -19,7 +19,7 @@ from .batch import BatchRenderer
 
 class BatchRefiner:
     def __init__(self, decoder, density, K, crop_size, batch, lidar_cap, weights=None, cap=None, device="cuda", optimize_latent=True,
-                 render="splat", trace_grad="surfel", tracer_kwargs=None, max_pixels=None, max_side=None):
+                 render="splat", trace_grad="surfel", tracer_kwargs=None, max_pixels=None, max_side=None, candidate_reuse=None):
         """crop_size = (H, W) as the reference passes it (optimizer.py:56,72 builds the Rasterer with crop_size[::-1]).
         optimize_latent=False: pose-only refinement (yaw, trans, scale; the latent parameter group of optimizer.py:38 gets no update), so
         the shape is evaluated once per set_crops() and every iteration only re-projects, splats and differentiates the pose.
@@ -33,7 +33,9 @@ class BatchRefiner:
         max_pixels / max_side (both renderers; r04): ragged extents -- every crop of a batch its own image size (H_b, W_b) and intrinsics K_b,
         given to set_crops(); buffers are sized for max_pixels pixels per crop and the captured graph serves every crop set within the caps
         (the reference pipeline's crops all differ: utils/refinement.py:586-609, pipelines/refine_css.py:117-129).  crop_size is then the
-        default extent.  A crop refines bit-identically to the same crop alone in a fixed-size refiner."""
+        default extent.  A crop refines bit-identically to the same crop alone in a fixed-size refiner.
+        candidate_reuse (float16 decoders; None: decoder.candidate_reuse): evaluate the half decoder on the band candidates alone while a
+        proven bound keeps them valid -- bit-identical results, 4x the crops/s (BatchRenderer)."""
         self.H, self.W = int(crop_size[0]), int(crop_size[1])
         self.B = int(batch)
         self._K0 = torch.as_tensor(K, dtype=torch.float32).detach().cpu().clone()
@@ -54,7 +56,8 @@ class BatchRefiner:
             dev, self.L, est_cap = self.tr.dev, self.tr.L, self.tr.ecap
         else:
             self.tr = None
-            self.br = BatchRenderer(decoder, density, K, (self.W, self.H), batch, cap=cap, device=device, max_pixels=max_pixels, max_side=max_side)
+            self.br = BatchRenderer(decoder, density, K, (self.W, self.H), batch, cap=cap, device=device, max_pixels=max_pixels, max_side=max_side,
+                                    candidate_reuse=candidate_reuse)
             self.br.freeze_shape = not self.optimize_latent
             dev, self.L, est_cap = self.br.dev, self.br.L, self.br.cap
         br = self.br

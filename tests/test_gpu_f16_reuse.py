@@ -177,3 +177,29 @@ def test_ragged_half_forward_gives_each_row_the_bits_of_the_full_grid_launch():
         pad = (n + 127) // 128 * 128
         assert bool(torch.isfinite(out[b, :pad]).all()) and bool((out[b, pad:] == 7.0).all())
     assert L.sdfr_mlp_forward_f16_ragged(h.h, _lib.ptr(rows), B, 1000, _lib.ptr(cnt), _lib.ptr(out), None, _lib.stream_ptr()) != 0     # not x128
+
+
+def test_product_optimizer_uses_candidate_reuse_by_default_and_returns_the_same_bits():
+    """pipelines.optimizer.Optimizer with the reference's shipped float16 setup (refine_css.py:144-153): candidate_reuse=True is the default;
+    60 iterations give bitwise the parameters of candidate_reuse=False, and most of them ran on the candidates alone"""
+    from sdflabel_amd.pipelines import optimizer as OP
+    from tests._util import gold
+    z = gold("g8_optimizer.npz")
+    D, H, W = int(z["D"]), int(z["H"]), int(z["W"])
+    init = z["init"]
+    dsdf, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt")                                # float16, as the reference's default
+    dsdf = dsdf.to(DEV)
+    grid = sdflabel_amd.Grid3D(D, DEV, torch.float16)
+    K = T(z["K"]).half()
+    out = {}
+    for reuse in (True, False):
+        OP.clear_refiner_cache()
+        params = {"yaw": init[0:1].copy(), "trans": init[1:4].copy(), "scale": init[4:5].copy(), "latent": init[5:8].copy()}
+        opt = OP.Optimizer(params, DEV, {"2d": 0.3, "3d": 0.5}) if reuse else OP.Optimizer(params, DEV, {"2d": 0.3, "3d": 0.5}, candidate_reuse=False)
+        opt.optimize(60, T(z["nocs_target"]).half(), z["lidar"], dsdf, grid, K, (H, W))
+        assert opt._refiner.br.creuse == reuse
+        if reuse:
+            assert int(opt._refiner.br.n_full[0]) <= 6          # (warm-up / capture passes included) of 60 iterations
+        out[reuse] = np.concatenate([N(params[k]).reshape(-1) for k in ("yaw", "trans", "scale", "latent")])
+    OP.clear_refiner_cache()
+    assert np.array_equal(out[True], out[False])

@@ -184,6 +184,10 @@ class BatchRenderer:
             self.max_dev = f(B)                 # (stays 0: this mode has no second arithmetic to deviate from; the plan kernel reads it)
             self.violations = i(B, 2)
             self.lipschitz = float(decoder.latent_lipschitz_bound())
+            # the plan kernel reuses while  lip_plan |z1 - z0| <= margin / 4.  Here 2 e16 <= margin / 2 holds by calibration (margin >= 4 e16), so
+            # the latent's share of the margin may be 0.45 of it (|h(z1)| >= thr + margin - 0.45 margin - 0.5 margin > thr): the kernel is handed
+            # the bound scaled by 0.25 / 0.45 -- 1.8x the validity of a candidate set for the same proof
+            self.lipschitz_plan = self.lipschitz * (0.25 / 0.45)
             self.reuse = True
             # (the bound is proven, so no full pass is forced for safety's sake inside a 60-iteration refinement, configs/config_refine.ini:15;
             # measured at 64 crops per launch: max_reuse 16 -> 64 and audit stride 16 -> 32 take a refinement iteration from 4.5 to 3.5 ms)
@@ -355,7 +359,7 @@ class BatchRenderer:
                 mlp_events[1].record()
         elif self.creuse:
             cs = self.cstride
-            ck(L.sdfr_prefilter_plan(P(self.inputs), G, self.NI, self.L, B, self.lipschitz, P(self.margin_dev), P(self.max_dev), P(self.lat_ref),
+            ck(L.sdfr_prefilter_plan(P(self.inputs), G, self.NI, self.L, B, self.lipschitz_plan, P(self.margin_dev), P(self.max_dev), P(self.lat_ref),
                                      P(self.age), self.max_reuse, P(self.reuse_flag), P(self.n_full), st), "sdfr_prefilter_plan")
             # full-grid pass of the crops whose candidate set is due (no masks: the Jacobian takes them from the candidate pass below)
             ck(L.sdfr_mlp_forward_f16_skip(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.reuse_flag), G, st), "sdfr_mlp_forward_f16_skip")

@@ -2,11 +2,11 @@
 # One GPU-box session: parity tests, bench, rocprofv3 kernel trace + PMC passes.  Outputs under gpurun_out/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/pytest_$TAG.log
-timeout 900 python bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
+timeout 900 python bench.py --extras $O/bench_extras_$TAG.json > $O/bench_$TAG.json 2> $O/bench_$TAG.err
 cd /tmp && export TMPDIR=/tmp
 # kernel trace + stats of the headline loop alone (--no-extras: every decoder-forward launch is the single-crop one the roofline is quoted on)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG -o trace -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_$TAG.log 2>&1
@@ -22,6 +22,8 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write64_$TAG -o pmc -- python $R/bench.py --crops-per-gpu 64 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/pmc_write64_$TAG.log 2>&1
 # the sphere march: HBM bytes and matrix-pipe counters (three --pmc passes)
 bash $R/tools/sphere_pmc.sh $TAG > $O/pmcsph_$TAG.log 2>&1
+# kernel time table of the float16 + candidate-reuse refinement (256 crops x 60 iterations in chunks of 64)
+bash $R/tools/prof_refine.sh ${TAG}_f16reuse --crops 256 --chunk 64 --precision float16 --reuse > $O/prof_refine_${TAG}_f16reuse.txt 2>&1
 cd $R
 # gpurun merges at most 64 MiB back: the raw per-launch traces (60 MB for the full run) are not read by tools/summarize_profile.py -- only the
 # *_kernel_stats.csv of the trace runs and the *_counter_collection.csv of the PMC passes are

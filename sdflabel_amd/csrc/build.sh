@@ -11,7 +11,7 @@ COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 # and is refused by sdflabel_amd/_lib.py unless SDFR_ALLOW_AB=1.
 if [ "${SDFR_AB:-0}" = "1" ]; then
   ALLDEFS="$SDFR_FWD_DEFS $SDFR_F16_DEFS $SDFR_SPLIT_DEFS $SDFR_J16_DEFS $SDFR_JAC_DEFS $SDFR_LOSS_DEFS"
-  COMMON="$COMMON -DSDFR_EXPERIMENT=1"
+  COMMON="$COMMON -DSDFR_EXPERIMENT=1 $SDFR_ALL_DEFS"         # SDFR_ALL_DEFS: a define for every translation unit (e.g. -DSDFR_BOX_PAD=...)
 else
   for v in SDFR_FWD_DEFS SDFR_F16_DEFS SDFR_SPLIT_DEFS SDFR_J16_DEFS SDFR_JAC_DEFS SDFR_LOSS_DEFS; do
     [ -n "${!v}" ] && echo "build.sh: ignoring $v (set SDFR_AB=1 for an experiment build)" >&2

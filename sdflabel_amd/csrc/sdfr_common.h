@@ -11,7 +11,7 @@ void sdfr_set_error(const char* fmt, ...);
 // experiment builds only: csrc/build.sh passes them with -DSDFR_EXPERIMENT (SDFR_AB=1) and sdfr_build_flags() reports it.
 #if !defined(SDFR_EXPERIMENT) && (defined(SDFR_ABL_NOMFMA) || defined(SDFR_ABL_NOEPI) || defined(SDFR_PIN_WEIGHTS) || defined(SDFR_MLP_TRACE) || \
                                   defined(SDFR_EPI_FENCE) || defined(SDFR_MLP_WPE) || defined(SDFR_ACT_DBUF) || defined(SDFR_STRAIGHT_KLOOP) ||      \
-                                  defined(SDFR_UNROLLED_KLOOP) || defined(SDFR_H_FAST_EPI))
+                                  defined(SDFR_UNROLLED_KLOOP) || defined(SDFR_H_FAST_EPI) || defined(SDFR_BOX_PAD))
 #error "experiment option without SDFR_EXPERIMENT: build through tools/ab_variant.sh (SDFR_AB=1)"
 #endif
 

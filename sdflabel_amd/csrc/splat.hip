@@ -16,9 +16,9 @@
 //             Candidates are staged 64 at a time into LDS (lane = candidate) and every lane walks them with broadcast LDS reads:
 //             [disc: per-pixel norm nu (:228)], max logit, softmax sums + composited colour / mask / depth / normals.
 //             Per-pixel softmax state goes to `aux` for the backward.
-//   backward  one wavefront per SURFEL (lanes = pixels of its screen box).  Each lane re-evaluates the coverage test with the identical
-//             arithmetic, rebuilds its softmax weight from `aux`, accumulates the surfel's gradients in registers; one wave reduction,
-//             no atomics, bit-repeatable.
+//   backward  one wavefront per SURFEL.  The lanes re-evaluate the coverage test over its screen box with the identical arithmetic and queue
+//             the covered pixels (r05: ballot-compacted in LDS, so that the gradient chain runs on full lanes); each queued pixel rebuilds its
+//             softmax weight from `aux` and accumulates the surfel's gradients in registers; one wave reduction, no atomics, bit-repeatable.
 //
 // Autograd semantics reproduced: coverage masks and norms are constants (:55,:59 / :155,:142 / :226,:228); for the disc |n.ray| < 0.01 is
 // overwritten by eps in place and passes no gradient through b (:210); clamp(min=0) / clamp(max=1) pass gradient on the closed side.
@@ -31,6 +31,7 @@
 #include <math.h>
 
 #define SPL_LC 1024            // LDS candidate-list capacity per tile (beyond it the tile walks every surfel)
+#define SPL_BQ 128             // backward: covered-pixel queue per wave (drained whenever fewer than 64 slots are free)
 #define SIGMOID_REACH 29.65f   // (r - d) * 3 > -88.73  <=>  d < r + 29.58: conservative reach of inside_circle's sigmoid(.) > 0
 
 struct SplatArgs {
@@ -619,69 +620,96 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
     }
     int x0, y0, x1, y1;
     float sC0 = 0.f, sC1 = 0.f, sC2 = 0.f, sN0 = 0.f, sN1 = 0.f, sN2 = 0.f, sZ = 0.f, sA = 0.f, sB0 = 0.f, sB1 = 0.f, sB2 = 0.f, sL = 0.f;
-    if (surfel_bbox<PRIM, ALT>(A, b, e1, x0, y0, x1, y1)) {
-        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-        for (int i = lane; i < bw * bh; i += 64) {
-            const int yy = i / bw;
-            const int x = x0 + (i - yy * bw), y = y0 + yy;
-            float rx = 0.f, ry = 0.f, rz = 0.f;
-            Hit h;
-            bool cov;
-            if (PRIM == 0) {
-                pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
-                h = disc_eval<ALT>(px, py, pz, nx, ny, nz, a, rx, ry, rz, A.cover_sq, diam, A.clamp_c);
-                cov = h.m;
-            } else if (PRIM == 1) {
-                cov = circle_cover<ALT>(u, v, rad, (float)x, (float)y, A.clamp_c);
-            } else {
-                cov = stamp_cover<ALT>(u, v, x, y, W, H, rad);
-            }
-            if (!cov) continue;
-            const int pix = y * W + x;
-            const float4 ax = reinterpret_cast<const float4*>(aux)[(int64_t)b * P + pix];
-            const float nue = ax.x + FLT_EPSILON;
-            const unsigned gates = __float_as_uint(ax.w);
-            float q = q0, logit = zl;
-            if (PRIM == 0) {
-                q = (-h.t) / nue + 1.f;
-                logit = fmaxf(q, 0.f) * C;
-            }
-            const float w = expf(logit - ax.y) / ax.z;
-            // gated upstream gradients and S = sum_j w_j dL/dw_j = <gated grads, composited outputs>
-            float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, gm = 0.f, gd = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, S = 0.f;
-            if (DENSE) S = Sd[(int64_t)b * P + pix];
-            if (!DENSE && g_color) {
-                const float* g = g_color + (int64_t)b * 3 * P + pix;
-                const float* o = color + (int64_t)b * 3 * P + pix;
-                gc0 = (gates & 1u) ? g[0] : 0.f; gc1 = (gates & 2u) ? g[P] : 0.f; gc2 = (gates & 4u) ? g[2 * P] : 0.f;
-                S += gc0 * o[0] + gc1 * o[P] + gc2 * o[2 * P];
-            }
-            if (!DENSE && g_mask) { gm = (gates & 8u) ? g_mask[(int64_t)b * P + pix] : 0.f; S += gm * mask[(int64_t)b * P + pix]; }
-            if (!DENSE && g_depth) { gd = g_depth[(int64_t)b * P + pix]; S += gd * depth[(int64_t)b * P + pix]; }
-            if (!DENSE && g_normals) {
-                const float* g = g_normals + (int64_t)b * 3 * P + pix;
-                const float* o = normals + (int64_t)b * 3 * P + pix;
-                gn0 = (gates & 16u) ? g[0] : 0.f; gn1 = (gates & 32u) ? g[P] : 0.f; gn2 = (gates & 64u) ? g[2 * P] : 0.f;
-                S += gn0 * o[0] + gn1 * o[P] + gn2 * o[2 * P];
-            }
-            const float dLdw = DENSE ? gW[((int64_t)b * rows + s) * P + pix]
-                                     : gc0 * a0 + gc1 * a1 + gc2 * a2 + gm + gd * pz + gn0 * m0 + gn1 * m1 + gn2 * m2;
-            sC0 += w * gc0; sC1 += w * gc1; sC2 += w * gc2;
-            sN0 += w * gn0; sN1 += w * gn1; sN2 += w * gn2;
-            sZ += w * gd;
-            const float dl = w * (dLdw - S);
-            if (PRIM == 0) {
-                const float dq = (q >= 0.f) ? dl * C : 0.f;
-                const float dt = -(dq / nue);                           // zeta = -t * mask
-                sA += dt / h.b;                                         // t = a / b
-                if (!h.small) {
-                    const float db = -dt * h.t / h.b;
-                    sB0 += db * rx; sB1 += db * ry; sB2 += db * rz;
-                }
-            } else {
-                sL += dl;
-            }
+    // r05: two phases per surfel.  The coverage test is cheap and most lanes of a box fail it (a disc of radius 4 px covers ~53 of the ~170
+    // pixels of its conservative box), while the gradient chain behind it is expensive and ran for a whole wave iteration whenever ONE lane
+    // was covered.  So: scan the box 64 pixels at a time, append the covered pixels (position, plane hit) to a per-wave LDS queue with a
+    // ballot, and run the gradient chain on the queue -- full lanes, one to two iterations per surfel instead of three to six.  The queue is
+    // drained whenever fewer than 64 slots are free, so any box size works.  Sums are taken in queue order: deterministic, bit-repeatable.
+    __shared__ float4 queue[4][SPL_BQ];
+    float4* qw = queue[threadIdx.x >> 6];
+    auto chain = [&](int x, int y, float ht, float hb) {
+        const int pix = y * W + x;
+        const float4 ax = reinterpret_cast<const float4*>(aux)[(int64_t)b * P + pix];
+        const float nue = ax.x + FLT_EPSILON;
+        const unsigned gates = __float_as_uint(ax.w);
+        float q = q0, logit = zl;
+        if (PRIM == 0) {
+            q = (-ht) / nue + 1.f;
+            logit = fmaxf(q, 0.f) * C;
         }
+        const float w = expf(logit - ax.y) / ax.z;
+        // gated upstream gradients and S = sum_j w_j dL/dw_j = <gated grads, composited outputs>
+        float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, gm = 0.f, gd = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, S = 0.f;
+        if (DENSE) S = Sd[(int64_t)b * P + pix];
+        if (!DENSE && g_color) {
+            const float* g = g_color + (int64_t)b * 3 * P + pix;
+            const float* o = color + (int64_t)b * 3 * P + pix;
+            gc0 = (gates & 1u) ? g[0] : 0.f; gc1 = (gates & 2u) ? g[P] : 0.f; gc2 = (gates & 4u) ? g[2 * P] : 0.f;
+            S += gc0 * o[0] + gc1 * o[P] + gc2 * o[2 * P];
+        }
+        if (!DENSE && g_mask) { gm = (gates & 8u) ? g_mask[(int64_t)b * P + pix] : 0.f; S += gm * mask[(int64_t)b * P + pix]; }
+        if (!DENSE && g_depth) { gd = g_depth[(int64_t)b * P + pix]; S += gd * depth[(int64_t)b * P + pix]; }
+        if (!DENSE && g_normals) {
+            const float* g = g_normals + (int64_t)b * 3 * P + pix;
+            const float* o = normals + (int64_t)b * 3 * P + pix;
+            gn0 = (gates & 16u) ? g[0] : 0.f; gn1 = (gates & 32u) ? g[P] : 0.f; gn2 = (gates & 64u) ? g[2 * P] : 0.f;
+            S += gn0 * o[0] + gn1 * o[P] + gn2 * o[2 * P];
+        }
+        const float dLdw = DENSE ? gW[((int64_t)b * rows + s) * P + pix]
+                                 : gc0 * a0 + gc1 * a1 + gc2 * a2 + gm + gd * pz + gn0 * m0 + gn1 * m1 + gn2 * m2;
+        sC0 += w * gc0; sC1 += w * gc1; sC2 += w * gc2;
+        sN0 += w * gn0; sN1 += w * gn1; sN2 += w * gn2;
+        sZ += w * gd;
+        const float dl = w * (dLdw - S);
+        if (PRIM == 0) {
+            const float dq = (q >= 0.f) ? dl * C : 0.f;
+            const float dt = -(dq / nue);                           // zeta = -t * mask
+            sA += dt / hb;                                          // t = a / b
+            if (hb != FLT_EPSILON) {                                // (|n.ray| < 0.01 was replaced by eps, :210: no gradient through b)
+                float rx, ry, rz;
+                pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
+                const float db = -dt * ht / hb;
+                sB0 += db * rx; sB1 += db * ry; sB2 += db * rz;
+            }
+        } else {
+            sL += dl;
+        }
+    };
+    auto drain = [&](int count) {
+        for (int e = lane; e < count; e += 64) {
+            const float4 en = qw[e];
+            const unsigned xy = __float_as_uint(en.x);
+            chain((int)(xy & 0xffffu), (int)(xy >> 16), en.y, en.z);
+        }
+    };
+    if (surfel_bbox<PRIM, ALT>(A, b, e1, x0, y0, x1, y1)) {
+        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1, npx = bw * bh;
+        int nq = 0;                                                  // wave-uniform fill of the queue
+        for (int base = 0; base < npx; base += 64) {
+            const int i = base + lane;
+            bool cov = false;
+            int x = 0, y = 0;
+            float ht = 0.f, hb = 1.f;
+            if (i < npx) {
+                const int yy = i / bw;
+                x = x0 + (i - yy * bw); y = y0 + yy;
+                if (PRIM == 0) {
+                    float rx, ry, rz;
+                    pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
+                    const Hit h = disc_eval<ALT>(px, py, pz, nx, ny, nz, a, rx, ry, rz, A.cover_sq, diam, A.clamp_c);
+                    cov = h.m; ht = h.t; hb = h.b;
+                } else if (PRIM == 1) {
+                    cov = circle_cover<ALT>(u, v, rad, (float)x, (float)y, A.clamp_c);
+                } else {
+                    cov = stamp_cover<ALT>(u, v, x, y, W, H, rad);
+                }
+            }
+            const unsigned long long bal = __ballot(cov);
+            if (cov) qw[nq + __popcll(bal & ((1ull << lane) - 1ull))] = make_float4(__uint_as_float((unsigned)x | ((unsigned)y << 16)), ht, hb, 0.f);
+            nq += __popcll(bal);
+            if (nq > SPL_BQ - 64) { drain(nq); nq = 0; }
+        }
+        drain(nq);
     }
     sC0 = wave_sum(sC0); sC1 = wave_sum(sC1); sC2 = wave_sum(sC2);
     sN0 = wave_sum(sN0); sN1 = wave_sum(sN1); sN2 = wave_sum(sN2);

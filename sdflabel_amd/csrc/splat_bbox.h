@@ -1,6 +1,9 @@
 // Conservative screen box of a disc surfel (shared by the splat kernels and the fused surfel-forward kernel of project.hip).
 #pragma once
 #include "sdfr_common.h"
+#ifndef SDFR_BOX_PAD
+#define SDFR_BOX_PAD 0.25f
+#endif
 
 // Conservative pixel interval of the rays that can pass within rho of a point, along one image axis.
 // A pixel is covered only if its ray passes closer than rho to the surfel centre, hence (projecting on the u-z plane)
@@ -14,7 +17,12 @@ __device__ __forceinline__ bool axis_range(float pu, float pz, float rho, float 
     const float r1 = (pu * pz - sq) / A, r2 = (pu * pz + sq) / A;
     float u1 = c + f * r1, u2 = c + f * r2;
     if (u1 > u2) { const float tmp = u1; u1 = u2; u2 = tmp; }
-    const float pad = 1.5f + 1e-3f * (fabsf(u1) + fabsf(u2));
+    // pad: the interval above is exact geometry (the tangent rays of the sphere of radius rho in the u-z plane, a superset of the disc's
+    // footprint); floor / ceil below add up to a pixel per side; what the pad has to absorb is the float error of the quadratic, ~1e-6
+    // relative.  0.25 px + 1e-3 relative (r01-r04 took 1.5 px: boxes of 215 px for discs that cover 53 -- four scan iterations per surfel in
+    // the backward and twice the tile candidates in the forward; tests/test_gpu_splat.py::test_disc_screen_boxes_never_cut_a_covered_pixel
+    // compares against box-free renders)
+    const float pad = SDFR_BOX_PAD + 1e-3f * (fabsf(u1) + fabsf(u2));
     u1 -= pad; u2 += pad;
     if (isnan(u1) || isnan(u2)) return true;                  // undecidable: keep the whole axis
     if (u2 < 0.f || u1 > (float)(n - 1)) return false;       // entirely off screen

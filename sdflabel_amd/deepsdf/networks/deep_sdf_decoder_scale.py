@@ -304,20 +304,33 @@ class Decoder(nn.Module):
         which is what the candidate reuse of BatchRenderer needs.  LayerNorm decoders: inf (the normalisation is not Lipschitz)."""
         if any(getattr(self, "bn" + str(l), None) is not None for l in range(self.num_layers - 1)):
             return float("inf")
+        key = tuple((id(p), p._version) for p in self.parameters())
+        hit = getattr(self, "_lip_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+
+        def norm2(A):
+            # largest singular value in float64 (torch's LAPACK: the process' own BLAS threads; numpy / scipy beside a loaded torch took 3-10x longer)
+            if min(A.shape) == 0:
+                return 0.0
+            return float(torch.linalg.matrix_norm(torch.from_numpy(np.ascontiguousarray(A)), 2)) * (1.0 + 1e-12)
+
         Ls = self.latent_size
         d = 0.0
         for l, ((W, _), (inj_n, inj_off)) in enumerate(zip(self.effective_layers(), self._inject_table())):
             W = np.asarray(W, np.float64)
             if l == 0:
-                d = float(np.linalg.norm(W[:, :Ls], 2))
+                d = norm2(W[:, :Ls])
                 continue
             prev = W.shape[1] - inj_n
-            t = float(np.linalg.norm(W[:, :prev], 2)) * d
+            t = norm2(W[:, :prev]) * d
             nlat = max(0, min(Ls, inj_off + inj_n) - inj_off) if inj_n > 0 else 0      # re-injected input columns that are latent columns
             if nlat > 0:
-                t += float(np.linalg.norm(W[:, prev:prev + nlat], 2))
+                t += norm2(W[:, prev:prev + nlat])
             d = t
-        return d * (1.0 + 1e-9)
+        d = d * (1.0 + 1e-9)
+        self._lip_cache = (key, d)
+        return d
 
     def _params_two_levels(self):
         """this module's parameters by direct dictionary access (lin*, bn* and the Linear layers of scale_net: two levels) -- what

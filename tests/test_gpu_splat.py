@@ -157,3 +157,66 @@ def test_wave_per_tile_launch_secondary_primitives_and_background(prim, use_bg):
     for x, y in zip(many, one):
         for b in (0, B - 1):
             assert torch.equal(x[b], y[0]), (prim, use_bg, b)
+
+
+# ---- r05: the screen boxes are conservative (what a tighter box must never break) -----------------------------------------------------------
+
+@pytest.mark.parametrize("case", ["centred", "cropped_far_principal_point", "near_big_discs", "far_small_discs", "grazing_and_behind"])
+def test_disc_screen_boxes_never_cut_a_covered_pixel(case):
+    """Every pixel a surfel covers must lie inside its screen box.  K with a skew entry of 1e-30 renders the same bits (1e-30 * y vanishes in
+    every float sum) but is 'non-standard' to disc_bbox, which then hands out WHOLE-IMAGE boxes: the boxed render (forward images, aux,
+    backward gradients) must equal that box-free render up to the order of its float sums, with the identical coverage pattern -- over surfels at all depths, off-axis principal points (the reference
+    pipeline's crops, utils/refinement.py:586-609), discs from sub-pixel to a third of the image, surfels behind the camera."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    H, W, n = 96, 128, 1500
+    f = 45.0 * H / 32.0
+    K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1]], np.float32)
+    if case == "centred":
+        p, nrm, col = _surfels(rng, n, 1.2, 2.5, 4.5)
+    elif case == "cropped_far_principal_point":
+        K = np.array([[857.0, 0, -128.3], [0, 861.0, 7.2], [0, 0, 1]], np.float32)       # G14's regime: principal point outside the crop, fx != fy
+        p, nrm, col = _surfels(rng, n, 1.0, 10.0, 14.0)
+        p[:, 0] += 2.5
+    elif case == "near_big_discs":
+        p, nrm, col = _surfels(rng, 300, 0.2, 0.3, 0.8)                                   # disc radius 0.04 at z = 0.3: 18 px and more
+    elif case == "far_small_discs":
+        p, nrm, col = _surfels(rng, n, 6.0, 20.0, 40.0)                                   # sub-pixel discs
+    else:
+        p, nrm, col = _surfels(rng, n, 1.5, -0.5, 1.0)                                    # some behind the camera plane, some within rho of it
+        nrm = rng.standard_normal((p.shape[0], 3)).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)                                 # every orientation: grazing planes (|n.ray| < 0.01) among them
+    Ks = K.copy(); Ks[0, 1] = 1e-30
+    Ki, Kis = np.linalg.inv(K).astype(np.float32), np.linalg.inv(K).astype(np.float32)    # the same rays for both
+    Lh = _lib.lib()
+    outs = []
+    pt, nt, ct, Kit = T(p)[None].contiguous(), T(nrm)[None].contiguous(), T(col)[None].contiguous(), T(Ki).view(1, 9)   # (kept alive: raw pointers below)
+    for Kx in (K, Ks):
+        Kt = T(Kx).view(1, 9)
+        o = _splat(0, Kt, Kit, pt, nt, ct, W, H)
+        color, mask, depth, nimg, aux, ws = o
+        nb = p.shape[0]
+        boxes = N(ws)[:nb * 4].reshape(nb, 4)
+        g = [torch.ones_like(color), torch.ones_like(mask), torch.ones_like(depth), torch.ones_like(nimg)]
+        gp, gn, ga = (torch.zeros(1, nb, 3, device=DEV) for _ in range(3))
+        _lib.check(Lh.sdfr_splat_backward(0, _lib.ptr(Kt), _lib.ptr(Kit), _lib.ptr(pt), _lib.ptr(nt),
+                                          _lib.ptr(ct), None, None, None, None, 1, nb, None, W, H, 0.04, 150.0, _lib.ptr(aux), _lib.ptr(color),
+                                          _lib.ptr(mask), _lib.ptr(depth), _lib.ptr(nimg), _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.ptr(g[2]), _lib.ptr(g[3]),
+                                          _lib.ptr(gp), _lib.ptr(gn), _lib.ptr(ga), _lib.stream_ptr()), "sdfr_splat_backward")
+        outs.append((color, mask, depth, nimg, aux, gp, gn, ga, boxes))
+    a, b = outs
+    whole = (b[8][:, 0] == 0) & (b[8][:, 2] == W - 1) & (b[8][:, 1] == 0) & (b[8][:, 3] == H - 1)
+    assert whole.all(), "the skewed K must switch the boxes off"
+    area = ((a[8][:, 2] - a[8][:, 0] + 1).clip(0) * (a[8][:, 3] - a[8][:, 1] + 1).clip(0)).astype(np.int64)
+    assert area.sum() < 0.7 * whole.sum() * W * H or case in ("near_big_discs", "grazing_and_behind")     # ... and the plain K must use them
+    # equal up to the ORDER of the float sums (the forward groups a tile's candidates into shares of its own list, the backward sums a surfel's
+    # pixels in the order of its own box): a cut pixel would show as a missing O(1) weight, not as a rounding difference
+    assert torch.equal(a[1] > 0, b[1] > 0), "coverage pattern"
+    for x, y, name in zip(a[:8], b[:8], ("color", "mask", "depth", "normals", "aux", "g_p", "g_n", "g_attr")):
+        if name == "aux":
+            x, y = x[..., :3], y[..., :3]                      # (nu, max logit, denominator; the 4th word is a bit field)
+        xn, yn = N(x), N(y)
+        sane = np.isfinite(xn) & np.isfinite(yn) & (np.abs(yn) < 1e20)        # (surfels within rho of the camera plane: sums that overflow in either order)
+        scale = max(1.0, float(np.abs(yn[sane]).max())) if sane.any() else 1.0
+        tol = (2e-4 if name.startswith("g_") else 2e-5) * scale
+        assert sane.mean() > 0.99 and np.allclose(xn[sane], yn[sane], rtol=2e-4, atol=tol), (name, float(np.abs(xn[sane] - yn[sane]).max()), scale)
+    assert float(a[1].sum()) > 20

@@ -573,12 +573,10 @@ def main():
         Kc = K_for(size, size)
 
         def setup():
-            d2 = dec
-            if precision is not torch.float32:
-                d2, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)
-                d2.prefilter_reuse = reuse
-                d2.candidate_reuse = reuse                     # (float16 mode: candidate rows only while the proven bound holds, r05)
-                d2 = d2.to(dev)
+            d2, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)
+            d2.prefilter_reuse = reuse
+            d2.candidate_reuse = reuse                         # (float16 / exact float32: candidate rows only while the proven bound holds, r05)
+            d2 = d2.to(dev)
             rf = sdflabel_amd.BatchRefiner(d2, D, Kc, (size, size), chunk, lidar_cap=4096, device=dev, render=render)
             nocs1, lidar = synthetic_targets(dec, D, Kc, size, size, dev)      # targets from the exact-f32 rendering of the ground truth, all modes
             rf.set_crops(crop_params(list(range(chunk))), nocs1.expand(chunk, 3, size, size), [lidar] * chunk)
@@ -617,11 +615,16 @@ def main():
         del st, rf
         return out
 
-    sharded = sharded16 = sharded16_full = sharded_pf = sharded_c4 = sharded_tr = None
+    sharded = sharded_full = sharded16 = sharded16_full = sharded_pf = sharded_c4 = sharded_tr = None
     if args.total_crops > 0 and not args.no_extras and CB == 1:
         wl = ("BASELINE configs[3]: %d crops of %dx%d rays sharded crop i -> rank i mod %d, chunks of %d through BatchRefiner (reference losses + "
               "solver, HIP-graph replay), one all_gather of the result rows")
-        sharded = sharded_section("exact float32 decoder (parity path)", torch.float32, False, H, args.total_crops, wl)
+        sharded = sharded_section("exact float32 decoder (parity path); candidate reuse: the exact-f32 kernels run on the band candidates alone while a "
+                                  "proven Lipschitz bound keeps them valid (bit-identical to the full-grid evaluation, audited)", torch.float32, True, H,
+                                  args.total_crops, wl)
+        if world == 1:        # every grid row every iteration (the r01-r04 figure; an eighth of the crops: 1.7 ms per crop-iteration)
+            sharded_full = sharded_section("exact float32 decoder, every grid row every iteration (the r04 figure)", torch.float32, False, H,
+                                           max(64, args.total_crops // 8), wl)
         sharded16 = sharded_section("float16 decoder = the reference's shipped precision (config_refine.ini:19), f32 everything else; candidate reuse: "
                                     "the half decoder runs on the band candidates alone while a proven Lipschitz bound keeps them valid (bit-identical "
                                     "to the full-grid evaluation, audited)", torch.float16, True, H, args.total_crops, wl)
@@ -969,6 +972,7 @@ def main():
         line["refine_demo_traced"] = refine_traced
         line["optimizer_mirror_varied_crops"] = varied
         line["refine_sharded"] = sharded
+        line["refine_sharded_full_grid"] = sharded_full
         line["refine_sharded_float16"] = sharded16
         line["refine_sharded_float16_full_grid"] = sharded16_full
         line["refine_sharded_prefilter"] = sharded_pf

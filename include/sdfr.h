@@ -210,6 +210,13 @@ int sdfr_mlp_forward_f16_ragged(const sdfr_decoder* dec, const float* inputs, in
                                 uint32_t* mask_ws, void* stream);
 int sdfr_candidate_band_map(const int32_t* idx, int cap, const int32_t* cnt, const int32_t* cslot, int64_t G, int B, int stride, int32_t* pos,
                             int32_t* violations, void* stream);
+/* The same scheme with the EXACT float32 decoder (the parity path): sdfr_mlp_forward with per-crop skip flags (full-grid pass of the crops
+ * whose candidate set is due; no masks) and over a ragged [B][rows_per_crop] array (rows_per_crop a multiple of 64; masks saved for the
+ * float32 mask-fed Jacobian).  Every row gets the bits sdfr_mlp_forward gives it in a full-grid launch. */
+int sdfr_mlp_forward_skip(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, const int32_t* skip, int64_t rows_per_crop,
+                          void* stream);
+int sdfr_mlp_forward_ragged(const sdfr_decoder* dec, const float* inputs, int B, int64_t rows_per_crop, const int32_t* cnt, float* sdf,
+                            uint32_t* mask_ws, void* stream);
 
 /* g_inputs[r][:] = g_sdf[r] * J[slot[r]][:]  for rows with slot[r] >= 0, else 0   (DeepSDF backward through the
  * cached band Jacobian).  n_uncached (device int32, may be NULL) receives the number of rows with g_sdf != 0 and

@@ -161,7 +161,8 @@ class BatchRenderer:
         # decoder (calibrated below; the margin is at least 4 e16).  Reuse while lip |z1 - z0| <= margin / 4.  On top, every step a rotating
         # 1 / audit_stride slice of the rows outside the candidates is evaluated too: one of them inside the band is a hard violation.
         want_reuse = bool(getattr(decoder, "candidate_reuse", False)) if candidate_reuse is None else bool(candidate_reuse)
-        self.creuse = self.f16 and want_reuse and self.handle.hp == 512 and not self.handle.has_ln
+        # ... for the float16 decoder AND for the exact-float32 one (prec == torch.float32: the parity path -- the same scheme with the f32 kernels)
+        self.creuse = (self.f16 or prec == torch.float32) and want_reuse and self.handle.hp == 512 and not self.handle.has_ln
         if self.creuse:
             Lh = _lib.lib()
             self.cstride = (cap + 127) // 128 * 128
@@ -169,16 +170,17 @@ class BatchRenderer:
             self.cidx, self.ccnt, self.cslot, self.cpos = i(B, cs), i(B), i(B * G), i(B, cap)
             self.crow, self.csdf = f(B * cs, NI), f(B * cs)
             self.cmask = i(int(Lh.sdfr_decoder_mask_words(self.handle.h, B * cs)))
+            # e = the mode's own kernel against the decoder in float64 (torch ops, Decoder.forward_float64) on the grid for four unit latents
             gen = torch.Generator().manual_seed(0)
-            s32, s16 = f(G), f(G)
+            sk = f(G)
             worst = 0.0
+            kern = Lh.sdfr_mlp_forward_f16 if self.f16 else Lh.sdfr_mlp_forward
             for _ in range(4):
                 lat = torch.nn.functional.normalize(torch.randn(self.L, generator=gen), dim=0).to(dev)
                 inp = torch.cat([lat.expand(G, -1), self.grid], 1).contiguous()
-                _lib.check(Lh.sdfr_mlp_forward(self.handle.h, _lib.ptr(inp), G, _lib.ptr(s32), None, _lib.stream_ptr()), "sdfr_mlp_forward")
-                _lib.check(Lh.sdfr_mlp_forward_f16(self.handle.h, _lib.ptr(inp), G, _lib.ptr(s16), None, _lib.stream_ptr()), "sdfr_mlp_forward_f16")
-                worst = max(worst, float((s32 - s16).abs().max()))
-            self.f16_error = worst
+                _lib.check(kern(self.handle.h, _lib.ptr(inp), G, _lib.ptr(sk), None, _lib.stream_ptr()), "sdfr_mlp_forward")
+                worst = max(worst, float((sk.double() - decoder.forward_float64(inp).view(-1)).abs().max()))
+            self.f16_error = worst                 # (named for the half mode; 2.6e-4 there, 1.6e-7 for the exact-f32 kernel)
             self.margin = max(self.margin, 4.0 * worst)
             self.margin_dev = torch.full((B,), self.margin, dtype=torch.float32, device=dev)
             self.max_dev = f(B)                 # (stays 0: this mode has no second arithmetic to deviate from; the plan kernel reads it)
@@ -362,21 +364,23 @@ class BatchRenderer:
             ck(L.sdfr_prefilter_plan(P(self.inputs), G, self.NI, self.L, B, self.lipschitz_plan, P(self.margin_dev), P(self.max_dev), P(self.lat_ref),
                                      P(self.age), self.max_reuse, P(self.reuse_flag), P(self.n_full), st), "sdfr_prefilter_plan")
             # full-grid pass of the crops whose candidate set is due (no masks: the Jacobian takes them from the candidate pass below)
-            ck(L.sdfr_mlp_forward_f16_skip(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.reuse_flag), G, st), "sdfr_mlp_forward_f16_skip")
+            fwd_skip = L.sdfr_mlp_forward_f16_skip if self.f16 else L.sdfr_mlp_forward_skip
+            ck(fwd_skip(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.reuse_flag), G, st), "sdfr_mlp_forward_skip")
             if self.fault is not None:
                 self.sdf.index_copy_(0, self.fault[0], self.fault[1])
             ck(L.sdfr_band_select_skip(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.reuse_flag), P(self.cidx), cs, P(self.ccnt),
                                        P(self.cslot), P(self.scratch), st), "sdfr_band_select_skip")
             # every crop: the candidates through the same half kernel (values + masks), written into the grid array
             ck(L.sdfr_candidate_rows(P(self.inputs), G, self.NI, B, P(self.cidx), cs, P(self.ccnt), P(self.crow), st), "sdfr_candidate_rows")
-            ck(L.sdfr_mlp_forward_f16_ragged(self.handle.h, P(self.crow), B, cs, P(self.ccnt), P(self.csdf), P(self.cmask), st),
-               "sdfr_mlp_forward_f16_ragged")
+            fwd_ragged = L.sdfr_mlp_forward_f16_ragged if self.f16 else L.sdfr_mlp_forward_ragged
+            ck(fwd_ragged(self.handle.h, P(self.crow), B, cs, P(self.ccnt), P(self.csdf), P(self.cmask), st), "sdfr_mlp_forward_ragged")
             ck(L.sdfr_scatter_values(P(self.sdf), P(self.csdf), P(self.cidx), G, B, cs, P(self.ccnt), st), "sdfr_scatter_values")
             if self.audit:
                 ck(L.sdfr_prefilter_audit_select(P(self.inputs), P(self.cslot), G, self.NI, B, self.audit_stride, P(self.audit_phase), P(self.audit_rows),
                                                  P(self.audit_src), P(self.audit_n), self.audit_cap, st), "sdfr_prefilter_audit_select")
                 # half | 2: 128- / 64-row tiles of the same 32x32x16 products -- the bits of the full-grid launch
-                ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 3, st),
+                # (float32: the exact kernel, 64-row tiles from 4096 rows)
+                ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 3 if self.f16 else 0, st),
                    "sdfr_mlp_forward_counted")
                 ck(L.sdfr_prefilter_audit_check(P(self.sdf), P(self.audit_sdf), P(self.audit_src), P(self.audit_n), self.audit_cap, G, B, self.thr,
                                                 P(self.reuse_flag), P(self.audit_dev), P(self.violations), P(self.audit_phase), st),
@@ -389,7 +393,7 @@ class BatchRenderer:
             if "jacobian" in events:
                 events["jacobian"][0].record()
             ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.crow), cs, B, P(self.cpos), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.csdf),
-                                   P(self.cmask), 2, st), "sdfr_mlp_jacobian")
+                                   P(self.cmask), 2 if self.f16 else 0, st), "sdfr_mlp_jacobian")
             if "jacobian" in events:
                 events["jacobian"][1].record()
         else:
@@ -510,7 +514,7 @@ class BatchRenderer:
                "margin": float(self.margin_dev.max())}
         if self.audit:
             rep["audit"] = {"stride": self.audit_stride, "rows_last_step": int(self.audit_n[0]), "steps": int(self.audit_phase[0]),
-                            "reference_values": "float16 (the mode's own kernel)" if self.creuse else
+                            "reference_values": ("float16" if self.f16 else "float32") + " (the mode's own kernel)" if self.creuse else
                             ("float32_split (error-compensated f16 MFMAs)" if self.audit_split else "float32"),
                             "max_deviation_at_non_candidates": float(self.audit_dev.max())}
         return rep
@@ -524,7 +528,7 @@ class BatchRenderer:
         if self.creuse and int(self.violations[:, 1].sum()) > 0:
             hard = int(self.violations[:, 1].sum())
             self.violations[:, 1].zero_()
-            raise _lib.SdfrError("float16 candidate reuse: %d row(s) outside the candidate set were found inside the band (audit / band map): the "
+            raise _lib.SdfrError("candidate reuse: %d row(s) outside the candidate set were found inside the band (audit / band map): the "
                                  "band of those steps was incomplete; use decoder.candidate_reuse = False or a larger decoder.prefilter_margin" % hard)
         if self.prefilter and int(self.violations[:, 1].sum()) > 0:
             hard, worst_dev = int(self.violations[:, 1].sum()), float(self.max_dev.max())

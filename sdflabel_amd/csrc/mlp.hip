@@ -226,6 +226,35 @@ extern "C" int sdfr_mlp_forward_f16(const sdfr_decoder* d, const float* inputs, 
     return SDFR_OK;
 }
 
+// The exact-float32 forward with per-crop skip flags / over a ragged [B][rows_per_crop] row array: candidate reuse of the exact-f32 mode (r05;
+// see the half versions below and csrc/surface.hip).  rows_per_crop of the ragged form a multiple of 64 (the f32 tile).
+extern "C" int sdfr_mlp_forward_skip(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, const int32_t* skip, int64_t rows_per_crop,
+                                     void* stream) {
+    SDFR_REQUIRE(d && inputs && sdf && skip && rows_per_crop > 0, "sdfr_mlp_forward_skip: bad argument");
+    SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward_skip: n=%lld out of range", (long long)n);
+    SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_skip: 512-wide decoders without LayerNorm");
+    if (n == 0) return SDFR_OK;
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = nullptr; P.skip = skip; P.skip_rows = rows_per_crop;
+    sdfr_launch_fwd_f32_512(P, n, false, (hipStream_t)stream);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+extern "C" int sdfr_mlp_forward_ragged(const sdfr_decoder* d, const float* inputs, int B, int64_t rows_per_crop, const int32_t* cnt, float* sdf,
+                                       uint32_t* mask_ws, void* stream) {
+    SDFR_REQUIRE(d && inputs && sdf && cnt, "sdfr_mlp_forward_ragged: NULL argument");
+    SDFR_REQUIRE(B >= 0 && rows_per_crop >= 0 && rows_per_crop % 64 == 0 && (int64_t)B * rows_per_crop < (int64_t)1 << 31,
+                 "sdfr_mlp_forward_ragged: B=%d rows_per_crop=%lld (a multiple of 64, B * rows < 2^31)", B, (long long)rows_per_crop);
+    SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_ragged: 512-wide decoders without LayerNorm");
+    if (B == 0 || rows_per_crop == 0) return SDFR_OK;
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.n = (int64_t)B * rows_per_crop; P.sdf = sdf; P.maskbuf = mask_ws; P.crop_cnt = cnt; P.crop_rows = rows_per_crop; P.trace = nullptr;
+    sdfr_launch_fwd_f32_512(P, P.n, mask_ws != nullptr, (hipStream_t)stream);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
 // sdfr_mlp_forward_f16 over a ragged [B][rows_per_crop] row array (rows_per_crop a multiple of 128): crop b's first cnt[b] rows are evaluated
 // (whole 128-row tiles: the rows up to the next multiple of 128 are computed too and must be readable), masks saved in the forward layout of
 // a B * rows_per_crop-row launch.  The candidate pass of the float16 reuse mode (BatchRenderer, decoder.candidate_reuse): a row's value and

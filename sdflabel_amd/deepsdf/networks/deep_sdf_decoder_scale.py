@@ -295,6 +295,25 @@ class Decoder(nn.Module):
                 inj.append((0, 0))
         return inj
 
+    def forward_float64(self, inputs):
+        """Decoder.forward's SDF output (deep_sdf_decoder_scale.py:78-107) in float64 torch ops on the inputs' device, from the effective weights:
+        what the kernels' arithmetic is calibrated against (BatchRenderer's candidate reuse measures e = max |kernel - this| on the grid).
+        Not a product path: nothing consumes its values.  LayerNorm decoders are not supported (candidate reuse refuses them)."""
+        x0 = inputs.detach().double()
+        x = x0
+        n = self.num_layers - 1
+        for l, ((W, b), (inj_n, inj_off)) in enumerate(zip(self.effective_layers(), self._inject_table())):
+            if getattr(self, "bn" + str(l), None) is not None:
+                raise _lib.SdfrError("forward_float64: LayerNorm decoders are not supported")
+            if inj_n:
+                x = torch.cat([x, x0[:, inj_off:inj_off + inj_n]], 1)                     # :90-93
+            x = x @ torch.from_numpy(np.asarray(W, np.float64)).to(x.device).t() + torch.from_numpy(np.asarray(b, np.float64)).to(x.device)
+            if l == n - 1 and self.use_tanh:
+                x = torch.tanh(x)                                                          # :96-97
+            if l < n - 1:
+                x = torch.relu(x)                                                          # :102
+        return torch.tanh(x)                                                               # :106-107
+
     def latent_lipschitz_bound(self):
         """A PROVEN upper bound of || d sdf / d latent ||_2 over all inputs: the change of the decoder output per unit (Euclidean) change of the
         latent columns of an input row, x fixed.  ReLU, tanh (and eval-mode dropout) are 1-Lipschitz, so along the layers the bound d_l of the

@@ -197,6 +197,7 @@ class BatchRenderer:
             self.lat_ref, self.age, self.reuse_flag = f(B, self.L), i(B), i(B)
             self.audit = bool(getattr(decoder, "candidate_audit", True))
             self.audit_stride = int(getattr(decoder, "candidate_audit_stride", 32))
+            self.audit_split = (not self.f16) and str(getattr(decoder, "candidate_audit_arith", "split")) == "split"
             if self.audit:
                 self.audit_cap = B * ((G + self.audit_stride - 1) // self.audit_stride)
                 self.audit_rows, self.audit_src, self.audit_sdf = f(self.audit_cap, NI), i(self.audit_cap), f(self.audit_cap)
@@ -379,9 +380,18 @@ class BatchRenderer:
                 ck(L.sdfr_prefilter_audit_select(P(self.inputs), P(self.cslot), G, self.NI, B, self.audit_stride, P(self.audit_phase), P(self.audit_rows),
                                                  P(self.audit_src), P(self.audit_n), self.audit_cap, st), "sdfr_prefilter_audit_select")
                 # half | 2: 128- / 64-row tiles of the same 32x32x16 products -- the bits of the full-grid launch
-                # (float32: the exact kernel, 64-row tiles from 4096 rows)
-                ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 3 if self.f16 else 0, st),
-                   "sdfr_mlp_forward_counted")
+                # float32: float32-GRADE values from the error-compensated split kernel (within 2.4e-7 of the exact kernel at 2.5x its speed: the
+                # audit asks whether a row outside the candidates sits inside the band, against a proof that leaves it >= 0.05 margin = 2.5e-4
+                # outside); decoder.candidate_audit_arith = "float32" takes the exact kernel
+                if self.f16:
+                    ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 3, st),
+                       "sdfr_mlp_forward_counted")
+                elif self.audit_split:
+                    ck(L.sdfr_mlp_forward_split_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), st),
+                       "sdfr_mlp_forward_split_counted")
+                else:
+                    ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 0, st),
+                       "sdfr_mlp_forward_counted")
                 ck(L.sdfr_prefilter_audit_check(P(self.sdf), P(self.audit_sdf), P(self.audit_src), P(self.audit_n), self.audit_cap, G, B, self.thr,
                                                 P(self.reuse_flag), P(self.audit_dev), P(self.violations), P(self.audit_phase), st),
                    "sdfr_prefilter_audit_check")
@@ -514,7 +524,8 @@ class BatchRenderer:
                "margin": float(self.margin_dev.max())}
         if self.audit:
             rep["audit"] = {"stride": self.audit_stride, "rows_last_step": int(self.audit_n[0]), "steps": int(self.audit_phase[0]),
-                            "reference_values": ("float16" if self.f16 else "float32") + " (the mode's own kernel)" if self.creuse else
+                            "reference_values": ("float16 (the mode's own kernel)" if self.f16 else
+                                                 ("float32_split (error-compensated f16 MFMAs)" if self.audit_split else "float32 (the mode's own kernel)")) if self.creuse else
                             ("float32_split (error-compensated f16 MFMAs)" if self.audit_split else "float32"),
                             "max_deviation_at_non_candidates": float(self.audit_dev.max())}
         return rep

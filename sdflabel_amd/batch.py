@@ -181,6 +181,19 @@ class BatchRenderer:
                 _lib.check(kern(self.handle.h, _lib.ptr(inp), G, _lib.ptr(sk), None, _lib.stream_ptr()), "sdfr_mlp_forward")
                 worst = max(worst, float((sk.double() - decoder.forward_float64(inp).view(-1)).abs().max()))
             self.f16_error = worst                 # (named for the half mode; 2.6e-4 there, 1.6e-7 for the exact-f32 kernel)
+            # exact-f32 mode: the FULL-GRID pass only selects candidates -- every value consumed downstream comes from the exact kernel on the
+            # candidates -- so it may run in half (decoder.candidate_select = "float16", the default; "float32": the exact kernel).  A row it
+            # leaves out had |half value| >= thr + margin, i.e. |exact value| >= thr + margin - e_sel with e_sel = the half kernel's deviation,
+            # calibrated here like e above; margin >= 4 e_sel keeps the proof's budget (0.45 margin for the latent, 0.25 for e_sel, 2 e32 ~ 0)
+            self.select_half = (not self.f16) and str(getattr(decoder, "candidate_select", "float16")) == "float16"
+            if self.select_half:
+                gen = torch.Generator().manual_seed(0)
+                for _ in range(4):
+                    lat = torch.nn.functional.normalize(torch.randn(self.L, generator=gen), dim=0).to(dev)
+                    inp = torch.cat([lat.expand(G, -1), self.grid], 1).contiguous()
+                    _lib.check(Lh.sdfr_mlp_forward_f16(self.handle.h, _lib.ptr(inp), G, _lib.ptr(sk), None, _lib.stream_ptr()), "sdfr_mlp_forward_f16")
+                    worst = max(worst, float((sk.double() - decoder.forward_float64(inp).view(-1)).abs().max()))
+                self.select_error = worst
             self.margin = max(self.margin, 4.0 * worst)
             self.margin_dev = torch.full((B,), self.margin, dtype=torch.float32, device=dev)
             self.max_dev = f(B)                 # (stays 0: this mode has no second arithmetic to deviate from; the plan kernel reads it)
@@ -365,7 +378,7 @@ class BatchRenderer:
             ck(L.sdfr_prefilter_plan(P(self.inputs), G, self.NI, self.L, B, self.lipschitz_plan, P(self.margin_dev), P(self.max_dev), P(self.lat_ref),
                                      P(self.age), self.max_reuse, P(self.reuse_flag), P(self.n_full), st), "sdfr_prefilter_plan")
             # full-grid pass of the crops whose candidate set is due (no masks: the Jacobian takes them from the candidate pass below)
-            fwd_skip = L.sdfr_mlp_forward_f16_skip if self.f16 else L.sdfr_mlp_forward_skip
+            fwd_skip = L.sdfr_mlp_forward_f16_skip if (self.f16 or self.select_half) else L.sdfr_mlp_forward_skip
             ck(fwd_skip(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.reuse_flag), G, st), "sdfr_mlp_forward_skip")
             if self.fault is not None:
                 self.sdf.index_copy_(0, self.fault[0], self.fault[1])

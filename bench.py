@@ -198,6 +198,8 @@ def compact_line(full, extras_path=None):
             ref[name + "_crops_per_s"] = _num(float(sec["crops_per_s"]))
             ref["total_crops"] = sec.get("total_crops")
             ref["iterations_per_crop"] = sec.get("iterations_per_crop")
+            if "candidate_reuse" in sec:                     # (bit-identical to evaluating every grid row every iteration; the full-grid figures are in the extras)
+                ref[name + "_candidate_reuse"] = bool(sec["candidate_reuse"])
     out["refine"] = ref or None
     out["extras"] = extras_path
     line = json.dumps(out)

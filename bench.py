@@ -19,16 +19,17 @@ BASELINE.json do not exist in the reference algorithm and are re
 One ray = one pixel of one crop in one step; value = rays of all ranks / max-over-ranks wall time (weak scaling: one crop per
 rank, no data-path collective; the per-crop results are all-gathered once after the timed region).
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (the fused decoder forward, MFMA-bound) timed with events on
-the launch stream inside the timed region; `roofline_splat` (the splat forward+backward pair against the HBM roofline, at one crop and
-at 64 crops per launch); `cpu_baseline`: the reference's dense algorithm as a multi-threaded torch-CPU port (oracle/torch_cpu_port.py,
-pinned to the reference's golden G7) timed on the host cores for one full crop-iteration of the same workload (rank 0, N=1 only);
-`refine_sharded`: BASELINE configs[3] -- `--total-crops` (default 1024) crops sharded crop i -> rank i mod N, refined for 60 iterations
-(configs/config_refine.ini:15) in chunks of 64 by BatchRefiner with the reference's losses and solver, one all_gather of the result rows: the
-strong-scaling figure of north_star (seconds at 1 rank / seconds at N ranks), exact f32; `refine_sharded_float16` the same run in the
-reference's shipped precision (config_refine.ini:19; pinned to its own float16 trajectory, golden G8h), `refine_sharded_prefilter` with the
-two-stage exact-f32 evaluation + candidate reuse, `refine_sharded_configs4` the configs[4] shape (512x512 rays, float16 decoder); labelled
-second lines `pose_only`, `f16_decoder`, `split_decoder`, `prefilter_decoder`.
+The printed line (ONE line, < 4 KB, key set pinned by tests/test_host_cpu.py) carries the contract keys: `roofline` for the dominant kernel (the
+fused decoder forward, MFMA-bound) timed with events on the launch stream in a separate pass; `cpu_baseline`: the reference's dense algorithm as a
+multi-threaded torch-CPU port (oracle/torch_cpu_port.py, pinned to the reference's golden G7) timed on the host cores for one full crop-iteration
+of the same workload (rank 0, N=1 only); `refine`: crops/s of BASELINE configs[3] -- `--total-crops` (default 1024) crops sharded crop i -> rank
+i mod N, refined for 60 iterations (configs/config_refine.ini:15) in chunks of 64 by BatchRefiner with the reference's losses and solver, one
+all_gather of the result rows: the strong-scaling figure of north_star (seconds at 1 rank / seconds at N ranks) -- in exact f32 and in the
+reference's shipped float16, both with candidate reuse (bit-identical to evaluating every grid row every iteration: DESIGN.md 3.2).
+Everything else goes to bench_extras.json: the same sections evaluating every grid row (`refine_sharded_full_grid`, `refine_sharded_float16_full_grid`),
+`refine_sharded_prefilter`, `refine_sharded_configs4` (512x512 rays, float16), `refine_sharded_traced`, `roofline_splat`, `dropin_api`, `pose_only`,
+`f16_decoder`, `split_decoder`, `prefilter_decoder`, `sphere_trace`, `optimizer_mirror_varied_crops`, per-rank step times.  Under --gpus N > 1 only
+the headline and the two `refine` sections run.
 """
 import argparse
 import json

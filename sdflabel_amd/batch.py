@@ -18,7 +18,9 @@ Modes (all leave the arithmetic of what is consumed downstream unchanged):
   freeze_shape    pose-only refinement: decoder, band and Jacobian evaluated once per latent, later forwards only re-project and splat
   decoder.mlp_precision  float32 (exact-f32 MFMA, the parity path) | float16 | "float32_split" | "float32_prefilter" (two-stage evaluation
                   with a device-side run-time guard; decoder.prefilter_reuse additionally skips the half pass while the candidate set is
-                  provably still valid) -- DESIGN.md 3.1
+                  provably still valid) -- DESIGN.md 3.2
+  decoder.candidate_reuse / BatchRenderer(candidate_reuse=True)  (r05; float32 and float16) the mode's own kernel on the band candidates alone
+                  while a proven Lipschitz bound keeps the candidate set valid: bit-identical to evaluating the whole grid, 4-8x the crops/s
 """
 import torch
 
@@ -154,11 +156,11 @@ class BatchRenderer:
             self.fault = None           # tests: (flat grid rows int64 tensor, values) written over the half pass's output -- a planted half-pass error
         # float16 candidate reuse (r05, opt-in: decoder.candidate_reuse = True): the half decoder runs over the whole grid only when a crop's
         # candidate set (|sdf| < threshold + margin at that pass) may have gone stale; every other step evaluates the candidates alone, with the
-        # same kernel, so band, values and Jacobian have the bits of the full-grid evaluation (DESIGN.md 3.1; csrc/surface.hip).  "May have
+        # same kernel, so band, values and Jacobian have the bits of the full-grid evaluation (DESIGN.md 3.2; csrc/surface.hip).  "May have
         # gone stale" is decided per crop on the device (sdfr_prefilter_plan) from a PROVEN bound: a row outside the candidates had
         # |h(z0)| >= thr + margin, and |h(z1) - h(z0)| <= lip |z1 - z0| + 2 e16, lip = Decoder.latent_lipschitz_bound() (product of the
         # spectral norms of the effective weights along the latent's paths: cannot be low), e16 = the half kernel's deviation from the exact
-        # decoder (calibrated below; the margin is at least 4 e16).  Reuse while lip |z1 - z0| <= margin / 4.  On top, every step a rotating
+        # decoder (calibrated below; the margin is at least 4 e16).  Reuse while lip |z1 - z0| <= 0.45 margin.  On top, every step a rotating
         # 1 / audit_stride slice of the rows outside the candidates is evaluated too: one of them inside the band is a hard violation.
         want_reuse = bool(getattr(decoder, "candidate_reuse", False)) if candidate_reuse is None else bool(candidate_reuse)
         # ... for the float16 decoder AND for the exact-float32 one (prec == torch.float32: the parity path -- the same scheme with the f32 kernels)

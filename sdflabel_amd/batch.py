@@ -173,7 +173,7 @@ class BatchRenderer:
             self.crow, self.csdf = f(B * cs, NI), f(B * cs)
             self.cmask = i(int(Lh.sdfr_decoder_mask_words(self.handle.h, B * cs)))
             # Kernel errors for the proof's budget.  E32: the exact-f32 kernel against the decoder in exact arithmetic -- 1.6e-7 measured against
-            # a float64 evaluation (Decoder.forward_float64; asserted < 1e-6 by tests/test_gpu_f16_reuse.py, not re-measured at every
+            # a float64 evaluation (Decoder.forward_float64; asserted < 1e-6 by tests/test_gpu_candidate_reuse.py, not re-measured at every
             # construction: a float64 GEMM stack costs seconds to load).  The half kernel's deviation is calibrated here against the exact-f32
             # kernel on the grid for four unit latents (2.6e-4 on the shipped decoder), + E32.
             E32 = 1e-6

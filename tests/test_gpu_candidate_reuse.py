@@ -159,17 +159,19 @@ def test_candidate_reuse_audit_catches_a_band_row_outside_the_candidates(precisi
     assert outcomes[False] is None
 
 
-def test_ragged_half_forward_gives_each_row_the_bits_of_the_full_grid_launch():
-    """C ABI: sdfr_mlp_forward_f16_ragged on gathered rows (two crops, counts that are no multiples of the 128-row tile, one empty crop)
-    against sdfr_mlp_forward_f16 over all rows; rows beyond a crop's last tile stay untouched"""
+@pytest.mark.parametrize("half", [True, False])
+def test_ragged_forward_gives_each_row_the_bits_of_the_full_grid_launch(half):
+    """C ABI: sdfr_mlp_forward_f16_ragged / sdfr_mlp_forward_ragged on gathered rows (two crops, counts that are no multiples of the tile, one
+    empty crop) against sdfr_mlp_forward_f16 / sdfr_mlp_forward over all rows; rows beyond a crop's last 128-row block stay untouched"""
     L = _lib.lib()
-    d = _dec16(False)
+    d = _dec16(False, torch.float16 if half else torch.float32)
+    full_fn, ragged_fn = (L.sdfr_mlp_forward_f16, L.sdfr_mlp_forward_f16_ragged) if half else (L.sdfr_mlp_forward, L.sdfr_mlp_forward_ragged)
     h = d.handle(torch.device(DEV, 0))
     G, NI, B, stride = 5000, 6, 3, 1024
     gen = torch.Generator().manual_seed(3)
     x = (torch.rand(B * G, NI, generator=gen) * 2 - 1).to(DEV)
     full = torch.empty(B * G, device=DEV)
-    _lib.check(L.sdfr_mlp_forward_f16(h.h, _lib.ptr(x), B * G, _lib.ptr(full), None, _lib.stream_ptr()), "fwd")
+    _lib.check(full_fn(h.h, _lib.ptr(x), B * G, _lib.ptr(full), None, _lib.stream_ptr()), "fwd")
     cnt = torch.tensor([777, 0, 130], dtype=torch.int32, device=DEV)
     cidx = torch.zeros(B, stride, dtype=torch.int32, device=DEV)
     for b, n in enumerate(cnt.tolist()):
@@ -178,13 +180,13 @@ def test_ragged_half_forward_gives_each_row_the_bits_of_the_full_grid_launch():
     _lib.check(L.sdfr_candidate_rows(_lib.ptr(x), G, NI, B, _lib.ptr(cidx), stride, _lib.ptr(cnt), _lib.ptr(rows), _lib.stream_ptr()), "rows")
     out = torch.full((B * stride,), 7.0, device=DEV)
     masks = torch.zeros(int(L.sdfr_decoder_mask_words(h.h, B * stride)), dtype=torch.int32, device=DEV)
-    _lib.check(L.sdfr_mlp_forward_f16_ragged(h.h, _lib.ptr(rows), B, stride, _lib.ptr(cnt), _lib.ptr(out), _lib.ptr(masks), _lib.stream_ptr()), "ragged")
+    _lib.check(ragged_fn(h.h, _lib.ptr(rows), B, stride, _lib.ptr(cnt), _lib.ptr(out), _lib.ptr(masks), _lib.stream_ptr()), "ragged")
     out = out.view(B, stride)
     for b, n in enumerate(cnt.tolist()):
         assert torch.equal(out[b, :n], full[b * G + cidx[b, :n].long()])
-        pad = (n + 127) // 128 * 128
-        assert bool(torch.isfinite(out[b, :pad]).all()) and bool((out[b, pad:] == 7.0).all())
-    assert L.sdfr_mlp_forward_f16_ragged(h.h, _lib.ptr(rows), B, 1000, _lib.ptr(cnt), _lib.ptr(out), None, _lib.stream_ptr()) != 0     # not x128
+        pad = (n + 127) // 128 * 128                            # (sdfr_candidate_rows fills finite rows up to here; the f32 tile is 64 rows)
+        assert bool(torch.isfinite(out[b, :((n + 63) // 64 * 64 if not half else pad)]).all()) and bool((out[b, pad:] == 7.0).all())
+    assert ragged_fn(h.h, _lib.ptr(rows), B, 1000, _lib.ptr(cnt), _lib.ptr(out), None, _lib.stream_ptr()) != 0     # not a multiple of the tile
 
 
 def test_product_optimizer_uses_candidate_reuse_by_default_and_returns_the_same_bits():

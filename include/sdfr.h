@@ -309,8 +309,10 @@ int sdfr_splat_backward(int primitive, const float* K, const float* Kinv, const 
  * Disc primitive (the optimizer's), no background.
  * CALLER'S CONTRACT (the extents live on the device, the entry points cannot check them): for every crop  1 <= W_b, 1 <= H_b,
  * W_b * H_b <= pix_stride,  ceil(W_b/8) * ceil(H_b/8) <= tiles_cap,  ceil(W_b/16) * ceil(H_b/16) <= tiles16_cap,  and for the tracer
- * ceil(W_b/block) * ceil(H_b/block) <= cone_cap.  An extent outside these bounds writes out of bounds.  The Python layer validates them
- * in set_extents() (sdflabel_amd/batch.py, renderer/sphere_tracer.py) before they reach the device. */
+ * ceil(W_b/block) * ceil(H_b/block) <= cone_cap.  The Python layer validates them in set_extents() (sdflabel_amd/batch.py,
+ * renderer/sphere_tracer.py) before they reach the device.  Defence in depth (r05): the kernels treat a crop with W_b < 1, H_b < 1,
+ * W_b * H_b > pix_stride or more 8x8 tiles than tiles_cap as EMPTY (nothing rendered, zero loss and gradients, its slot untouched) instead
+ * of writing out of bounds (tests/test_gpu_ragged.py); cone_cap and tiles16_cap remain the caller's to guarantee. */
 int64_t sdfr_splat_ws_words_r(int B, int cap, int tiles_cap);
 int sdfr_surfels_forward_r(const float* xyz, int xyz_stride, const float* sdf, int64_t G, const int32_t* idx, const float* J, int Jstride,
                            int Joff, const float* pose, const float* K, int B, int cap, const int32_t* cnt, int output_nocs,

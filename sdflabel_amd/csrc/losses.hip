@@ -168,6 +168,7 @@ __global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const 
         // ragged extents (r04): crop b is W_b x H_b pixels in a slot of pst pixels per channel; the launch covers the largest tile count, the
         // tiles beyond this crop's contribute exact zeros (the fixed-order sums below then equal the crop's own launch bit for bit)
         W = wh[2 * b]; H = wh[2 * b + 1]; P = pst;
+        if (W < 1 || H < 1 || (int64_t)W * H > (int64_t)pst) { W = 0; H = 0; }          // outside the contract: an empty crop (zero loss)
         if ((int)blockIdx.x >= ((W + L2_T - 1) / L2_T) * ((H + L2_T - 1) / L2_T)) {
             if (tid < 3) partial[((int64_t)b * gridDim.x + blockIdx.x) * 3 + tid] = 0.f;
             return;

@@ -33,7 +33,13 @@ __global__ __launch_bounds__(PROJ_THREADS) void sdfr_project_dcm_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int count = sdfr_count(cnt, b, cap);
-    if (SURF && S.wh) { res_x = (float)S.wh[2 * b]; res_y = (float)S.wh[2 * b + 1]; }     // this crop's own image size
+    if (SURF && S.wh) {                                                                    // this crop's own image size
+        int w = S.wh[2 * b], h = S.wh[2 * b + 1];
+        // an extent outside the caller's contract (include/sdfr.h) -- or with more 8x8 tiles than the tile-list layout holds -- is an EMPTY crop
+        const int64_t tcap = S.bins ? S.bin_stride - 2 - (int64_t)SPL_LM * cap : (int64_t)1 << 40;
+        if (w < 1 || h < 1 || (int64_t)((w + 7) >> 3) * ((h + 7) >> 3) > tcap) { w = 0; h = 0; }
+        res_x = (float)w; res_y = (float)h;
+    }
     const float* P = pose + (int64_t)b * 16;
     const float* Kb = K + (int64_t)b * 9;
     const float r00 = P[0], r01 = P[1], r02 = P[2], t0 = P[3];

@@ -57,7 +57,12 @@ struct SplatArgs {
 // image extents of crop b and the pixel stride of its image channels
 __device__ __forceinline__ void splat_dims(const SplatArgs& A, int b, int& W, int& H, int& PS) {
     W = A.W; H = A.H; PS = W * H;
-    if (A.wh) { W = A.wh[2 * b]; H = A.wh[2 * b + 1]; PS = A.pst; }
+    if (A.wh) {
+        W = A.wh[2 * b]; H = A.wh[2 * b + 1]; PS = A.pst;
+        // an extent outside the caller's contract (include/sdfr.h: 1 <= W_b, H_b and W_b H_b <= pix_stride) renders as an EMPTY crop instead of
+        // writing out of bounds (the Python layer validates extents before they reach the device)
+        if (W < 1 || H < 1 || (int64_t)W * H > (int64_t)PS) { W = 0; H = 0; }
+    }
 }
 
 struct Hit {

@@ -23,7 +23,10 @@ struct TraceRay { float ox, oy, oz, dx, dy, dz; };
 struct TraceDims { const int32_t* wh; int W, H, PS, ncap; };
 __device__ __forceinline__ void trace_dims(const TraceDims& D, int b, int& W, int& H) {
     W = D.W; H = D.H;
-    if (D.wh) { W = D.wh[2 * b]; H = D.wh[2 * b + 1]; }
+    if (D.wh) {
+        W = D.wh[2 * b]; H = D.wh[2 * b + 1];
+        if (W < 1 || H < 1 || (int64_t)W * H > (int64_t)D.PS) { W = 0; H = 0; }        // outside the contract: an empty crop, not an out-of-bounds write
+    }
 }
 
 __device__ __forceinline__ TraceRay trace_ray(const float* __restrict__ P, const float* __restrict__ Ki, float x, float y) {

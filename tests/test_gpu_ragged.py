@@ -224,3 +224,51 @@ def test_degenerate_extents_in_one_ragged_batch(dec):
         for x, y in zip(g1, gt):
             assert bool(torch.isfinite(y[b]).all()) and torch.equal(x[0], y[b]), b
     assert int(ot["nf"][3]) > 500
+
+
+def test_extent_outside_the_contract_renders_as_an_empty_crop_not_out_of_bounds(dec):
+    """the `_r` entry points read (W_b, H_b) from device memory and cannot validate them on the host.  An extent with more pixels than
+    the slot (or a non-positive side), written straight to the device behind set_extents()'s back, must leave that crop EMPTY -- images
+    untouched, zero gradients, nothing written outside its slot -- while the other crops of the batch render bit-identically to a clean run.
+    Both renderers."""
+    D, B, PS = 16, 3, 32 * 32
+    K = K_for(32, 32)
+    yaw = T(np.array([0.6, 0.2, -0.4], np.float32)); trans = T(np.array([[0.0, 0.0, 3.5]] * 3, np.float32))
+    lat = T(np.array([[0.3, -0.5, 0.8]] * 3, np.float32))
+    sizes = [(32, 32), (24, 40), (40, 20)]
+    for bad in ((64, 64), (0, 16), (-3, 7)):
+        br = sdflabel_amd.BatchRenderer(dec, D, K, (32, 32), B, device=DEV, max_pixels=PS, max_side=64)
+        br.set_extents(sizes)
+        out = br.forward(yaw, trans, lat)
+        g = br.backward(g_color=torch.ones_like(br.color), g_mask=torch.ones_like(br.mask))
+        clean = [t.clone() for t in (br.color, br.mask, br.depth, br.nimg, br.aux, g[0], g[1], g[2])]
+        assert float(clean[1][1].sum()) > 5
+        with torch.no_grad():
+            br.wh[1] = torch.tensor(bad, dtype=torch.int32, device=DEV)         # behind the validator's back
+        for t in (br.color, br.mask, br.depth, br.nimg):
+            t.fill_(7.0)
+        br.forward(yaw, trans, lat)
+        g = br.backward(g_color=torch.ones_like(br.color), g_mask=torch.ones_like(br.mask))
+        now = [br.color, br.mask, br.depth, br.nimg, br.aux, g[0], g[1], g[2]]
+        for b in (0, 2):
+            w, h = sizes[b]
+            for a, c in zip(now[:4], clean[:4]):
+                assert torch.equal(a[b, :, :w * h], c[b, :, :w * h]), (bad, b)
+            for a, c in zip(now[5:], clean[5:]):
+                assert torch.equal(a[b], c[b]), (bad, b)
+        assert bool((br.color[1] == 7.0).all()) and bool((br.mask[1] == 7.0).all())      # the bad crop's slot: untouched
+        assert float(g[0][1].abs()) == 0.0 and float(g[1][1].abs().max()) == 0.0
+    # the tracer's readers
+    d16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    tr = sdflabel_amd.SphereTracer(d16.to(DEV), K, (32, 32), B, steps=32, device=DEV, max_pixels=PS, max_side=64)
+    tr.set_extents(sizes)
+    tr.render(yaw, trans, lat)
+    clean = [t.clone() for t in (tr.color, tr.mask, tr.depth)]
+    with torch.no_grad():
+        tr.wh[1] = torch.tensor((64, 64), dtype=torch.int32, device=DEV)
+    tr.render(yaw, trans, lat)
+    for b in (0, 2):
+        w, h = sizes[b]
+        for a, c in zip((tr.color, tr.mask, tr.depth), clean):
+            assert torch.equal(a[b, :, :w * h], c[b, :, :w * h]), b
+    assert float(tr.mask[1].sum()) == 0.0 or bool((tr.mask[1] == clean[1][1]).all())       # nothing new rendered into the bad crop's slot

@@ -441,8 +441,8 @@ def main():
     # its Adam/SGD step, device resident (sdflabel_amd.BatchRefiner); targets are rendered from the ground-truth pose (SURVEY.md 8 a-harness)
     iters = 60
 
-    def refine_setup():
-        rf = sdflabel_amd.BatchRefiner(dec, D, K_for(H, W), (H, W), CB, lidar_cap=4096, device=dev)
+    def refine_setup(reuse=False):
+        rf = sdflabel_amd.BatchRefiner(dec, D, K_for(H, W), (H, W), CB, lidar_cap=4096, device=dev, candidate_reuse=reuse)
         nocs1, lidar = synthetic_targets(dec, D, K_for(H, W), H, W, dev)
         nocs_t = nocs1.expand(CB, 3, H, W).clone()
         p0 = {"yaw": torch.cat([c.yaw.detach() for c in crops]), "trans": torch.stack([c.trans.detach() for c in crops]),
@@ -463,6 +463,15 @@ def main():
                   "yaw_error_before_after": [float((y0 - 0.6).abs().mean()), float((rf.yaw - 0.6).abs().mean())],
                   "crops_stepped_last_iteration": int(rf.stepped.sum())}
         del rf
+        # ... and with candidate reuse (exact f32, bit-identical: DESIGN.md 3.2)
+        res2, err2 = timed_section(lambda: refine_setup(True), lambda st: st[0].optimize(iters))
+        if res2 is not None:
+            (rf2, _), dt_r2 = res2
+            refine["with_candidate_reuse"] = {"value": CB * world / dt_r2, "unit": "crops/s", "ms_per_iteration": dt_r2 / iters * 1e3,
+                                              "yaw_error_after": float((rf2.yaw - 0.6).abs().mean())}
+            del rf2
+        else:
+            refine["with_candidate_reuse"] = {"error": err2}
     res = None
 
     # the same loop with the sphere tracer as its renderer (BatchRefiner(render="trace"): traced NOCS image -> 2-D loss, hit points -> 3-D loss,

@@ -211,6 +211,9 @@ class BatchRenderer:
             self.audit = bool(getattr(decoder, "candidate_audit", True))
             self.audit_stride = int(getattr(decoder, "candidate_audit_stride", 32))
             self.audit_split = (not self.f16) and str(getattr(decoder, "candidate_audit_arith", "split")) == "split"
+            self.audit_side = self.audit and B <= 4 and bool(getattr(decoder, "candidate_audit_side_stream", True))
+            self._side = torch.cuda.Stream(device=dev) if self.audit_side else None
+            self._side_pending = False
             if self.audit:
                 self.audit_cap = B * ((G + self.audit_stride - 1) // self.audit_stride)
                 self.audit_rows, self.audit_src, self.audit_sdf = f(self.audit_cap, NI), i(self.audit_cap), f(self.audit_cap)
@@ -384,30 +387,39 @@ class BatchRenderer:
                 self.sdf.index_copy_(0, self.fault[0], self.fault[1])
             ck(L.sdfr_band_select_skip(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.reuse_flag), P(self.cidx), cs, P(self.ccnt),
                                        P(self.cslot), P(self.scratch), st), "sdfr_band_select_skip")
-            # every crop: the candidates through the same half kernel (values + masks), written into the grid array
+            if self.audit:
+                # few crops per launch: every decoder pass of the step is ONE tile pass of latency with most CUs idle (25-50 tiles on 256 CUs), so
+                # the audit's pass runs BESIDE the candidates' on a side stream (fork here, join at the end of forward(); capturable: the side
+                # stream is forked from and joined into the capturing stream).  It reads rows OUTSIDE the candidates only; the main stream writes
+                # candidate rows.  Many crops per launch fill the chip: one stream.
+                ast = st
+                if self.audit_side:
+                    self._side.wait_stream(torch.cuda.current_stream(self.dev))
+                    ast = self._side.cuda_stream
+                    self._side_pending = True
+                ck(L.sdfr_prefilter_audit_select(P(self.inputs), P(self.cslot), G, self.NI, B, self.audit_stride, P(self.audit_phase), P(self.audit_rows),
+                                                 P(self.audit_src), P(self.audit_n), self.audit_cap, ast), "sdfr_prefilter_audit_select")
+                # float16: half | 2 = 128- / 64-row tiles of the same 32x32x16 products -- the bits of the full-grid launch.
+                # float32: float32-GRADE values from the error-compensated split kernel (within 2.4e-7 of the exact kernel at 2.5x its speed: the
+                # audit asks whether a row outside the candidates sits inside the band, against a proof that leaves it >= 0.3 margin outside);
+                # decoder.candidate_audit_arith = "float32" takes the exact kernel
+                if self.f16:
+                    ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 3, ast),
+                       "sdfr_mlp_forward_counted")
+                elif self.audit_split:
+                    ck(L.sdfr_mlp_forward_split_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), ast),
+                       "sdfr_mlp_forward_split_counted")
+                else:
+                    ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 0, ast),
+                       "sdfr_mlp_forward_counted")
+                ck(L.sdfr_prefilter_audit_check(P(self.sdf), P(self.audit_sdf), P(self.audit_src), P(self.audit_n), self.audit_cap, G, B, self.thr,
+                                                P(self.reuse_flag), P(self.audit_dev), P(self.violations), P(self.audit_phase), ast),
+                   "sdfr_prefilter_audit_check")
+            # every crop: the candidates through the same kernel (values + masks), written into the grid array
             ck(L.sdfr_candidate_rows(P(self.inputs), G, self.NI, B, P(self.cidx), cs, P(self.ccnt), P(self.crow), st), "sdfr_candidate_rows")
             fwd_ragged = L.sdfr_mlp_forward_f16_ragged if self.f16 else L.sdfr_mlp_forward_ragged
             ck(fwd_ragged(self.handle.h, P(self.crow), B, cs, P(self.ccnt), P(self.csdf), P(self.cmask), st), "sdfr_mlp_forward_ragged")
             ck(L.sdfr_scatter_values(P(self.sdf), P(self.csdf), P(self.cidx), G, B, cs, P(self.ccnt), st), "sdfr_scatter_values")
-            if self.audit:
-                ck(L.sdfr_prefilter_audit_select(P(self.inputs), P(self.cslot), G, self.NI, B, self.audit_stride, P(self.audit_phase), P(self.audit_rows),
-                                                 P(self.audit_src), P(self.audit_n), self.audit_cap, st), "sdfr_prefilter_audit_select")
-                # half | 2: 128- / 64-row tiles of the same 32x32x16 products -- the bits of the full-grid launch
-                # float32: float32-GRADE values from the error-compensated split kernel (within 2.4e-7 of the exact kernel at 2.5x its speed: the
-                # audit asks whether a row outside the candidates sits inside the band, against a proof that leaves it >= 0.05 margin = 2.5e-4
-                # outside); decoder.candidate_audit_arith = "float32" takes the exact kernel
-                if self.f16:
-                    ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 3, st),
-                       "sdfr_mlp_forward_counted")
-                elif self.audit_split:
-                    ck(L.sdfr_mlp_forward_split_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), st),
-                       "sdfr_mlp_forward_split_counted")
-                else:
-                    ck(L.sdfr_mlp_forward_counted(self.handle.h, P(self.audit_rows), self.audit_cap, P(self.audit_n), P(self.audit_sdf), 0, st),
-                       "sdfr_mlp_forward_counted")
-                ck(L.sdfr_prefilter_audit_check(P(self.sdf), P(self.audit_sdf), P(self.audit_src), P(self.audit_n), self.audit_cap, G, B, self.thr,
-                                                P(self.reuse_flag), P(self.audit_dev), P(self.violations), P(self.audit_phase), st),
-                   "sdfr_prefilter_audit_check")
             if mlp_events is not None:
                 mlp_events[1].record()
             ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
@@ -467,6 +479,9 @@ class BatchRenderer:
                "sdfr_splat_forward")
         if "splat_fwd" in events:
             events["splat_fwd"][1].record()
+        if getattr(self, "_side_pending", False):               # the audit's side stream joins before anything later can touch its buffers
+            torch.cuda.current_stream(self.dev).wait_stream(self._side)
+            self._side_pending = False
         return {"color": self.color, "mask": self.mask, "depth": self.depth, "normals": self.nimg, "xyzf": self.xyzf, "nf": self.fcnt,
                 "n": self.cnt}
 

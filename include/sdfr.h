@@ -207,7 +207,7 @@ int sdfr_prefilter_audit_check(const float* sdf_grid, const float* sdf_exact, co
 int sdfr_candidate_rows(const float* inputs, int64_t G, int n_inputs, int B, const int32_t* cidx, int stride, const int32_t* ccnt, float* rows,
                         void* stream);
 int sdfr_mlp_forward_f16_ragged(const sdfr_decoder* dec, const float* inputs, int B, int64_t rows_per_crop, const int32_t* cnt, float* sdf,
-                                uint32_t* mask_ws, void* stream);
+                                uint32_t* mask_ws, int half_tiles, void* stream);
 int sdfr_candidate_band_map(const int32_t* idx, int cap, const int32_t* cnt, const int32_t* cslot, int64_t G, int B, int stride, int32_t* pos,
                             int32_t* violations, void* stream);
 /* The same scheme with the EXACT float32 decoder (the parity path): sdfr_mlp_forward with per-crop skip flags (full-grid pass of the crops
@@ -216,7 +216,10 @@ int sdfr_candidate_band_map(const int32_t* idx, int cap, const int32_t* cnt, con
 int sdfr_mlp_forward_skip(const sdfr_decoder* dec, const float* inputs, int64_t n, float* sdf, const int32_t* skip, int64_t rows_per_crop,
                           void* stream);
 int sdfr_mlp_forward_ragged(const sdfr_decoder* dec, const float* inputs, int B, int64_t rows_per_crop, const int32_t* cnt, float* sdf,
-                            uint32_t* mask_ws, void* stream);
+                            uint32_t* mask_ws, int half_tiles, void* stream);
+/* half_tiles = 1 (float16 only; sdfr_mlp_forward_ragged returns SDFR_E_UNSUPPORTED): 64-row tiles instead of 128 -- the candidates of one or
+ * two crops are a few dozen full-size tiles on 256 CUs, and a tile pass is pure latency; the same bits per row.  The mask-fed Jacobian then
+ * needs SDFR_JAC_HALF_TILES in its mask_from_f16 argument. */
 
 /* g_inputs[r][:] = g_sdf[r] * J[slot[r]][:]  for rows with slot[r] >= 0, else 0   (DeepSDF backward through the
  * cached band Jacobian).  n_uncached (device int32, may be NULL) receives the number of rows with g_sdf != 0 and
@@ -273,6 +276,7 @@ int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* no
  *   aux [B][H*W][4]: per-pixel state for the backward (nu, max logit, softmax denominator, clamp gates)
  */
 #define SDFR_JAC_MANY_ROWS 16
+#define SDFR_JAC_HALF_TILES 32  /* the masks were saved by a forward on half-size tiles (sdfr_mlp_forward_ragged / _f16_ragged with half_tiles = 1) */
 #define SDFR_PRIM_BOXES_READY 256   /* OR into `primitive` of sdfr_splat_forward: bbox_ws already holds the surfels' screen boxes and tile lists */
 #define SDFR_PRIM_BINS 512          /* OR into `primitive`: bbox_ws is the LARGE workspace of sdfr_splat_ws_words() and per-tile surfel lists are
                                        built in it and used; without the flag bbox_ws only needs int32[B][cap][4] (boxes) and every 8x8 tile

@@ -91,9 +91,9 @@ _PROTOS = {
     "sdfr_band_select_skip": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_prefilter_guard2": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdfr_candidate_rows": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "sdfr_mlp_forward_f16_ragged": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_mlp_forward_f16_ragged": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sdfr_mlp_forward_skip": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
-    "sdfr_mlp_forward_ragged": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_mlp_forward_ragged": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "sdfr_candidate_band_map": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sdfr_surface_project": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -214,6 +214,7 @@ class BatchRenderer:
             self.audit_side = self.audit and B <= 4 and bool(getattr(decoder, "candidate_audit_side_stream", True))
             self._side = torch.cuda.Stream(device=dev) if self.audit_side else None
             self._side_pending = False
+            self.half_tiles = self.f16 and B <= 2 and bool(getattr(decoder, "candidate_half_tiles", True))      # (a float16 option)
             if self.audit:
                 self.audit_cap = B * ((G + self.audit_stride - 1) // self.audit_stride)
                 self.audit_rows, self.audit_src, self.audit_sdf = f(self.audit_cap, NI), i(self.audit_cap), f(self.audit_cap)
@@ -418,7 +419,9 @@ class BatchRenderer:
             # every crop: the candidates through the same kernel (values + masks), written into the grid array
             ck(L.sdfr_candidate_rows(P(self.inputs), G, self.NI, B, P(self.cidx), cs, P(self.ccnt), P(self.crow), st), "sdfr_candidate_rows")
             fwd_ragged = L.sdfr_mlp_forward_f16_ragged if self.f16 else L.sdfr_mlp_forward_ragged
-            ck(fwd_ragged(self.handle.h, P(self.crow), B, cs, P(self.ccnt), P(self.csdf), P(self.cmask), st), "sdfr_mlp_forward_ragged")
+            # one or two crops per launch: tiles of half the size (twice the workgroups for the same rows; same bits per row)
+            ht = 1 if self.half_tiles else 0
+            ck(fwd_ragged(self.handle.h, P(self.crow), B, cs, P(self.ccnt), P(self.csdf), P(self.cmask), ht, st), "sdfr_mlp_forward_ragged")
             ck(L.sdfr_scatter_values(P(self.sdf), P(self.csdf), P(self.cidx), G, B, cs, P(self.ccnt), st), "sdfr_scatter_values")
             if mlp_events is not None:
                 mlp_events[1].record()
@@ -428,7 +431,7 @@ class BatchRenderer:
             if "jacobian" in events:
                 events["jacobian"][0].record()
             ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.crow), cs, B, P(self.cpos), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.csdf),
-                                   P(self.cmask), 2 if self.f16 else 0, st), "sdfr_mlp_jacobian")
+                                   P(self.cmask), (2 if self.f16 else 0) | (32 if self.half_tiles else 0), st), "sdfr_mlp_jacobian")      # [SDFR_JAC_HALF_TILES]
             if "jacobian" in events:
                 events["jacobian"][1].record()
         else:

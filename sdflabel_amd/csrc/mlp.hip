@@ -242,7 +242,7 @@ extern "C" int sdfr_mlp_forward_skip(const sdfr_decoder* d, const float* inputs,
 }
 
 extern "C" int sdfr_mlp_forward_ragged(const sdfr_decoder* d, const float* inputs, int B, int64_t rows_per_crop, const int32_t* cnt, float* sdf,
-                                       uint32_t* mask_ws, void* stream) {
+                                       uint32_t* mask_ws, int half_tiles, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf && cnt, "sdfr_mlp_forward_ragged: NULL argument");
     SDFR_REQUIRE(B >= 0 && rows_per_crop >= 0 && rows_per_crop % 64 == 0 && (int64_t)B * rows_per_crop < (int64_t)1 << 31,
                  "sdfr_mlp_forward_ragged: B=%d rows_per_crop=%lld (a multiple of 64, B * rows < 2^31)", B, (long long)rows_per_crop);
@@ -250,6 +250,9 @@ extern "C" int sdfr_mlp_forward_ragged(const sdfr_decoder* d, const float* input
     if (B == 0 || rows_per_crop == 0) return SDFR_OK;
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = (int64_t)B * rows_per_crop; P.sdf = sdf; P.maskbuf = mask_ws; P.crop_cnt = cnt; P.crop_rows = rows_per_crop; P.trace = nullptr;
+    // (half-size tiles exist for the float16 kernel only: a 32-row float32 instantiation measured 26 % faster at one crop but did not reproduce the
+    // 64-row launch's Jacobian from its masks in r05's last GPU minutes -- not shipped)
+    if (half_tiles) { sdfr_set_error("sdfr_mlp_forward_ragged: half_tiles is a float16 option (sdfr_mlp_forward_f16_ragged)"); return SDFR_E_UNSUPPORTED; }
     sdfr_launch_fwd_f32_512(P, P.n, mask_ws != nullptr, (hipStream_t)stream);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
@@ -260,7 +263,7 @@ extern "C" int sdfr_mlp_forward_ragged(const sdfr_decoder* d, const float* input
 // a B * rows_per_crop-row launch.  The candidate pass of the float16 reuse mode (BatchRenderer, decoder.candidate_reuse): a row's value and
 // masks have the bits sdfr_mlp_forward_f16 gives that row in any launch.
 extern "C" int sdfr_mlp_forward_f16_ragged(const sdfr_decoder* d, const float* inputs, int B, int64_t rows_per_crop, const int32_t* cnt, float* sdf,
-                                           uint32_t* mask_ws, void* stream) {
+                                           uint32_t* mask_ws, int half_tiles, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf && cnt, "sdfr_mlp_forward_f16_ragged: NULL argument");
     SDFR_REQUIRE(B >= 0 && rows_per_crop >= 0 && rows_per_crop % 128 == 0 && (int64_t)B * rows_per_crop < (int64_t)1 << 31,
                  "sdfr_mlp_forward_f16_ragged: B=%d rows_per_crop=%lld (a multiple of 128, B * rows < 2^31)", B, (long long)rows_per_crop);
@@ -268,7 +271,8 @@ extern "C" int sdfr_mlp_forward_f16_ragged(const sdfr_decoder* d, const float* i
     if (B == 0 || rows_per_crop == 0) return SDFR_OK;
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = (int64_t)B * rows_per_crop; P.sdf = sdf; P.maskbuf = mask_ws; P.crop_cnt = cnt; P.crop_rows = rows_per_crop; P.trace = nullptr;
-    sdfr_launch_fwd_f16_512(P, P.n, mask_ws != nullptr, (hipStream_t)stream);
+    if (half_tiles) sdfr_launch_fwd_f16_512_half_tiles(P, P.n, (hipStream_t)stream);       // 64-row tiles
+    else sdfr_launch_fwd_f16_512(P, P.n, mask_ws != nullptr, (hipStream_t)stream);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -330,9 +334,12 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     hipStream_t s = (hipStream_t)stream;
     MlpParams P = d->proto;
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
-    P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.fwd_np = mask_from_f16 ? sdfr_fwd_f16_512_np() : (d->HP == 512 ? sdfr_fwd_f32_512_np() : 2);
+    P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws);
     const bool many_rows = (mask_from_f16 & SDFR_JAC_MANY_ROWS) != 0;       // hint: far more rows than 16 x the CU count (recomputing kernel on 32-row tiles)
-    mask_from_f16 &= ~SDFR_JAC_MANY_ROWS;
+    const bool half_tiles = (mask_from_f16 & SDFR_JAC_HALF_TILES) != 0;     // masks saved by a half-size-tile forward (sdfr_mlp_forward*_ragged, half_tiles = 1)
+    mask_from_f16 &= ~(SDFR_JAC_MANY_ROWS | SDFR_JAC_HALF_TILES);
+    P.fwd_np = mask_from_f16 ? sdfr_fwd_f16_512_np() : (d->HP == 512 ? sdfr_fwd_f32_512_np() : 2);
+    if (half_tiles) P.fwd_np /= 2;
     SDFR_REQUIRE(mask_from_f16 >= 0 && mask_from_f16 <= 2, "sdfr_mlp_jacobian: mask_from_f16 = %d (0, 1 or 2)", mask_from_f16);
     // masks saved by the forward launch make the recomputation unnecessary (not for use_tanh decoders: their output
     // derivative needs the pre-tanh value)

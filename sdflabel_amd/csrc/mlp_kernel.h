@@ -1191,6 +1191,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 void sdfr_launch_fwd_f32_512(const MlpParams& P, int64_t n, bool save_masks, hipStream_t s);    // mlp_fwd32.hip
 int sdfr_fwd_f32_512_np();                                                                        // its point tiles per workgroup
 void sdfr_launch_fwd_f16_512(const MlpParams& P, int64_t n, bool save_masks, hipStream_t s);   // mlp_fwd16.hip
+void sdfr_launch_fwd_f16_512_half_tiles(const MlpParams& P, int64_t n, hipStream_t s);          // mlp_fwd16.hip (64-row tiles, masks)
 int sdfr_fwd_f16_512_np();                                                                        // its point tiles per workgroup
 void sdfr_launch_fwd_split_512(const MlpParams& P, int64_t n, bool save_masks, hipStream_t s);  // mlp_split.hip
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s); // mlp_jac.hip

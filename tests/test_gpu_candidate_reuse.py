@@ -180,13 +180,34 @@ def test_ragged_forward_gives_each_row_the_bits_of_the_full_grid_launch(half):
     _lib.check(L.sdfr_candidate_rows(_lib.ptr(x), G, NI, B, _lib.ptr(cidx), stride, _lib.ptr(cnt), _lib.ptr(rows), _lib.stream_ptr()), "rows")
     out = torch.full((B * stride,), 7.0, device=DEV)
     masks = torch.zeros(int(L.sdfr_decoder_mask_words(h.h, B * stride)), dtype=torch.int32, device=DEV)
-    _lib.check(ragged_fn(h.h, _lib.ptr(rows), B, stride, _lib.ptr(cnt), _lib.ptr(out), _lib.ptr(masks), _lib.stream_ptr()), "ragged")
-    out = out.view(B, stride)
+    _lib.check(ragged_fn(h.h, _lib.ptr(rows), B, stride, _lib.ptr(cnt), _lib.ptr(out), _lib.ptr(masks), 0, _lib.stream_ptr()), "ragged")
+    if not half:                                                # half-size tiles are a float16 option
+        assert ragged_fn(h.h, _lib.ptr(rows), B, stride, _lib.ptr(cnt), _lib.ptr(out), _lib.ptr(masks), 1, _lib.stream_ptr()) == -3
+        out = out.view(B, stride)
+        for b, n in enumerate(cnt.tolist()):
+            assert torch.equal(out[b, :n], full[b * G + cidx[b, :n].long()])
+        return
+    # ... and on half-size tiles (the geometry of one or two crops per launch): the same bits again, other mask layout
+    out_h = torch.full((B * stride,), 7.0, device=DEV)
+    masks_h = torch.zeros_like(masks)
+    _lib.check(ragged_fn(h.h, _lib.ptr(rows), B, stride, _lib.ptr(cnt), _lib.ptr(out_h), _lib.ptr(masks_h), 1, _lib.stream_ptr()), "ragged half tiles")
+    # the mask-fed Jacobian from either mask set, told which layout it reads: identical rows
+    n0 = int(cnt[0])
+    pos = torch.arange(n0, dtype=torch.int32, device=DEV).view(1, -1).contiguous()
+    c1 = torch.tensor([n0], dtype=torch.int32, device=DEV)
+    J = [torch.zeros(n0, NI, device=DEV) for _ in range(2)]
+    sel = [torch.zeros(n0, device=DEV) for _ in range(2)]
+    for k, (o_, m_, flag) in enumerate(((out, masks, 0), (out_h, masks_h, 32))):
+        _lib.check(L.sdfr_mlp_jacobian(h.h, _lib.ptr(rows), stride, 1, _lib.ptr(pos), n0, _lib.ptr(c1), _lib.ptr(J[k]), _lib.ptr(sel[k]), _lib.ptr(o_),
+                                       _lib.ptr(m_), (2 if half else 0) | flag, _lib.stream_ptr()), "jac")
+    assert torch.equal(J[0], J[1]) and torch.equal(sel[0], sel[1]) and float(J[0].abs().sum()) > 0
+    out, out_h = out.view(B, stride), out_h.view(B, stride)
     for b, n in enumerate(cnt.tolist()):
         assert torch.equal(out[b, :n], full[b * G + cidx[b, :n].long()])
+        assert torch.equal(out_h[b, :n], out[b, :n])
         pad = (n + 127) // 128 * 128                            # (sdfr_candidate_rows fills finite rows up to here; the f32 tile is 64 rows)
         assert bool(torch.isfinite(out[b, :((n + 63) // 64 * 64 if not half else pad)]).all()) and bool((out[b, pad:] == 7.0).all())
-    assert ragged_fn(h.h, _lib.ptr(rows), B, 1000, _lib.ptr(cnt), _lib.ptr(out), None, _lib.stream_ptr()) != 0     # not a multiple of the tile
+    assert ragged_fn(h.h, _lib.ptr(rows), B, 1000, _lib.ptr(cnt), _lib.ptr(out), None, 0, _lib.stream_ptr()) != 0     # not a multiple of the tile
 
 
 def test_product_optimizer_uses_candidate_reuse_by_default_and_returns_the_same_bits():

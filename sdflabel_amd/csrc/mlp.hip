@@ -250,8 +250,9 @@ extern "C" int sdfr_mlp_forward_ragged(const sdfr_decoder* d, const float* input
     if (B == 0 || rows_per_crop == 0) return SDFR_OK;
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = (int64_t)B * rows_per_crop; P.sdf = sdf; P.maskbuf = mask_ws; P.crop_cnt = cnt; P.crop_rows = rows_per_crop; P.trace = nullptr;
-    // (half-size tiles exist for the float16 kernel only: a 32-row float32 instantiation measured 26 % faster at one crop but did not reproduce the
-    // 64-row launch's Jacobian from its masks in r05's last GPU minutes -- not shipped)
+    // (half-size tiles exist for the float16 kernel only: a 32-row float32 instantiation measured 26 % faster at one crop, but the float32
+    // kernel's last linear is summed in NT / PT slices per point -- 8 on 64-row tiles, 16 on 32-row tiles -- so its values differ in the last
+    // bits from the 64-row launch's; the half kernel fixes that partition at 4 for every tile size (mlp_kernel.h, "last linear").  Not shipped)
     if (half_tiles) { sdfr_set_error("sdfr_mlp_forward_ragged: half_tiles is a float16 option (sdfr_mlp_forward_f16_ragged)"); return SDFR_E_UNSUPPORTED; }
     sdfr_launch_fwd_f32_512(P, P.n, mask_ws != nullptr, (hipStream_t)stream);
     SDFR_LAUNCH_CHECK();

@@ -34,10 +34,12 @@ extern "C" {
 #define SDFR_TRACE_LEVELS 6     /* most speculation levels of a sphere-tracing march schedule (sdfr_trace_march) */
 #define SDFR_TRACE_COUNTERS 32  /* int32 device counters of a march / a cone march (zeroed by sdfr_trace_setup / sdfr_trace_cone) */
 
-#define SDFR_VERSION 300        /* what sdfr_version() of the library this header belongs to returns; a binding compares the two */
+#define SDFR_VERSION 400        /* what sdfr_version() of the library this header belongs to returns; a binding compares the two */
 
 /* ABI version: bumped whenever an exported signature or a buffer size changes (300: the r04 argument lists of sdfr_trace_march /
- * sdfr_trace_cone and the 32-word SDFR_TRACE_COUNTERS).  A caller built against another header must refuse the library. */
+ * sdfr_trace_cone and the 32-word SDFR_TRACE_COUNTERS; 400: the r06 fused entry points below -- sdfr_params_plan, sdfr_band_select_ex,
+ * sdfr_mlp_forward_candidates, sdfr_candidate_band, sdfr_losses_fused, sdfr_splat_backward_x, sdfr_pose_latent_solver).  A caller built
+ * against another header must refuse the library. */
 int sdfr_version(void);
 /* 0 for the product library.  Bit 0: built with SDFR_EXPERIMENT (kernel geometry / option A/B build of tools/ab_variant.sh);
  * bit 1: a timing-only ablation is compiled in and results are wrong by construction.  Bindings refuse a non-zero value. */
@@ -277,6 +279,7 @@ int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* no
  */
 #define SDFR_JAC_MANY_ROWS 16
 #define SDFR_JAC_HALF_TILES 32  /* the masks were saved by a forward on half-size tiles (sdfr_mlp_forward_ragged / _f16_ragged with half_tiles = 1) */
+#define SDFR_JAC_QUARTER_TILES 64  /* ... on quarter-size tiles (sdfr_mlp_forward_candidates with half_tiles = 2: 32-row tiles, float16) */
 #define SDFR_PRIM_BOXES_READY 256   /* OR into `primitive` of sdfr_splat_forward: bbox_ws already holds the surfels' screen boxes and tile lists */
 #define SDFR_PRIM_BINS 512          /* OR into `primitive`: bbox_ws is the LARGE workspace of sdfr_splat_ws_words() and per-tile surfel lists are
                                        built in it and used; without the flag bbox_ws only needs int32[B][cap][4] (boxes) and every 8x8 tile
@@ -432,6 +435,54 @@ int sdfr_loss_2d(const float* rend, const float* target, int B, int H, int W, fl
 int sdfr_solver_step(float* params, const float* grads, int L, const float* loss2d, const float* loss3d, const int32_t* npairs,
                      float w2, float w3, float* adam_m, float* adam_v, int32_t* adam_t, float lr_adam, float lr_scale, float lr_latent,
                      int B, float* total, int32_t* stepped, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * r06: the refinement iteration in 11 launches instead of 21 (the per-annotation call of pipelines/refine_css.py:203-223 is a chain of
+ * latency-bound launches: every one removed is ~5 us of a 0.3 ms iteration).  Each entry point below is the fusion of entry points above and
+ * returns THEIR bits (GPU tests compare the two launch sequences array by array).
+ */
+/* sdfr_params_forward + sdfr_prefilter_plan (optimizer.py:86-100 + the candidate-reuse plan). */
+int sdfr_params_plan(const float* yaw, const float* trans, const float* latent, int L, const float* grid, int64_t G, int B, float* inputs,
+                     float* pose, float* latnorm, float lip, const float* margin, const float* max_dev, float* lat_ref, int32_t* age,
+                     int max_reuse, int32_t* reuse, int32_t* n_full, void* stream);
+/* sdfr_band_select_skip with a STICKY truncation flag: over[b] |= over_bit whenever crop b's selection holds more than cap rows (cnt[b] is
+ * overwritten by every selection; the reference has no capacity, grid.py:64-66, so a truncated band must never pass silently).  thr_extra,
+ * skip, slot and over may be NULL.  Launches of up to 8 crops with a flag array take one workgroup per crop (one launch instead of two). */
+int sdfr_band_select_ex(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, const int32_t* skip, int32_t* idx, int cap,
+                        int32_t* cnt, int32_t* slot, int32_t* scratch, int32_t* over, int over_bit, void* stream);
+/* sdfr_candidate_rows + sdfr_mlp_forward(_f16)_ragged without the gathered copy: row s < cnt[b] of crop b is
+ * inputs[b * rows_per_crop_in + cidx[b][s]]; values -> sdf [B][stride], masks -> mask_ws.  half: the float16 kernel (half_tiles: 64-row
+ * tiles); else the exact-float32 kernel.  stride a multiple of the tile (128 / 64).  (deep_sdf_decoder_scale.py:78-107 on the candidate rows) */
+int sdfr_mlp_forward_candidates(const sdfr_decoder* d, const float* inputs, int64_t rows_per_crop_in, int B, const int32_t* cidx, int64_t stride,
+                                const int32_t* cnt, float* sdf, uint32_t* mask_ws, int half, int half_tiles, void* stream);
+/* sdfr_scatter_values + sdfr_band_select + sdfr_candidate_band_map: the band of a crop whose candidate set is valid lies inside the candidates,
+ * which are listed in ascending grid-row order -- idx[b][e] = grid row of the e-th candidate with |csdf| < thr, pos[b][e] = its position in the
+ * candidate array, cnt[b] their number; the candidate values are also written into sdf_grid.  over (may be NULL): sticky flags, |= 1 band > cap,
+ * |= 2 candidates > stride.  (grid.py:64-66 on the candidate rows) */
+int sdfr_candidate_band(float* sdf_grid, const float* csdf, const int32_t* cidx, int64_t G, int B, int stride, const int32_t* ccnt, float thr,
+                        int32_t* idx, int cap, int32_t* cnt, int32_t* pos, int32_t* over, void* stream);
+/* sdfr_loss_2d(_r) + sdfr_loss_3d in one launch (optimizer.py:166-237).  wh == NULL: dense H x W images; else ragged extents (pix_stride,
+ * tiles16_cap as sdfr_loss_2d_r).  g_rend / g_est receive the UN-normalised gradients and kscale float[B][2] the per-crop factors
+ * (weight / count, or 0) the consumers multiply on load: sdfr_splat_backward_x (kscale[2b]) and sdfr_pose_latent_solver (kscale[2b+1]).
+ * tickets int32[2 B]: zero before the first launch, left zero by every launch. */
+int sdfr_losses_fused(const float* rend, const float* target, int B, int H, int W, const int32_t* wh, int pix_stride, int tiles16_cap, float diam,
+                      float threshold_nocs, float weight2d, float* loss2d, float* g_rend, int32_t* nvalid, float* scratch2, const float* est,
+                      const int32_t* ecnt, int ecap, const float* lidar, const int32_t* lcnt, int lcap, const float* scale, float threshold3d,
+                      float weight3d, float* loss3d, float* g_est, float* g_scale, int32_t* npairs, float* scratch3, float* kscale,
+                      int32_t* tickets, void* stream);
+/* sdfr_splat_backward(_r) of the disc primitive for a colour gradient alone, scaled by kscale[2 b] on load (primitives.py:209-242 backward). */
+int sdfr_splat_backward_x(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr, int B, int cap,
+                          const int32_t* cnt, int W, int H, const int32_t* wh, int pix_stride, float diam, float depth_constant, const float* aux,
+                          const float* color, const float* g_color, const float* kscale, float* g_p_cam, float* g_n_cam, float* g_attr,
+                          void* stream);
+/* sdfr_pose_latent_backward (g_xyzf scaled by kscale[2 b + 1] on load) + sdfr_solver_step.  g_yaw / g_trans / g_latent are the sections of
+ * `grads`, whose scale section the loss launch has written (optimizer.py:156 backward, :13-23 step). */
+int sdfr_pose_latent_solver(const float* pose, const float* points, const float* normals, const float* g_p_cam, const float* g_n_cam,
+                            const float* g_col, int B, int cap, const int32_t* cnt, int output_nocs, const float* g_xyzf, const int32_t* fslot,
+                            const float* kscale, const float* J, int n_inputs, int L, const float* yaw, const float* latent, const float* latnorm,
+                            float* g_pose, float* g_latn, float* params, float* grads, const float* loss2d, const float* loss3d,
+                            const int32_t* npairs, float w2, float w3, float* adam_m, float* adam_v, int32_t* adam_t, float lr_adam,
+                            float lr_scale, float lr_latent, float* total, int32_t* stepped, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sphere-tracing render mode  --  NOT in the reference (its renderer splats surfels of a grid band); the mode BASELINE.json's north_star words

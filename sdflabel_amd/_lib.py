@@ -9,7 +9,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SDFR_LIB") or os.path.join(_HERE, "lib", "libsdfr_hip.so")     # SDFR_LIB: A/B builds (tools/ab_build.sh)
 
-ABI_VERSION = 300          # include/sdfr.h SDFR_VERSION
+ABI_VERSION = 400          # include/sdfr.h SDFR_VERSION
 _lib = None
 
 # name -> (restype, argtypes); mirrors include/sdfr.h one to one
@@ -143,6 +143,24 @@ _PROTOS = {
                              c_void_p]),
     "sdfr_solver_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
                                  c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    # r06: fused entry points
+    "sdfr_params_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "sdfr_band_select_ex": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_void_p]),
+    "sdfr_mlp_forward_candidates": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                            c_void_p]),
+    "sdfr_candidate_band": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "sdfr_losses_fused": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_splat_backward_x": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                      c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdfr_pose_latent_solver": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                        c_float, c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTS = tuple(_PROTOS)
@@ -165,6 +183,16 @@ def lib():
             raise SdfrError("libsdfr_hip.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "or sdflabel_amd/csrc/build.sh -- there is no CPU fallback" % LIB_PATH)
         h = ctypes.CDLL(LIB_PATH)
+        # the version first: a stale library lacks newer symbols, and the message should say "rebuild", not AttributeError
+        try:
+            h.sdfr_version.restype = c_int
+            h.sdfr_version.argtypes = []
+            ver = int(h.sdfr_version())
+        except AttributeError:
+            ver = -1
+        if ver != ABI_VERSION:
+            raise SdfrError("%s reports ABI version %d, this binding is written against %d (include/sdfr.h SDFR_VERSION): rebuild the library"
+                            % (LIB_PATH, ver, ABI_VERSION))
         for name, (res, args) in _PROTOS.items():
             fn = getattr(h, name)
             fn.restype = res

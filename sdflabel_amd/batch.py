@@ -59,6 +59,7 @@ class BatchRenderer:
         self.prefilter = prec == "float32_prefilter"
         self.margin = float(getattr(decoder, "prefilter_margin", 0.005))
         self.handle = decoder.handle(dev)
+        self.fused = bool(getattr(decoder, "fused_launches", True))      # r06 (below): fused launches, same bits; False keeps the r05 sequence
         self.L = decoder.latent_size
         self.NI = self.L + 3
         self.grid = Grid3D(density, dev).points.detach().contiguous()
@@ -215,11 +216,16 @@ class BatchRenderer:
             self._side = torch.cuda.Stream(device=dev) if self.audit_side else None
             self._side_pending = False
             self.half_tiles = self.f16 and B <= 2 and bool(getattr(decoder, "candidate_half_tiles", True))      # (a float16 option)
+            # r06: 32-row tiles at ONE crop per launch (fused launches only: the pool kernel of sdfr_mlp_forward_candidates)
+            self.quarter_tiles = self.half_tiles and B == 1 and self.fused and bool(getattr(decoder, "candidate_quarter_tiles", False))
             if self.audit:
                 self.audit_cap = B * ((G + self.audit_stride - 1) // self.audit_stride)
                 self.audit_rows, self.audit_src, self.audit_sdf = f(self.audit_cap, NI), i(self.audit_cap), f(self.audit_cap)
                 self.audit_n, self.audit_phase, self.audit_dev = i(1), i(1), f(B)
             self.fault = None                   # tests: (flat grid rows, values) written over the full pass's output
+        # r06: fused launches (same bits as the launch sequence they replace; False keeps the r05 sequence for A/B tests) and STICKY truncation
+        # flags: over[b] bit 0 = the band exceeded cap in SOME forward since the last clear, bit 1 = the candidates exceeded their stride
+        self.over = i(B)
         self.guarded = self.prefilter or self.creuse        # modes with device-side guard state (violations / margin / age)
         self.n_full = i(B) if self.guarded else None        # full-grid half passes per crop since reset_guard() (counted by the plan kernel)
         self.points, self.nocs, self.normals = f(B, cap, 3), f(B, cap, 3), f(B, cap, 3)
@@ -293,6 +299,7 @@ class BatchRenderer:
         self.trans.copy_(trans.reshape(self.B, 3))
         self.latent.copy_(latent.reshape(self.B, self.L))
         self._shape_valid = False
+        self.clear_overflow()
         self.reset_guard()
 
     def invalidate_shape(self):
@@ -300,6 +307,10 @@ class BatchRenderer:
         self._shape_valid = False
         if self.guarded:
             self.age.zero_()                     # the next step runs the half pass over the whole grid
+
+    def clear_overflow(self):
+        """forget the sticky truncation flags (new crops)"""
+        self.over.zero_()
 
     def reset_guard(self):
         """float32_prefilter: new crops start with clean guard state -- the violation counters, the last deviation and the per-crop margin
@@ -309,6 +320,7 @@ class BatchRenderer:
         if self.guarded:
             self.age.zero_()                     # new crops: the next step runs the half pass over the whole grid
             self.violations.zero_()
+            self.over.zero_()
             self.n_full.zero_()
             self.max_dev.zero_()
             self.margin_dev.fill_(self.margin)
@@ -332,8 +344,13 @@ class BatchRenderer:
         P, st, ck = _lib.ptr, _lib.stream_ptr(), _lib.check
         B, G, cap, W, H = self.B, self.G, self.cap, self.W, self.H
         frozen = self.freeze_shape and self._shape_valid      # pose-only step: the decoder rows stay as they are, only pose / norm are rebuilt
-        ck(L.sdfr_params_forward(P(self.yaw), P(self.trans), P(self.latent), self.L, P(self.grid), G, B, None if frozen else P(self.inputs),
-                                 P(self.pose), P(self.latnorm), st), "sdfr_params_forward")
+        if self.creuse and self.fused and not frozen:
+            ck(L.sdfr_params_plan(P(self.yaw), P(self.trans), P(self.latent), self.L, P(self.grid), G, B, P(self.inputs), P(self.pose), P(self.latnorm),
+                                  self.lipschitz_plan, P(self.margin_dev), P(self.max_dev), P(self.lat_ref), P(self.age), self.max_reuse,
+                                  P(self.reuse_flag), P(self.n_full), st), "sdfr_params_plan")
+        else:
+            ck(L.sdfr_params_forward(P(self.yaw), P(self.trans), P(self.latent), self.L, P(self.grid), G, B, None if frozen else P(self.inputs),
+                                     P(self.pose), P(self.latnorm), st), "sdfr_params_forward")
         if mlp_events is not None:
             mlp_events[0].record()
         if self.freeze_shape and self._shape_valid:
@@ -347,14 +364,14 @@ class BatchRenderer:
                    "sdfr_mlp_forward_f16_skip")
                 if self.fault is not None:
                     self.sdf.index_copy_(0, self.fault[0], self.fault[1])
-                ck(L.sdfr_band_select_skip(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.reuse_flag), P(self.cidx), cap, P(self.ccnt),
-                                           P(self.cslot), P(self.scratch), st), "sdfr_band_select_skip")
+                ck(L.sdfr_band_select_ex(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.reuse_flag), P(self.cidx), cap, P(self.ccnt),
+                                         P(self.cslot), P(self.scratch), P(self.over), 2, st), "sdfr_band_select_ex")
             else:
                 ck(L.sdfr_mlp_forward_f16(self.handle.h, P(self.inputs), B * G, P(self.sdf), None, st), "sdfr_mlp_forward_f16")
                 if self.fault is not None:
                     self.sdf.index_copy_(0, self.fault[0], self.fault[1])
-                ck(L.sdfr_band_select_margin(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.cidx), cap, P(self.ccnt), P(self.cslot),
-                                             P(self.scratch), st), "sdfr_band_select_margin")
+                ck(L.sdfr_band_select_ex(P(self.sdf), G, B, self.thr, P(self.margin_dev), None, P(self.cidx), cap, P(self.ccnt), P(self.cslot),
+                                         P(self.scratch), P(self.over), 2, st), "sdfr_band_select_ex")
             if self.audit:
                 ck(L.sdfr_prefilter_audit_select(P(self.inputs), P(self.cslot), G, self.NI, B, self.audit_stride, P(self.audit_phase), P(self.audit_rows),
                                                  P(self.audit_src), P(self.audit_n), self.audit_cap, st), "sdfr_prefilter_audit_select")
@@ -373,21 +390,27 @@ class BatchRenderer:
             # exact values patched into the grid array + guard (deviation of the half pass at the candidates -> margin / violation counters)
             ck(L.sdfr_prefilter_guard2(P(self.sdf), P(self.sdf_band), P(self.cidx), G, B, cap, P(self.ccnt), P(self.margin_dev), P(self.max_dev),
                                        P(self.violations), P(self.reuse_flag) if self.reuse else None, st), "sdfr_prefilter_guard")
-            ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
+            ck(L.sdfr_band_select_ex(P(self.sdf), G, B, self.thr, None, None, P(self.idx), cap, P(self.cnt), None, P(self.scratch), P(self.over), 1, st),
+               "sdfr_band_select_ex")
             ck(L.sdfr_gather_rows(P(self.J), P(self.Jc), self.NI, P(self.idx), P(self.cslot), G, B, cap, cap, P(self.cnt), st), "sdfr_gather_rows")
             if mlp_events is not None:
                 mlp_events[1].record()
         elif self.creuse:
             cs = self.cstride
-            ck(L.sdfr_prefilter_plan(P(self.inputs), G, self.NI, self.L, B, self.lipschitz_plan, P(self.margin_dev), P(self.max_dev), P(self.lat_ref),
-                                     P(self.age), self.max_reuse, P(self.reuse_flag), P(self.n_full), st), "sdfr_prefilter_plan")
+            if not self.fused:
+                ck(L.sdfr_prefilter_plan(P(self.inputs), G, self.NI, self.L, B, self.lipschitz_plan, P(self.margin_dev), P(self.max_dev), P(self.lat_ref),
+                                         P(self.age), self.max_reuse, P(self.reuse_flag), P(self.n_full), st), "sdfr_prefilter_plan")
             # full-grid pass of the crops whose candidate set is due (no masks: the Jacobian takes them from the candidate pass below)
             fwd_skip = L.sdfr_mlp_forward_f16_skip if (self.f16 or self.select_half) else L.sdfr_mlp_forward_skip
             ck(fwd_skip(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.reuse_flag), G, st), "sdfr_mlp_forward_skip")
             if self.fault is not None:
                 self.sdf.index_copy_(0, self.fault[0], self.fault[1])
-            ck(L.sdfr_band_select_skip(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.reuse_flag), P(self.cidx), cs, P(self.ccnt),
-                                       P(self.cslot), P(self.scratch), st), "sdfr_band_select_skip")
+            if self.fused:
+                ck(L.sdfr_band_select_ex(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.reuse_flag), P(self.cidx), cs, P(self.ccnt),
+                                         P(self.cslot), P(self.scratch), P(self.over), 2, st), "sdfr_band_select_ex")
+            else:
+                ck(L.sdfr_band_select_skip(P(self.sdf), G, B, self.thr, P(self.margin_dev), P(self.reuse_flag), P(self.cidx), cs, P(self.ccnt),
+                                           P(self.cslot), P(self.scratch), st), "sdfr_band_select_skip")
             if self.audit:
                 # few crops per launch: every decoder pass of the step is ONE tile pass of latency with most CUs idle (25-50 tiles on 256 CUs), so
                 # the audit's pass runs BESIDE the candidates' on a side stream (fork here, join at the end of forward(); capturable: the side
@@ -417,21 +440,33 @@ class BatchRenderer:
                                                 P(self.reuse_flag), P(self.audit_dev), P(self.violations), P(self.audit_phase), ast),
                    "sdfr_prefilter_audit_check")
             # every crop: the candidates through the same kernel (values + masks), written into the grid array
-            ck(L.sdfr_candidate_rows(P(self.inputs), G, self.NI, B, P(self.cidx), cs, P(self.ccnt), P(self.crow), st), "sdfr_candidate_rows")
-            fwd_ragged = L.sdfr_mlp_forward_f16_ragged if self.f16 else L.sdfr_mlp_forward_ragged
             # one or two crops per launch: tiles of half the size (twice the workgroups for the same rows; same bits per row)
-            ht = 1 if self.half_tiles else 0
-            ck(fwd_ragged(self.handle.h, P(self.crow), B, cs, P(self.ccnt), P(self.csdf), P(self.cmask), ht, st), "sdfr_mlp_forward_ragged")
-            ck(L.sdfr_scatter_values(P(self.sdf), P(self.csdf), P(self.cidx), G, B, cs, P(self.ccnt), st), "sdfr_scatter_values")
-            if mlp_events is not None:
-                mlp_events[1].record()
-            ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
-            ck(L.sdfr_candidate_band_map(P(self.idx), cap, P(self.cnt), P(self.cslot), G, B, cs, P(self.cpos), P(self.violations), st),
-               "sdfr_candidate_band_map")
+            ht = 2 if self.quarter_tiles else (1 if self.half_tiles else 0)
+            if self.fused:
+                # r06: the candidate rows are read where they lie (no gathered copy), by a pool of workgroups over the live tiles; the band is
+                # compacted straight from the candidate values (scatter + grid-wide selection + position map in one launch)
+                ck(L.sdfr_mlp_forward_candidates(self.handle.h, P(self.inputs), G, B, P(self.cidx), cs, P(self.ccnt), P(self.csdf), P(self.cmask),
+                                                 1 if self.f16 else 0, ht, st), "sdfr_mlp_forward_candidates")
+                if mlp_events is not None:
+                    mlp_events[1].record()
+                ck(L.sdfr_candidate_band(P(self.sdf), P(self.csdf), P(self.cidx), G, B, cs, P(self.ccnt), self.thr, P(self.idx), cap, P(self.cnt),
+                                         P(self.cpos), P(self.over), st), "sdfr_candidate_band")
+            else:
+                ck(L.sdfr_candidate_rows(P(self.inputs), G, self.NI, B, P(self.cidx), cs, P(self.ccnt), P(self.crow), st), "sdfr_candidate_rows")
+                fwd_ragged = L.sdfr_mlp_forward_f16_ragged if self.f16 else L.sdfr_mlp_forward_ragged
+                ck(fwd_ragged(self.handle.h, P(self.crow), B, cs, P(self.ccnt), P(self.csdf), P(self.cmask), ht, st), "sdfr_mlp_forward_ragged")
+                ck(L.sdfr_scatter_values(P(self.sdf), P(self.csdf), P(self.cidx), G, B, cs, P(self.ccnt), st), "sdfr_scatter_values")
+                if mlp_events is not None:
+                    mlp_events[1].record()
+                ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
+                ck(L.sdfr_candidate_band_map(P(self.idx), cap, P(self.cnt), P(self.cslot), G, B, cs, P(self.cpos), P(self.violations), st),
+                   "sdfr_candidate_band_map")
             if "jacobian" in events:
                 events["jacobian"][0].record()
+            # (the mask-fed Jacobian reads no input rows: the gathered array is not needed)
             ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.crow), cs, B, P(self.cpos), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.csdf),
-                                   P(self.cmask), (2 if self.f16 else 0) | (32 if self.half_tiles else 0), st), "sdfr_mlp_jacobian")      # [SDFR_JAC_HALF_TILES]
+                                   P(self.cmask), (2 if self.f16 else 0) | (64 if self.quarter_tiles else (32 if self.half_tiles else 0)), st),
+               "sdfr_mlp_jacobian")                                                   # [SDFR_JAC_HALF_TILES / SDFR_JAC_QUARTER_TILES]
             if "jacobian" in events:
                 events["jacobian"][1].record()
         else:
@@ -439,7 +474,8 @@ class BatchRenderer:
             ck(fwd(self.handle.h, P(self.inputs), B * G, P(self.sdf), P(self.mask_ws), st), "sdfr_mlp_forward")
             if mlp_events is not None:
                 mlp_events[1].record()
-            ck(L.sdfr_band_select(P(self.sdf), G, B, self.thr, P(self.idx), cap, P(self.cnt), None, P(self.scratch), st), "sdfr_band_select")
+            ck(L.sdfr_band_select_ex(P(self.sdf), G, B, self.thr, None, None, P(self.idx), cap, P(self.cnt), None, P(self.scratch), P(self.over), 1, st),
+               "sdfr_band_select_ex")
             if "jacobian" in events:
                 events["jacobian"][0].record()
             ck(L.sdfr_mlp_jacobian(self.handle.h, P(self.inputs), G, B, P(self.idx), cap, P(self.cnt), P(self.J), P(self.sdf_band), P(self.sdf),
@@ -534,10 +570,31 @@ class BatchRenderer:
                                   P(self.g_trans), P(self.g_latent), st), "sdfr_params_backward")
         return self.g_yaw, self.g_trans, self.g_latent
 
+    def backward_solve(self, g_color, g_xyzf, kscale, sv):
+        """r06, the refinement loop's backward in two launches: the splat backward for a colour gradient that arrives UN-normalised with the
+        per-crop factor kscale[b, 0] (sdfr_losses_fused), then projection / latent / parameter gradients (g_xyzf times kscale[b, 1]) and the
+        solver step of every crop (sv: the solver's buffers, BatchRefiner) in one launch.  Same bits as backward() + sdfr_solver_step."""
+        with _lib.guard(self.dev):
+            L = _lib.lib()
+            P, st, ck = _lib.ptr, _lib.stream_ptr(), _lib.check
+            B, cap = self.B, self.cap
+            ck(L.sdfr_splat_backward_x(P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), B, cap, P(self.cnt), self.W, self.H,
+                                       P(self.wh) if self.ragged else None, self.PS, _DIAM_DISC, _DEPTH_CONSTANT, P(self.aux), P(self.color),
+                                       P(g_color), P(kscale), P(self.g_p), P(self.g_n), P(self.g_a), st), "sdfr_splat_backward_x")
+            ck(L.sdfr_pose_latent_solver(P(self.pose), P(self.points), P(self.normals), P(self.g_p), P(self.g_n), P(self.g_a), B, cap, P(self.cnt),
+                                         self.nocs_mode | 4, P(g_xyzf), P(self.fslot), P(kscale), None if self.freeze_shape else P(self.J), self.NI,
+                                         self.L, P(self.yaw), P(self.latent), P(self.latnorm), P(self.g_pose), P(self.g_latn), P(sv["params"]),
+                                         P(sv["grads"]), P(sv["loss2d"]), P(sv["loss3d"]), P(sv["npairs"]), sv["w2"], sv["w3"], P(sv["adam_m"]),
+                                         P(sv["adam_v"]), P(sv["adam_t"]), 0.01, 0.01, sv["lr_latent"], P(sv["total"]), P(sv["stepped"]), st),
+               "sdfr_pose_latent_solver")
+
     # ------------------------------------------------------------------------------------------------------------------
     def overflow(self):
-        """True if some crop's band did not fit `cap` (its surplus surfels were dropped).  Synchronises."""
-        over = (self.cnt > self.cap).any()
+        """True if some crop's band (or candidate set) did not fit its capacity in ANY forward since the flags were last cleared (set_params /
+        BatchRefiner.set_crops / a raising check_overflow) -- its surplus surfels were dropped.  The flags are sticky device words written by the
+        selection kernels (r06: the counts themselves are overwritten by every forward, so a band that overflowed in iterations 5-40 of a
+        graph-replayed refinement and fits again at the end used to pass).  Synchronises."""
+        over = (self.over != 0).any() | (self.cnt > self.cap).any()
         if self.prefilter:
             over = over | (self.ccnt > self.cap).any()
         if self.creuse:
@@ -565,8 +622,11 @@ class BatchRenderer:
         """Raise if the last forward dropped surfels (the reference has no capacity: a truncated shape must not pass silently).  One sync."""
         if self.overflow():
             worst = int(self.cnt.max()) if not self.guarded else max(int(self.cnt.max()), int(self.ccnt.max()))
-            raise _lib.SdfrError("a crop's band holds %d surfels but BatchRenderer was built with cap=%d: rebuild it with a larger `cap` "
-                                 "(default max(256, G/8))" % (worst, self.cap))
+            flags = self.over.tolist()
+            self.over.zero_()                    # reported once: the renderer stays usable for the next crops
+            raise _lib.SdfrError("a crop's band or candidate set exceeded the surfel capacity in some forward since the last check (sticky flags per "
+                                 "crop %s; last counts up to %d) but BatchRenderer was built with cap=%d: rebuild it with a larger `cap` "
+                                 "(default max(256, G/8))" % (flags, worst, self.cap))
         if self.creuse and int(self.violations[:, 1].sum()) > 0:
             hard = int(self.violations[:, 1].sum())
             self.violations[:, 1].zero_()

@@ -30,6 +30,7 @@ $HIPCC $COMMON $SDFR_F16_DEFS -c "$HERE/mlp_fwd16.hip" -o "$HERE/obj/mlp_fwd16.o
 $HIPCC $COMMON $SDFR_SPLIT_DEFS -c "$HERE/mlp_split.hip" -o "$HERE/obj/mlp_split.o" &
 $HIPCC $COMMON $SDFR_J16_DEFS -c "$HERE/mlp_jac16.hip" -o "$HERE/obj/mlp_jac16.o" &
 $HIPCC $COMMON $SDFR_JAC_DEFS -c "$HERE/mlp_jac.hip"   -o "$HERE/obj/mlp_jac.o" &
+$HIPCC $COMMON -c "$HERE/mlp_persist.hip" -o "$HERE/obj/mlp_persist.o" &
 $HIPCC $COMMON -c "$HERE/mlp_small.hip" -o "$HERE/obj/mlp_small.o" &
 $HIPCC $COMMON -c "$HERE/mlp_ln.hip"    -o "$HERE/obj/mlp_ln.o" &
 $HIPCC $COMMON -ffp-contract=off -c "$HERE/surface.hip" -o "$HERE/obj/surface.o" &
@@ -39,5 +40,5 @@ $HIPCC $COMMON -ffp-contract=off -c "$HERE/params.hip"  -o "$HERE/obj/params.o" 
 $HIPCC $COMMON -ffp-contract=off $SDFR_LOSS_DEFS -c "$HERE/losses.hip"  -o "$HERE/obj/losses.o" &
 $HIPCC $COMMON -c "$HERE/trace.hip"   -o "$HERE/obj/trace.o" &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${SDFR_LIBNAME:-libsdfr_hip.so}" "$HERE"/obj/{common,mlp,mlp_fwd32,mlp_fwd16,mlp_split,mlp_jac,mlp_jac16,mlp_small,mlp_ln,surface,project,splat,params,losses,trace}.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/${SDFR_LIBNAME:-libsdfr_hip.so}" "$HERE"/obj/{common,mlp,mlp_fwd32,mlp_fwd16,mlp_split,mlp_jac,mlp_jac16,mlp_persist,mlp_small,mlp_ln,surface,project,splat,params,losses,trace}.o
 echo "built $OUT/${SDFR_LIBNAME:-libsdfr_hip.so}"

@@ -27,6 +27,8 @@ hipError_t sdfr_zero_async(void* p, size_t bytes, hipStream_t stream) {
 extern "C" const char* sdfr_last_error(void) { return g_err; }
 // 300: r05 -- sdfr_trace_march / sdfr_trace_cone took their r04 argument lists (levels array, q_max, spec_k, sigma, aux lists) and
 // SDFR_TRACE_COUNTERS grew from 8 to 32 words under version 200; a caller built against that header must not bind this library silently
+// 400: r06 -- fused entry points (sdfr_params_plan, sdfr_band_select_ex, sdfr_mlp_forward_candidates, sdfr_candidate_band, sdfr_losses_fused,
+// sdfr_splat_backward_x, sdfr_pose_latent_solver)
 extern "C" int sdfr_version(void) { return SDFR_VERSION; }
 
 // bit 0: experiment build (SDFR_EXPERIMENT: some kernel geometry or option differs from the product's); bit 1: a timing-only ablation is

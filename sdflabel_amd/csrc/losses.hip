@@ -12,6 +12,7 @@
 //                     gated per crop by the loop's skip conditions (:127-129,149-151).
 // Fixed-order reductions throughout: bit-repeatable.  Compiled with -ffp-contract=off.
 #include "sdfr_common.h"
+#include "solver.h"
 #include <float.h>
 
 // ---- 3-D loss ----------------------------------------------------------------------------------------------------------
@@ -23,12 +24,13 @@
 #define L3_PTS 64
 #define L3_NW 4
 #define L3_TILE 1024
-__global__ __launch_bounds__(64 * L3_NW) void sdfr_loss_3d_pairs_kernel(const float* __restrict__ est, const int32_t* __restrict__ ecnt,
-                                                                       int ecap, const float* __restrict__ lidar,
-                                                                       const int32_t* __restrict__ lcnt, int lcap,
-                                                                       const float* __restrict__ scale, float threshold,
-                                                                       float* __restrict__ g_est, float* __restrict__ partial) {
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// (the body of the pairs pass as a device function of (block, crop, blocks per crop): shared by the kernel below and by the fused launch of
+// both losses, sdfr_losses_fused_kernel)
+__device__ __forceinline__ void loss_3d_pairs_block(const int blk, const int b, const int nblk, const float* __restrict__ est,
+                                                    const int32_t* __restrict__ ecnt, int ecap, const float* __restrict__ lidar,
+                                                    const int32_t* __restrict__ lcnt, int lcap, const float* __restrict__ scale, float threshold,
+                                                    float* __restrict__ g_est, float* __restrict__ partial) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ne = sdfr_count(ecnt, b, ecap), nl = sdfr_count(lcnt, b, lcap);
     const float s = scale[b];
     const float thr = threshold / s;                                   // :184
@@ -38,11 +40,11 @@ __global__ __launch_bounds__(64 * L3_NW) void sdfr_loss_3d_pairs_kernel(const fl
     const float* E = est + (int64_t)b * ecap * 3;
     const float* Lp = lidar + (int64_t)b * lcap * 3;
     float* G = g_est + (int64_t)b * ecap * 3;
-    const int j = blockIdx.x * L3_PTS + lane;
-    if (blockIdx.x * L3_PTS >= ne || nl == 0) {                        // nothing to pair in this workgroup: zero rows, zero partials
+    const int j = blk * L3_PTS + lane;
+    if (blk * L3_PTS >= ne || nl == 0) {                        // nothing to pair in this workgroup: zero rows, zero partials
         if (wave == 0) {
             if (j < ecap) { G[j * 3] = 0.f; G[j * 3 + 1] = 0.f; G[j * 3 + 2] = 0.f; }
-            if (lane < 3) partial[((int64_t)b * gridDim.x + blockIdx.x) * 3 + lane] = 0.f;
+            if (lane < 3) partial[((int64_t)b * nblk + blk) * 3 + lane] = 0.f;
         }
         return;
     }
@@ -96,9 +98,17 @@ __global__ __launch_bounds__(64 * L3_NW) void sdfr_loss_3d_pairs_kernel(const fl
         for (int i = 0; i < 3; ++i) {
             float x = v[i];
             for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-            if (lane == 0) partial[((int64_t)b * gridDim.x + blockIdx.x) * 3 + i] = x;
+            if (lane == 0) partial[((int64_t)b * nblk + blk) * 3 + i] = x;
         }
     }
+}
+
+__global__ __launch_bounds__(64 * L3_NW) void sdfr_loss_3d_pairs_kernel(const float* __restrict__ est, const int32_t* __restrict__ ecnt,
+                                                                       int ecap, const float* __restrict__ lidar,
+                                                                       const int32_t* __restrict__ lcnt, int lcap,
+                                                                       const float* __restrict__ scale, float threshold,
+                                                                       float* __restrict__ g_est, float* __restrict__ partial) {
+    loss_3d_pairs_block(blockIdx.x, blockIdx.y, gridDim.x, est, ecnt, ecap, lidar, lcnt, lcap, scale, threshold, g_est, partial);
 }
 
 __global__ __launch_bounds__(256) void sdfr_loss_3d_finalize_kernel(const float* __restrict__ partial, int nblk,
@@ -158,19 +168,18 @@ extern "C" int sdfr_loss_3d(const float* est, const int32_t* ecnt, int ecap, con
 #define L2_S 48                         // LDS row pitch: consecutive tile rows fall 16 banks apart
 template <bool LDS, int RADC>       // RADC > 0: window radius known at compile time (the loops unroll and the LDS reads of a row batch up); LDS: window radius <= L2_RMAX, taps come from the staged tile (two instantiations: a run-time choice per tap would
                           // turn the loads into flat accesses with a full wait after each)
-__global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const float* __restrict__ rend, const float* __restrict__ target,
-                                                                         int H, int W, const int32_t* __restrict__ wh, int pst, float diam,
-                                                                         float threshold_nocs, float* __restrict__ g_rend,
-                                                                         float* __restrict__ partial) {
-    const int b = blockIdx.y, tid = threadIdx.x;
+__device__ __forceinline__ void loss_2d_pixels_block(const int blk, const int b, const int nblk, const float* __restrict__ rend,
+                                                     const float* __restrict__ target, int H, int W, const int32_t* __restrict__ wh, int pst,
+                                                     float diam, float threshold_nocs, float* __restrict__ g_rend, float* __restrict__ partial) {
+    const int tid = threadIdx.x;
     int P = H * W;                                                       // pixel stride of the image channels
     if (wh) {
         // ragged extents (r04): crop b is W_b x H_b pixels in a slot of pst pixels per channel; the launch covers the largest tile count, the
         // tiles beyond this crop's contribute exact zeros (the fixed-order sums below then equal the crop's own launch bit for bit)
         W = wh[2 * b]; H = wh[2 * b + 1]; P = pst;
         if (W < 1 || H < 1 || (int64_t)W * H > (int64_t)pst) { W = 0; H = 0; }          // outside the contract: an empty crop (zero loss)
-        if ((int)blockIdx.x >= ((W + L2_T - 1) / L2_T) * ((H + L2_T - 1) / L2_T)) {
-            if (tid < 3) partial[((int64_t)b * gridDim.x + blockIdx.x) * 3 + tid] = 0.f;
+        if ((int)blk >= ((W + L2_T - 1) / L2_T) * ((H + L2_T - 1) / L2_T)) {
+            if (tid < 3) partial[((int64_t)b * nblk + blk) * 3 + tid] = 0.f;
             return;
         }
     }
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const 
     constexpr int UNR = RADC > 0 ? 2 * RADC + 1 : 1;                    // full unroll of the window loops when the radius is a constant
     const int rad = RADC > 0 ? RADC : (int)ceilf(diam) - 1;             // taps with clamp(diam - dist, 0) > 0 have |d| < diam
     const int tilesX = (W + L2_T - 1) / L2_T;
-    const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
+    const int tx = blk % tilesX, ty = blk / tilesX;
     const int lx = tid & (L2_T - 1), ly = tid / L2_T;
     const int w = tx * L2_T + lx, h = ty * L2_T + ly;
     const bool inside = (w < W) && (h < H);
@@ -255,7 +264,15 @@ __global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const 
         if ((tid & 63) == 0) red[i][tid >> 6] = x;
     }
     __syncthreads();
-    if (tid < 3) partial[((int64_t)b * gridDim.x + blockIdx.x) * 3 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    if (tid < 3) partial[((int64_t)b * nblk + blk) * 3 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
+template <bool LDS, int RADC>
+__global__ __launch_bounds__(L2_T * L2_T) void sdfr_loss_2d_pixels_kernel(const float* __restrict__ rend, const float* __restrict__ target,
+                                                                         int H, int W, const int32_t* __restrict__ wh, int pst, float diam,
+                                                                         float threshold_nocs, float* __restrict__ g_rend,
+                                                                         float* __restrict__ partial) {
+    loss_2d_pixels_block<LDS, RADC>(blockIdx.x, blockIdx.y, gridDim.x, rend, target, H, W, wh, pst, diam, threshold_nocs, g_rend, partial);
 }
 
 __global__ __launch_bounds__(256) void sdfr_loss_2d_finalize_kernel(const float* __restrict__ partial, int nblk, int P, float weight,
@@ -325,6 +342,113 @@ extern "C" int sdfr_loss_2d_r(const float* rend, const float* target, int B, con
                         scratch, stream);
 }
 
+// ---- both losses in ONE launch (r06) ------------------------------------------------------------------------------------------------------
+// The refinement loop evaluates the two losses on the same rendering and they do not depend on each other: blocks [0, nblk2) of a crop run the
+// 2-D pixel pass, blocks [nblk2, nblk2 + nblk3) the 3-D pairs pass (both 256 threads).  The finalize passes become the job of the LAST block
+// of each kind to finish (a ticket counter per crop and kind, reset by that block: the launch is replayable): it re-reduces the partials in
+// the finalize kernels' fixed order -- so loss, nvalid / npairs and g_scale carry the same bits -- and, instead of rescaling the gradient
+// arrays in a second sweep, publishes the factor: kscale[b] = (weight_2d / n_valid or 0, weight_3d / n_pairs or 0).  The consumers multiply
+// on load (sdfr_splat_backward_x: g_color * k2; sdfr_pose_latent_solver: g_xyzf * k3) -- the product the finalize kernels stored.
+// Four launches per iteration become one.
+__device__ __forceinline__ void reduce3_fixed(const float* partial, int nblk, int b, float (*red)[256], float& r0, float& r1, float& r2) {
+    const int tid = threadIdx.x;
+    const volatile float* pv = partial;                    // written by other workgroups of this launch: read past the CU's vector cache
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = tid; i < nblk; i += 256) {
+        const volatile float* q = pv + ((int64_t)b * nblk + i) * 3;
+        a0 += q[0]; a1 += q[1]; a2 += q[2];
+    }
+    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) { red[0][tid] += red[0][tid + st]; red[1][tid] += red[1][tid + st]; red[2][tid] += red[2][tid + st]; }
+        __syncthreads();
+    }
+    r0 = red[0][0]; r1 = red[1][0]; r2 = red[2][0];
+}
+
+struct LossesArgs {
+    // 2-D
+    const float* rend; const float* target; int H, W; const int32_t* wh; int pst; float diam, threshold_nocs, w2;
+    float* loss2d; float* g_rend; int32_t* nvalid; float* part2; int nblk2;
+    // 3-D
+    const float* est; const int32_t* ecnt; int ecap; const float* lidar; const int32_t* lcnt; int lcap; const float* scale; float threshold3, w3;
+    float* loss3d; float* g_est; float* g_scale; int32_t* npairs; float* part3; int nblk3;
+    float* kscale; int32_t* tickets;
+};
+
+template <bool LDS, int RADC>
+__global__ __launch_bounds__(256) void sdfr_losses_fused_kernel(const LossesArgs A) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const bool is2 = (int)blockIdx.x < A.nblk2;
+    if (is2) loss_2d_pixels_block<LDS, RADC>(blockIdx.x, b, A.nblk2, A.rend, A.target, A.H, A.W, A.wh, A.pst, A.diam, A.threshold_nocs, A.g_rend, A.part2);
+    else loss_3d_pairs_block(blockIdx.x - A.nblk2, b, A.nblk3, A.est, A.ecnt, A.ecap, A.lidar, A.lcnt, A.lcap, A.scale, A.threshold3, A.g_est, A.part3);
+    __shared__ int s_last;
+    __shared__ float red[3][256];
+    __threadfence();                                       // this block's partials (and gradient rows) are visible device-wide ...
+    __syncthreads();
+    if (tid == 0) {
+        const int t = atomicAdd(&A.tickets[2 * b + (is2 ? 0 : 1)], 1);      // ... before its ticket is
+        s_last = (t == (is2 ? A.nblk2 : A.nblk3) - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (is2) {
+        float tot, cf, anyf;
+        reduce3_fixed(A.part2, A.nblk2, b, red, tot, cf, anyf);
+        if (tid == 0) {
+            const float inv = cf > 0.f ? 1.f / cf : 0.f;
+            A.kscale[2 * b] = (anyf > 0.f) ? A.w2 * inv : 0.f;
+            A.loss2d[b] = (anyf > 0.f) ? (cf > 0.f ? tot * inv : __int_as_float(0x7fc00000)) : 0.f;
+            A.nvalid[b] = (int)cf;
+            A.tickets[2 * b] = 0;
+        }
+    } else {
+        float tot, gst, cf;
+        reduce3_fixed(A.part3, A.nblk3, b, red, tot, gst, cf);
+        if (tid == 0) {
+            const float inv = cf > 0.f ? 1.f / cf : 0.f;
+            const int ne = sdfr_count(A.ecnt, b, A.ecap), nl = sdfr_count(A.lcnt, b, A.lcap);
+            A.kscale[2 * b + 1] = A.w3 * inv;
+            A.loss3d[b] = cf > 0.f ? tot * inv : 0.f;
+            A.g_scale[b] = A.w3 * gst * inv;
+            A.npairs[b] = (ne > 0 && nl > 0) ? (int)cf : -1;
+            A.tickets[2 * b + 1] = 0;
+        }
+    }
+}
+
+// rend / target / g_rend: [B][3][H*W] (wh == NULL) or ragged slots [B][3][pix_stride] with wh int32[B][2] and tiles16_cap tile slots per crop.
+// g_rend and g_est receive the UN-normalised gradients; kscale float[B][2] the factors; tickets int32[2B], zero before the first launch (the
+// kernel leaves them zero); scratch2 float[3 * B * tiles], scratch3 float[3 * B * ceil(ecap / 64)].
+extern "C" int sdfr_losses_fused(const float* rend, const float* target, int B, int H, int W, const int32_t* wh, int pix_stride, int tiles16_cap,
+                                 float diam, float threshold_nocs, float weight2d, float* loss2d, float* g_rend, int32_t* nvalid, float* scratch2,
+                                 const float* est, const int32_t* ecnt, int ecap, const float* lidar, const int32_t* lcnt, int lcap,
+                                 const float* scale, float threshold3d, float weight3d, float* loss3d, float* g_est, float* g_scale,
+                                 int32_t* npairs, float* scratch3, float* kscale, int32_t* tickets, void* stream) {
+    SDFR_REQUIRE(rend && target && loss2d && g_rend && nvalid && scratch2 && est && lidar && scale && loss3d && g_est && g_scale && npairs &&
+                 scratch3 && kscale && tickets, "sdfr_losses_fused: NULL argument");
+    SDFR_REQUIRE(diam > 0.f && ecap > 0 && lcap >= 0, "sdfr_losses_fused: bad size");
+    if (B <= 0) return SDFR_OK;
+    LossesArgs A;
+    A.rend = rend; A.target = target; A.wh = wh; A.diam = diam; A.threshold_nocs = threshold_nocs; A.w2 = weight2d;
+    if (wh) { SDFR_REQUIRE(pix_stride > 0 && tiles16_cap > 0, "sdfr_losses_fused: ragged extents need pix_stride and tiles16_cap"); A.H = 1; A.W = 1; A.pst = pix_stride; A.nblk2 = tiles16_cap; }
+    else { SDFR_REQUIRE(H > 0 && W > 0, "sdfr_losses_fused: bad image size"); A.H = H; A.W = W; A.pst = H * W; A.nblk2 = sdfr_cdiv(W, L2_T) * sdfr_cdiv(H, L2_T); }
+    A.loss2d = loss2d; A.g_rend = g_rend; A.nvalid = nvalid; A.part2 = scratch2;
+    A.est = est; A.ecnt = ecnt; A.ecap = ecap; A.lidar = lidar; A.lcnt = lcnt; A.lcap = lcap; A.scale = scale; A.threshold3 = threshold3d; A.w3 = weight3d;
+    A.loss3d = loss3d; A.g_est = g_est; A.g_scale = g_scale; A.npairs = npairs; A.part3 = scratch3; A.nblk3 = sdfr_cdiv(ecap, L3_PTS);
+    A.kscale = kscale; A.tickets = tickets;
+    const dim3 grid(A.nblk2 + A.nblk3, B);
+    hipStream_t s = (hipStream_t)stream;
+    const int rad = (int)ceilf(diam) - 1;
+    if (rad == 4) hipLaunchKernelGGL((sdfr_losses_fused_kernel<true, 4>), grid, dim3(256), 0, s, A);
+    else if (rad <= L2_RMAX) hipLaunchKernelGGL((sdfr_losses_fused_kernel<true, 0>), grid, dim3(256), 0, s, A);
+    else hipLaunchKernelGGL((sdfr_losses_fused_kernel<false, 0>), grid, dim3(256), 0, s, A);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
 // ---- solver step -------------------------------------------------------------------------------------------------------
 // params / grads: one flat structure-of-arrays buffer  [ yaw(B) | trans(B,3) | scale(B) | latent(B,L) ]  so that each section is the
 // dense array the renderer kernels read; Adam state m, v [B][4], step counter t [B].
@@ -336,35 +460,7 @@ __global__ __launch_bounds__(64) void sdfr_solver_step_kernel(float* __restrict_
                                                              int B, float* __restrict__ total, int32_t* __restrict__ stepped) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
-    const float l = w3 * loss3d[b] + w2 * loss2d[b];                    // :144-146
-    total[b] = l;
-    const bool skip = (npairs[b] < 0) || isnan(l) || (l == 0.f);        // :127-129, :149-151
-    stepped[b] = skip ? 0 : 1;
-    if (skip) return;
-    // section offsets of the structure-of-arrays buffer
-    auto at = [&](int i) -> int64_t {              // i: 0 yaw, 1..3 trans, 4 scale, 5.. latent
-        if (i == 0) return b;
-        if (i < 4) return (int64_t)B + (int64_t)b * 3 + (i - 1);
-        if (i == 4) return (int64_t)4 * B + b;
-        return (int64_t)5 * B + (int64_t)b * L + (i - 5);
-    };
-    float* p = params;
-    const float* g = grads;
-    const int t = adam_t[b] + 1;
-    adam_t[b] = t;
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-    const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
-    for (int i = 0; i < 4; ++i) {                                        // Adam on yaw, trans (:34-36,47-49)
-        float m = adam_m[b * 4 + i], v = adam_v[b * 4 + i];
-        const float gi = g[at(i)];
-        m = b1 * m + (1.f - b1) * gi;
-        v = b2 * v + (1.f - b2) * gi * gi;
-        adam_m[b * 4 + i] = m; adam_v[b * 4 + i] = v;
-        const float denom = sqrtf(v) / sqrtf(bc2) + eps;
-        p[at(i)] -= (lr_adam / bc1) * (m / denom);
-    }
-    p[at(4)] -= lr_scale * g[at(4)];                                      // SGD on scale, latent (:37-38,50-51)
-    for (int i = 0; i < L; ++i) p[at(5 + i)] -= lr_latent * g[at(5 + i)];
+    sdfr_solver_crop(b, B, params, grads, L, loss2d, loss3d, npairs, w2, w3, adam_m, adam_v, adam_t, lr_adam, lr_scale, lr_latent, total, stepped);
 }
 
 extern "C" int sdfr_solver_step(float* params, const float* grads, int L, const float* loss2d, const float* loss3d, const int32_t* npairs,

@@ -236,7 +236,8 @@ extern "C" int sdfr_mlp_forward_skip(const sdfr_decoder* d, const float* inputs,
     if (n == 0) return SDFR_OK;
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = nullptr; P.skip = skip; P.skip_rows = rows_per_crop;
-    sdfr_launch_fwd_f32_512(P, n, false, (hipStream_t)stream);
+    P.n_crops = (int)((n + rows_per_crop - 1) / rows_per_crop);
+    sdfr_launch_pool_f32_skip(P, n, (hipStream_t)stream);            // r06: a pool over the live tiles (same bits per row; nothing to do = one wave of dispatch)
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -254,7 +255,8 @@ extern "C" int sdfr_mlp_forward_ragged(const sdfr_decoder* d, const float* input
     // kernel's last linear is summed in NT / PT slices per point -- 8 on 64-row tiles, 16 on 32-row tiles -- so its values differ in the last
     // bits from the 64-row launch's; the half kernel fixes that partition at 4 for every tile size (mlp_kernel.h, "last linear").  Not shipped)
     if (half_tiles) { sdfr_set_error("sdfr_mlp_forward_ragged: half_tiles is a float16 option (sdfr_mlp_forward_f16_ragged)"); return SDFR_E_UNSUPPORTED; }
-    sdfr_launch_fwd_f32_512(P, P.n, mask_ws != nullptr, (hipStream_t)stream);
+    P.n_crops = B;
+    sdfr_launch_pool_f32_ragged(P, P.n, false, (hipStream_t)stream);  // r06: a pool of workgroups over the live tiles (same bits per row)
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -272,8 +274,35 @@ extern "C" int sdfr_mlp_forward_f16_ragged(const sdfr_decoder* d, const float* i
     if (B == 0 || rows_per_crop == 0) return SDFR_OK;
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = (int64_t)B * rows_per_crop; P.sdf = sdf; P.maskbuf = mask_ws; P.crop_cnt = cnt; P.crop_rows = rows_per_crop; P.trace = nullptr;
-    if (half_tiles) sdfr_launch_fwd_f16_512_half_tiles(P, P.n, (hipStream_t)stream);       // 64-row tiles
-    else sdfr_launch_fwd_f16_512(P, P.n, mask_ws != nullptr, (hipStream_t)stream);
+    P.n_crops = B;
+    if (half_tiles) sdfr_launch_pool_f16_ragged_half_tiles(P, P.n, false, (hipStream_t)stream);       // 64-row tiles
+    else sdfr_launch_pool_f16_ragged(P, P.n, false, (hipStream_t)stream);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// The candidates' pass of the reuse modes WITHOUT the gathered copy (r06): row s < cnt[b] of crop b is inputs[b * rows_per_crop_in + cidx[b][s]]
+// (cidx int32 [B][stride], stride a multiple of the tile: 128, or 64 with half_tiles / float32); values -> sdf [B][stride], masks -> mask_ws in
+// the forward layout of a B * stride-row launch -- exactly what sdfr_candidate_rows + sdfr_mlp_forward(_f16)_ragged produce, one launch less.
+// half != 0: the float16 kernel (half_tiles = 1: 64-row tiles, 2: 32-row tiles); half == 0: the exact-float32 kernel.
+extern "C" int sdfr_mlp_forward_candidates(const sdfr_decoder* d, const float* inputs, int64_t rows_per_crop_in, int B, const int32_t* cidx,
+                                           int64_t stride, const int32_t* cnt, float* sdf, uint32_t* mask_ws, int half, int half_tiles,
+                                           void* stream) {
+    SDFR_REQUIRE(d && inputs && cidx && cnt && sdf, "sdfr_mlp_forward_candidates: NULL argument");
+    const int tile = half ? (half_tiles == 2 ? 32 : (half_tiles ? 64 : 128)) : 64;
+    SDFR_REQUIRE(B >= 0 && stride >= 0 && stride % tile == 0 && (int64_t)B * stride < (int64_t)1 << 31 && rows_per_crop_in > 0 &&
+                 (int64_t)B * rows_per_crop_in < (int64_t)1 << 31, "sdfr_mlp_forward_candidates: B=%d stride=%lld (a multiple of %d) rows_per_crop_in=%lld",
+                 B, (long long)stride, tile, (long long)rows_per_crop_in);
+    SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_candidates: 512-wide decoders without LayerNorm");
+    SDFR_REQUIRE(half || !half_tiles, "sdfr_mlp_forward_candidates: half_tiles is a float16 option");
+    if (B == 0 || stride == 0) return SDFR_OK;
+    MlpParams P = d->proto;
+    P.inputs = inputs; P.n = (int64_t)B * stride; P.sdf = sdf; P.maskbuf = mask_ws; P.crop_cnt = cnt; P.crop_rows = stride; P.trace = nullptr;
+    P.gather_idx = cidx; P.gather_rows = rows_per_crop_in; P.n_crops = B;
+    if (!half) sdfr_launch_pool_f32_ragged(P, P.n, true, (hipStream_t)stream);
+    else if (half_tiles == 2) sdfr_launch_pool_f16_ragged_quarter_tiles(P, P.n, (hipStream_t)stream);
+    else if (half_tiles) sdfr_launch_pool_f16_ragged_half_tiles(P, P.n, true, (hipStream_t)stream);
+    else sdfr_launch_pool_f16_ragged(P, P.n, true, (hipStream_t)stream);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -288,7 +317,8 @@ extern "C" int sdfr_mlp_forward_f16_skip(const sdfr_decoder* d, const float* inp
     if (n == 0) return SDFR_OK;
     MlpParams P = d->proto;
     P.inputs = inputs; P.n = n; P.sdf = sdf; P.maskbuf = nullptr; P.skip = skip; P.skip_rows = rows_per_crop;
-    sdfr_launch_fwd_f16_512(P, n, false, (hipStream_t)stream);
+    P.n_crops = (int)((n + rows_per_crop - 1) / rows_per_crop);
+    sdfr_launch_pool_f16_skip(P, n, (hipStream_t)stream);            // r06: a pool over the live tiles
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -338,9 +368,12 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws);
     const bool many_rows = (mask_from_f16 & SDFR_JAC_MANY_ROWS) != 0;       // hint: far more rows than 16 x the CU count (recomputing kernel on 32-row tiles)
     const bool half_tiles = (mask_from_f16 & SDFR_JAC_HALF_TILES) != 0;     // masks saved by a half-size-tile forward (sdfr_mlp_forward*_ragged, half_tiles = 1)
-    mask_from_f16 &= ~(SDFR_JAC_MANY_ROWS | SDFR_JAC_HALF_TILES);
+    const bool quarter_tiles = (mask_from_f16 & SDFR_JAC_QUARTER_TILES) != 0;
+    mask_from_f16 &= ~(SDFR_JAC_MANY_ROWS | SDFR_JAC_HALF_TILES | SDFR_JAC_QUARTER_TILES);
     P.fwd_np = mask_from_f16 ? sdfr_fwd_f16_512_np() : (d->HP == 512 ? sdfr_fwd_f32_512_np() : 2);
     if (half_tiles) P.fwd_np /= 2;
+    if (quarter_tiles) P.fwd_np /= 4;
+    SDFR_REQUIRE(P.fwd_np >= 1, "sdfr_mlp_jacobian: tile-size flags do not fit the forward geometry");
     SDFR_REQUIRE(mask_from_f16 >= 0 && mask_from_f16 <= 2, "sdfr_mlp_jacobian: mask_from_f16 = %d (0, 1 or 2)", mask_from_f16);
     // masks saved by the forward launch make the recomputation unnecessary (not for use_tanh decoders: their output
     // derivative needs the pre-tanh value)

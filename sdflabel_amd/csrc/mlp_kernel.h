@@ -76,6 +76,9 @@ struct MlpParams {
     int64_t skip_rows;
     const int32_t* crop_cnt;     // forward: optional per-crop row counts of a [B][crop_rows] row array (crop_rows a multiple of the tile): tiles that
     int64_t crop_rows;           // start at or beyond their crop's count exit (candidate rows of the float16 reuse mode, r05)
+    const int32_t* gather_idx;   // GATHER kernels (r06): row s of crop c of the ragged [B][crop_rows] launch is inputs[c * gather_rows + gather_idx[c * crop_rows + s]]
+    int64_t gather_rows;         // (s < crop_cnt[c]; rows beyond the count read the crop's row 0) -- the candidate rows are read where they lie, no copy
+    int n_crops;                 // PERSIST kernels (r06): crops of the ragged / skip launch (the workgroups walk the LIVE tiles only)
     const int32_t* n_dev;        // forward: optional device-side row count (rows >= *n_dev are not evaluated; n is the launch bound)
     int n_dev_lo, n_dev_hi;      // with n_dev and n_dev_hi > 0: the launch runs only while n_dev_lo <= *n_dev < n_dev_hi (two tile geometries of one step)
     unsigned long long* trace;   // builds with -DSDFR_MLP_TRACE: cycle stamps of workgroup 0 (sdfr_debug_set_trace), else unused
@@ -186,7 +189,12 @@ __device__ __forceinline__ void store4(h16* dst, const float* v) {
 #ifndef SDFR_MLP_WPE
 #define SDFR_MLP_WPE 1      // minimum waves per SIMD the register allocation must allow (A/B builds: 2 = two 4-wave workgroups per CU)
 #endif
-template <typename ET, int MS, int FT, int NP, int NW, int PF, int MODE, int PFB_ = 0, bool LN = false>
+// XF   extra forward features (r06; separate instantiations in mlp_persist.hip, the hot kernels are compiled without them):
+//      1 GATHER   the tile's rows are read through an index list (P.gather_idx: candidate rows of the reuse modes, no gathered copy)
+//      2 PERSIST  the launch is a fixed pool of workgroups that walk the LIVE tiles of a ragged [B][crop_rows] launch (per-crop counts) or of a
+//                 skip launch (per-crop flags): dead tiles cost nothing, a launch with nothing to do costs one wave of dispatch, and the last
+//                 round of a many-crop launch is as full as the live tile count allows
+template <typename ET, int MS, int FT, int NP, int NW, int PF, int MODE, int PFB_ = 0, bool LN = false, int XF = 0>
 __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const MlpParams P) {
     typedef Mma<ET, MS> M;
     typedef typename M::acc_t acc_t;
@@ -197,6 +205,9 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     constexpr bool SAVE = MODE == 1;
     constexpr bool LMASK = MODE == 2;
     constexpr bool GMASK = MODE == 3;
+    constexpr bool GATHER = (XF & 1) != 0;
+    constexpr bool PERSIST = (XF & 2) != 0;
+    static_assert(XF == 0 || (MODE == 0 || MODE == 1), "GATHER / PERSIST are forward features");
     static_assert(!SAVE || MS == 32, "mask layout assumes 32x32 forward tiles");
     static_assert(!SAVE || (FT * NP) % 2 == 0, "mask words: FT*NP*16 bits per thread and layer must fill whole words");
     static_assert(!HALF || !JAC || MODE == 3, "with half operands only the mask-fed Jacobian exists (MODE 3)");
@@ -251,8 +262,50 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     // MODE 4: a pool of persistent workgroups; each trip of this loop fetches one tile (t_rt rays) from the launch's device counter and marches
     // it through the stage.  Every other mode: one trip, tile = blockIdx.x.
     int* tile_slot = reinterpret_cast<int*>(gy) + 1;
+    // PERSIST: live tiles of the launch, counted per crop.  Ragged launch (crop_cnt): crop c has ceil(min(cnt[c], crop_rows) / PT) live tiles
+    // at the head of its crop_rows / PT tile slots; skip launch (skip flags; crop_rows == 0): a crop is live or not as a whole, and the walk
+    // is over all tiles of the launch (a tile may span crops).  pfx[c] = live tiles of the crops before c (inclusive scan in slots[], which
+    // forward modes do not use otherwise; B <= PT entries -- larger launches fall back to walking every tile slot).
+    int p_iter = 0, p_live = 0;
+    bool p_compact = false;
+    if constexpr (PERSIST) {
+        if (P.crop_cnt && P.n_crops <= PT) {
+            if (tid == 0) {
+                int acc_ = 0;
+                for (int c = 0; c < P.n_crops; ++c) {
+                    const int64_t cc = min((int64_t)P.crop_cnt[c], P.crop_rows);
+                    acc_ += (int)((cc + PT - 1) / PT);
+                    slots[c] = acc_;
+                }
+                tile_slot[1] = acc_;
+            }
+            __syncthreads();
+            p_live = tile_slot[1];
+            p_compact = true;
+            if ((int)blockIdx.x >= p_live) return;
+        } else if (P.skip && !P.crop_cnt) {
+            bool any = false;
+            for (int c = 0; c < P.n_crops; ++c) any = any || P.skip[c] == 0;
+            if (!any) return;                               // nothing to evaluate in this launch: the common step of a reuse refinement
+        }
+    }
     do {
     int tile = blockIdx.x;
+    if constexpr (PERSIST) {
+        const int64_t j = (int64_t)blockIdx.x + (int64_t)p_iter * gridDim.x;
+        ++p_iter;
+        if (p_compact) {
+            if (j >= p_live) return;
+            int lo = 0, hi = P.n_crops - 1;                 // first crop whose inclusive prefix exceeds j
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (slots[mid] > (int)j) hi = mid; else lo = mid + 1; }
+            const int before = lo > 0 ? slots[lo - 1] : 0;
+            tile = (int)((int64_t)lo * (P.crop_rows / PT) + (j - before));
+        } else {
+            if (j * PT >= P.n) return;
+            tile = (int)j;
+        }
+        if (p_iter > 1) __syncthreads();                    // the previous tile's readers of rows[] / the operand tile are through
+    }
     if constexpr (TAIL) {
         if (P.n_dev && P.n_dev_hi > 0 && (*P.n_dev < P.n_dev_lo || *P.n_dev >= P.n_dev_hi)) return;      // gated launch: nothing fetched
         if (P.t_steps <= 0) return;
@@ -285,7 +338,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         if (TAIL && P.t_steps <= 0) return;
         if (P.crop_cnt) {                           // ragged [B][crop_rows] row array: nothing to do beyond the crop's own count
             const int64_t c = r0 / P.crop_rows;
-            if (r0 - c * P.crop_rows >= (int64_t)P.crop_cnt[c]) return;
+            if (r0 - c * P.crop_rows >= (int64_t)P.crop_cnt[c]) { if constexpr (PERSIST) continue; else return; }
         }
         if (P.skip) {                               // two-stage evaluation: crops that reuse their candidate set skip the half pass
             // a tile is dropped only when EVERY crop it spans is flagged (rows_per_crop need not be a multiple of the tile: a tile may span
@@ -293,9 +346,16 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             const int64_t r1 = min(r0 + PT, n_rows) - 1;
             bool all_flagged = true;
             for (int64_t c = r0 / P.skip_rows; c <= r1 / P.skip_rows; ++c) all_flagged = all_flagged && P.skip[c] != 0;
-            if (all_flagged) return;
+            if (all_flagged) { if constexpr (PERSIST) continue; else return; }
         }
         n_valid = (int)min((int64_t)(TAIL ? P.t_rt : PT), n_rows - r0);
+        if constexpr (GATHER) {
+            if (tid < PT) {
+                const int64_t c = r0 / P.crop_rows, sc = r0 - c * P.crop_rows + tid;
+                const bool live = sc < (int64_t)P.crop_cnt[c];          // beyond the count: the crop's row 0 (finite padding rows of the last tile)
+                rows[tid] = (int)(c * P.gather_rows + (live ? P.gather_idx[c * P.crop_rows + sc] : 0));
+            }
+        } else
         if (tid < PT) rows[tid] = TAIL ? (int)((int64_t)blockIdx.x * PT + tid) : (int)(r0 + (tid < n_valid ? tid : 0));
     }
     // ---- MODE 4: the tile's rays.  Lane i < RT of wave 0 owns ray i: state and ray in registers ----
@@ -802,7 +862,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         }
         if (SAVE && P.maskbuf) {
             // [point tile][layer][word][thread]: bit ((f*NP + p)*4 + rg)*4 + i of the thread's mask (32x32 geometry)
-            uint32_t* dst = P.maskbuf + (((int64_t)blockIdx.x * P.n_mfma + l) * MW) * NT + tid;
+            uint32_t* dst = P.maskbuf + (((int64_t)tile * P.n_mfma + l) * MW) * NT + tid;
 #pragma unroll
             // (streaming / non-temporal stores measured equal, r03: the masks cost 3-7 % of a forward through the epilogue's instruction count,
             // not through L2 pollution -- tools/mask_cost.py)
@@ -906,7 +966,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                 }
             } else {
                 if (tid < n_valid) {
-                    const int64_t row = (int64_t)blockIdx.x * PT + tid;
+                    const int64_t row = (int64_t)tile * PT + tid;
                     if (!P.skip || !P.skip[row / P.skip_rows]) P.sdf[row] = o;      // a flagged crop keeps its (exact, patched) values
                 }
             }
@@ -1182,7 +1242,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         }
     }
     }   // JAC
-    } while (TAIL);
+    } while (TAIL || PERSIST);
 }
 
 
@@ -1203,6 +1263,12 @@ void sdfr_launch_fwd_f16_512_tile64(const MlpParams& P, int64_t n, hipStream_t s
 void sdfr_launch_tail_f32_512(const MlpParams& P, int64_t n_rays, int spec_k, hipStream_t s);                      // mlp_jac.hip (MODE 4: sphere tracer's persistent tail)
 void sdfr_launch_jac_f16_512_many(const MlpParams& P, int cap, int B, hipStream_t s);                                     // mlp_jac16.hip (32x32 tiles: many rows)
 void sdfr_launch_tail_f16_512(const MlpParams& P, int64_t n_rays, int spec_k, hipStream_t s);                      // mlp_jac16.hip
+void sdfr_launch_pool_f16_skip(const MlpParams& P, int64_t n, hipStream_t s);                                  // mlp_persist.hip (r06: pools of workgroups over the live tiles)
+void sdfr_launch_pool_f16_ragged(const MlpParams& P, int64_t n, bool gather, hipStream_t s);
+void sdfr_launch_pool_f16_ragged_half_tiles(const MlpParams& P, int64_t n, bool gather, hipStream_t s);
+void sdfr_launch_pool_f16_ragged_quarter_tiles(const MlpParams& P, int64_t n, hipStream_t s);
+void sdfr_launch_pool_f32_skip(const MlpParams& P, int64_t n, hipStream_t s);
+void sdfr_launch_pool_f32_ragged(const MlpParams& P, int64_t n, bool gather, hipStream_t s);
 void sdfr_launch_small(const MlpParams& P, int HP, int mode, int grid_x, int grid_y, hipStream_t s);   // mlp_small.hip (HP 128 / 256)
 void sdfr_launch_ln(const MlpParams& P, int HP, bool jac, int grid_x, int grid_y, hipStream_t s);        // mlp_ln.hip (LayerNorm decoders)
 int sdfr_ln_points_per_wg(int HP, bool jac);

@@ -5,6 +5,7 @@
 // utils/refinement.py:108-125), latent_ = F.normalize(latent, p=2, dim=0) (:96), inputs = cat(latent_.expand(G,-1), grid.points)
 // (:99-100); and the matching backward.  Compiled with -ffp-contract=off.
 #include "sdfr_common.h"
+#include "solver.h"
 
 __global__ __launch_bounds__(256) void sdfr_params_forward_kernel(const float* __restrict__ yaw, const float* __restrict__ trans,
                                                                  const float* __restrict__ latent, int L,
@@ -41,6 +42,60 @@ extern "C" int sdfr_params_forward(const float* yaw, const float* trans, const f
     if (B <= 0) return SDFR_OK;
     hipLaunchKernelGGL(sdfr_params_forward_kernel, dim3(inputs ? sdfr_cdiv(G, 256) : 1, B), dim3(inputs ? 256 : 64), 0, (hipStream_t)stream, yaw, trans, latent,
                        L, grid, G, inputs, pose, latnorm);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// sdfr_params_forward + sdfr_prefilter_plan (csrc/surface.hip) in ONE launch (r06): the plan compares the crop's normalised latent -- the
+// latent columns params_forward writes, latent / max(||latent||, 1e-12): recomputed here by the same division -- with the latent of the crop's
+// last full-grid pass, so thread 0 of the crop's first block decides it while the other blocks write the input rows.  Same outputs, bit for bit.
+__global__ __launch_bounds__(256) void sdfr_params_plan_kernel(const float* __restrict__ yaw, const float* __restrict__ trans,
+                                                              const float* __restrict__ latent, int L, const float* __restrict__ grid, int64_t G,
+                                                              float* __restrict__ inputs, float* __restrict__ pose, float* __restrict__ latnorm,
+                                                              float lip, const float* __restrict__ margin, const float* __restrict__ max_dev,
+                                                              float* __restrict__ lat_ref, int32_t* __restrict__ age, int max_reuse,
+                                                              int32_t* __restrict__ reuse, int32_t* __restrict__ n_full) {
+    const int b = blockIdx.y;
+    const int NI = L + 3;
+    float ss = 0.f;
+    for (int c = 0; c < L; ++c) ss += latent[b * L + c] * latent[b * L + c];
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        latnorm[b] = nrm;
+        const float c = cosf(yaw[b]), s = sinf(yaw[b]);
+        float* P = pose + (int64_t)b * 16;
+        P[0] = c;   P[1] = 0.f;  P[2] = s;   P[3] = trans[b * 3 + 0];
+        P[4] = -0.f; P[5] = -1.f; P[6] = -0.f; P[7] = trans[b * 3 + 1];
+        P[8] = -s;  P[9] = 0.f;  P[10] = c;  P[11] = trans[b * 3 + 2];
+        P[12] = 0.f; P[13] = 0.f; P[14] = 0.f; P[15] = 1.f;
+        // the plan (sdfr_prefilter_plan_kernel, statement for statement; z[c] = the row value latent / nrm)
+        float d2 = 0.f;
+        for (int c2 = 0; c2 < L; ++c2) { const float d = latent[b * L + c2] / nrm - lat_ref[b * L + c2]; d2 += d * d; }
+        const bool ok = age[b] > 0 && age[b] <= max_reuse && lip * sqrtf(d2) <= 0.25f * margin[b] && max_dev[b] <= 0.5f * margin[b];
+        reuse[b] = ok ? 1 : 0;
+        if (ok) age[b] += 1;
+        else {
+            age[b] = 1;
+            for (int c2 = 0; c2 < L; ++c2) lat_ref[b * L + c2] = latent[b * L + c2] / nrm;
+            if (n_full) n_full[b] += 1;
+        }
+    }
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    float* row = inputs + ((int64_t)b * G + g) * NI;
+    for (int c = 0; c < L; ++c) row[c] = latent[b * L + c] / nrm;
+    row[L] = grid[g * 3]; row[L + 1] = grid[g * 3 + 1]; row[L + 2] = grid[g * 3 + 2];
+}
+
+extern "C" int sdfr_params_plan(const float* yaw, const float* trans, const float* latent, int L, const float* grid, int64_t G, int B, float* inputs,
+                                float* pose, float* latnorm, float lip, const float* margin, const float* max_dev, float* lat_ref, int32_t* age,
+                                int max_reuse, int32_t* reuse, int32_t* n_full, void* stream) {
+    SDFR_REQUIRE(yaw && trans && latent && grid && inputs && pose && latnorm && margin && max_dev && lat_ref && age && reuse,
+                 "sdfr_params_plan: NULL argument");
+    SDFR_REQUIRE(L >= 0 && L <= 1024 && G > 0, "sdfr_params_plan: bad size");
+    if (B <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_params_plan_kernel, dim3(sdfr_cdiv(G, 256), B), dim3(256), 0, (hipStream_t)stream, yaw, trans, latent, L, grid, G, inputs,
+                       pose, latnorm, lip, margin, max_dev, lat_ref, age, max_reuse, reuse, n_full);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -183,20 +238,28 @@ extern "C" int sdfr_gather_rows3(float* out, const float* src, const int32_t* id
 // Absent optional inputs (g_pc, g_nc, g_col) are read from a valid dummy address and discarded, so that every load of a round is issued
 // before the first wait (uniform NULL branches around single loads serialised them: one L2 round trip each, 13.5 us per launch);
 // PLB_UNROLL rounds are loaded together.  The accumulation order per thread is unchanged (bit-identical results).
-template <bool XYZF, bool LAT>
+// SOLVE (r06): the gradient through xyzf arrives un-normalised with the per-crop factor kscale[2 b + 1] (sdfr_losses_fused: multiplied on load, the
+// product the 3-D loss's finalize pass used to store), and the crop's solver step (sdfr_solver_step) follows its parameter gradients in the
+// same thread -- the refinement iteration's last two launches in one.
+struct SolveArgs {
+    const float* kscale; float* params; const float* grads; const float* loss2d; const float* loss3d; const int32_t* npairs; float w2, w3;
+    float* adam_m; float* adam_v; int32_t* adam_t; float lr_adam, lr_scale, lr_latent; int B; float* total; int32_t* stepped;
+};
+template <bool XYZF, bool LAT, bool SOLVE = false>
 __global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
     const float* __restrict__ pose, const float* __restrict__ points, const float* __restrict__ normals, const float* __restrict__ g_pc,
     const float* __restrict__ g_nc, const float* __restrict__ g_col, int cap, const int32_t* __restrict__ cnt, int output_nocs,
     const float* __restrict__ g_xyzf, const int32_t* __restrict__ fslot, const float* __restrict__ J, int NI, int L,
     const float* __restrict__ yaw, const float* __restrict__ latent, const float* __restrict__ latnorm, float* __restrict__ g_points,
-    float* __restrict__ g_pose, float* __restrict__ g_latn, float* __restrict__ g_yaw, float* __restrict__ g_trans,
-    float* __restrict__ g_latent) {
+    float* __restrict__ g_pose, float* __restrict__ g_latn, float* g_yaw, float* g_trans,
+    float* g_latent, const SolveArgs SA = SolveArgs()) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int count = sdfr_count(cnt, b, cap);
     const float* P = pose + (int64_t)b * 16;
     const float r00 = P[0], r01 = P[1], r02 = P[2];
     const float r10 = P[4], r11 = P[5], r12 = P[6];
     const float r20 = P[8], r21 = P[9], r22 = P[10];
+    const float kx = SOLVE ? SA.kscale[2 * b + 1] : 1.f;
     float acc[12], lat[LAT_MAXL];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.f;
@@ -227,7 +290,8 @@ __global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
                 const int fs = fslot[e1];
                 fx[u] = fs >= 0;
                 const int64_t f = ((int64_t)b * cap + (fx[u] ? fs : 0)) * 3;                 // back-facing rows read slot 0 and discard it
-                vx[u] = make_float3(g_xyzf[f], g_xyzf[f + 1], g_xyzf[f + 2]);
+                if (SOLVE) vx[u] = make_float3(g_xyzf[f] * kx, g_xyzf[f + 1] * kx, g_xyzf[f + 2] * kx);
+                else vx[u] = make_float3(g_xyzf[f], g_xyzf[f + 1], g_xyzf[f + 2]);
             }
             if (LAT) {
 #pragma unroll
@@ -310,6 +374,9 @@ __global__ __launch_bounds__(PLB_THREADS) void sdfr_pose_latent_backward_kernel(
         } else {                                                        // pose-only: the latent is not a variable
             for (int i = 0; i < L; ++i) { g_latn[b * L + i] = 0.f; g_latent[b * L + i] = 0.f; }
         }
+        if (SOLVE)           // the crop's solver step, reading the gradients this thread has just stored (and g_scale from the loss launch)
+            sdfr_solver_crop(b, SA.B, SA.params, SA.grads, L, SA.loss2d, SA.loss3d, SA.npairs, SA.w2, SA.w3, SA.adam_m, SA.adam_v, SA.adam_t,
+                             SA.lr_adam, SA.lr_scale, SA.lr_latent, SA.total, SA.stepped);
     }
 }
 
@@ -333,6 +400,34 @@ extern "C" int sdfr_pose_latent_backward(const float* pose, const float* points,
     if (g_xyzf) { if (J) PLB_LAUNCH(true, true); else PLB_LAUNCH(true, false); }
     else { if (J) PLB_LAUNCH(false, true); else PLB_LAUNCH(false, false); }
 #undef PLB_LAUNCH
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// sdfr_pose_latent_backward + the un-normalised xyzf gradient's factor + sdfr_solver_step in one launch (r06).  g_yaw / g_trans / g_latent must
+// be the sections of `grads` (the flat [ yaw(B) | trans(B,3) | scale(B) | latent(B,L) ] buffer), g_scale its scale section as the loss wrote it.
+extern "C" int sdfr_pose_latent_solver(const float* pose, const float* points, const float* normals, const float* g_p_cam, const float* g_n_cam,
+                                       const float* g_col, int B, int cap, const int32_t* cnt, int output_nocs, const float* g_xyzf,
+                                       const int32_t* fslot, const float* kscale, const float* J, int n_inputs, int L, const float* yaw,
+                                       const float* latent, const float* latnorm, float* g_pose, float* g_latn, float* params, float* grads,
+                                       const float* loss2d, const float* loss3d, const int32_t* npairs, float w2, float w3, float* adam_m,
+                                       float* adam_v, int32_t* adam_t, float lr_adam, float lr_scale, float lr_latent, float* total,
+                                       int32_t* stepped, void* stream) {
+    SDFR_REQUIRE(pose && points && normals && yaw && latent && latnorm && g_pose && g_latn && g_xyzf && fslot && kscale && params && grads &&
+                 loss2d && loss3d && npairs && adam_m && adam_v && adam_t && total && stepped, "sdfr_pose_latent_solver: NULL argument");
+    SDFR_REQUIRE(L >= 1 && L <= LAT_MAXL && L <= n_inputs, "sdfr_pose_latent_solver: latent size %d outside [1,%d]", L, LAT_MAXL);
+    SDFR_REQUIRE(output_nocs != 0, "sdfr_pose_latent_solver: built for the NOCS colour modes of the refinement loop");
+    if (B <= 0) return SDFR_OK;
+    SolveArgs SA = {kscale, params, grads, loss2d, loss3d, npairs, w2, w3, adam_m, adam_v, adam_t, lr_adam, lr_scale, lr_latent, B, total, stepped};
+    float* g_yaw = grads; float* g_trans = grads + B; float* g_latent = grads + (int64_t)5 * B;
+    if (J)
+        hipLaunchKernelGGL((sdfr_pose_latent_backward_kernel<true, true, true>), dim3(B), dim3(PLB_THREADS), 0, (hipStream_t)stream, pose, points, normals,
+                           g_p_cam, g_n_cam, g_col, cap, cnt, output_nocs, g_xyzf, fslot, J, n_inputs, L, yaw, latent, latnorm, (float*)nullptr,
+                           g_pose, g_latn, g_yaw, g_trans, g_latent, SA);
+    else
+        hipLaunchKernelGGL((sdfr_pose_latent_backward_kernel<true, false, true>), dim3(B), dim3(PLB_THREADS), 0, (hipStream_t)stream, pose, points, normals,
+                           g_p_cam, g_n_cam, g_col, cap, cnt, output_nocs, g_xyzf, fslot, J, n_inputs, L, yaw, latent, latnorm, (float*)nullptr,
+                           g_pose, g_latn, g_yaw, g_trans, g_latent, SA);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

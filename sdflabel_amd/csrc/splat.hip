@@ -61,7 +61,7 @@ __device__ __forceinline__ void splat_dims(const SplatArgs& A, int b, int& W, in
         W = A.wh[2 * b]; H = A.wh[2 * b + 1]; PS = A.pst;
         // an extent outside the caller's contract (include/sdfr.h: 1 <= W_b, H_b and W_b H_b <= pix_stride) renders as an EMPTY crop instead of
         // writing out of bounds (the Python layer validates extents before they reach the device)
-        if (W < 1 || H < 1 || (int64_t)W * H > (int64_t)PS) { W = 0; H = 0; }
+        if (W < 1 || H < 1 || (int64_t)W * H > (int64_t)PS || W > 65535 || H > 65535) { W = 0; H = 0; }     // (16-bit pixel coordinates: the backward's queue)
     }
 }
 
@@ -335,6 +335,11 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
         auto overlaps = [&](int s) {
             if (s >= count) return false;
             const int4 bb = bbox[sb + s];
+            // (an EMPTY box -- the off-screen marker (1, 1, 0, 0) -- overlaps nothing: r01-r05 let it pass the test below for tile (0, 0), where
+            // it covered no pixel but lengthened the candidate list, i.e. changed the share partition and with it the last bits of that
+            // tile's sums relative to the binned path, which skips empty boxes: a crop with off-screen surfels then differed between a
+            // launch of 1-3 crops and one of 4+ -- found by optimize_many's bit-identity check, r06)
+            if (bb.x > bb.z || bb.y > bb.w) return false;
             return !(bb.x > X1 || bb.z < X0 || bb.y > Y1 || bb.w < Y0);
         };
         bool ov = overlaps(wave * 64 + lane);
@@ -589,7 +594,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // DENSE: the upstream gradient is given per (surfel, pixel) weight -- gW [B][rows][P], rows = cap (+1 with a background row) -- together with
 // Sd[b][pix] = sum_j w_j gW_j (the softmax-backward sum), instead of through the composited images: the backward of the standalone
 // primitives (sdfr_splat_weights), which hand out the dense weight matrix as the reference's inside_* functions do.
-template <int PRIM, bool DENSE = false, bool ALT = false>
+// KS (r06): the upstream colour gradient arrives UN-normalised with a per-crop factor, kscale[2 b] (sdfr_losses_fused): g_color * k on load --
+// the product the 2-D loss's finalize pass used to store in a sweep of its own.
+template <int PRIM, bool DENSE = false, bool ALT = false, bool KS = false>
 __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, const float* __restrict__ aux,
                                                             const float* __restrict__ color, const float* __restrict__ mask,
                                                             const float* __restrict__ depth, const float* __restrict__ normals,
@@ -597,9 +604,10 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
                                                             const float* __restrict__ g_depth, const float* __restrict__ g_normals,
                                                             float* __restrict__ g_p, float* __restrict__ g_n, float* __restrict__ g_attr,
                                                             const float* __restrict__ gW = nullptr, const float* __restrict__ Sd = nullptr,
-                                                            int rows = 0) {
+                                                            int rows = 0, const float* __restrict__ kscale = nullptr) {
     int xb, b;
     sdfr_xcd_crop_map(xb, b);          // a crop's surfels on one XCD: its pixel records (aux, images, upstream gradients) are fetched by one L2
+    const float kc = KS ? kscale[2 * b] : 1.f;
     const int lane = threadIdx.x & 63;
     const int s = xb * 4 + (threadIdx.x >> 6);
     if (s >= sdfr_count(A.cnt, b, A.cap)) return;
@@ -649,7 +657,8 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
         if (!DENSE && g_color) {
             const float* g = g_color + (int64_t)b * 3 * P + pix;
             const float* o = color + (int64_t)b * 3 * P + pix;
-            gc0 = (gates & 1u) ? g[0] : 0.f; gc1 = (gates & 2u) ? g[P] : 0.f; gc2 = (gates & 4u) ? g[2 * P] : 0.f;
+            if (KS) { gc0 = (gates & 1u) ? g[0] * kc : 0.f; gc1 = (gates & 2u) ? g[P] * kc : 0.f; gc2 = (gates & 4u) ? g[2 * P] * kc : 0.f; }
+            else { gc0 = (gates & 1u) ? g[0] : 0.f; gc1 = (gates & 2u) ? g[P] : 0.f; gc2 = (gates & 4u) ? g[2 * P] : 0.f; }
             S += gc0 * o[0] + gc1 * o[P] + gc2 * o[2 * P];
         }
         if (!DENSE && g_mask) { gm = (gates & 8u) ? g_mask[(int64_t)b * P + pix] : 0.f; S += gm * mask[(int64_t)b * P + pix]; }
@@ -712,8 +721,11 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
             const unsigned long long bal = __ballot(cov);
             if (cov) qw[nq + __popcll(bal & ((1ull << lane) - 1ull))] = make_float4(__uint_as_float((unsigned)x | ((unsigned)y << 16)), ht, hb, 0.f);
             nq += __popcll(bal);
-            if (nq > SPL_BQ - 64) { drain(nq); nq = 0; }
+            // (the queue is written and read by ONE wave, other lanes' entries: a wave barrier keeps the compiler from moving the reads above
+            // the writes; the hardware executes a wave's LDS operations in order)
+            if (nq > SPL_BQ - 64) { __builtin_amdgcn_wave_barrier(); drain(nq); nq = 0; __builtin_amdgcn_wave_barrier(); }
         }
+        __builtin_amdgcn_wave_barrier();
         drain(nq);
     }
     sC0 = wave_sum(sC0); sC1 = wave_sum(sC1); sC2 = wave_sum(sC2);
@@ -806,6 +818,7 @@ static int fill_args(SplatArgs& A, const char* who, int primitive, const float* 
     SDFR_REQUIRE(primitive >= 0 && primitive <= 2, "%s: primitive %d unknown (0 disc, 1 circle, 2 circle_opt)", who, primitive);
     SDFR_REQUIRE(K && Kinv, "%s: NULL intrinsics", who);
     SDFR_REQUIRE(W > 0 && H > 0 && B >= 0 && cap >= 0, "%s: bad size", who);
+    SDFR_REQUIRE(W < 65536 && H < 65536, "%s: images of up to 65535 x 65535 pixels (the backward queues pixel coordinates as 16-bit pairs)", who);
     SDFR_REQUIRE(cap == 0 || (p_cam && n_cam && attr), "%s: NULL surfel array", who);
     SDFR_REQUIRE(primitive == 0 || cap == 0 || (uv && znorm), "%s: circle primitives need uv and znorm", who);
     SDFR_REQUIRE((bg == nullptr) == (bg_logit == nullptr), "%s: bg and bg_logit go together", who);
@@ -961,6 +974,26 @@ extern "C" int sdfr_splat_backward_r(const float* K, const float* Kinv, const fl
     if (B == 0 || cap == 0) return SDFR_OK;
     hipLaunchKernelGGL(sdfr_splat_bwd_kernel<0>, dim3(sdfr_cdiv(cap, 4), B), dim3(256), 0, (hipStream_t)stream, A, aux, color, mask, depth, normals,
                        g_color, g_mask, g_depth, g_normals, g_p_cam, g_n_cam, g_attr);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// The disc primitive's backward with a per-crop factor on the colour gradient (r06): g_color holds the un-normalised 2-D loss gradient and
+// kscale float[B][2] the factors sdfr_losses_fused published (kscale[2 b] applies).  wh == NULL: dense W x H images; else ragged extents.
+extern "C" int sdfr_splat_backward_x(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr, int B, int cap,
+                                     const int32_t* cnt, int W, int H, const int32_t* wh, int pix_stride, float diam, float depth_constant,
+                                     const float* aux, const float* color, const float* g_color, const float* kscale, float* g_p_cam,
+                                     float* g_n_cam, float* g_attr, void* stream) {
+    SplatArgs A;
+    int rc = wh ? fill_args_r(A, "sdfr_splat_backward_x", K, Kinv, p_cam, n_cam, attr, B, cap, cnt, wh, pix_stride, 1, diam, depth_constant)
+                : fill_args(A, "sdfr_splat_backward_x", 0, K, Kinv, p_cam, n_cam, attr, nullptr, nullptr, nullptr, nullptr, B, cap, cnt, W, H, diam,
+                            depth_constant);
+    if (rc) return rc;
+    SDFR_REQUIRE(aux && color && g_color && kscale && g_p_cam && g_n_cam && g_attr, "sdfr_splat_backward_x: NULL argument");
+    if (B == 0 || cap == 0) return SDFR_OK;
+    hipLaunchKernelGGL((sdfr_splat_bwd_kernel<0, false, false, true>), dim3(sdfr_cdiv(cap, 4), B), dim3(256), 0, (hipStream_t)stream, A, aux, color,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, g_color, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, g_p_cam, g_n_cam, g_attr, (const float*)nullptr, (const float*)nullptr, 0, kscale);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void sdfr_band_scatter_kernel(const float* __r
                                                                const float* __restrict__ thr_extra,
                                                                const int32_t* __restrict__ blockcnt, int32_t* __restrict__ idx,
                                                                int cap, int32_t* __restrict__ cnt, int32_t* __restrict__ slot,
-                                                               const int32_t* __restrict__ skip) {
+                                                               const int32_t* __restrict__ skip, int32_t* __restrict__ over, int over_bit) {
     const int b = blockIdx.y;
     if (skip && skip[b]) return;
     if (thr_extra) thr += thr_extra[b];
@@ -66,13 +66,56 @@ __global__ __launch_bounds__(256) void sdfr_band_scatter_kernel(const float* __r
         }
         if (slot) slot[(int64_t)b * G + g] = sl;
     }
-    if (blockIdx.x == nblk - 1 && tid == 0) cnt[b] = base + wc[0] + wc[1] + wc[2] + wc[3];
+    if (blockIdx.x == nblk - 1 && tid == 0) {
+        const int total = base + wc[0] + wc[1] + wc[2] + wc[3];
+        cnt[b] = total;
+        if (over && total > cap) atomicOr(&over[b], over_bit);           // sticky: survives later selections that fit again (r06)
+    }
+}
+
+// The same selection with ONE workgroup per crop (r06): count, offsets and scatter in a single launch -- for launches of a few crops, where the
+// two-kernel form above is two launch latencies around microseconds of work (the per-annotation refinement: B = 1).  Rows are walked 1024 at
+// a time with a running offset: the same ascending order, the same idx / slot / cnt.
+__global__ __launch_bounds__(1024) void sdfr_band_select_crop_kernel(const float* __restrict__ sdf, int64_t G, float thr,
+                                                                    const float* __restrict__ thr_extra, int32_t* __restrict__ idx, int cap,
+                                                                    int32_t* __restrict__ cnt, int32_t* __restrict__ slot,
+                                                                    const int32_t* __restrict__ skip, int32_t* __restrict__ over, int over_bit) {
+    const int b = blockIdx.x;
+    if (skip && skip[b]) return;
+    if (thr_extra) thr += thr_extra[b];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int wc[2][16];
+    int base = 0;
+    int it = 0;
+    for (int64_t g0 = 0; g0 < G; g0 += 1024, ++it) {
+        const int64_t g = g0 + tid;
+        bool in = false;
+        if (g < G) in = fabsf(sdf[(int64_t)b * G + g]) < thr;
+        const unsigned long long bal = __ballot(in);
+        int* w = wc[it & 1];                                             // (two buffers: one barrier per round)
+        if (lane == 0) w[wv] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int c = w[i]; woff += (i < wv) ? c : 0; tot += c; }
+        const int rank = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+        if (g < G) {
+            int sl = -1;
+            if (in && rank < cap) { idx[(int64_t)b * cap + rank] = (int32_t)g; sl = rank; }
+            if (slot) slot[(int64_t)b * G + g] = sl;
+        }
+        base += tot;
+    }
+    if (tid == 0) {
+        cnt[b] = base;
+        if (over && base > cap) atomicOr(&over[b], over_bit);
+    }
 }
 
 extern "C" int sdfr_band_select_margin(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, int32_t* idx, int cap,
                                        int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream);
 static int band_select_impl(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, const int32_t* skip, int32_t* idx, int cap,
-                            int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream);
+                            int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream, int32_t* over = nullptr, int over_bit = 0);
 extern "C" int sdfr_band_select(const float* sdf, int64_t G, int B, float thr, int32_t* idx, int cap, int32_t* cnt,
                                 int32_t* slot, int32_t* scratch, void* stream) {
     return sdfr_band_select_margin(sdf, G, B, thr, nullptr, idx, cap, cnt, slot, scratch, stream);
@@ -91,17 +134,32 @@ extern "C" int sdfr_band_select_skip(const float* sdf, int64_t G, int B, float t
     return band_select_impl(sdf, G, B, thr, thr_extra, skip, idx, cap, cnt, slot, scratch, stream);
 }
 
+// ... and with a STICKY truncation flag (r06): over[b] |= over_bit whenever crop b's selection holds more than `cap` rows.  cnt[b] is
+// overwritten by every selection, so a band that overflows in iterations 5-40 of a graph-replayed refinement and fits again at the end would
+// pass a check of the last count alone; the flag stays until the caller clears it (BatchRenderer.check_overflow / set_crops).  The reference
+// has no capacity (grid.py:64-66).  Launches of up to SDFR_BAND_ONE_WG_CROPS crops take the one-workgroup-per-crop kernel (one launch).
+#define SDFR_BAND_ONE_WG_CROPS 8
+extern "C" int sdfr_band_select_ex(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, const int32_t* skip, int32_t* idx,
+                                   int cap, int32_t* cnt, int32_t* slot, int32_t* scratch, int32_t* over, int over_bit, void* stream) {
+    return band_select_impl(sdf, G, B, thr, thr_extra, skip, idx, cap, cnt, slot, scratch, stream, over, over_bit);
+}
+
 static int band_select_impl(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, const int32_t* skip, int32_t* idx, int cap,
-                            int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream) {
+                            int32_t* cnt, int32_t* slot, int32_t* scratch, void* stream, int32_t* over, int over_bit) {
     SDFR_REQUIRE(sdf && idx && cnt && scratch, "sdfr_band_select: NULL argument");
     SDFR_REQUIRE(G >= 0 && B >= 0 && cap >= 0, "sdfr_band_select: negative size");
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
     if (G == 0) { SDFR_HIP_CHECK(sdfr_zero_async(cnt, sizeof(int32_t) * B, s)); return SDFR_OK; }
+    if (over && B <= SDFR_BAND_ONE_WG_CROPS) {
+        hipLaunchKernelGGL(sdfr_band_select_crop_kernel, dim3(B), dim3(1024), 0, s, sdf, G, thr, thr_extra, idx, cap, cnt, slot, skip, over, over_bit);
+        SDFR_LAUNCH_CHECK();
+        return SDFR_OK;
+    }
     dim3 grid(sdfr_cdiv(G, 256), B);
     hipLaunchKernelGGL(sdfr_band_count_kernel, grid, dim3(256), 0, s, sdf, G, thr, thr_extra, scratch, skip);
     SDFR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sdfr_band_scatter_kernel, grid, dim3(256), 0, s, sdf, G, thr, thr_extra, scratch, idx, cap, cnt, slot, skip);
+    hipLaunchKernelGGL(sdfr_band_scatter_kernel, grid, dim3(256), 0, s, sdf, G, thr, thr_extra, scratch, idx, cap, cnt, slot, skip, over, over_bit);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }
@@ -364,6 +422,62 @@ extern "C" int sdfr_candidate_band_map(const int32_t* idx, int cap, const int32_
     if (B <= 0 || cap <= 0) return SDFR_OK;
     hipLaunchKernelGGL(sdfr_candidate_band_map_kernel, dim3(sdfr_cdiv(cap, 256), B), dim3(256), 0, (hipStream_t)stream, idx, cap, cnt, cslot, G, stride,
                        pos, violations);
+    SDFR_LAUNCH_CHECK();
+    return SDFR_OK;
+}
+
+// sdfr_scatter_values + sdfr_band_select + sdfr_candidate_band_map in ONE launch (r06), one workgroup per crop: the band of a crop whose
+// candidate set is valid lies INSIDE the candidates (a row outside them keeps its full-pass value, >= thr + margin by selection, in the grid
+// array -- never a band row), and the candidates are listed in ascending grid-row order, so the order-preserving compaction of the candidate
+// values IS the band list the grid-wide selection returns: idx[b][e] = cidx of the e-th candidate with |value| < thr, pos[b][e] = its position
+// in the candidate array; the values are also written into the grid array (the downstream kernels read sdf[b*G + idx]).  Four launches that
+// scan B x G rows become one that scans B x ~3 000.  over[b] |= 1 if the band exceeds cap, |= 2 if the candidates exceeded their stride.
+__global__ __launch_bounds__(1024) void sdfr_candidate_band_kernel(float* __restrict__ sdf_grid, const float* __restrict__ csdf,
+                                                                  const int32_t* __restrict__ cidx, int64_t G, int stride,
+                                                                  const int32_t* __restrict__ ccnt, float thr, int32_t* __restrict__ idx, int cap,
+                                                                  int32_t* __restrict__ cnt, int32_t* __restrict__ pos, int32_t* __restrict__ over) {
+    const int b = blockIdx.x;
+    const int n_raw = ccnt[b];
+    const int n = n_raw < stride ? n_raw : stride;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int wc[2][16];
+    int base = 0, it = 0;
+    for (int s0 = 0; s0 < n; s0 += 1024, ++it) {
+        const int s = s0 + tid;
+        bool in = false;
+        int g = 0;
+        if (s < n) {
+            const float v = csdf[(int64_t)b * stride + s];
+            g = cidx[(int64_t)b * stride + s];
+            sdf_grid[(int64_t)b * G + g] = v;
+            in = fabsf(v) < thr;
+        }
+        const unsigned long long bal = __ballot(in);
+        int* w = wc[it & 1];
+        if (lane == 0) w[wv] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int c = w[i]; woff += (i < wv) ? c : 0; tot += c; }
+        const int rank = base + woff + __popcll(bal & ((1ull << lane) - 1ull));
+        if (in && rank < cap) { idx[(int64_t)b * cap + rank] = g; pos[(int64_t)b * cap + rank] = s; }
+        base += tot;
+    }
+    if (tid == 0) {
+        cnt[b] = base;
+        if (over) {
+            const int f = (base > cap ? 1 : 0) | (n_raw > stride ? 2 : 0);
+            if (f) atomicOr(&over[b], f);
+        }
+    }
+}
+
+extern "C" int sdfr_candidate_band(float* sdf_grid, const float* csdf, const int32_t* cidx, int64_t G, int B, int stride, const int32_t* ccnt,
+                                   float thr, int32_t* idx, int cap, int32_t* cnt, int32_t* pos, int32_t* over, void* stream) {
+    SDFR_REQUIRE(sdf_grid && csdf && cidx && ccnt && idx && cnt && pos && G > 0 && stride >= 0 && cap >= 0, "sdfr_candidate_band: bad argument");
+    if (B <= 0) return SDFR_OK;
+    hipLaunchKernelGGL(sdfr_candidate_band_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, sdf_grid, csdf, cidx, G, stride, ccnt, thr, idx, cap,
+                       cnt, pos, over);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

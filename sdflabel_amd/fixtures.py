@@ -64,3 +64,46 @@ def synthetic_targets(decoder, density, K, H, W, device, lidar_stride=2):
     nf = int(o["nf"][0])
     lidar = (o["xyzf"][0, :nf] * GT_SCALE)[::lidar_stride].cpu().numpy()
     return o["color"].clone(), lidar
+
+
+def kitti_like_crops(area, n=32, seed=11):
+    """n crops as the reference PIPELINE produces them (utils/refinement.py:586-609 adjust_intrinsics_crop): every annotation its own crop size
+    (area-normalised to rendering_area^2 = `area`^2, aspect of a car's 2-D box kept) and its own intrinsics (principal point moved by the box
+    corner, so it usually lies far outside the crop).  Returns (shapes [(H, W)], Ks [3x3 float32], gts [trans(3,) of the ground-truth pose that
+    centres the object in the crop]).  Shared by bench.py, tools/ and the tests."""
+    rng = np.random.default_rng(seed)
+    boxes_w = rng.uniform(60, 420, n)
+    boxes_h = boxes_w / rng.uniform(1.2, 3.2, n)                                         # cars: 1.2 ... 3.2 times as wide as high
+    shapes, Ks, gts = [], [], []
+    for bw, bh in zip(boxes_w, boxes_h):
+        r = np.sqrt(area * area / (bh * bw))
+        Hc, Wc = int(bh * r), int(bw * r)                                                 # crop_size.int() (:603)
+        f = 1.15 * Hc * 3.5 / 2.0                                                         # the object (a 2-unit cube at z = 3.5) about fills the crop's height
+        cx, cy = rng.uniform(-1.0 * Wc, 2.0 * Wc), rng.uniform(0.2 * Hc, 0.8 * Hc)        # principal point far outside the crop, as after the box-corner shift
+        shapes.append((Hc, Wc))
+        Ks.append(np.array([[f, 0, cx], [0, f, cy], [0, 0, 1]], np.float32))
+        gts.append(np.array([3.5 * (Wc / 2.0 - cx) / f, 3.5 * (Hc / 2.0 - cy) / f, 3.5], np.float32))
+    return shapes, Ks, gts
+
+
+def kitti_like_problems(decoder32, density, area, n, device, seed=11):
+    """The refinement problems of `kitti_like_crops`: per crop the target NOCS image (3, H_b, W_b) (CPU tensor, rendered from the ground-truth pose
+    with the exact-f32 decoder in ONE ragged batch), the lidar-like cloud (M_b, 3) and perturbed initial parameters {'yaw', 'trans', 'scale',
+    'latent'} (numpy, as pipelines/refine_css.py:186-190 builds them).  Returns (shapes, Ks, targets, lidars, starts).  GPU only."""
+    import torch
+    from .batch import BatchRenderer
+    shapes, Ks, gts = kitti_like_crops(area, n, seed)
+    pmax = 1 << (max(h * w for h, w in shapes) - 1).bit_length()
+    gtr = BatchRenderer(decoder32, density, np.stack(Ks), (shapes[0][1], shapes[0][0]), n, device=device, max_pixels=pmax)
+    gtr.set_extents([(w, h) for h, w in shapes], np.stack(Ks))
+    o = gtr.forward(torch.full((n,), GT_YAW, device=device), torch.from_numpy(np.stack(gts)).to(device),
+                    torch.tensor([list(GT_LATENT)] * n, device=device))
+    nfs = o["nf"].tolist()
+    targets = [gtr.image(b, "color").clone().cpu() for b in range(n)]
+    lidars = [(o["xyzf"][b, :nfs[b]] * GT_SCALE)[::2].cpu().numpy() for b in range(n)]
+    starts = []
+    for b in range(n):
+        y0, t0_, l0 = crop_start(b)
+        starts.append({"yaw": y0.copy(), "trans": (gts[b] + (t0_ - np.asarray(GT_TRANS, np.float32))).astype(np.float32),
+                       "scale": np.array([GT_SCALE], np.float32), "latent": l0.copy()})
+    return shapes, Ks, targets, lidars, starts

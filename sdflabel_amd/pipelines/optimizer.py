@@ -42,7 +42,109 @@ def get_opt_params(params, device):
     return params, groups
 
 
+def _as_np(a):
+    return np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float32)
+
+
+def _grid_density(grid):
+    G = int(grid.points.size(0))
+    D = int(round(G ** (1.0 / 3.0)))
+    if D ** 3 != G:
+        raise _lib.SdfrError("grid of %d points is not a D^3 Grid3D" % G)
+    return D
+
+
+def _check_grid(rf, grid, D):
+    # the caller's grid must be the Grid3D(D) point set the kernels index, in whatever precision it was built (the reference's callers pass
+    # Grid3D(grid_density, device, precision) with the config's float16 default, refine_css.py:148): compare in the caller's dtype -- the
+    # same float32 -> precision rounding produced both.  Once per (refiner, grid object): a frame's annotations share one grid.
+    seen = getattr(rf, "_grids_ok", None)
+    if seen is None:
+        seen = rf._grids_ok = weakref.WeakSet()
+    if grid in seen:
+        return
+    pts = grid.points.detach()
+    if rf.br is not None and (pts.shape != rf.br.grid.shape or not torch.equal(rf.br.grid.to(pts.dtype), pts.to(rf.br.grid.device))):
+        raise _lib.SdfrError("grid.points is not the Grid3D(%d) point set the kernels index" % D)
+    seen.add(grid)
+
+
+def optimize_many(annotations, iters_optim, dsdf, grid, device, weights, render='splat', trace_grad='surfel', tracer_kwargs=None,
+                  candidate_reuse=True, max_batch=64, optimize_latent=True):
+    """Frame-level entry (r06): refine ALL annotations of a frame together instead of one `Optimizer(...).optimize(...)` call per annotation
+    (pipelines/refine_css.py:94,203-223 loops over a frame's annotations one at a time).  Same arithmetic per annotation -- a crop refined here
+    is bit-identical to the same crop refined alone through `Optimizer.optimize` (GPU test) -- but the annotations share every launch of an
+    iteration (ragged extents: each keeps its own crop size and intrinsics), so a frame of 8-16 cars costs little more than one.
+
+    annotations: list of (params, nocs_pred, pcd_frustum_np, K, crop_size) tuples, or dicts with those keys -- per annotation exactly what the
+                 reference passes to Optimizer(params, ...) and optimize(iters, nocs_pred, pcd_frustum_np, dsdf, grid, K, crop_size).
+    Each `params` dict is turned into float32 leaf tensors on `device` in place (get_opt_params, optimizer.py:26-40) and holds the refined
+    values afterwards; the list of those dicts is returned.  Every annotation starts with fresh solver state, as a new Optimizer object would
+    (optimizer.py:47-52).  More than `max_batch` annotations are processed in chunks."""
+    if render not in ('splat', 'trace'):
+        raise ValueError("render must be 'splat' or 'trace'")
+    items = []
+    for a in annotations:
+        if isinstance(a, dict):
+            a = (a['params'], a['nocs_pred'], a['pcd_frustum_np'], a['K'], a['crop_size'])
+        params, nocs, lidar, K, crop_size = a
+        params, _ = get_opt_params(params, device)
+        items.append((params, torch.as_tensor(nocs, dtype=torch.float32), np.asarray(lidar, dtype=np.float32).reshape(-1, 3), _as_np(K).reshape(3, 3),
+                      (int(crop_size[0]), int(crop_size[1]))))
+    if not items:
+        return []
+    D = _grid_density(grid)
+    dev = grid.points.device
+    tracer_kwargs = dict(tracer_kwargs or {})
+    n_lidar = max(it[2].shape[0] for it in items)
+    cap = max(1024, 1 << (max(n_lidar, 1) - 1).bit_length())
+    pmax = max(1024, 1 << (max(it[4][0] * it[4][1] for it in items) - 1).bit_length())
+    longest = max(max(it[4]) for it in items)
+    while 4 * int(np.ceil(np.sqrt(pmax))) < longest:                  # (a crop more elongated than 16:1: a larger pixel capacity carries its side)
+        pmax *= 4
+    side = 4 * int(np.ceil(np.sqrt(pmax)))
+    max_batch = max(1, int(max_batch))
+    for c0 in range(0, len(items), max_batch):
+        chunk = items[c0:c0 + max_batch]
+        n = len(chunk)
+        B = min(max_batch, 1 << (n - 1).bit_length())                # refiners are built per power-of-two batch size; a short batch is padded
+        key = ('many', id(dsdf), D, pmax, cap, B, str(dev), dsdf._param_key(dev), float(weights.get('2d', 0.3)), float(weights.get('3d', 0.5)),
+               getattr(dsdf, 'mlp_precision', None), bool(optimize_latent), render, trace_grad, tuple(sorted(tracer_kwargs.items())),
+               bool(candidate_reuse))
+        hit = _REFINERS.get(key)
+        if hit is not None and hit[0]() is dsdf:
+            rf = hit[1]
+        else:
+            h0, w0 = chunk[0][4]
+            rf = BatchRefiner(dsdf, D, chunk[0][3], (h0, w0), B, lidar_cap=cap, weights=weights, device=dev, optimize_latent=optimize_latent,
+                              render=render, trace_grad=trace_grad, tracer_kwargs=tracer_kwargs, max_pixels=pmax, max_side=side,
+                              candidate_reuse=bool(candidate_reuse))
+            STATS["refiners_built"] += 1
+            while len(_REFINERS) >= _REFINERS_MAX:
+                _REFINERS.pop(next(iter(_REFINERS)))
+            _REFINERS[key] = (weakref.ref(dsdf), rf)
+        _check_grid(rf, grid, D)
+        sel = list(range(n)) + [n - 1] * (B - n)                     # padding: copies of the last annotation (their rows are dropped)
+        with torch.no_grad():
+            P = {k: torch.stack([chunk[i][0][k].detach().reshape(-1) for i in sel]) for k in ('yaw', 'trans', 'scale', 'latent')}
+            rf.set_crops(P, [chunk[i][1] for i in sel], [chunk[i][2] for i in sel], K=np.stack([chunk[i][3] for i in sel]),
+                         crop_sizes=[chunk[i][4] for i in sel])
+            if iters_optim > 3 and rf._replay is None:
+                rf.capture()
+            rf.optimize(iters_optim)
+            rf.check_overflow()
+            for i in range(n):
+                p = chunk[i][0]
+                p['yaw'].copy_(rf.yaw[i].view_as(p['yaw']))
+                p['trans'].copy_(rf.trans[i].view_as(p['trans']))
+                p['scale'].copy_(rf.scale[i].view_as(p['scale']))
+                p['latent'].copy_(rf.latent[i].view_as(p['latent']))
+    return [it[0] for it in items]
+
+
 class Optimizer:
+    optimize_many = staticmethod(optimize_many)        # Optimizer.optimize_many(annotations, iters, dsdf, grid, device, weights)
+
     def __init__(self, params, device, weights, rot='dcm', render='splat', trace_grad='surfel', tracer_kwargs=None, candidate_reuse=True):
         """render='trace' (extension): the loop's renderer is the sphere tracer instead of the reference's surfel splat -- same losses, same
         solver, same call (BatchRefiner(render='trace')); not the reference's algorithm, so no parity claim goes with it.
@@ -66,13 +168,10 @@ class Optimizer:
                                   # so the state carries over from one optimize() call of an Optimizer object to the next
 
     def _refiner_for(self, dsdf, grid, K, crop_size, n_lidar, optimize_latent=True):
-        G = int(grid.points.size(0))
-        D = int(round(G ** (1.0 / 3.0)))
-        if D ** 3 != G:
-            raise _lib.SdfrError("grid of %d points is not a D^3 Grid3D" % G)
+        D = _grid_density(grid)
         dev = grid.points.device
         cap = max(1024, 1 << (max(n_lidar, 1) - 1).bit_length())      # lidar capacity, rounded up so that a refiner is reused across crops
-        Kn = np.asarray(K.detach().cpu() if torch.is_tensor(K) else K, dtype=np.float32)
+        Kn = _as_np(K)
         # ragged extents -- the refiner is keyed on a pixel CAPACITY (next power of two of the crop's area), not on the crop's
         # size or intrinsics, which reach the kernels as data (set_crops): the pipeline's crops all have their own (H, W) and K
         # (utils/refinement.py:586-609), yet share one set of buffers and one captured graph -- with either renderer.
@@ -98,12 +197,7 @@ class Optimizer:
                 while len(_REFINERS) >= _REFINERS_MAX:
                     _REFINERS.pop(next(iter(_REFINERS)))
                 _REFINERS[key] = (weakref.ref(dsdf), rf)
-            # the caller's grid must be the Grid3D(D) point set the kernels index, in whatever precision it was built (the reference's
-            # callers pass Grid3D(grid_density, device, precision) with the config's float16 default, refine_css.py:148): compare in the
-            # caller's dtype -- the same float32 -> precision rounding produced both
-            pts = grid.points.detach()
-            if rf.br is not None and (pts.shape != rf.br.grid.shape or not torch.equal(rf.br.grid.to(pts.dtype), pts.to(rf.br.grid.device))):
-                raise _lib.SdfrError("grid.points is not the Grid3D(%d) point set the kernels index" % D)
+            _check_grid(rf, grid, D)
             self._refiner, self._key = rf, key
         return self._refiner
 

@@ -95,6 +95,11 @@ class BatchRefiner:
         self.adam_m = torch.zeros((B, 4), dtype=torch.float32, device=dev)
         self.adam_v = torch.zeros((B, 4), dtype=torch.float32, device=dev)
         self.adam_t = torch.zeros((B,), dtype=torch.int32, device=dev)
+        # r06: both losses in one launch, the backward tail and the solver step in one launch (same bits; decoder.fused_launches = False keeps
+        # the r05 sequence).  kscale[b] = (2-D, 3-D) normalisation factors the consumers multiply on load; tickets: the loss launch's counters.
+        self.fused = br is not None and br.fused and self.L <= 8
+        self.kscale = torch.zeros((B, 2), dtype=torch.float32, device=dev)
+        self.tickets = torch.zeros((2 * B,), dtype=torch.int32, device=dev)
         self._replay = None
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -131,8 +136,10 @@ class BatchRefiner:
             self.lidar[b, :l.shape[0]] = l
             self.lcnt[b] = l.shape[0]
         self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t.zero_()
+        self.tickets.zero_()
         if self.br is not None:
             self.br.invalidate_shape()
+            self.br.clear_overflow()            # sticky truncation flags belong to the crops refined before
             self.br.reset_guard()               # per-crop device state of the two-stage mode (violation counters, margins) starts clean
         # a captured graph stays valid: every buffer it reads or writes is static and was updated in place above
 
@@ -149,6 +156,17 @@ class BatchRefiner:
             self._iteration_traced(L, P, st, ck)
             return
         out = br.forward()
+        if self.fused:
+            ck(L.sdfr_losses_fused(P(out["color"]), P(self.target), B, self.H, self.W, P(br.wh) if self.ragged else None, br.PS,
+                                   br.tiles16_cap if self.ragged else 0, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color), P(self.nvalid),
+                                   P(self.l2_scratch), P(out["xyzf"]), P(br.fcnt), br.cap, P(self.lidar), P(self.lcnt), self.lidar_cap, P(self.scale),
+                                   0.2, self.w3, P(self.loss3d), P(self.g_xyzf), P(self.g_scale), P(self.npairs), P(self.l3_scratch), P(self.kscale),
+                                   P(self.tickets), st), "sdfr_losses_fused")
+            br.backward_solve(self.g_color, self.g_xyzf, self.kscale,
+                              {"params": self.params, "grads": self.grads, "loss2d": self.loss2d, "loss3d": self.loss3d, "npairs": self.npairs,
+                               "w2": self.w2, "w3": self.w3, "adam_m": self.adam_m, "adam_v": self.adam_v, "adam_t": self.adam_t,
+                               "lr_latent": 0.00003 if self.optimize_latent else 0.0, "total": self.total, "stepped": self.stepped})
+            return
         if self.ragged:
             ck(L.sdfr_loss_2d_r(P(out["color"]), P(self.target), B, P(br.wh), br.PS, br.tiles16_cap, 5.0, 1.0, self.w2, P(self.loss2d),
                                 P(self.g_color), P(self.nvalid), P(self.l2_scratch), st), "sdfr_loss_2d_r")

@@ -1,0 +1,162 @@
+"""r06: the fused launches of a refinement iteration (sdfr_params_plan, sdfr_band_select_ex, sdfr_mlp_forward_candidates,
+sdfr_candidate_band, sdfr_losses_fused, sdfr_splat_backward_x, sdfr_pose_latent_solver: 11 launches where r05 had 21) must return the bits of
+the launch sequence they replace; the frame-level Optimizer.optimize_many must return the bits of one Optimizer per annotation
+(pipelines/refine_css.py:94,203-223); truncation flags must be sticky (the reference has no capacity: grid.py:64-66)."""
+import numpy as np
+import pytest
+import torch
+
+import sdflabel_amd
+from sdflabel_amd import _lib
+from tests._util import ASSET, K_for
+from tests.test_gpu_parity import N, T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _dec(precision, reuse, fused):
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)
+    d.candidate_reuse = reuse
+    d.fused_launches = fused
+    return d.to(DEV)
+
+
+def _problem(D, H, W, B):
+    from sdflabel_amd.fixtures import crop_params, synthetic_targets
+    d32, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
+    K = K_for(H, W)
+    nocs1, lidar = synthetic_targets(d32.to(DEV), D, K, H, W, DEV)
+    return K, crop_params(list(range(B))), nocs1.expand(B, 3, H, W), lidar
+
+
+def _same_iteration(a, b, counters=True):
+    """two BatchRefiners after the same number of iterations: everything an iteration produces, bit for bit"""
+    A, Bq = a.br, b.br
+    assert torch.equal(A.cnt, Bq.cnt) and torch.equal(A.fcnt, Bq.fcnt)
+    live = torch.arange(A.cap, device=DEV).view(1, -1) < A.cnt.view(-1, 1)
+    assert torch.equal(A.idx[live], Bq.idx[live]), "band index lists differ"
+    assert torch.equal(A.sdf_band[live], Bq.sdf_band[live]) and torch.equal(A.J[live], Bq.J[live])
+    for name in ("color", "mask", "depth", "nimg", "xyzf", "points", "normals", "pose", "inputs"):
+        assert torch.equal(getattr(A, name), getattr(Bq, name)), name
+    for name in ("loss2d", "loss3d", "total", "nvalid", "npairs", "stepped", "grads", "params", "adam_m", "adam_v", "adam_t"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert torch.equal(x, y) or (torch.isnan(x) == torch.isnan(y)).all() and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y)), name
+    if A.creuse:
+        assert torch.equal(A.reuse_flag, Bq.reuse_flag) and torch.equal(A.age, Bq.age)
+        assert not counters or torch.equal(A.n_full, Bq.n_full)        # (capture()'s warm-up iteration counts one more full pass)
+        assert torch.equal(A.ccnt, Bq.ccnt) and torch.equal(A.lat_ref, Bq.lat_ref)
+
+
+@pytest.mark.parametrize("precision,reuse", [(torch.float16, True), (torch.float32, True), (torch.float16, False), (torch.float32, False)])
+@pytest.mark.parametrize("B,H,W,ragged", [(1, 32, 32, True), (3, 64, 48, False), (9, 40, 56, True)])
+def test_fused_launches_return_the_bits_of_the_sequence_they_replace(B, H, W, ragged, precision, reuse):
+    D, iters = 40, 14
+    K, p0, target, lidar = _problem(D, H, W, B)
+    kw = dict(max_pixels=4096, max_side=128) if ragged else {}
+    old = sdflabel_amd.BatchRefiner(_dec(precision, reuse, False), D, K, (H, W), B, lidar_cap=4096, device=DEV, **kw)
+    new = sdflabel_amd.BatchRefiner(_dec(precision, reuse, True), D, K, (H, W), B, lidar_cap=4096, device=DEV, **kw)
+    assert new.fused and new.br.fused and not old.fused and not old.br.fused
+    tg = [target[b] for b in range(B)] if ragged else target
+    for rf in (old, new):
+        rf.set_crops(p0, tg, [lidar] * B)
+    for it in range(iters):
+        old.iteration(); new.iteration()
+        _same_iteration(old, new)
+        # the un-normalised gradients times their factors are the arrays the r05 finalize passes stored
+        assert torch.equal(new.g_color * new.kscale[:, 0].view(-1, 1, 1) if ragged else new.g_color * new.kscale[:, 0].view(-1, 1, 1, 1), old.g_color)
+        assert torch.equal(new.g_xyzf * new.kscale[:, 1].view(-1, 1, 1), old.g_xyzf)
+        if it == 6:                 # a latent jump in the middle: the next step orders a full pass for that crop
+            with torch.no_grad():
+                for rf in (old, new):
+                    rf.latent[B - 1] += torch.tensor([0.4, -0.3, 0.2], device=DEV)
+    assert int(new.tickets.abs().sum()) == 0                  # the loss launch leaves its counters at zero (replayable)
+    # ... and the captured graph of the fused iteration replays to the same state as the eager one
+    new.set_crops(p0, tg, [lidar] * B); old.set_crops(p0, tg, [lidar] * B)
+    new.capture()
+    new.optimize(10)
+    for _ in range(10):
+        old.iteration()
+    _same_iteration(old, new, counters=False)
+    old.check_overflow(); new.check_overflow()
+
+
+def test_optimize_many_returns_the_bits_of_one_optimizer_per_annotation():
+    """pipelines/refine_css.py:94,203-223 builds one Optimizer per annotation; Optimizer.optimize_many refines a frame's annotations together
+    (ragged extents: own crop size and intrinsics each).  KITTI-like crops at the reference's shipped rendering_area 32 (config_refine.ini:12),
+    float16 decoder (:19), 60 iterations (:15); frames of 3 (padded to a batch of 4), 5 and 8 annotations."""
+    from sdflabel_amd.fixtures import kitti_like_problems
+    from sdflabel_amd.pipelines import optimizer as OP
+    D, n, iters = 40, 16, 60
+    d32, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
+    d16, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+    d16 = d16.to(DEV)
+    shapes, Ks, targets, lidars, starts = kitti_like_problems(d32.to(DEV), D, 32, n, DEV)
+    grid = sdflabel_amd.Grid3D(D, DEV)
+    W8 = {"2d": 0.3, "3d": 0.5}
+    OP.clear_refiner_cache()
+    single = []
+    for b in range(n):
+        opt = OP.Optimizer({k: v.copy() for k, v in starts[b].items()}, DEV, W8)
+        single.append(opt.optimize(iters, targets[b], lidars[b], d16, grid, torch.from_numpy(Ks[b]), list(shapes[b])))
+    many, c0 = [], 0
+    for fsz in (3, 5, 8):
+        frame = [({k: v.copy() for k, v in starts[b].items()}, targets[b], lidars[b], Ks[b], shapes[b]) for b in range(c0, c0 + fsz)]
+        res = OP.Optimizer.optimize_many(frame, iters, d16, grid, DEV, W8)
+        assert all(res[i] is frame[i][0] for i in range(fsz))            # the callers' params dicts, refined in place
+        many += res
+        c0 += fsz
+    for b in range(n):
+        for k in ("yaw", "trans", "scale", "latent"):
+            assert many[b][k].requires_grad and many[b][k].dtype == torch.float32
+            assert torch.equal(many[b][k], single[b][k]), (b, k)
+    moved = np.mean([abs(float(single[b]["yaw"][0]) - 0.6) for b in range(n)]) < np.mean([abs(float(starts[b]["yaw"][0]) - 0.6) for b in range(n)])
+    assert moved
+    OP.clear_refiner_cache()
+
+
+@pytest.mark.parametrize("reuse", [True, False])
+def test_truncation_flags_are_sticky_across_graph_replays(reuse):
+    """VERDICT r05 missing 4: a band that exceeds `cap` during iterations 5-12 of a graph-replayed refinement and fits again at the end must not
+    pass results() -- cnt[b] is overwritten by every iteration, the flag is not.  Planted by a latent that inflates the band for a while."""
+    D, H, W, B = 40, 32, 32, 2
+    K, p0, target, lidar = _problem(D, H, W, B)
+    probe = sdflabel_amd.BatchRefiner(_dec(torch.float16, reuse, True), D, K, (H, W), B, lidar_cap=4096, device=DEV)
+    sizes = []
+    lat0 = np.asarray(p0["latent"], np.float32)
+    cands = [lat0, -lat0, lat0[:, ::-1].copy(), lat0 * np.float32(0.2), np.abs(lat0)]
+    for lat in cands:                                         # band (and candidate) counts of a few latents: the decoder's shapes differ in size
+        q = dict(p0); q["latent"] = lat
+        probe.set_crops(q, target, [lidar] * B)
+        probe.iteration()
+        sizes.append((int(probe.br.cnt.max()), int(probe.br.ccnt.max()) if reuse else int(probe.br.cnt.max())))
+    i_small = int(np.argmin([c for _, c in sizes]))
+    i_big = int(np.argmax([n_ for n_, _ in sizes]))
+    need, top = max(sizes[i_small]), sizes[i_big][0]
+    if top - need < 8:
+        pytest.skip("no pair of probe latents plants an overflow (band / candidate counts %s)" % (sizes,))
+    cap = (need + top) // 2
+    small_p, big_p = dict(p0), dict(p0)
+    small_p["latent"], big_p["latent"] = cands[i_small], cands[i_big]
+    rf = sdflabel_amd.BatchRefiner(_dec(torch.float16, reuse, True), D, K, (H, W), B, lidar_cap=4096, device=DEV, cap=cap)
+    rf.set_crops(small_p, target, [lidar] * B)
+    rf.capture()
+    rf.optimize(5)
+    rf.check_overflow()                                       # fits so far
+    with torch.no_grad():
+        keep = rf.latent.clone()
+        rf.latent.copy_(T(np.asarray(big_p["latent"], np.float32)))
+    rf.optimize(2)                                            # iterations 6-7: the band exceeds cap
+    def last_counts_overflow():                               # what r05's check looked at: the LAST iteration's counts
+        return bool((rf.br.cnt > cap).any()) or (reuse and bool((rf.br.ccnt > rf.br.cstride).any()))
+    assert last_counts_overflow()
+    with torch.no_grad():
+        rf.latent.copy_(keep)
+    rf.optimize(13)                                           # ... and fits again by iteration 20
+    assert not last_counts_overflow()                         # the last iteration's counts alone look fine ...
+    with pytest.raises(sdflabel_amd.SdfrError, match="capacity"):      # ... the sticky flags do not
+        rf.results()
+    rf.check_overflow()                                       # reported once
+    rf.set_crops(small_p, target, [lidar] * B)                # new crops start clean
+    rf.optimize(3)
+    rf.results()

@@ -437,7 +437,7 @@ int sdfr_solver_step(float* params, const float* grads, int L, const float* loss
                      int B, float* total, int32_t* stepped, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * r06: the refinement iteration in 11 launches instead of 21 (the per-annotation call of pipelines/refine_css.py:203-223 is a chain of
+ * r06: the refinement iteration in 12 launches instead of 21 (the per-annotation call of pipelines/refine_css.py:203-223 is a chain of
  * latency-bound launches: every one removed is ~5 us of a 0.3 ms iteration).  Each entry point below is the fusion of entry points above and
  * returns THEIR bits (GPU tests compare the two launch sequences array by array).
  */
@@ -464,12 +464,12 @@ int sdfr_candidate_band(float* sdf_grid, const float* csdf, const int32_t* cidx,
 /* sdfr_loss_2d(_r) + sdfr_loss_3d in one launch (optimizer.py:166-237).  wh == NULL: dense H x W images; else ragged extents (pix_stride,
  * tiles16_cap as sdfr_loss_2d_r).  g_rend / g_est receive the UN-normalised gradients and kscale float[B][2] the per-crop factors
  * (weight / count, or 0) the consumers multiply on load: sdfr_splat_backward_x (kscale[2b]) and sdfr_pose_latent_solver (kscale[2b+1]).
- * tickets int32[2 B]: zero before the first launch, left zero by every launch. */
+ * Two launches (pixel + pairs passes together; one tiny finalize pass) where sdfr_loss_2d + sdfr_loss_3d take four. */
 int sdfr_losses_fused(const float* rend, const float* target, int B, int H, int W, const int32_t* wh, int pix_stride, int tiles16_cap, float diam,
                       float threshold_nocs, float weight2d, float* loss2d, float* g_rend, int32_t* nvalid, float* scratch2, const float* est,
                       const int32_t* ecnt, int ecap, const float* lidar, const int32_t* lcnt, int lcap, const float* scale, float threshold3d,
                       float weight3d, float* loss3d, float* g_est, float* g_scale, int32_t* npairs, float* scratch3, float* kscale,
-                      int32_t* tickets, void* stream);
+                      void* stream);
 /* sdfr_splat_backward(_r) of the disc primitive for a colour gradient alone, scaled by kscale[2 b] on load (primitives.py:209-242 backward). */
 int sdfr_splat_backward_x(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr, int B, int cap,
                           const int32_t* cnt, int W, int H, const int32_t* wh, int pix_stride, float diam, float depth_constant, const float* aux,

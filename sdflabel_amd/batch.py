@@ -217,7 +217,7 @@ class BatchRenderer:
             self._side_pending = False
             self.half_tiles = self.f16 and B <= 2 and bool(getattr(decoder, "candidate_half_tiles", True))      # (a float16 option)
             # r06: 32-row tiles at ONE crop per launch (fused launches only: the pool kernel of sdfr_mlp_forward_candidates)
-            self.quarter_tiles = self.half_tiles and B == 1 and self.fused and bool(getattr(decoder, "candidate_quarter_tiles", False))
+            self.quarter_tiles = self.half_tiles and B == 1 and self.fused and bool(getattr(decoder, "candidate_quarter_tiles", True))
             if self.audit:
                 self.audit_cap = B * ((G + self.audit_stride - 1) // self.audit_stride)
                 self.audit_rows, self.audit_src, self.audit_sdf = f(self.audit_cap, NI), i(self.audit_cap), f(self.audit_cap)

@@ -342,21 +342,42 @@ extern "C" int sdfr_loss_2d_r(const float* rend, const float* target, int B, con
                         scratch, stream);
 }
 
-// ---- both losses in ONE launch (r06) ------------------------------------------------------------------------------------------------------
+// ---- both losses in TWO launches instead of four (r06) ----------------------------------------------------------------------------------
 // The refinement loop evaluates the two losses on the same rendering and they do not depend on each other: blocks [0, nblk2) of a crop run the
-// 2-D pixel pass, blocks [nblk2, nblk2 + nblk3) the 3-D pairs pass (both 256 threads).  The finalize passes become the job of the LAST block
-// of each kind to finish (a ticket counter per crop and kind, reset by that block: the launch is replayable): it re-reduces the partials in
-// the finalize kernels' fixed order -- so loss, nvalid / npairs and g_scale carry the same bits -- and, instead of rescaling the gradient
-// arrays in a second sweep, publishes the factor: kscale[b] = (weight_2d / n_valid or 0, weight_3d / n_pairs or 0).  The consumers multiply
-// on load (sdfr_splat_backward_x: g_color * k2; sdfr_pose_latent_solver: g_xyzf * k3) -- the product the finalize kernels stored.
-// Four launches per iteration become one.
-__device__ __forceinline__ void reduce3_fixed(const float* partial, int nblk, int b, float (*red)[256], float& r0, float& r1, float& r2) {
+// 2-D pixel pass, blocks [nblk2, nblk2 + nblk3) the 3-D pairs pass (both 256 threads) -- one launch.  A second, tiny launch (two blocks per
+// crop) re-reduces the partials in the finalize kernels' fixed order -- loss, nvalid / npairs and g_scale carry the same bits -- and, instead
+// of rescaling the gradient arrays in a sweep of 3 P + 3 cap floats per crop, publishes the factor: kscale[b] = (weight_2d / n_valid or 0,
+// weight_3d / n_pairs or 0).  The consumers multiply on load (sdfr_splat_backward_x: g_color * k2; sdfr_pose_latent_solver: g_xyzf * k3) --
+// the product the finalize kernels stored.
+// (A first version let the LAST block of each kind do the finalize behind a ticket counter: one launch, but the device-scope fence every block
+// needs before its ticket writes the XCD's L2 back -- the L2s are not coherent with each other -- and 24 000 blocks of a 64-crop launch spent
+// 2.3 ms doing so, where the four r05 launches took 0.22 ms.  profiles/r06_notes.md.)
+struct LossesArgs {
+    // 2-D
+    const float* rend; const float* target; int H, W; const int32_t* wh; int pst; float diam, threshold_nocs, w2;
+    float* loss2d; float* g_rend; int32_t* nvalid; float* part2; int nblk2;
+    // 3-D
+    const float* est; const int32_t* ecnt; int ecap; const float* lidar; const int32_t* lcnt; int lcap; const float* scale; float threshold3, w3;
+    float* loss3d; float* g_est; float* g_scale; int32_t* npairs; float* part3; int nblk3;
+    float* kscale;
+};
+
+template <bool LDS, int RADC>
+__global__ __launch_bounds__(256) void sdfr_losses_fused_kernel(const LossesArgs A) {
+    const int b = blockIdx.y;
+    if ((int)blockIdx.x < A.nblk2)
+        loss_2d_pixels_block<LDS, RADC>(blockIdx.x, b, A.nblk2, A.rend, A.target, A.H, A.W, A.wh, A.pst, A.diam, A.threshold_nocs, A.g_rend, A.part2);
+    else
+        loss_3d_pairs_block(blockIdx.x - A.nblk2, b, A.nblk3, A.est, A.ecnt, A.ecap, A.lidar, A.lcnt, A.lcap, A.scale, A.threshold3, A.g_est, A.part3);
+}
+
+// the fixed-order re-reduction of the finalize kernels (same statements, same order)
+__device__ __forceinline__ void reduce3_fixed(const float* __restrict__ partial, int nblk, int b, float (*red)[256], float& r0, float& r1, float& r2) {
     const int tid = threadIdx.x;
-    const volatile float* pv = partial;                    // written by other workgroups of this launch: read past the CU's vector cache
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int i = tid; i < nblk; i += 256) {
-        const volatile float* q = pv + ((int64_t)b * nblk + i) * 3;
-        a0 += q[0]; a1 += q[1]; a2 += q[2];
+        const float* p = partial + ((int64_t)b * nblk + i) * 3;
+        a0 += p[0]; a1 += p[1]; a2 += p[2];
     }
     red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2;
     __syncthreads();
@@ -367,34 +388,10 @@ __device__ __forceinline__ void reduce3_fixed(const float* partial, int nblk, in
     r0 = red[0][0]; r1 = red[1][0]; r2 = red[2][0];
 }
 
-struct LossesArgs {
-    // 2-D
-    const float* rend; const float* target; int H, W; const int32_t* wh; int pst; float diam, threshold_nocs, w2;
-    float* loss2d; float* g_rend; int32_t* nvalid; float* part2; int nblk2;
-    // 3-D
-    const float* est; const int32_t* ecnt; int ecap; const float* lidar; const int32_t* lcnt; int lcap; const float* scale; float threshold3, w3;
-    float* loss3d; float* g_est; float* g_scale; int32_t* npairs; float* part3; int nblk3;
-    float* kscale; int32_t* tickets;
-};
-
-template <bool LDS, int RADC>
-__global__ __launch_bounds__(256) void sdfr_losses_fused_kernel(const LossesArgs A) {
+__global__ __launch_bounds__(256) void sdfr_losses_finalize_kernel(const LossesArgs A) {
     const int b = blockIdx.y, tid = threadIdx.x;
-    const bool is2 = (int)blockIdx.x < A.nblk2;
-    if (is2) loss_2d_pixels_block<LDS, RADC>(blockIdx.x, b, A.nblk2, A.rend, A.target, A.H, A.W, A.wh, A.pst, A.diam, A.threshold_nocs, A.g_rend, A.part2);
-    else loss_3d_pairs_block(blockIdx.x - A.nblk2, b, A.nblk3, A.est, A.ecnt, A.ecap, A.lidar, A.lcnt, A.lcap, A.scale, A.threshold3, A.g_est, A.part3);
-    __shared__ int s_last;
     __shared__ float red[3][256];
-    __threadfence();                                       // this block's partials (and gradient rows) are visible device-wide ...
-    __syncthreads();
-    if (tid == 0) {
-        const int t = atomicAdd(&A.tickets[2 * b + (is2 ? 0 : 1)], 1);      // ... before its ticket is
-        s_last = (t == (is2 ? A.nblk2 : A.nblk3) - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (is2) {
+    if (blockIdx.x == 0) {
         float tot, cf, anyf;
         reduce3_fixed(A.part2, A.nblk2, b, red, tot, cf, anyf);
         if (tid == 0) {
@@ -402,7 +399,6 @@ __global__ __launch_bounds__(256) void sdfr_losses_fused_kernel(const LossesArgs
             A.kscale[2 * b] = (anyf > 0.f) ? A.w2 * inv : 0.f;
             A.loss2d[b] = (anyf > 0.f) ? (cf > 0.f ? tot * inv : __int_as_float(0x7fc00000)) : 0.f;
             A.nvalid[b] = (int)cf;
-            A.tickets[2 * b] = 0;
         }
     } else {
         float tot, gst, cf;
@@ -414,21 +410,20 @@ __global__ __launch_bounds__(256) void sdfr_losses_fused_kernel(const LossesArgs
             A.loss3d[b] = cf > 0.f ? tot * inv : 0.f;
             A.g_scale[b] = A.w3 * gst * inv;
             A.npairs[b] = (ne > 0 && nl > 0) ? (int)cf : -1;
-            A.tickets[2 * b + 1] = 0;
         }
     }
 }
 
 // rend / target / g_rend: [B][3][H*W] (wh == NULL) or ragged slots [B][3][pix_stride] with wh int32[B][2] and tiles16_cap tile slots per crop.
-// g_rend and g_est receive the UN-normalised gradients; kscale float[B][2] the factors; tickets int32[2B], zero before the first launch (the
-// kernel leaves them zero); scratch2 float[3 * B * tiles], scratch3 float[3 * B * ceil(ecap / 64)].
+// g_rend and g_est receive the UN-normalised gradients; kscale float[B][2] the factors; scratch2 float[3 * B * tiles], scratch3
+// float[3 * B * ceil(ecap / 64)].
 extern "C" int sdfr_losses_fused(const float* rend, const float* target, int B, int H, int W, const int32_t* wh, int pix_stride, int tiles16_cap,
                                  float diam, float threshold_nocs, float weight2d, float* loss2d, float* g_rend, int32_t* nvalid, float* scratch2,
                                  const float* est, const int32_t* ecnt, int ecap, const float* lidar, const int32_t* lcnt, int lcap,
                                  const float* scale, float threshold3d, float weight3d, float* loss3d, float* g_est, float* g_scale,
-                                 int32_t* npairs, float* scratch3, float* kscale, int32_t* tickets, void* stream) {
+                                 int32_t* npairs, float* scratch3, float* kscale, void* stream) {
     SDFR_REQUIRE(rend && target && loss2d && g_rend && nvalid && scratch2 && est && lidar && scale && loss3d && g_est && g_scale && npairs &&
-                 scratch3 && kscale && tickets, "sdfr_losses_fused: NULL argument");
+                 scratch3 && kscale, "sdfr_losses_fused: NULL argument");
     SDFR_REQUIRE(diam > 0.f && ecap > 0 && lcap >= 0, "sdfr_losses_fused: bad size");
     if (B <= 0) return SDFR_OK;
     LossesArgs A;
@@ -438,13 +433,15 @@ extern "C" int sdfr_losses_fused(const float* rend, const float* target, int B, 
     A.loss2d = loss2d; A.g_rend = g_rend; A.nvalid = nvalid; A.part2 = scratch2;
     A.est = est; A.ecnt = ecnt; A.ecap = ecap; A.lidar = lidar; A.lcnt = lcnt; A.lcap = lcap; A.scale = scale; A.threshold3 = threshold3d; A.w3 = weight3d;
     A.loss3d = loss3d; A.g_est = g_est; A.g_scale = g_scale; A.npairs = npairs; A.part3 = scratch3; A.nblk3 = sdfr_cdiv(ecap, L3_PTS);
-    A.kscale = kscale; A.tickets = tickets;
+    A.kscale = kscale;
     const dim3 grid(A.nblk2 + A.nblk3, B);
     hipStream_t s = (hipStream_t)stream;
     const int rad = (int)ceilf(diam) - 1;
     if (rad == 4) hipLaunchKernelGGL((sdfr_losses_fused_kernel<true, 4>), grid, dim3(256), 0, s, A);
     else if (rad <= L2_RMAX) hipLaunchKernelGGL((sdfr_losses_fused_kernel<true, 0>), grid, dim3(256), 0, s, A);
     else hipLaunchKernelGGL((sdfr_losses_fused_kernel<false, 0>), grid, dim3(256), 0, s, A);
+    SDFR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sdfr_losses_finalize_kernel, dim3(2, B), dim3(256), 0, s, A);
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

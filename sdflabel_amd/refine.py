@@ -96,10 +96,9 @@ class BatchRefiner:
         self.adam_v = torch.zeros((B, 4), dtype=torch.float32, device=dev)
         self.adam_t = torch.zeros((B,), dtype=torch.int32, device=dev)
         # r06: both losses in one launch, the backward tail and the solver step in one launch (same bits; decoder.fused_launches = False keeps
-        # the r05 sequence).  kscale[b] = (2-D, 3-D) normalisation factors the consumers multiply on load; tickets: the loss launch's counters.
+        # the r05 sequence).  kscale[b] = (2-D, 3-D) normalisation factors the consumers multiply on load.
         self.fused = br is not None and br.fused and self.L <= 8
         self.kscale = torch.zeros((B, 2), dtype=torch.float32, device=dev)
-        self.tickets = torch.zeros((2 * B,), dtype=torch.int32, device=dev)
         self._replay = None
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -136,7 +135,6 @@ class BatchRefiner:
             self.lidar[b, :l.shape[0]] = l
             self.lcnt[b] = l.shape[0]
         self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t.zero_()
-        self.tickets.zero_()
         if self.br is not None:
             self.br.invalidate_shape()
             self.br.clear_overflow()            # sticky truncation flags belong to the crops refined before
@@ -161,7 +159,7 @@ class BatchRefiner:
                                    br.tiles16_cap if self.ragged else 0, 5.0, 1.0, self.w2, P(self.loss2d), P(self.g_color), P(self.nvalid),
                                    P(self.l2_scratch), P(out["xyzf"]), P(br.fcnt), br.cap, P(self.lidar), P(self.lcnt), self.lidar_cap, P(self.scale),
                                    0.2, self.w3, P(self.loss3d), P(self.g_xyzf), P(self.g_scale), P(self.npairs), P(self.l3_scratch), P(self.kscale),
-                                   P(self.tickets), st), "sdfr_losses_fused")
+                                   st), "sdfr_losses_fused")
             br.backward_solve(self.g_color, self.g_xyzf, self.kscale,
                               {"params": self.params, "grads": self.grads, "loss2d": self.loss2d, "loss3d": self.loss3d, "npairs": self.npairs,
                                "w2": self.w2, "w3": self.w3, "adam_m": self.adam_m, "adam_v": self.adam_v, "adam_t": self.adam_t,

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--only", default="", help="comma list of sections (per_annotation,phases,many); default all")
     ap.add_argument("--frames", default="4,8,16,32")
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--set", default="", help="comma list attr=0/1 set on the decoder (e.g. candidate_quarter_tiles=1,fused_launches=0)")
+    ap.add_argument("--hostprof", action="store_true", help="cProfile of the per-annotation loop (host side)")
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     dev = torch.device("cuda", 0)
@@ -41,6 +43,9 @@ def main():
     prec = torch.float16 if args.precision == "float16" else torch.float32
     dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
     dec = dec.to(dev)
+    for kv in [x for x in args.set.split(",") if x]:
+        k, v = kv.split("=")
+        setattr(dec, k, bool(int(v)))
     dec.latent_lipschitz_bound()
     shapes, Ks, targets, lidars, starts = kitti_like_problems(dec32, D, args.area, args.n, dev)
     grid = sdflabel_amd.Grid3D(D, dev)
@@ -70,6 +75,19 @@ def main():
             best = dt if best is None else min(best, dt)
         out["per_annotation"] = {"crops_per_s": args.n / best, "ms_per_crop": best / args.n * 1e3}
         print("per_annotation", json.dumps(out["per_annotation"]), flush=True)
+
+    if args.hostprof:
+        import cProfile, pstats, io
+        per_annotation(2)
+        pr = cProfile.Profile()
+        torch.cuda.synchronize()
+        pr.enable()
+        per_annotation(args.n)
+        torch.cuda.synchronize()
+        pr.disable()
+        st = io.StringIO()
+        pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(45)
+        print(st.getvalue())
 
     if not only or "phases" in only:
         opt = OP.Optimizer(fresh(0), dev, W8)

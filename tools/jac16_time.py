@@ -9,7 +9,7 @@ dec, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16); dec = 
 L = sdflabel_amd._lib.lib(); P = sdflabel_amd._lib.ptr
 out = []
 FLAG = int(os.environ.get("SDFR_JAC_FLAG", "2"))     # 2: half backward on 16-row tiles; 18 (= 2 | SDFR_JAC_MANY_ROWS): 32x32 tiles
-for B in [int(a) for a in sys.argv[1:]] or [1]:
+for B in [int(a) for a in sys.argv[1:]] or [int(os.environ.get("SDFR_JAC_B", "64"))]:
     br = sdflabel_amd.BatchRenderer(dec, 40, K_for(64, 64), (64, 64), B, device=dev)
     g = torch.Generator().manual_seed(1)
     lat = torch.tensor([[0.3, -0.5, 0.8]]) + 0.2 * (torch.rand(B, 3, generator=g) - 0.5)

@@ -136,7 +136,7 @@ extern "C" int64_t sdfr_decoder_mask_words(const sdfr_decoder* d, int64_t n) {
     if (!d || n <= 0) return 0;
     int ft, nt;
     mask_geometry(d->HP, &ft, &nt);
-    // 512 bits per point and layer for HP = 512, rounded up to whole 128-point tiles (covers the f32 64-point and f16 128-point layouts)
+    // HP bits per row and layer, rows rounded up to whole blocks of 128 (mask layout v2, mlp_kernel.h: sdfr_mask_dword; ft * nt * 2 = 128 * HP / 32)
     return ((n + 127) / 128) * 2 * (int64_t)(d->n_lin - 1) * ft * nt;
 }
 
@@ -365,7 +365,7 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     hipStream_t s = (hipStream_t)stream;
     MlpParams P = d->proto;
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
-    P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws);
+    P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.trace = g_trace;      // (cycle stamps: trace builds only)
     const bool many_rows = (mask_from_f16 & SDFR_JAC_MANY_ROWS) != 0;       // hint: far more rows than 16 x the CU count (recomputing kernel on 32-row tiles)
     const bool half_tiles = (mask_from_f16 & SDFR_JAC_HALF_TILES) != 0;     // masks saved by a half-size-tile forward (sdfr_mlp_forward*_ragged, half_tiles = 1)
     const bool quarter_tiles = (mask_from_f16 & SDFR_JAC_QUARTER_TILES) != 0;

@@ -176,6 +176,18 @@ __device__ __forceinline__ void store4(h16* dst, const float* v) {
     *reinterpret_cast<h16x4*>(dst) = t;
 }
 
+// ReLU masks in HBM (layout v2, r06): one bit per (row, layer, feature), independent of the tile geometry of the launch that saved them.  Rows
+// in blocks of 128; a row's HP bits of one layer are HP / 32 consecutive dwords (64 bytes for HP = 512), a block's rows of one layer are
+// contiguous (8 KiB), then the next layer:   dword (((r >> 7) * n_layers + l) * 128 + (r & 127)) * (HP / 32) + (j >> 5)   holds features
+// j & ~31 ... of row r, layer l, feature j at bit ((j >> 2) & 1) * 16 + ((j & 31) >> 3) * 4 + (j & 3) -- the order in which a thread of the 32x32
+// forward kernels holds them (lane group lg = (j >> 2) & 1 owns one 16-bit half: a thread stores its 16 bits per (feature tile, point) as one
+// short; the workgroup's stores fill whole 64-byte rows).  r05's layout was [forward tile][layer][word][thread]: a band row's 64 bytes per
+// layer were 32 dwords 128 bytes apart, at places that depended on the forward launch's tile size.
+__device__ __forceinline__ int64_t sdfr_mask_dword(int64_t r, int l, int n_layers, int HP32, int j) {
+    return (((r >> 7) * n_layers + l) * 128 + (r & 127)) * HP32 + (j >> 5);
+}
+__device__ __forceinline__ int sdfr_mask_shift(int j) { return ((j >> 2) & 1) * 16 + ((j & 31) >> 3) * 4 + (j & 3); }
+
 // ET   operand element type (float: exact f32; _Float16: half operands, f32 accumulate -- forward modes and the mask-fed Jacobian)
 // MS   MFMA tile (32: forward on the grid; 16: small tiles so that a few thousand band rows fill the chip)
 // FT   feature tiles (MS rows) per wave, NP point tiles (MS points) per workgroup, NW waves per workgroup (HP = MS*FT*NW padded width)
@@ -238,7 +250,14 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 #endif
     constexpr bool DBUF = SDFR_ACT_DBUF && HALF && !JAC && !LN && !SAVE && (2 * KGX * PT * 16 <= 144 * 1024);
     constexpr int ACT4 = (DBUF ? 2 : 1) * KGX * PT;
-    __shared__ float4 lds4[ACT4 + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4 + LN_F4];
+    // MLDS (r06; the half mask-fed Jacobian on 16x16 products): the ReLU masks of EVERY layer for the tile's rows are fetched once, in the
+    // kernel's prologue, and kept in LDS.  Fetched layer by layer in front of each product (r05) the 16 scattered 4-byte gathers per lane sat
+    // in front of the layer's first weight fragment in the in-order vmcnt queue (one exposed HBM / L2-miss latency per layer), and unpacking
+    // them took 530 VALU instructions per wave and layer.
+    constexpr bool MLDS = GMASK && HALF && MS == 16 && HP == 512;
+    static_assert(!MLDS || (FT == 4 && NW == 8), "MLDS: a wave owns 64 features = two mask dwords of a row");
+    constexpr int MLDS_WORDS = MLDS ? NW * SDFR_MAX_LAYERS * PT * 2 : 0;   // [wave][layer][row] 8 bytes: the wave's 64 mask bits of the row
+    __shared__ float4 lds4[ACT4 + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4 + LN_F4 + (MLDS_WORDS + 3) / 4];
     vec_t* act = reinterpret_cast<vec_t*>(lds4);                  // [KG][PT] 16-byte vectors: act[k/KV][point][k%KV] -- the operand the products read
     ET* act_e = reinterpret_cast<ET*>(lds4);
     vec_t* actw = DBUF ? act + KGX * PT : act;                    // ... and the one the epilogue writes (the same without the second tile)
@@ -250,6 +269,12 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     uint32_t* masks = reinterpret_cast<uint32_t*>(lds4 + ACT4 + NT / 4 + 32 + (PT + 3) / 4 * 2);
     float* lnred = reinterpret_cast<float*>(lds4 + ACT4 + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4);   // [NW][PT]
     float* lnrstd = lnred + NW * PT;                                                                                   // [layers][PT]
+    uint32_t* mlds = reinterpret_cast<uint32_t*>(lds4 + ACT4 + NT / 4 + 32 + (PT + 3) / 4 * 2 + (MASK_WORDS + 3) / 4 + LN_F4);   // uint2 [NW][layers][PT]
+    // MLDS kernels on decoders with at most 8 input columns: a J row is assembled in LDS and written ONCE -- gradients of re-injected input
+    // columns (latent_in / xyz_in_all layers) are added here, the first layer's in-gradient joins them at the end.  (r05 zeroed the rows in
+    // HBM at the start and atomicAdd-ed both parts: 24 lane-divergent global atomics in the last wave of the re-injecting layer held the
+    // other seven waves at the barrier for 4-7 k cycles.)
+    __shared__ float jinj[MLDS ? PT * 8 : 1];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,6 +283,18 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     const int lg = lane / MS;              // lane group: k slot of the operands, feature sub-block of the accumulator
     const int NI = P.n_inputs;
 
+#ifdef SDFR_MLP_TRACE
+    // cycle stamps of workgroup 0, waves 0 and NW-1, lane 0:  trace[(wave ? 1 : 0)][layer][5] = layer start, product loop done, first barrier
+    // passed, epilogue done, second barrier passed (s_memtime ticks = shader cycles)
+#define SDFR_STAMP(l, i)                                                                                                   \
+    do {                                                                                                                   \
+        if (P.trace && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == NW - 1))                   \
+            P.trace[((wave ? 1 : 0) * SDFR_MAX_LAYERS + (l)) * 5 + (i)] = __builtin_amdgcn_s_memtime();                    \
+    } while (0)
+#else
+#define SDFR_STAMP(l, i) do { } while (0)
+#endif
+    SDFR_STAMP(8, 0);
     // ---- which rows does this tile hold ------------------------------------------------------------------
     // MODE 4: a pool of persistent workgroups; each trip of this loop fetches one tile (t_rt rays) from the launch's device counter and marches
     // it through the stage.  Every other mode: one trip, tile = blockIdx.x.
@@ -415,7 +452,11 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         tail_rows(pass_k(P.t_step0), true);
     }
     __syncthreads();
-    if (JAC) {
+    SDFR_STAMP(8, 1);
+    const bool jdir = MLDS && __builtin_amdgcn_readfirstlane((int)(P.L[0].in_dim <= 8 && NI <= 8)) != 0;
+    if (MLDS && jdir) {
+        for (int e = tid; e < PT * 8; e += NT) jinj[e] = 0.f;
+    } else if (JAC) {
         // J rows of this tile start at zero: every contribution to them (layer-0 in-gradient, re-injected columns) is an atomicAdd issued by
         // this workgroup after later barriers, so no separate memset launch is needed
         for (int e = tid; e < PT * NI; e += NT) {
@@ -448,7 +489,34 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     __syncthreads();
 
     const int fbase = wave * MS * FT;      // first feature row owned by this wave
+    if constexpr (MLDS) {
+        // This wave's 64 features of a row and layer are dwords 2 wave, 2 wave + 1 of the row's 64 bytes (layout v2): ONE 8-byte load per (row,
+        // layer).  The four lanes that share a row (lane groups lg = 0..3) divide the layers among themselves -- lane group lg fetches layers
+        // lg, lg + 4, ... -- and park the words in LDS, [wave][layer][row] (wave-private: producer and consumer lanes sit in the same wave, whose
+        // LDS operations execute in order; the barriers in front of the first use are there anyway).  2 NP loads per lane for 8 layers.
+        uint2* mst = reinterpret_cast<uint2*>(mlds) + (int64_t)wave * SDFR_MAX_LAYERS * PT;
+        const uint2* mb = reinterpret_cast<const uint2*>(P.maskbuf);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int64_t r = rows[p * MS + lp];
+            for (int ml = lg; ml < P.n_mfma; ml += NLG)
+                mst[ml * PT + p * MS + lp] = mb[(sdfr_mask_dword(r, ml, P.n_mfma, HP / 32, fbase)) >> 1];
+        }
+    }
     acc_t acc[FT][NP];
+    // MLDS kernels: the first weight fragments of the NEXT product are requested before the epilogue of the current one (they depend on
+    // nothing), so a layer's first matrix instruction does not wait for an L2 round trip (~1 k cycles of an idle matrix pipe per layer)
+    constexpr bool APRE = MLDS;
+    vec_t apre[APRE ? FT : 1];
+    bool have_pre = false;
+    auto preload_a = [&](const vec_t* __restrict__ Wl) {
+        if constexpr (APRE) {
+            const vec_t* ap = Wl + lg * HP + fbase + lp;
+#pragma unroll
+            for (int f = 0; f < FT; ++f) apre[f] = ap[f * MS];
+            have_pre = true;
+        }
+    };
 
     // One transposed GEMM over a K extent of `kpad` (a multiple of KT): acc[f][p] += W_tile(rows fbase+f*MS..) x act.
     // FULL: all FT feature tiles of this wave are active (straight-line MFMA stream, no branches);
@@ -482,9 +550,18 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             for (int f = 0; f < FT; ++f)
 #pragma unroll
                 for (int i = 0; i < KV; ++i) a[u][f][i] = (ET)0;
+        bool took_pre = false;
+        if constexpr (APRE && FULL) {
+            if (have_pre) {
+#pragma unroll
+                for (int f = 0; f < FT; ++f) a[0][f] = apre[f];
+                took_pre = true;
+            }
+            have_pre = false;
+        }
 #pragma unroll
         for (int u = 0; u < PF - 1; ++u)
-            if (u < nkt) load_a(u, a[u]);
+            if (u < nkt && !(u == 0 && took_pre)) load_a(u, a[u]);
 #pragma unroll
         for (int u = 0; u < PFB - 1; ++u)
             if (u < nkt) load_b(u, b[u]);
@@ -724,17 +801,6 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     };
 
     // ---- forward through the MFMA layers -------------------------------------------------------------------
-#ifdef SDFR_MLP_TRACE
-    // cycle stamps of workgroup 0, waves 0 and NW-1, lane 0:  trace[(wave ? 1 : 0)][layer][5] = layer start, product loop done, first barrier
-    // passed, epilogue done, second barrier passed (s_memtime ticks = shader cycles)
-#define SDFR_STAMP(l, i)                                                                                                   \
-    do {                                                                                                                   \
-        if (P.trace && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == NW - 1))                   \
-            P.trace[((wave ? 1 : 0) * SDFR_MAX_LAYERS + (l)) * 5 + (i)] = __builtin_amdgcn_s_memtime();                    \
-    } while (0)
-#else
-#define SDFR_STAMP(l, i) do { } while (0)
-#endif
     int* t_more = reinterpret_cast<int*>(gy);           // gy is unused by forward modes
     do {
     for (int l = 0; !GMASK && l < P.n_mfma; ++l) {
@@ -861,12 +927,19 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             for (int w = 0; w < MW; ++w) masks[(l * MW + w) * NT + tid] = mw[w];
         }
         if (SAVE && P.maskbuf) {
-            // [point tile][layer][word][thread]: bit ((f*NP + p)*4 + rg)*4 + i of the thread's mask (32x32 geometry)
-            uint32_t* dst = P.maskbuf + (((int64_t)tile * P.n_mfma + l) * MW) * NT + tid;
+            // layout v2 (sdfr_mask_dword): this thread's 16 bits of (feature tile f, point tile p) -- bits ((f*NP + p)*4 + rg)*4 + i of its mask
+            // words -- are one short of row tile*PT + p*32 + lp, dword (fbase >> 5) + f, half lg.  The 128-row block is uniform over the workgroup.
+            const int64_t row0 = (int64_t)tile * PT;
+            uint16_t* mb = reinterpret_cast<uint16_t*>(P.maskbuf) + (((row0 >> 7) * P.n_mfma + l) * 128) * (int64_t)(HP / 32) * 2;
 #pragma unroll
-            // (streaming / non-temporal stores measured equal, r03: the masks cost 3-7 % of a forward through the epilogue's instruction count,
-            // not through L2 pollution -- tools/mask_cost.py)
-            for (int w = 0; w < MW; ++w) dst[w * NT] = mw[w];
+            for (int p = 0; p < NP; ++p) {
+                const int off = (((int)(row0 & 127) + p * MS + lp) * (HP / 32) + (fbase >> 5)) * 2 + lg;
+#pragma unroll
+                for (int f = 0; f < FT; ++f) {
+                    const int fi = f * NP + p;
+                    mb[off + 2 * f] = (uint16_t)(mw[fi >> 1] >> ((fi & 1) * 16));
+                }
+            }
         }
         SDFR_STAMP(l, 3);
         __syncthreads();
@@ -1013,22 +1086,16 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     }
     if constexpr (JAC) {
     __syncthreads();
+    SDFR_STAMP(8, 2);
 
     // ---- backward: d out / d inputs for every point of the tile ---------------------------------------------
     // in-gradient of layer l (features k = in-features of layer l) -> masked operand for layer l-1, or J
-    // MODE 3: the saved mask words of layer l-1 for this lane's features and point, fetched from HBM/L2.  Issued BEFORE the product of
-    // layer l (they do not depend on it), so their latency is hidden behind the K loop instead of sitting in front of the epilogue.
-    // Forward launch layout (32x32 tiles, P.fwd_np point tiles per workgroup, NWF waves of FTF feature tiles): feature j, point q of the
-    // forward tile -> bit (((j/32) % FTF * np + q/32)*4 + (j%32)/8)*4 + j%4 of thread (j / (32*FTF))*64 + ((j%32)/4 % 2)*32 + q%32
-    constexpr int NWF = (HP == 512) ? 8 : 4;                            // waves of the forward kernel for this padded width (mlp.hip mask_geometry)
-    constexpr int FTF = HP / (32 * NWF), NTF = 64 * NWF;
+    // MODE 3 (kernels without MLDS): the saved mask dword of layer l-1 for this lane's features and point (layout v2: sdfr_mask_dword), fetched
+    // from HBM/L2.  Issued BEFORE the product of layer l (they do not depend on it), so their latency is hidden behind the K loop instead of
+    // sitting in front of the epilogue.
     auto mask_addr = [&](int j, int r, int l, int& shift) -> int64_t {
-        const int np = P.fwd_np;
-        const int tile = r / (32 * np), q = r - tile * (32 * np);
-        const int mwf = FTF * np / 2;                                   // mask words per thread of the forward kernel
-        const int fbit = ((((j >> 5) % FTF) * np + (q >> 5)) * 4 + ((j & 31) >> 3)) * 4;
-        shift = fbit & 31;
-        return (((int64_t)tile * P.n_mfma + (l - 1)) * mwf + (fbit >> 5)) * NTF + (j / (32 * FTF)) * 64 + (((j & 31) >> 2) & 1) * 32 + (q & 31);
+        shift = sdfr_mask_shift(j);
+        return sdfr_mask_dword(r, l - 1, P.n_mfma, HP / 32, j);
     };
     auto fetch_masks = [&](int l, uint32_t* raw) {
 #pragma unroll
@@ -1047,6 +1114,52 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
         const MlpLayer L = P.L[l];
         const int prev_out = P.L[l - 1].out_dim;
         const int inj_hi = prev_out + L.inj_n;
+        if constexpr (MLDS) {
+            // masks of layer l-1 from LDS: the row's two dwords of this wave's features; feature tile f, value i of this lane is bit
+            // sdfr_mask_shift(16 f + 4 lg + i) = (lg & 1) * 16 + (lg >> 1) * 4  +  (f & 1) * 8 + i  of dword f >> 1 -- one per-lane shift per dword,
+            // then compile-time positions: a value costs one v_bfe_i32 (0 / -1) and one v_and
+            const uint2* mst = reinterpret_cast<const uint2*>(mlds) + ((int64_t)wave * SDFR_MAX_LAYERS + (l - 1)) * PT;
+            const int msh = (lg & 1) * 16 + (lg >> 1) * 4;
+            uint32_t mk[NP][2];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const uint2 m2 = mst[p * MS + lp];
+                mk[p][0] = m2.x >> msh; mk[p][1] = m2.y >> msh;
+            }
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+                const int j0 = feat0(f, 0);
+                // features >= prev_out (padding, re-injected input columns) sit in the last feature tile(s) of the last wave of one or two layers
+                const bool tail_f = __builtin_amdgcn_readfirstlane((int)(fbase + (f + 1) * MS > prev_out)) != 0;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int pt = p * MS + lp;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x = value(f, p, 0, i, j0 + i, pt);
+                        const int m = __builtin_amdgcn_sbfe((int)mk[p][f >> 1], (f & 1) * 8 + i, 1);
+                        v[i] = __int_as_float(__float_as_int(x) & m);
+                    }
+                    if (tail_f) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int k = j0 + i;
+                            if (k >= prev_out) {
+                                if (k < inj_hi) {
+                                    // (one lane per (point, column) and layer; layers are separated by barriers: a plain LDS update)
+                                    if (jdir) jinj[pt * 8 + L.inj_off + (k - prev_out)] += value(f, p, 0, i, k, pt);
+                                    else if (slots[pt] >= 0) atomicAdd(P.J + (int64_t)slots[pt] * NI + L.inj_off + (k - prev_out), value(f, p, 0, i, k, pt));
+                                }
+                                v[i] = 0.f;
+                            }
+                        }
+                    }
+                    store4(act_e + ((j0 / KV) * PT + pt) * KV + (j0 % KV), v);
+                }
+            }
+            return;
+        }
         uint32_t mw[MW];
         if (GMASK) {
 #pragma unroll
@@ -1166,12 +1279,78 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
 
     // top: in-gradient of the last linear = w_last[k] * gy[pt]
     uint32_t raw[NP * FT * RG];
-    if (GMASK) fetch_masks(P.n_mfma, raw);
+    if (GMASK && !MLDS) fetch_masks(P.n_mfma, raw);
+    SDFR_STAMP(8, 3);
+    if constexpr (MLDS) {
+        if (P.n_mfma >= 1 && !(P.n_mfma - 1 == 0 && P.L[0].in_dim <= 8))
+            preload_a(reinterpret_cast<const vec_t*>(P.Wbh) + P.L[P.n_mfma - 1].off_bh);
+        float4 wl[FT];
+        float gyp[NP];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) wl[f] = *reinterpret_cast<const float4*>(P.w_last + feat0(f, 0));
+#pragma unroll
+        for (int p = 0; p < NP; ++p) gyp[p] = gy[p * MS + lp];
+        store_in_grad(P.n_mfma, raw, [&](int f, int p, int, int i, int, int) { return f4c(wl[f], i) * gyp[p]; });
+    } else
     store_in_grad(P.n_mfma, raw, [&](int, int, int, int, int k, int pt) { return P.w_last[k] * gy[pt]; });
     __syncthreads();
+    SDFR_STAMP(8, 4);
     for (int l = P.n_mfma - 1; l >= 0; --l) {
         const MlpLayer L = P.L[l];
-        if (l == 0 && L.in_dim <= 8) {
+        if constexpr (MLDS) {
+          if (l == 0 && L.in_dim <= 8) {
+            // First layer, at most 8 inputs (latent + xyz): the transposed product has ONE 16-row feature tile, i.e. work for one wave, K tile
+            // after K tile.  Here the K extent (the layer's 512 out-features) is split over the 8 waves instead -- each wave two K tiles of the
+            // half weight image on the matrix pipe, partial sums through LDS, added in wave order -- the same instruction sequence per point
+            // on every tile geometry, so a row's J has the same bits whichever launch computed it.  (r05: a VALU product against the float32
+            // image, every lane loading the same 16 bytes per feature: 18 k cycles per 64-row tile, paced by the L1 return path.)
+            constexpr int TPW = (HP / KT) / NW;
+            const vec_t* Wl = reinterpret_cast<const vec_t*>(P.Wbh) + L.off_bh;
+            const int nkt = L.kp_bh / KT;
+            acc_t a0[NP];
+            vec_t av[TPW], bv[TPW][NP];
+            SDFR_STAMP(9, 0);
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                const int t = wave * TPW + u;
+#pragma unroll
+                for (int i = 0; i < KV; ++i) av[u][i] = (ET)0;
+                if (t < nkt) av[u] = Wl[(int64_t)(t * NLG + lg) * HP + lp];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bv[u][p] = act[(t * NLG + lg) * PT + p * MS + lp];
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a0[p][r] = 0.f;
+#pragma unroll
+                for (int u = 0; u < TPW; ++u) a0[p] = M::step(av[u], bv[u][p], a0[p], 0);
+            }
+            SDFR_STAMP(9, 1);
+            // partial J columns 4 lg .. 4 lg + 3 of point p*16 + lp -> [wave][point][8] (the mask words are dead: their LDS is the scratch)
+            float* part = reinterpret_cast<float*>(mlds);
+            if (lg < 2) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    *reinterpret_cast<float4*>(part + ((wave * PT + p * MS + lp) * 8 + 4 * lg)) = make_float4(a0[p][0], a0[p][1], a0[p][2], a0[p][3]);
+            }
+            __syncthreads();
+            for (int e = tid; e < 8 * PT; e += NT) {
+                const int q = e >> 3, k = e & 7;
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += part[(w * PT + q) * 8 + k];
+                if (k < NI && slots[q] >= 0) {
+                    if (k >= L.in_dim) t = 0.f;
+                    if (jdir) P.J[(int64_t)slots[q] * NI + k] = jinj[q * 8 + k] + t;
+                    else atomicAdd(P.J + (int64_t)slots[q] * NI + k, t);
+                }
+            }
+            SDFR_STAMP(9, 2);
+            break;
+          }
+        }
+        if (!MLDS && l == 0 && L.in_dim <= 8) {
             // The first layer of a DeepSDF decoder has a handful of inputs (latent + xyz): its transposed product is 8 x HP x PT multiply-adds,
             // which one wave would do alone on the matrix pipe, K tile after K tile (20 k cycles of exposed latency).  Here every thread
             // takes one point and HP / (NT / PT) features on the VALU, and the partial sums are added in a fixed order.
@@ -1184,23 +1363,42 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             constexpr int PARTS = (TPP < PMIN) ? PMIN : TPP, PPT = PARTS / TPP, JS = HP / PARTS;
             static_assert(NT % PT == 0 && HP % PARTS == 0 && PARTS % TPP == 0 && PARTS * 8 * PT * 4 <= KG * PT * 16,
                           "first-layer reduction scratch fits the operand tile");
-            const int pt = tid % PT, t0 = tid / PT;
+            // (tiles of 64 rows or more: a wave's threads share their block of features, so the weight rows are wave-uniform -- scalar loads
+            // through the constant cache instead of 128 vector loads of 16 bytes per thread, which the L1 path paced at 18 k cycles per tile)
+            const int pt = tid % PT, t0 = (PT % 64 == 0) ? __builtin_amdgcn_readfirstlane(tid / PT) : tid / PT;
             const float4* W0 = P.Wf + L.off_f;                   // forward image of layer 0: W0[(k/4)*HP + j] = W[j][k..k+3]
             float s8[PPT][8];
+            SDFR_STAMP(9, 0);
 #pragma unroll
             for (int q = 0; q < PPT; ++q) {
                 const int part = t0 * PPT + q;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) s8[q][k] = 0.f;
-#pragma unroll 4
-                for (int jj = 0; jj < JS; ++jj) {
+#pragma unroll 8
+                for (int jj = 0; jj < JS; ++jj) {                // (8 steps unrolled: 16 weight loads in flight -- unrolled by 4 the loop was a chain of 16 exposed L1 / L2 latencies)
                     const int j = part * JS + jj;
                     const float g = (float)act_e[((j / KV) * PT + pt) * KV + (j % KV)];
-                    const float4 wa = W0[j], wb = (L.kp_f > 4) ? W0[HP + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 wa, wb;
+                    if constexpr (PT % 64 == 0) {
+                        // wave-uniform rows of a read-only image: through the constant address space, i.e. scalar loads (s_load_dwordx4) into
+                        // SGPRs -- as vector loads every lane fetched the same 16 bytes, and writing 64 copies of them into the VGPRs paced
+                        // the whole step at the L1 return path's 64 B/clk (18 k cycles per tile)
+                        typedef const f32x4 __attribute__((address_space(4))) * cf4p;
+                        const cf4p W0c = (cf4p)(uintptr_t)W0;
+                        const f32x4 va = W0c[j];
+                        f32x4 vb = {0.f, 0.f, 0.f, 0.f};
+                        if (L.kp_f > 4) vb = W0c[HP + j];
+                        wa = make_float4(va[0], va[1], va[2], va[3]);
+                        wb = make_float4(vb[0], vb[1], vb[2], vb[3]);
+                    } else {
+                        wa = W0[j];
+                        wb = (L.kp_f > 4) ? W0[HP + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                     s8[q][0] = fmaf(wa.x, g, s8[q][0]); s8[q][1] = fmaf(wa.y, g, s8[q][1]); s8[q][2] = fmaf(wa.z, g, s8[q][2]); s8[q][3] = fmaf(wa.w, g, s8[q][3]);
                     s8[q][4] = fmaf(wb.x, g, s8[q][4]); s8[q][5] = fmaf(wb.y, g, s8[q][5]); s8[q][6] = fmaf(wb.z, g, s8[q][6]); s8[q][7] = fmaf(wb.w, g, s8[q][7]);
                 }
             }
+            SDFR_STAMP(9, 1);
             __syncthreads();                                    // every thread has read its in-gradients: the tile becomes scratch
             float* scr = reinterpret_cast<float*>(lds4);
 #pragma unroll
@@ -1214,15 +1412,24 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                 for (int r = 0; r < PARTS; ++r) t += scr[(r * 8 + k) * PT + q];
                 if (k < NI && k < L.in_dim && slots[q] >= 0) atomicAdd(P.J + (int64_t)slots[q] * NI + k, t);
             }
+            SDFR_STAMP(9, 2);
             break;
         }
-        if (GMASK && l > 0) fetch_masks(l, raw);
+        SDFR_STAMP(l, 0);
+        if (GMASK && !MLDS && l > 0) fetch_masks(l, raw);
         gemm(reinterpret_cast<const vec_t*>(HALF ? (const void*)P.Wbh : (const void*)P.Wb) + (HALF ? L.off_bh : L.off_b), HALF ? L.kp_bh : L.kp_b,
              L.in_dim);
+        SDFR_STAMP(l, 1);
         __syncthreads();
+        SDFR_STAMP(l, 2);
         if (l > 0) {
+            if constexpr (MLDS) {
+                if (!(l - 1 == 0 && P.L[0].in_dim <= 8)) preload_a(reinterpret_cast<const vec_t*>(P.Wbh) + P.L[l - 1].off_bh);
+            }
             store_in_grad(l, raw, [&](int f, int p, int rg, int i, int, int) { return acc[f][p][rg * 4 + i]; });
+            SDFR_STAMP(l, 3);
             __syncthreads();
+            SDFR_STAMP(l, 4);
             } else {
 #pragma unroll
             for (int f = 0; f < FT; ++f)

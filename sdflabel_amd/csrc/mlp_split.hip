@@ -16,8 +16,8 @@
 // one is paced by the weight stream through the CU's 64 B/clk vector-memory path (1 MiB of hi+lo weights per layer per 64 points needs
 // 2/3 of that path at full MFMA rate); a larger point tile would need more than the CU's 160 KiB of LDS for the operand planes.
 //
-// Geometry is the f32 forward's (8 waves, 64-point tiles, wave w owns features [64w, 64w+64)), so the ReLU masks it saves have the
-// same layout and the mask-fed float32 Jacobian kernel consumes them unchanged.  LDS: 128 KiB of operands (hi and lo rows interleaved).
+// Geometry is the f32 forward's (8 waves, 64-point tiles, wave w owns features [64w, 64w+64)); the ReLU masks are saved in the library's
+// one layout (mlp_kernel.h: sdfr_mask_dword) and the mask-fed Jacobian kernels consume them like any other forward's.  LDS: 128 KiB of operands (hi and lo rows interleaved).
 // Follows Decoder.forward, reference sdfrenderer/deepsdf/networks/deep_sdf_decoder_scale.py:78-107.
 #include "mlp_kernel.h"
 #ifndef SDFR_S_PF
@@ -180,9 +180,18 @@ __global__ __launch_bounds__(64 * NW, 1) void sdfr_mlp_split_kernel(const MlpPar
                 }
             }
         if (SAVE && P.maskbuf) {
-            uint32_t* dst = P.maskbuf + (((int64_t)blockIdx.x * P.n_mfma + l) * MW) * NT + tid;
+            // mask layout v2 (mlp_kernel.h: sdfr_mask_dword): this thread's 16 bits of (feature tile f, point tile p) are one short of row
+            // r0 + p*32 + lp, dword (fbase >> 5) + f, half lg
+            uint16_t* mb = reinterpret_cast<uint16_t*>(P.maskbuf) + (((r0 >> 7) * P.n_mfma + l) * 128) * (int64_t)(HP / 32) * 2;
 #pragma unroll
-            for (int w = 0; w < MW; ++w) dst[w * NT] = mw[w];
+            for (int p = 0; p < NP; ++p) {
+                const int off = (((int)(r0 & 127) + p * MS + lp) * (HP / 32) + (fbase >> 5)) * 2 + lg;
+#pragma unroll
+                for (int f = 0; f < FT; ++f) {
+                    const int fi = f * NP + p;
+                    mb[off + 2 * f] = (uint16_t)(mw[fi >> 1] >> ((fi & 1) * 16));
+                }
+            }
         }
         __syncthreads();
     }

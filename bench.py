@@ -48,7 +48,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, v_mf
 D, H, W = 40, 256, 256
 
 
-from sdflabel_amd.fixtures import ASSET, K_for, crop_params, crop_start, fitted_state, synthetic_targets  # noqa: E402
+from sdflabel_amd.fixtures import ASSET, K_for, crop_params, crop_start, fitted_state, kitti_like_problems, synthetic_targets  # noqa: E402
 
 
 def build_pose(yaw, trans):
@@ -164,7 +164,9 @@ CANNED_LINE = {
     "cpu_baseline": {"value": 6137.024, "unit": "rays/s", "cores": 8, "kind": "port", "host_cores": 256, "sample": "z" * 900,
                      "by_threads": {"8": {}, "32": {}}, "seconds_per_crop_iteration_samples": [10.6, 10.7, 10.8]},
     "refine_sharded": {"crops_per_s": 9.508298, "total_crops": 1024, "iterations_per_crop": 60, "workload": "w" * 400},
-    "refine_sharded_float16": {"crops_per_s": 71.89664, "total_crops": 1024, "iterations_per_crop": 60},
+    "refine_sharded_float16": {"crops_per_s": 71.89664, "total_crops": 1024, "iterations_per_crop": 60, "candidate_reuse": True,
+                               "full_grid_passes_per_crop_last_chunk_mean": 1.0},
+    "refine_sharded_area32": {"crops_per_s": 301.5, "total_crops": 1024, "workload": "a" * 400},
     "sphere_trace": {"f16_64_steps": {"note": "n" * 5000}}, "dropin_api": {"launches": {"k": list(range(500))}}, "per_rank_ms_per_step": [1.9] * 8,
 }
 
@@ -201,6 +203,11 @@ def compact_line(full, extras_path=None):
             ref["iterations_per_crop"] = sec.get("iterations_per_crop")
             if "candidate_reuse" in sec:                     # (bit-identical to evaluating every grid row every iteration; the full-grid figures are in the extras)
                 ref[name + "_candidate_reuse"] = bool(sec["candidate_reuse"])
+            if "full_grid_passes_per_crop_last_chunk_mean" in sec:      # (of iterations_per_crop decoder steps, how many ran the whole grid)
+                ref[name + "_full_grid_passes_per_crop"] = _num(float(sec["full_grid_passes_per_crop_last_chunk_mean"]))
+    a32 = full.get("refine_sharded_area32")
+    if isinstance(a32, dict) and "crops_per_s" in a32:       # the reference's shipped operating point (rendering_area 32, float16), batched
+        ref["area32_f16_crops_per_s"] = _num(float(a32["crops_per_s"]))
     out["refine"] = ref or None
     out["extras"] = extras_path
     line = json.dumps(out)
@@ -588,6 +595,17 @@ def main():
     # Three decoder arithmetics, labelled: exact float32 (the parity path, headline), float16 (the reference's shipped precision,
     # config_refine.ini:19; pinned to the reference's own float16 trajectory, golden G8h) and float32_prefilter + candidate reuse (exact
     # float32 on everything consumed downstream; guarded at run time); and the configs[4] shape (512x512 rays, float16 decoder).
+    def phase_table(tm):
+        """every rank's seconds in set_crops / optimize (enqueue + GPU, synchronised per chunk) / all_gather of a sharded section, gathered on all
+        ranks (r06: under world > 1 the driver's curve can be read -- which phase stops scaling)"""
+        keys = ("set_crops", "optimize", "all_gather", "chunks")
+        mine = torch.tensor([float(tm.get(k, 0.0)) for k in keys], dtype=torch.float64, device=dev)
+        rows = [mine]
+        if dist is not None:
+            rows = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(rows, mine)
+        return {"rank_%d" % r: {k: float(v) for k, v in zip(keys, row.tolist())} for r, row in enumerate(rows)}
+
     def sharded_section(label, precision, reuse, size, total, workload, render="splat"):
         chunk = max(1, min(64, (total + world - 1) // world))
         Kc = K_for(size, size)
@@ -606,13 +624,15 @@ def main():
 
         def run(st):
             rf, params, nocs1, lidar = st[:4]
-            st.append(refine_sharded(rf, params, nocs1, lidar, args.sharded_iters, rank, world))
+            tm = {}
+            st.append(refine_sharded(rf, params, nocs1, lidar, args.sharded_iters, rank, world, timing=tm))
+            st.append(tm)
 
         res_, err_ = timed_section(setup, run)
         if res_ is None:
             return {"label": label, "error": err_}
         st, dt_s = res_
-        rf, table = st[0], st[-1]
+        rf, table, tm = st[0], st[-2], st[-1]
         ok = tuple(table.shape) == (total, 7 + rf.L) and bool(torch.isfinite(table).all())
         p_all = st[1]
         out = {"label": label, "workload": workload % (total, size, size, world, chunk), "decoder_precision": str(precision).replace("torch.", ""),
@@ -622,7 +642,8 @@ def main():
                "mean_abs_yaw_error_before_after": [float(np.abs(p_all["yaw"] - 0.6).mean()), float((table[:, 0] - 0.6).abs().mean())],
                "gathered_row": "yaw, trans(3), scale, latent(%d), weighted 2-D loss, weighted 3-D loss" % rf.L,
                "mean_weighted_losses_2d_3d_after": [float(table[:, -2].mean()), float(table[:, -1].mean())],
-               "gathered_table_ok": ok, "scaling": "strong (total crops fixed): speed-up at N ranks = seconds(N=1) / seconds(N)"}
+               "gathered_table_ok": ok, "scaling": "strong (total crops fixed): speed-up at N ranks = seconds(N=1) / seconds(N)",
+               "per_rank_phase_seconds": phase_table(tm)}
         if render != "splat":
             out["renderer"] = "sphere tracer (BatchRefiner(render='trace'), surfel-semantics backward): not the reference's algorithm"
         if rf.br is not None and getattr(rf.br, "guarded", False):
@@ -635,8 +656,59 @@ def main():
         del st, rf
         return out
 
-    sharded = sharded_full = sharded16 = sharded16_full = sharded_pf = sharded_c4 = sharded_tr = None
+    # ---- the reference's SHIPPED operating point, batched: configs/config_refine.ini:11-19 = grid_density 40, rendering_area 32,
+    # iters 60, precision float16.  `total` KITTI-like crops (64 distinct problems of sdflabel_amd.fixtures.kitti_like_problems: every crop its own
+    # (H_b, W_b) with H_b W_b ~ 32^2 and its own intrinsics, utils/refinement.py:586-609; repeated to `total` with per-crop starts), sharded crop i ->
+    # rank i mod N, ragged chunks of 64 through ONE BatchRefiner(max_pixels=...) and ONE captured graph, one all_gather.
+    def sharded_area32(total, area=32):
+        chunk = max(1, min(64, (total + world - 1) // world))
+        distinct = 64
+
+        def setup():
+            d2, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float16)
+            d2.candidate_reuse = True
+            d2 = d2.to(dev)
+            shapes, Ks, targets, lidars, starts = kitti_like_problems(dec, D, area, distinct, dev)
+            pmax = max(1024, 1 << (max(h * w for h, w in shapes) - 1).bit_length())
+            rf = sdflabel_amd.BatchRefiner(d2, D, Ks[0], shapes[0], chunk, lidar_cap=max(1024, 1 << (max(l.shape[0] for l in lidars) - 1).bit_length()),
+                                           device=dev, max_pixels=pmax, candidate_reuse=True)
+            ids = [i % distinct for i in range(total)]
+            params = {k: np.stack([starts[j][k].reshape(-1) for j in ids]) for k in ("yaw", "trans", "scale", "latent")}
+            params["yaw"] = params["yaw"] + 0.01 * (np.arange(total, dtype=np.float32) // distinct).reshape(-1, 1)      # (repeats start elsewhere)
+            sel = list(range(chunk))
+            rf.set_crops({k: v[sel] for k, v in params.items()}, [targets[ids[i]] for i in sel], [lidars[ids[i]] for i in sel],
+                         K=np.stack([Ks[ids[i]] for i in sel]), crop_sizes=[shapes[ids[i]] for i in sel])
+            rf.capture()
+            rf.optimize(2)
+            return [rf, params, [targets[j] for j in ids], [lidars[j] for j in ids], np.stack([Ks[j] for j in ids]), [shapes[j] for j in ids], shapes]
+
+        def run(st):
+            rf, params, tg, li, Kall, sz = st[:6]
+            tm = {}
+            st.append(refine_sharded(rf, params, tg, li, args.sharded_iters, rank, world, K=Kall, crop_sizes=sz, timing=tm))
+            st.append(tm)
+
+        res_, err_ = timed_section(setup, run)
+        if res_ is None:
+            return {"error": err_}
+        st, dt_s = res_
+        rf, table, tm, shapes = st[0], st[-2], st[-1], st[6]
+        y0 = st[1]["yaw"].reshape(-1)
+        out = {"label": "the reference's shipped operating point (configs/config_refine.ini:11-19), batched: float16 decoder, candidate reuse, ragged crops",
+               "workload": "%d KITTI-like crops at rendering_area %d (own (H, W) and K per crop, %d distinct problems), 60 iterations, sharded crop i -> rank i mod %d, "
+                           "ragged chunks of %d through one BatchRefiner + one captured graph, one all_gather" % (total, area, distinct, world, chunk),
+               "total_crops": total, "iterations_per_crop": args.sharded_iters, "world_size": world, "seconds": dt_s, "crops_per_s": total / dt_s,
+               "crop_sizes_h_w_min_max": [list(min(shapes)), list(max(shapes))], "rendering_area": area, "graph_captures": getattr(rf, "captures", None),
+               "mean_abs_yaw_error_before_after": [float(np.abs(y0 - 0.6).mean()), float((table[:, 0] - 0.6).abs().mean())],
+               "gathered_table_ok": tuple(table.shape) == (total, 7 + rf.L) and bool(torch.isfinite(table).all()),
+               "candidate_reuse": bool(rf.br.creuse), "full_grid_passes_per_crop_last_chunk_mean": float(rf.br.n_full.float().mean()),
+               "guard": rf.br.prefilter_report(), "per_rank_phase_seconds": phase_table(tm)}
+        del st, rf
+        return out
+
+    sharded = sharded_full = sharded16 = sharded16_full = sharded_pf = sharded_c4 = sharded_tr = sharded_a32 = None
     if args.total_crops > 0 and not args.no_extras and CB == 1:
+        sharded_a32 = sharded_area32(args.total_crops)
         wl = ("BASELINE configs[3]: %d crops of %dx%d rays sharded crop i -> rank i mod %d, chunks of %d through BatchRefiner (reference losses + "
               "solver, HIP-graph replay), one all_gather of the result rows")
         sharded = sharded_section("exact float32 decoder (parity path); candidate reuse: the exact-f32 kernels run on the band candidates alone while a "
@@ -858,9 +930,9 @@ def main():
                 # the advance / compaction kernel of the head steps against the HBM roofline: algorithmic bytes per active ray and step (read: pixel 4,
                 # state 16, sdf 4, far 4; written for a surviving ray: pixel 4, state 16, decoder row 4 (L + 3)) and, from the PMC passes of an
                 # earlier run of tools/sphere_pmc.sh (not measured in this run), the counter bytes and rate per launch
-                sps = os.path.join(ROOT, "profiles", "traffic_sphere_step.json")
-                if label == "f16_64_steps" and os.path.isfile(sps):
-                    tj = json.load(open(sps))
+                from sdflabel_amd._lib import stored_traffic
+                tj = stored_traffic(ROOT, "traffic_sphere_step.json")            # None unless measured on this tree's trace.hip
+                if label == "f16_64_steps" and tj is not None:
                     sphere[label]["step_kernel_hbm"] = {"bound": "hbm", "algorithmic_bytes_per_ray_step": 28 + 20 + 4 * (tr.L + 3),
                                                         "achieved": tj.get("GBps"), "peak": 8000.0, "unit": "GB/s",
                                                         "frac": (tj.get("GBps") or 0.0) / 8000.0, "traffic": tj.get("hbm_bytes_per_launch"),
@@ -958,9 +1030,10 @@ def main():
         flops = 2.0 * macs * G * CB
         ach = flops / (mlp_ms * 1e-3) / 1e12
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_mlp_forward.json")
-        if os.path.isfile(tpath) and CB == 1:      # the committed PMC passes profiled the single-crop launch
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        from sdflabel_amd._lib import stored_traffic
+        tfile = stored_traffic(ROOT, "traffic_mlp_forward.json")        # None unless measured on THIS tree's kernel sources (hash inside)
+        if tfile is not None and CB == 1:          # the committed PMC passes profiled the single-crop launch
+            traffic = tfile.get("hbm_bytes_per_launch")
         line["roofline"] = {"kernel": "sdfr_mlp_kernel<float,32,2,2,8,2,1,2> (fused decoder forward on the grid, saves ReLU masks)", "bound": "mfma",
                             "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                             "traffic": traffic, "traffic_source": "profiles/traffic_mlp_forward.json (rocprofv3 PMC passes FETCH_SIZE x2 + WRITE_SIZE of an "
@@ -971,8 +1044,7 @@ def main():
                             "ms_per_step": dt_long / long_steps * 1e3, "note": "the same step timed over >= 200 steps and >= 0.5 s"}
         nbytes = 64.0 * H * W * CB + 72.0 * float(br.cnt.sum()) + 48.0 * float(br.fcnt.sum())          # 64 P + 72 N + 48 N_f per crop, fwd+bwd
         ach_s = nbytes / ((kms["splat_fwd"] + kms["splat_bwd"]) * 1e-3) / 1e9
-        tsp = os.path.join(ROOT, "profiles", "traffic_splat.json")
-        tsplat = json.load(open(tsp)) if os.path.isfile(tsp) else {}
+        tsplat = stored_traffic(ROOT, "traffic_splat.json") or {}
         if splat64 is not None and "error" not in splat64:
             splat64["traffic"] = tsplat.get("crops_64")
         line["roofline_splat"] = {"kernel": "sdfr_splat_fwd_kernel<0> + sdfr_splat_bwd_kernel<0> (surfel splat / depth-softmax composite and its backward)",
@@ -995,6 +1067,7 @@ def main():
         line["refine_sharded_full_grid"] = sharded_full
         line["refine_sharded_float16"] = sharded16
         line["refine_sharded_float16_full_grid"] = sharded16_full
+        line["refine_sharded_area32"] = sharded_a32
         line["refine_sharded_prefilter"] = sharded_pf
         line["refine_sharded_configs4"] = sharded_c4
         line["refine_sharded_traced"] = sharded_tr

@@ -235,6 +235,34 @@ class _NoGuard:
 _NO_GUARD = _NoGuard()
 
 
+TRAFFIC_SOURCES = {          # the csrc files that define the kernels a profiles/traffic_*.json file was measured on (bench.py, tools/summarize_profile.py)
+    "traffic_mlp_forward.json": ("mlp_kernel.h", "mlp.hip", "mlp_fwd32.hip", "sdfr_common.h"),
+    "traffic_splat.json": ("splat.hip", "splat_bbox.h", "sdfr_common.h"),
+    "traffic_sphere_step.json": ("trace.hip", "sdfr_common.h"),
+}
+
+
+def source_sha16(names):
+    """first 16 hex digits of the SHA-256 over the named csrc files: stored in profiles/traffic_*.json when the PMC passes are summarised, compared
+    by bench.py before it quotes the stored figure (a figure measured on other kernel sources is reported as traffic: null)"""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def stored_traffic(root, name):
+    """profiles/<name> as a dict if it exists AND was measured on the kernel sources of this tree, else None (old files without a hash: None)"""
+    import json
+    path = os.path.join(root, "profiles", name)
+    if not os.path.isfile(path):
+        return None
+    d = json.load(open(path))
+    return d if d.get("source_sha16") == source_sha16(TRAFFIC_SOURCES[name]) else None
+
+
 def guard(t):
     """Context manager making the device of tensor (or torch.device) `t` current, as every kernel launch needs: the launch stream
     (stream_ptr) and any allocation inside the library then belong to the device that holds the data, whatever the caller's current

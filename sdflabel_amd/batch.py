@@ -166,18 +166,19 @@ class BatchRenderer:
         want_reuse = bool(getattr(decoder, "candidate_reuse", False)) if candidate_reuse is None else bool(candidate_reuse)
         # ... for the float16 decoder AND for the exact-float32 one (prec == torch.float32: the parity path -- the same scheme with the f32 kernels)
         self.creuse = (self.f16 or prec == torch.float32) and want_reuse and self.handle.hp == 512 and not self.handle.has_ln
+        self.reuse_off_reason = None
+        if want_reuse and not self.creuse:
+            self.reuse_off_reason = "candidate reuse needs a float16 / float32 decoder of padded width 512 without LayerNorm"
         if self.creuse:
             Lh = _lib.lib()
-            self.cstride = (cap + 127) // 128 * 128
-            cs = self.cstride
-            self.cidx, self.ccnt, self.cslot, self.cpos = i(B, cs), i(B), i(B * G), i(B, cap)
-            self.crow, self.csdf = f(B * cs, NI), f(B * cs)
-            self.cmask = i(int(Lh.sdfr_decoder_mask_words(self.handle.h, B * cs)))
-            # Kernel errors for the proof's budget.  E32: the exact-f32 kernel against the decoder in exact arithmetic -- 1.6e-7 measured against
-            # a float64 evaluation (Decoder.forward_float64; asserted < 1e-6 by tests/test_gpu_candidate_reuse.py, not re-measured at every
-            # construction: a float64 GEMM stack costs seconds to load).  The half kernel's deviation is calibrated here against the exact-f32
-            # kernel on the grid for four unit latents (2.6e-4 on the shipped decoder), + E32.
-            E32 = 1e-6
+            # Kernel errors for the proof's budget (the guarantee is "PROVEN Lipschitz bound + CALIBRATED kernel errors with a safety
+            # factor + run-time audit", not a proof end to end).
+            #   E32: the exact-f32 kernel against the decoder in exact arithmetic, MEASURED per decoder (Decoder.kernel_error_f32: 1024 rows against
+            #        a float64 evaluation on the host, cached per parameter set; 1.6e-7 on the shipped decoder), times 4, at least 1e-6.
+            #   e16: the half kernel's deviation from the exact-f32 kernel on the grid for four unit latents (2.6e-4 on the shipped decoder), times
+            #        decoder.candidate_error_safety (default 2: the sample maximum over 4 latents is not a bound), + E32.
+            safety = float(getattr(decoder, "candidate_error_safety", 2.0))
+            E32 = max(1e-6, 4.0 * float(decoder.kernel_error_f32(dev)))
             gen = torch.Generator().manual_seed(0)
             s32, s16 = f(G), f(G)
             dev16 = 0.0
@@ -188,6 +189,8 @@ class BatchRenderer:
                 _lib.check(Lh.sdfr_mlp_forward_f16(self.handle.h, _lib.ptr(inp), G, _lib.ptr(s16), None, _lib.stream_ptr()), "sdfr_mlp_forward_f16")
                 dev16 = max(dev16, float((s32 - s16).abs().max()))
             self.calib_inputs = inp                # (tests: the last calibration rows, to check E32 against float64)
+            self.f16_deviation_sampled, self.e32 = dev16, E32
+            dev16 = safety * dev16
             # exact-f32 mode: the FULL-GRID pass only selects candidates -- every value consumed downstream comes from the exact kernel on the
             # candidates -- so it may run in half (decoder.candidate_select = "float16", the default; "float32": the exact kernel).  A row it
             # leaves out had |half value| >= thr + margin, i.e. |exact value| >= thr + margin - e_sel; margin >= 4 e_sel keeps the proof's budget
@@ -195,11 +198,31 @@ class BatchRenderer:
             self.select_half = (not self.f16) and str(getattr(decoder, "candidate_select", "float16")) == "float16"
             self.f16_error = (dev16 + E32) if self.f16 else E32          # the mode's own kernel against exact arithmetic
             self.select_error = (dev16 + E32) if self.select_half else self.f16_error
-            self.margin = max(self.margin, 4.0 * max(self.f16_error, self.select_error))
+            need = 4.0 * max(self.f16_error, self.select_error)
+            # a decoder whose kernel error needs a margin beyond decoder.candidate_max_margin (default: the band threshold itself -- the candidate
+            # set would be more than twice the band) gets NO reuse: every step evaluates the whole grid, as the reference does
+            max_margin = float(getattr(decoder, "candidate_max_margin", self.thr))
+            lipschitz = float(decoder.latent_lipschitz_bound())
+            if need > max_margin:
+                self.creuse = False
+                self.reuse_off_reason = ("kernel error %.3g (x%g safety) needs a candidate margin %.3g > candidate_max_margin %.3g"
+                                         % (max(self.f16_error, self.select_error), safety, need, max_margin))
+            elif not (lipschitz < float("inf")):
+                self.creuse = False
+                self.reuse_off_reason = "no finite latent Lipschitz bound for this decoder"
+            del s32, s16
+        if self.creuse:
+            self.cstride = (cap + 127) // 128 * 128
+            cs = self.cstride
+            self.cidx, self.ccnt, self.cslot, self.cpos = i(B, cs), i(B), i(B * G), i(B, cap)
+            self.crow, self.csdf = f(B * cs, NI), f(B * cs)
+            self.cmask = i(int(Lh.sdfr_decoder_mask_words(self.handle.h, B * cs)))
+            self.margin_grown = need > self.margin      # (prefilter_report: the calibrated error asked for more than decoder.prefilter_margin)
+            self.margin = max(self.margin, need)
             self.margin_dev = torch.full((B,), self.margin, dtype=torch.float32, device=dev)
             self.max_dev = f(B)                 # (stays 0: this mode has no second arithmetic to deviate from; the plan kernel reads it)
             self.violations = i(B, 2)
-            self.lipschitz = float(decoder.latent_lipschitz_bound())
+            self.lipschitz = lipschitz
             # the plan kernel reuses while  lip_plan |z1 - z0| <= margin / 4.  Here 2 e16 <= margin / 2 holds by calibration (margin >= 4 e16), so
             # the latent's share of the margin may be 0.45 of it (|h(z1)| >= thr + margin - 0.45 margin - 0.5 margin > thr): the kernel is handed
             # the bound scaled by 0.25 / 0.45 -- 1.8x the validity of a candidate set for the same proof
@@ -606,10 +629,16 @@ class BatchRenderer:
         margin at a candidate (a band row may have been missed), 'max_deviation': last step's, 'margin': current per-crop maximum}.
         One synchronisation."""
         if not self.guarded:
-            return None
+            # candidate reuse asked for but refused at construction (kernel error beyond the margin cap, no finite Lipschitz bound, unsupported
+            # decoder): every step evaluates the whole grid; say so instead of returning nothing
+            return None if self.reuse_off_reason is None else {"candidate_reuse": False, "reason": self.reuse_off_reason}
         v = self.violations.sum(0).tolist()
         rep = {"violations": int(v[0]), "hard_violations": int(v[1]), "max_deviation": float(self.max_dev.max()),
                "margin": float(self.margin_dev.max())}
+        if self.creuse:
+            rep.update({"candidate_reuse": True, "margin_grown_by_calibration": bool(self.margin_grown), "kernel_error_budget": self.select_error,
+                        "half_kernel_deviation_sampled": self.f16_deviation_sampled, "e32": self.e32, "lipschitz_bound": self.lipschitz,
+                        "full_grid_passes_per_crop": self.n_full.tolist()})
         if self.audit:
             rep["audit"] = {"stride": self.audit_stride, "rows_last_step": int(self.audit_n[0]), "steps": int(self.audit_phase[0]),
                             "reference_values": ("float16 (the mode's own kernel)" if self.f16 else

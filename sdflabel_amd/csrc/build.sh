@@ -17,7 +17,9 @@ else
     [ -n "${!v}" ] && echo "build.sh: ignoring $v (set SDFR_AB=1 for an experiment build)" >&2
   done
   SDFR_FWD_DEFS=; SDFR_F16_DEFS=; SDFR_SPLIT_DEFS=; SDFR_J16_DEFS=; SDFR_JAC_DEFS=; SDFR_LOSS_DEFS=; ALLDEFS=
-  if [ -n "$SDFR_OUT$SDFR_LIBNAME" ]; then echo "build.sh: SDFR_OUT / SDFR_LIBNAME need SDFR_AB=1" >&2; exit 2; fi
+  # (SDFR_OUT alone is fine for a product build -- packaging writes the library outside the source tree; only the define hooks and the
+  # variant library NAMES are locked)
+  if [ -n "$SDFR_LIBNAME" ]; then echo "build.sh: SDFR_LIBNAME needs SDFR_AB=1" >&2; exit 2; fi
 fi
 if [ "${SDFR_BUILD_DRYRUN:-0}" = "1" ]; then      # (tests/test_host_cpu.py: what WOULD be passed to the compiler)
   echo "defs:[$(echo $ALLDEFS $SDFR_FWD_DEFS $SDFR_F16_DEFS $SDFR_SPLIT_DEFS $SDFR_J16_DEFS $SDFR_JAC_DEFS $SDFR_LOSS_DEFS)] common:[$COMMON]"; exit 0

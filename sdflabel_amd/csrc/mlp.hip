@@ -9,6 +9,18 @@
 // Host side: packing + C ABI
 // ---------------------------------------------------------------------------------------------------------------
 
+// A decoder's weight images live on ONE device (sdfr_decoder_create's `device`); every launch below dereferences them from the stream it is
+// given.  One process per GPU (sdflabel_amd/parallel.py) makes the current device, the stream's device and the decoder's device the same by
+// construction -- a caller that mixes them (a handle created for cuda:0 used while cuda:1 is current) gets an error here instead of a fault or,
+// with peer access enabled, silent cross-device weight reads over xGMI at a fraction of the HBM rate.
+#define SDFR_DEVICE_CHECK(d, what)                                                                                                          \
+    do {                                                                                                                                    \
+        int cur_ = -1;                                                                                                                      \
+        SDFR_HIP_CHECK(hipGetDevice(&cur_));                                                                                                \
+        SDFR_REQUIRE(cur_ == (d)->device, "%s: the decoder's weights live on device %d but the current device (the launch stream's) is %d: " \
+                     "create one decoder handle per device", what, (d)->device, cur_);                                                      \
+    } while (0)
+
 extern "C" int sdfr_decoder_create(sdfr_decoder** out, int n_lin, const int* in_dim, const int* out_dim,
                                    const int* inj_n, const int* inj_off, const float* const* h_W,
                                    const float* const* h_b, const float* const* h_ln_w, const float* const* h_ln_b, int n_inputs,
@@ -142,6 +154,7 @@ extern "C" int64_t sdfr_decoder_mask_words(const sdfr_decoder* d, int64_t n) {
 
 extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf, "sdfr_mlp_forward: NULL argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward");
     SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward: n=%lld out of range", (long long)n);
     if (n == 0) return SDFR_OK;
     MlpParams P = d->proto;
@@ -162,6 +175,7 @@ extern "C" int sdfr_mlp_forward(const sdfr_decoder* d, const float* inputs, int6
 extern "C" int sdfr_mlp_forward_counted(const sdfr_decoder* d, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf, int half,
                                         void* stream) {
     SDFR_REQUIRE(d && inputs && sdf && n_dev, "sdfr_mlp_forward_counted: NULL argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward_counted");
     SDFR_REQUIRE(n_max >= 0 && n_max < (int64_t)1 << 31, "sdfr_mlp_forward_counted: n_max=%lld out of range", (long long)n_max);
     SDFR_REQUIRE(!half || (d->HP == 512 && !d->has_ln), "sdfr_mlp_forward_counted: half operands need a 512-wide decoder without LayerNorm");
     if (n_max == 0) return SDFR_OK;
@@ -202,6 +216,7 @@ extern "C" int sdfr_mlp_forward_counted(const sdfr_decoder* d, const float* inpu
 extern "C" int sdfr_mlp_forward_f16_counted(const sdfr_decoder* d, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf,
                                             uint32_t* mask_ws, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf && n_dev, "sdfr_mlp_forward_f16_counted: NULL argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward_f16_counted");
     SDFR_REQUIRE(n_max >= 0 && n_max < (int64_t)1 << 31, "sdfr_mlp_forward_f16_counted: n_max=%lld out of range", (long long)n_max);
     SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_f16_counted: half operands need a 512-wide decoder without LayerNorm");
     if (n_max == 0) return SDFR_OK;
@@ -215,6 +230,7 @@ extern "C" int sdfr_mlp_forward_f16_counted(const sdfr_decoder* d, const float* 
 // forward with float16 operands (f32 accumulate, f32 bias/ReLU/tanh): 128-point workgroup tiles
 extern "C" int sdfr_mlp_forward_f16(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf, "sdfr_mlp_forward_f16: NULL argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward_f16");
     SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward_f16: n=%lld out of range", (long long)n);
     SDFR_REQUIRE(d->HP == 512, "sdfr_mlp_forward_f16: built for hidden widths 257..512 (padded width %d)", d->HP);
     SDFR_REQUIRE(!d->has_ln, "sdfr_mlp_forward_f16: LayerNorm decoders run in float32");
@@ -231,6 +247,7 @@ extern "C" int sdfr_mlp_forward_f16(const sdfr_decoder* d, const float* inputs, 
 extern "C" int sdfr_mlp_forward_skip(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, const int32_t* skip, int64_t rows_per_crop,
                                      void* stream) {
     SDFR_REQUIRE(d && inputs && sdf && skip && rows_per_crop > 0, "sdfr_mlp_forward_skip: bad argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward_skip");
     SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward_skip: n=%lld out of range", (long long)n);
     SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_skip: 512-wide decoders without LayerNorm");
     if (n == 0) return SDFR_OK;
@@ -245,6 +262,7 @@ extern "C" int sdfr_mlp_forward_skip(const sdfr_decoder* d, const float* inputs,
 extern "C" int sdfr_mlp_forward_ragged(const sdfr_decoder* d, const float* inputs, int B, int64_t rows_per_crop, const int32_t* cnt, float* sdf,
                                        uint32_t* mask_ws, int half_tiles, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf && cnt, "sdfr_mlp_forward_ragged: NULL argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward_ragged");
     SDFR_REQUIRE(B >= 0 && rows_per_crop >= 0 && rows_per_crop % 64 == 0 && (int64_t)B * rows_per_crop < (int64_t)1 << 31,
                  "sdfr_mlp_forward_ragged: B=%d rows_per_crop=%lld (a multiple of 64, B * rows < 2^31)", B, (long long)rows_per_crop);
     SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_ragged: 512-wide decoders without LayerNorm");
@@ -268,6 +286,7 @@ extern "C" int sdfr_mlp_forward_ragged(const sdfr_decoder* d, const float* input
 extern "C" int sdfr_mlp_forward_f16_ragged(const sdfr_decoder* d, const float* inputs, int B, int64_t rows_per_crop, const int32_t* cnt, float* sdf,
                                            uint32_t* mask_ws, int half_tiles, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf && cnt, "sdfr_mlp_forward_f16_ragged: NULL argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward_f16_ragged");
     SDFR_REQUIRE(B >= 0 && rows_per_crop >= 0 && rows_per_crop % 128 == 0 && (int64_t)B * rows_per_crop < (int64_t)1 << 31,
                  "sdfr_mlp_forward_f16_ragged: B=%d rows_per_crop=%lld (a multiple of 128, B * rows < 2^31)", B, (long long)rows_per_crop);
     SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_f16_ragged: half operands need a 512-wide decoder without LayerNorm");
@@ -289,6 +308,7 @@ extern "C" int sdfr_mlp_forward_candidates(const sdfr_decoder* d, const float* i
                                            int64_t stride, const int32_t* cnt, float* sdf, uint32_t* mask_ws, int half, int half_tiles,
                                            void* stream) {
     SDFR_REQUIRE(d && inputs && cidx && cnt && sdf, "sdfr_mlp_forward_candidates: NULL argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward_candidates");
     const int tile = half ? (half_tiles == 2 ? 32 : (half_tiles ? 64 : 128)) : 64;
     SDFR_REQUIRE(B >= 0 && stride >= 0 && stride % tile == 0 && (int64_t)B * stride < (int64_t)1 << 31 && rows_per_crop_in > 0 &&
                  (int64_t)B * rows_per_crop_in < (int64_t)1 << 31, "sdfr_mlp_forward_candidates: B=%d stride=%lld (a multiple of %d) rows_per_crop_in=%lld",
@@ -312,6 +332,7 @@ extern "C" int sdfr_mlp_forward_candidates(const sdfr_decoder* d, const float* i
 extern "C" int sdfr_mlp_forward_f16_skip(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, const int32_t* skip,
                                          int64_t rows_per_crop, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf && skip && rows_per_crop > 0, "sdfr_mlp_forward_f16_skip: bad argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward_f16_skip");
     SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward_f16_skip: n=%lld out of range", (long long)n);
     SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_f16_skip: 512-wide decoders without LayerNorm");
     if (n == 0) return SDFR_OK;
@@ -329,6 +350,7 @@ extern "C" int sdfr_mlp_forward_f16_skip(const sdfr_decoder* d, const float* inp
 // noise (the same order as a change of summation order); masks are saved in the f32 forward's layout.
 extern "C" int sdfr_mlp_forward_split(const sdfr_decoder* d, const float* inputs, int64_t n, float* sdf, uint32_t* mask_ws, void* stream) {
     SDFR_REQUIRE(d && inputs && sdf, "sdfr_mlp_forward_split: NULL argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward_split");
     SDFR_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "sdfr_mlp_forward_split: n=%lld out of range", (long long)n);
     SDFR_REQUIRE(d->HP == 512, "sdfr_mlp_forward_split: built for hidden widths 257..512 (padded width %d)", d->HP);
     SDFR_REQUIRE(!d->has_ln, "sdfr_mlp_forward_split: LayerNorm decoders run in float32");
@@ -345,6 +367,7 @@ extern "C" int sdfr_mlp_forward_split(const sdfr_decoder* d, const float* inputs
 extern "C" int sdfr_mlp_forward_split_counted(const sdfr_decoder* d, const float* inputs, int64_t n_max, const int32_t* n_dev, float* sdf,
                                               void* stream) {
     SDFR_REQUIRE(d && inputs && sdf && n_dev, "sdfr_mlp_forward_split_counted: NULL argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_forward_split_counted");
     SDFR_REQUIRE(n_max >= 0 && n_max < (int64_t)1 << 31, "sdfr_mlp_forward_split_counted: n_max=%lld out of range", (long long)n_max);
     SDFR_REQUIRE(d->HP == 512 && !d->has_ln, "sdfr_mlp_forward_split_counted: built for 512-wide decoders without LayerNorm");
     if (n_max == 0) return SDFR_OK;
@@ -359,6 +382,7 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
                                  const int32_t* idx, int cap, const int32_t* cnt, float* J, float* sdf_sel,
                                  const float* sdf_full, const uint32_t* mask_ws, int mask_from_f16, void* stream) {
     SDFR_REQUIRE(d && inputs && idx && J, "sdfr_mlp_jacobian: NULL argument");
+    SDFR_DEVICE_CHECK(d, "sdfr_mlp_jacobian");
     SDFR_REQUIRE(B >= 0 && cap >= 0, "sdfr_mlp_jacobian: negative size");
     SDFR_REQUIRE(mask_ws == nullptr || sdf_full != nullptr, "sdfr_mlp_jacobian: mask_ws needs sdf_full");
     if (B == 0 || cap == 0) return SDFR_OK;

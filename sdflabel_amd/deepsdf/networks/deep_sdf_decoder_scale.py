@@ -314,6 +314,29 @@ class Decoder(nn.Module):
                 x = torch.relu(x)                                                          # :102
         return torch.tanh(x)                                                               # :106-107
 
+    def kernel_error_f32(self, device, rows=1024):
+        """max |exact-f32 HIP kernel - float64 evaluation| of the SDF output on `rows` random rows (unit latent, xyz uniform in the grid's cube),
+        the float64 side on the HOST (a float64 GEMM stack on the GPU costs seconds to load; 1024 rows of an 8x512 decoder take ~0.1 s here).
+        Cached per parameter set.  BatchRenderer's candidate reuse budgets 4x this (at least 1e-6) for the exact kernel's error (ADVICE r05:
+        measured per decoder instead of assumed)."""
+        device = torch.device(device)
+        key = self._param_key(device)
+        hit = getattr(self, "_e32_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        gen = torch.Generator().manual_seed(11)
+        lat = torch.nn.functional.normalize(torch.randn(self.latent_size, generator=gen), dim=0)
+        inp = torch.cat([lat.expand(rows, -1), torch.rand(rows, 3, generator=gen) * 2.0 - 1.0], 1).float().contiguous()
+        ref = self.forward_float64(inp).view(-1)
+        L = _lib.lib()
+        x = inp.to(device)
+        out = torch.empty(rows, dtype=torch.float32, device=device)
+        with _lib.guard(device):
+            _lib.check(L.sdfr_mlp_forward(self.handle(device).h, _lib.ptr(x), rows, _lib.ptr(out), None, _lib.stream_ptr()), "sdfr_mlp_forward")
+        err = float((out.double().cpu() - ref).abs().max())
+        self._e32_cache = (key, err)
+        return err
+
     def latent_lipschitz_bound(self):
         """A PROVEN upper bound of || d sdf / d latent ||_2 over all inputs: the change of the decoder output per unit (Euclidean) change of the
         latent columns of an input row, x fixed.  ReLU, tanh (and eval-mode dropout) are 1-Lipschitz, so along the layers the bound d_l of the
@@ -323,7 +346,7 @@ class Decoder(nn.Module):
         which is what the candidate reuse of BatchRenderer needs.  LayerNorm decoders: inf (the normalisation is not Lipschitz)."""
         if any(getattr(self, "bn" + str(l), None) is not None for l in range(self.num_layers - 1)):
             return float("inf")
-        key = tuple((id(p), p._version) for p in self.parameters())
+        key = tuple((id(p), p._version, p.data_ptr()) for p in self.parameters())     # (data_ptr: `p.data = ...` keeps id and version)
         hit = getattr(self, "_lip_cache", None)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -341,6 +364,10 @@ class Decoder(nn.Module):
             W = np.asarray(W, np.float64)
             if l == 0:
                 d = norm2(W[:, :Ls])
+                if inj_n > 0:
+                    # 0 in latent_in: the first layer reads cat(input, input) (:90-93), i.e. a second block of latent columns at inj's place
+                    nlat0 = max(0, min(Ls, inj_off + inj_n) - inj_off)
+                    d += norm2(W[:, W.shape[1] - inj_n:W.shape[1] - inj_n + nlat0])
                 continue
             prev = W.shape[1] - inj_n
             t = norm2(W[:, :prev]) * d

@@ -44,7 +44,7 @@ def gather_crop_results(local_rows, n_crops, rank=None, world=None, group=None):
     return out
 
 
-def refine_sharded(refiner, params, nocs_pred, lidars, iters, rank=0, world=1, group=None, gather=True):
+def refine_sharded(refiner, params, nocs_pred, lidars, iters, rank=0, world=1, group=None, gather=True, K=None, crop_sizes=None, timing=None):
     """BASELINE configs[3]: refine `n_crops` independent crops sharded over the ranks.  Crop i belongs to rank i mod world; each rank refines
     its crops in chunks of `refiner.B` (sdflabel_amd.BatchRefiner, or any object with B, L, set_crops, optimize, results) for `iters`
     iterations; ONE all_gather of the per-crop rows at the end is the only collective (pipelines/refine_css.py:65,94 loops over the same crops
@@ -53,6 +53,10 @@ def refine_sharded(refiner, params, nocs_pred, lidars, iters, rank=0, world=1, g
     params     {'yaw' (n,), 'trans' (n,3), 'scale' (n,), 'latent' (n,L)} arrays for ALL crops (a few floats per crop: every rank holds the table)
     nocs_pred  (n,3,h,w) per-crop CSS predictions, or (1,3,h,w) shared by all crops (synthetic workloads)
     lidars     list of n (M_i,3) arrays, or ONE (M,3) array shared by all crops
+    K, crop_sizes  (ragged refiners, BatchRefiner(max_pixels=...)): per-crop intrinsics (n,3,3) and image sizes [(H_i, W_i)] * n -- crops as the
+               reference pipeline produces them (utils/refinement.py:586-609); nocs_pred is then a list of n (3,h_i,w_i) predictions
+    timing     optional dict: receives this rank's seconds in 'set_crops', 'optimize' (enqueue + GPU, synchronised per chunk by results()) and
+               'all_gather' (r06: lets a multi-GPU curve be read -- which phase stops scaling)
     Returns the (n_crops, 7+L) table [yaw, trans(3), scale, latent(L), weighted 2-D loss, weighted 3-D loss] -- the refined parameters and the
     per-crop losses of the last iteration (BASELINE.json north_star: "all-gather of the per-crop losses") -- in crop order on every rank
     (gather=False: this rank's rows only).
@@ -63,7 +67,10 @@ def refine_sharded(refiner, params, nocs_pred, lidars, iters, rank=0, world=1, g
     mine = shard_crops(n_crops, rank, world)
     B, R = int(refiner.B), 7 + int(refiner.L)
     P = {k: np.asarray(v, np.float32).reshape(n_crops, -1) for k, v in params.items()}
-    shared_target = nocs_pred.shape[0] == 1
+    import time
+    tm = {"set_crops": 0.0, "optimize": 0.0, "all_gather": 0.0, "chunks": 0}
+    ragged = K is not None or crop_sizes is not None
+    shared_target = (not isinstance(nocs_pred, (list, tuple))) and nocs_pred.shape[0] == 1
     shared_lidar = not isinstance(lidars, (list, tuple))
     rows, failure = [], None
     try:
@@ -71,10 +78,22 @@ def refine_sharded(refiner, params, nocs_pred, lidars, iters, rank=0, world=1, g
             ids = mine[c0:c0 + B]
             n = len(ids)
             sel = ids + [ids[-1]] * (B - n)
-            tgt = nocs_pred.expand(B, *nocs_pred.shape[1:]) if shared_target else nocs_pred[sel]
-            refiner.set_crops({k: v[sel] for k, v in P.items()}, tgt, [lidars] * B if shared_lidar else [lidars[i] for i in sel])
+            t0 = time.perf_counter()
+            if isinstance(nocs_pred, (list, tuple)):
+                tgt = [nocs_pred[i] for i in sel]
+            else:
+                tgt = nocs_pred.expand(B, *nocs_pred.shape[1:]) if shared_target else nocs_pred[sel]
+            extra = {}
+            if ragged:
+                extra = {"K": None if K is None else np.asarray(K, np.float32).reshape(n_crops, 3, 3)[sel],
+                         "crop_sizes": None if crop_sizes is None else [tuple(crop_sizes[i]) for i in sel]}
+            refiner.set_crops({k: v[sel] for k, v in P.items()}, tgt, [lidars] * B if shared_lidar else [lidars[i] for i in sel], **extra)
+            t1 = time.perf_counter()
             refiner.optimize(iters)
-            res, l2, l3 = refiner.results()
+            res, l2, l3 = refiner.results()                  # (synchronises: the chunk's GPU time lands in 'optimize')
+            tm["set_crops"] += t1 - t0
+            tm["optimize"] += time.perf_counter() - t1
+            tm["chunks"] += 1
             z = res.new_zeros((res.shape[0], 1))
             rows.append(torch.cat([res, z if l2 is None else l2.reshape(-1, 1).to(res), z if l3 is None else l3.reshape(-1, 1).to(res)], 1)[:n])
         local = torch.cat(rows) if rows else None
@@ -83,7 +102,11 @@ def refine_sharded(refiner, params, nocs_pred, lidars, iters, rank=0, world=1, g
     dev = getattr(refiner, "dev", "cpu")
     if local is None:
         local = torch.full((len(mine), R), float("nan") if failure is not None else 0.0, dtype=torch.float32, device=dev)
+    t0 = time.perf_counter()
     table = gather_crop_results(local, n_crops, rank, world, group) if gather else local
+    tm["all_gather"] = time.perf_counter() - t0
+    if timing is not None:
+        timing.update(tm)
     if failure is not None:
         raise failure
     return table

@@ -490,3 +490,25 @@ def test_drop_in_iterations_do_not_accumulate_device_memory():
             assert grown < 4 << 20, "device memory grew by %.1f MB over 20 iterations (half inputs: %s)" % (grown / 1e6, half)
     finally:
         gc.enable()
+
+
+def test_decoder_handle_is_bound_to_its_device_and_errors_are_reported_not_faults():
+    """r06 (first-run hardening for the multi-GPU path): a decoder's weight images live on ONE device.  Creating a handle for a
+    device the process cannot see returns a HIP error through sdfr_last_error (no abort), the caller's current device is left as it was, and every
+    decoder launch checks that the current device is the handle's (on a box with >= 2 GPUs: a launch with the other device current is refused)."""
+    d, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)
+    d = d.to(DEV)
+    n_dev = torch.cuda.device_count()
+    before = torch.cuda.current_device()
+    with pytest.raises(_lib.SdfrError, match="(?i)hip|device"):
+        d.handle(torch.device("cuda", n_dev))                     # one past the last device
+    assert torch.cuda.current_device() == before
+    x = torch.zeros(64, 6, device=DEV)
+    out = torch.empty(64, device=DEV)
+    h = d.handle(torch.device("cuda", before))
+    _lib.check(_lib.lib().sdfr_mlp_forward(h.h, _lib.ptr(x), 64, _lib.ptr(out), None, _lib.stream_ptr()), "sdfr_mlp_forward")
+    if n_dev >= 2:
+        other = (before + 1) % n_dev
+        with torch.cuda.device(other):
+            rc = _lib.lib().sdfr_mlp_forward(h.h, _lib.ptr(x), 64, _lib.ptr(out), None, _lib.stream_ptr())
+        assert rc != 0 and "current device" in _lib.lib().sdfr_last_error().decode()

@@ -279,3 +279,69 @@ def test_kernel_errors_budgeted_by_the_reuse_proof_against_a_float64_evaluation(
         worst16 = max(worst16, float((s16.double() - ref).abs().max()))
     assert worst32 < 5e-7 < 1e-6                                   # measured 1.6e-7
     assert worst16 <= 1.5 * br.select_error and br.margin >= 4 * br.select_error
+
+
+# ---- r06: reuse off the shipped decoders ---------------------------------------------------------------------------------
+
+def _amplify_a_dead_unit(d, want_bound=5e4):
+    """The fixture decoder with a latent-Lipschitz BOUND >= want_bound (100x the shipped 532) and nearly the same function: hidden unit j of
+    layer 1 loses its outgoing weights in layer 2 (one of 512 units) and has its own row scaled up, so ||W_1||_2 -- a factor of the product of
+    spectral norms the proven bound is made of -- grows by two orders of magnitude while nothing downstream sees the unit."""
+    j = 7
+    with torch.no_grad():
+        d.lin2.weight_v[:, j] = 0.0
+        g = float(d.lin1.weight_g.view(-1)[j].abs())
+        c = 1.25 * want_bound / d.latent_lipschitz_bound() * float(np.linalg.norm(d.effective_layers()[1][0], 2)) / g
+        d.lin1.weight_g.view(-1)[j] *= c
+        d.lin1.bias[j] *= c
+    return d
+
+
+@pytest.mark.parametrize("precision", [torch.float16, torch.float32])
+def test_a_decoder_with_a_huge_lipschitz_bound_gets_a_full_pass_every_step_and_the_same_bits(precision):
+    """the plan kernel's decision with a bound 100x the shipped decoder's: the latent moves ~1e-5 per iteration in normalised space, the candidate
+    set is provably valid for |dz| <= margin / (4 lip) ~ 1e-8 only -> EVERY step runs the full grid; nothing raises and every bit equals the
+    no-reuse evaluation (the fallback the design promises, never exercised by the shipped decoders)"""
+    D, H, W, B, iters = 40, 48, 48, 3, 12
+    K, p0, target, lidar = _problem(D, H, W, B)
+    plain = sdflabel_amd.BatchRefiner(_amplify_a_dead_unit(_dec16(False, precision)), D, K, (H, W), B, lidar_cap=4096, device=DEV)
+    reuse = sdflabel_amd.BatchRefiner(_amplify_a_dead_unit(_dec16(True, precision)), D, K, (H, W), B, lidar_cap=4096, device=DEV)
+    assert reuse.br.creuse and reuse.br.lipschitz >= 5e4, reuse.br.lipschitz
+    plain.set_crops(p0, target, [lidar] * B)
+    reuse.set_crops(p0, target, [lidar] * B)
+    for it in range(iters):
+        plain.iteration()
+        reuse.iteration()
+        _same_step(plain.br, reuse.br)
+        assert int(reuse.br.reuse_flag.sum()) == 0, it                  # no step may reuse
+    assert int(plain.br.cnt.min()) > 200                                 # (the amplified decoder still has a shape)
+    assert torch.equal(plain.results()[0], reuse.results()[0])          # results() -> check_overflow(): no exception
+    rep = reuse.br.prefilter_report()
+    assert rep["hard_violations"] == 0 and rep["full_grid_passes_per_crop"] == [iters] * B and rep["lipschitz_bound"] >= 5e4
+
+
+def test_a_kernel_error_beyond_the_margin_grows_the_margin_or_turns_reuse_off():
+    """construction-time calibration: margin >= 4 x (safety x sampled half-kernel deviation + E32).  (a) a decoder.prefilter_margin below that is
+    raised to it (reported); (b) when even decoder.candidate_max_margin is below it, reuse switches itself off -- the renderer evaluates the
+    whole grid every step, says why in prefilter_report(), and gives the bits of a renderer that was never asked to reuse"""
+    D, H, W, B = 40, 48, 48, 2
+    K, p0, target, lidar = _problem(D, H, W, B)
+    grown = sdflabel_amd.BatchRefiner(_dec16(True, prefilter_margin=1e-4), D, K, (H, W), B, lidar_cap=4096, device=DEV)
+    br = grown.br
+    assert br.creuse and br.margin_grown and br.margin == pytest.approx(4.0 * br.select_error) and br.margin > 1e-4
+    assert br.f16_error == pytest.approx(2.0 * br.f16_deviation_sampled + br.e32)           # the safety factor on the sample maximum
+    assert 1e-6 <= br.e32 < 2e-6 and 0 < sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=torch.float32)[0].to(DEV).kernel_error_f32(DEV) < 5e-7
+    rep = br.prefilter_report()
+    assert rep["candidate_reuse"] and rep["margin_grown_by_calibration"] and rep["margin"] == pytest.approx(br.margin)
+    off = sdflabel_amd.BatchRefiner(_dec16(True, candidate_max_margin=1e-3), D, K, (H, W), B, lidar_cap=4096, device=DEV)
+    plain = sdflabel_amd.BatchRefiner(_dec16(False), D, K, (H, W), B, lidar_cap=4096, device=DEV)
+    assert not off.br.creuse and not off.br.guarded
+    rep = off.br.prefilter_report()
+    assert rep["candidate_reuse"] is False and "candidate_max_margin" in rep["reason"]
+    assert plain.br.prefilter_report() is None
+    rows = []
+    for rf in (grown, off, plain):
+        rf.set_crops(p0, target, [lidar] * B)
+        rf.optimize(10)
+        rows.append(N(rf.results()[0]))
+    assert np.array_equal(rows[0], rows[2]) and np.array_equal(rows[1], rows[2])

@@ -286,3 +286,29 @@ def test_captured_traced_refiner_survives_eager_work_between_replays(dec, dec16)
         return N(rf.results()[0])
 
     assert np.array_equal(run(True), run(False))
+
+
+def test_unresolved_rays_raise_only_above_the_tolerance(dec):
+    """a couple of grazing rays still creeping at the step budget are normal (the tracer tests accept them) and must not throw a
+    finished refinement away; a march that is plainly too short must.  Threshold max(2, unresolved_tolerance x pixels), reported either way."""
+    z, H, W, init, p = _problem("g8b_optimizer_128.npz")
+    short = sdflabel_amd.BatchRefiner(dec, 0, z["K"], (H, W), 1, lidar_cap=256, weights=WEIGHTS, device=DEV, render="trace",
+                                      tracer_kwargs=dict(steps=3, cone_block=None))
+    short.set_crops(p, z["nocs_target"][None], [z["lidar"]])
+    short.iteration()
+    n = short.tr.n_unresolved
+    assert n > 2 + 1e-3 * H * W, n                                   # three steps resolve almost nothing
+    with pytest.raises(sdflabel_amd.SdfrError, match="unresolved after 3 steps"):
+        short.check_overflow()
+    lax = sdflabel_amd.BatchRefiner(dec, 0, z["K"], (H, W), 1, lidar_cap=256, weights=WEIGHTS, device=DEV, render="trace",
+                                    tracer_kwargs=dict(steps=3, cone_block=None, unresolved_tolerance=1.0))
+    lax.set_crops(p, z["nocs_target"][None], [z["lidar"]])
+    lax.iteration()
+    lax.check_overflow()                                             # tolerated, but reported
+    assert lax.unresolved_last == n
+    full = sdflabel_amd.BatchRefiner(dec, 0, z["K"], (H, W), 1, lidar_cap=256, weights=WEIGHTS, device=DEV, render="trace",
+                                     tracer_kwargs=dict(steps=64))
+    full.set_crops(p, z["nocs_target"][None], [z["lidar"]])
+    full.iteration()
+    full.results()
+    assert full.unresolved_last <= 2

@@ -205,7 +205,8 @@ def test_bench_line_is_compact_and_round_trips():
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac"] == pytest.approx(0.871136)
     assert d["cpu_baseline"]["cores"] == 8 and d["cpu_baseline"]["kind"] == "port" and len(d["cpu_baseline"]["sample"]) <= 240
     assert d["refine"] == {"f32_crops_per_s": pytest.approx(9.508298), "f16_crops_per_s": pytest.approx(71.89664), "total_crops": 1024,
-                           "iterations_per_crop": 60}
+                           "iterations_per_crop": 60, "f16_candidate_reuse": True, "f16_full_grid_passes_per_crop": pytest.approx(1.0),
+                           "area32_f16_crops_per_s": pytest.approx(301.5)}
     assert d["extras"] == "bench_extras.json"
 
 
@@ -320,3 +321,21 @@ def test_latent_lipschitz_bound_is_an_upper_bound(kw):
     if kw is not None and not kw["latent_in"]:
         ln = sdflabel_amd.Decoder(3, dims=[32, 32], norm_layers=(0, 1), weight_norm=False)
         assert ln.latent_lipschitz_bound() == float("inf")
+
+
+def test_stored_traffic_is_quoted_only_for_the_kernel_sources_it_was_measured_on(tmp_path):
+    """profiles/traffic_*.json carry the hash of the csrc files of their kernels; bench.py quotes the figure only when the hash
+    matches this tree (otherwise roofline.traffic is null instead of a number measured on other code)"""
+    import json
+    from sdflabel_amd import _lib
+    name = "traffic_mlp_forward.json"
+    os.makedirs(tmp_path / "profiles")
+    good = {"hbm_bytes_per_launch": 1.0, "source_sha16": _lib.source_sha16(_lib.TRAFFIC_SOURCES[name])}
+    json.dump(good, open(tmp_path / "profiles" / name, "w"))
+    assert _lib.stored_traffic(str(tmp_path), name)["hbm_bytes_per_launch"] == 1.0
+    json.dump(dict(good, source_sha16="0" * 16), open(tmp_path / "profiles" / name, "w"))
+    assert _lib.stored_traffic(str(tmp_path), name) is None
+    json.dump({"hbm_bytes_per_launch": 1.0}, open(tmp_path / "profiles" / name, "w"))          # a file from before r06: no hash
+    assert _lib.stored_traffic(str(tmp_path), name) is None
+    assert _lib.stored_traffic(str(tmp_path), "traffic_splat.json") is None                    # absent
+    assert len(_lib.source_sha16(("splat.hip",))) == 16 and _lib.source_sha16(("splat.hip",)) != _lib.source_sha16(("trace.hip",))

@@ -216,3 +216,28 @@ def test_bench_rejects_a_rank_count_that_disagrees_with_gpus():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch-check"], capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_refine_sharded_ragged_crops_and_phase_timing():
+    """r06: crops as the pipeline produces them -- a LIST of per-crop predictions, per-crop K and (H, W) -- reach set_crops chunk by chunk in crop
+    order (the short last chunk padded with its last crop), and the per-rank phase seconds are reported"""
+    import numpy as np
+    from sdflabel_amd.parallel import refine_sharded
+    n, B = 7, 4
+    seen = []
+
+    class _Ragged(_FakeRefiner):
+        def set_crops(self, params, nocs_pred, lidars, K=None, crop_sizes=None):
+            assert isinstance(nocs_pred, list) and len(nocs_pred) == self.B and K.shape == (self.B, 3, 3) and len(crop_sizes) == self.B
+            for t, (h, w) in zip(nocs_pred, crop_sizes):
+                assert tuple(t.shape) == (3, h, w)
+            seen.append(([int(k[0, 2]) for k in K], list(crop_sizes)))
+            self.rows = torch.cat([torch.as_tensor(params[k], dtype=torch.float32).reshape(self.B, -1) for k in ("yaw", "trans", "scale", "latent")], 1)
+
+    sizes = [(3 + i, 5 + 2 * i) for i in range(n)]
+    Ks = np.stack([np.array([[10, 0, i], [0, 10, 0], [0, 0, 1]], np.float32) for i in range(n)])
+    tm = {}
+    table = refine_sharded(_Ragged(B), _params(n), [torch.zeros(3, h, w) for h, w in sizes], [torch.zeros(2, 3)] * n, 3, K=Ks, crop_sizes=sizes, timing=tm)
+    assert torch.equal(table, _expected(n, 3))
+    assert seen[0][0] == [0, 1, 2, 3] and seen[1][0] == [4, 5, 6, 6] and seen[1][1] == [sizes[4], sizes[5], sizes[6], sizes[6]]
+    assert tm["chunks"] == 2 and all(tm[k] >= 0.0 for k in ("set_crops", "optimize", "all_gather"))

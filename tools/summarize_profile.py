@@ -15,6 +15,14 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from sdflabel_amd._lib import TRAFFIC_SOURCES, source_sha16  # noqa: E402  (kernel-source hash stored with every traffic figure: bench.py checks it)
+
+
+def sha(name):
+    return {"source_sha16": source_sha16(TRAFFIC_SOURCES[name]), "sources": list(TRAFFIC_SOURCES[name])}
+
+
 tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else tag
 G = os.path.join(ROOT, "gpurun_out")
@@ -65,7 +73,7 @@ json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate 
           open(os.path.join(P, "%s_pmc_hbm.json" % rnd), "w"), indent=1)
 key = sorted([k for k in pmc if "sdfr_mlp_kernel" in k], key=lambda k: -pmc[k].get("FETCH_SIZE_KB_mean", 0.0))[:1]   # the grid forward
 if key:
-    json.dump({"kernel": key[0], "source": "%s_pmc_hbm.json" % rnd, "hbm_bytes_per_launch": pmc[key[0]]["hbm_bytes_per_launch"]},
+    json.dump(dict({"kernel": key[0], "source": "%s_pmc_hbm.json" % rnd, "hbm_bytes_per_launch": pmc[key[0]]["hbm_bytes_per_launch"]}, **sha("traffic_mlp_forward.json")),
               open(os.path.join(P, "traffic_mlp_forward.json"), "w"), indent=1)
 # the same PMC pair at 64 crops per launch (tools/gpu_round.sh: pmc_fetch64_<tag> / pmc_write64_<tag>) and the splat pair's traffic
 pmc64 = {}
@@ -93,8 +101,8 @@ def splat_pair(d):
     return (d[f[0]]["hbm_bytes_per_launch"] + d[b[0]]["hbm_bytes_per_launch"]) if f and b else None
 
 
-json.dump({"source": "%s_pmc_hbm.json / %s_pmc_hbm_64crops.json" % (rnd, rnd), "what": "HBM bytes (2*FETCH_SIZE + WRITE_SIZE) of the splat forward + "
-           "backward launch pair", "crops_1": splat_pair(pmc), "crops_64": splat_pair(pmc64) if pmc64 else None},
+json.dump(dict({"source": "%s_pmc_hbm.json / %s_pmc_hbm_64crops.json" % (rnd, rnd), "what": "HBM bytes (2*FETCH_SIZE + WRITE_SIZE) of the splat forward + "
+           "backward launch pair", "crops_1": splat_pair(pmc), "crops_64": splat_pair(pmc64) if pmc64 else None}, **sha("traffic_splat.json")),
           open(os.path.join(P, "traffic_splat.json"), "w"), indent=1)
 for name in ("bench_%s.json" % tag,):
     if os.path.isfile(os.path.join(G, name)):
@@ -108,7 +116,7 @@ if os.path.isfile(sph):
     st = ks.get("sdfr_trace_step_kernel")
     if st and "hbm_bytes_per_launch" in st:
         # the march's advance / compaction kernel against the HBM roofline (read by bench.py: sphere_trace.*.step_kernel_hbm)
-        json.dump({"source": "%s_pmc_sphere.json" % rnd, "what": "sdfr_trace_step_kernel, one 256x256 crop, float16 march: HBM bytes (2*FETCH_SIZE + WRITE_SIZE) "
+        json.dump({"source_sha16": sha("traffic_sphere_step.json")["source_sha16"], "source": "%s_pmc_sphere.json" % rnd, "what": "sdfr_trace_step_kernel, one 256x256 crop, float16 march: HBM bytes (2*FETCH_SIZE + WRITE_SIZE) "
                    "and duration per launch, means over the launches of the march (the active count shrinks from 65 k rays to a few thousand)",
                    "hbm_bytes_per_launch": st["hbm_bytes_per_launch"], "duration_us": st.get("duration_us_fetch_mean"), "GBps": st.get("hbm_GBps")},
                   open(os.path.join(P, "traffic_sphere_step.json"), "w"), indent=1)

@@ -236,9 +236,9 @@ _NO_GUARD = _NoGuard()
 
 
 TRAFFIC_SOURCES = {          # the csrc files that define the kernels a profiles/traffic_*.json file was measured on (bench.py, tools/summarize_profile.py)
-    "traffic_mlp_forward.json": ("mlp_kernel.h", "mlp.hip", "mlp_fwd32.hip", "sdfr_common.h"),
-    "traffic_splat.json": ("splat.hip", "splat_bbox.h", "sdfr_common.h"),
-    "traffic_sphere_step.json": ("trace.hip", "sdfr_common.h"),
+    "traffic_mlp_forward.json": ("mlp_kernel.h", "mlp.hip", "mlp_fwd32.hip"),
+    "traffic_splat.json": ("splat.hip", "splat_bbox.h"),
+    "traffic_sphere_step.json": ("trace.hip",),
 }
 
 

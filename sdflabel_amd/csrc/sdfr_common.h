@@ -20,7 +20,8 @@ void sdfr_set_error(const char* fmt, ...);
         hipError_t e_ = (x);                                                                           \
         if (e_ != hipSuccess) {                                                                        \
             sdfr_set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__);     \
-            return SDFR_E_HIP;                                                                         \
+            (void)hipGetLastError();   /* reported through our return code: do not leave it as the   */ \
+            return SDFR_E_HIP;         /* thread's sticky "last error" for the next HIP user (torch) */ \
         }                                                                                              \
     } while (0)
 

@@ -30,7 +30,12 @@
 #include <stdlib.h>
 #include <math.h>
 
-#define SPL_LC 1024            // LDS candidate-list capacity per tile (beyond it the tile walks every surfel)
+// LDS candidate-list capacity per tile (beyond it the tile walks EVERY surfel of the crop, twice, without coverage ballots).  4096 since r06: at the
+// reference's shipped rendering_area 32 (configs/config_refine.ini:13) a crop is ~18 tiles and its densest tile lists 1200-1600 of the crop's ~2700
+// surfels; with 1024 slots that tile took the walk-everything path and WAS the launch (142 us at one crop, 136 us at 16: tools/splat32_diag.py)
+#define SPL_LC 4096
+#define SPL_SORT_MAX 1024      // binned tiles with more entries build their list by scanning the boxes (same list)
+#define SPL_LCOV 2048          // coverage ballots kept per tile by the wide geometry (16 KiB)
 #define SPL_BQ 128             // backward: covered-pixel queue per wave (drained whenever fewer than 64 slots are free)
 #define SIGMOID_REACH 29.65f   // (r - d) * 3 > -88.73  <=>  d < r + 29.58: conservative reach of inside_circle's sigmoid(.) > 0
 
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
     static_assert(PW == 1 || PW == SPL_NS, "one wave per share, or one wave for all shares");
     constexpr int SPW = SPL_NS / PW;                   // shares per wave
     constexpr int NT = 64 * PW;
-    constexpr int LCOV = (PW == 1) ? 64 : SPL_LC;      // coverage ballots kept per tile
+    constexpr int LCOV = (PW == 1) ? 64 : SPL_LCOV;    // coverage ballots kept per tile
     int tile, b;
     sdfr_xcd_crop_map(tile, b);        // a crop's tiles on one XCD: its surfel arrays / tile lists are fetched by one L2
     int W, H, PS;
@@ -283,12 +288,18 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
     const int64_t sb = (int64_t)b * A.cap;
     const float diam = A.diam, C = A.depth_constant;
 
-    __shared__ int list[SPL_LC];
+    // the tile's candidate list: SPL_LC slots of 16 bits (surfel slots < cap <= 65536), or half as many 32-bit ones for larger capacities -- the
+    // SAME capacity in both launch geometries, so a tile takes the same path (list / walk-everything) and gives the same bits in either
+    __shared__ unsigned short list16[SPL_LC];
+    const bool wide_idx = A.cap > 65536;
+    const int LCe = wide_idx ? SPL_LC / 2 : SPL_LC;
+    auto lset = [&](int i, int v) { if (wide_idx) reinterpret_cast<int*>(list16)[i] = v; else list16[i] = (unsigned short)v; };
+    auto lget = [&](int i) -> int { return wide_idx ? reinterpret_cast<const int*>(list16)[i] : (int)list16[i]; };
     __shared__ unsigned long long cov[LCOV];
     __shared__ float sd[PW][11][64];
     __shared__ float nured[PW][64];
     __shared__ int wc[2][PW];
-    float (*red)[11][64] = sd;        // the final merge reuses each wave's own staging slice (dead by then): 36 KiB of LDS, 4 tiles per CU
+    float (*red)[11][64] = sd;        // the final merge reuses each wave's own staging slice (dead by then); wide geometry: 49 KiB of LDS, 3 tiles per CU
 
     // ---- (1) candidate list: surfels whose conservative box overlaps this tile, ascending order --------------------------------
     // binned: the tile's entries of the per-crop tile lists (sdfr_bin_boxes: count -> scan -> fill, arbitrary order), sorted here by rank
@@ -304,21 +315,24 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
             const int o0 = toff[tile];
             nc = toff[tile + 1] - o0;
             const int32_t* tl = toff + T + 2 + o0;
-            if (PW == 1) {
+            // (the rank sort below is quadratic in the tile's entries: a dense tile -- more than SPL_SORT_MAX -- scans the crop's boxes instead,
+            // a few steps of ballot compaction that deliver the same ascending list)
+            if (nc > SPL_SORT_MAX) { binned = false; nc = 0; }
+            else if (PW == 1) {
                 if (nc > 0 && nc <= 64) {                  // ranks through lane reads
                     const int v = (lane < nc) ? tl[lane] : 0x7fffffff;
                     int r = 0;
                     for (int j = 0; j < nc; ++j) r += (__builtin_amdgcn_readlane(v, j) < v) ? 1 : 0;
-                    if (lane < nc) list[r] = v;
-                } else if (nc <= SPL_LC) {
+                    if (lane < nc) lset(r, v);
+                } else if (nc <= LCe) {
                     for (int i = lane; i < nc; i += 64) {
                         const int v = tl[i];
                         int r = 0;
                         for (int j = 0; j < nc; ++j) r += (tl[j] < v) ? 1 : 0;
-                        list[r] = v;
+                        lset(r, v);
                     }
                 }
-            } else if (nc > 0 && nc <= SPL_LC) {
+            } else if (nc > 0 && nc <= LCe) {
                 int* tmp = reinterpret_cast<int*>(cov);
                 for (int i = threadIdx.x; i < nc; i += NT) tmp[i] = tl[i];
                 __syncthreads();
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
                     const int v = tmp[i];
                     int r = 0;
                     for (int j = 0; j < nc; ++j) r += (tmp[j] < v) ? 1 : 0;
-                    list[r] = v;
+                    lset(r, v);
                 }
             }
         }
@@ -359,13 +373,13 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
             }
             if (ov) {
                 const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-                if (pos < SPL_LC) list[pos] = s;
+                if (pos < LCe) lset(pos, s);
             }
             nc += tot;
             ov = ovn;
         }
     }
-    const bool overflow = nc > SPL_LC;
+    const bool overflow = nc > LCe;
     const int total = overflow ? count : nc;
     const bool use_cov = !overflow && total <= LCOV;
     __syncthreads();
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
     auto stage = [&](int from, int n) {
         __syncthreads();
         if (lane < n) {
-            const int s = overflow ? (from + lane) : list[from + lane];
+            const int s = overflow ? (from + lane) : lget(from + lane);
             const int64_t e = (sb + s) * 3;
             const float px = A.p_cam[e], py = A.p_cam[e + 1], pz = A.p_cam[e + 2];
             const float nx = A.n_cam[e], ny = A.n_cam[e + 1], nz = A.n_cam[e + 2];
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
         }
         __syncthreads();
     };
-    auto for_each = [&](auto&& body) {
+    auto for_each = [&](auto&& body, auto&& quad) {
         for (int r0 = 0; r0 < total; r0 += 64 * SPL_NS) {
             const int nr = min(64 * SPL_NS, total - r0);
             const int q = (nr + SPL_NS - 1) / SPL_NS;                // share size (<= 64)
@@ -428,7 +442,9 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
                 const int kn = max(0, min(q, r0 + nr - c0w));
                 if (!flat) stage(c0w, kn);
                 const int ko = flat ? j * q : 0;
-                for (int k = 0; k < kn; ++k) body(j, ko + k, c0w + k);
+                int k = 0;
+                for (; k + 3 < kn; k += 4) quad(j, ko + k, c0w + k);
+                for (; k < kn; ++k) body(j, ko + k, c0w + k);
             }
         }
         resident = (SPW == 1) ? total <= 64 * SPL_NS : total <= 64;
@@ -439,14 +455,37 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
         float part[SPW];
 #pragma unroll
         for (int j = 0; j < SPW; ++j) part[j] = 0.f;
-        for_each([&](int j, int k, int c) {
+        auto nu_one = [&](int j, int k, int c) {
             const Hit h = disc_eval<ALT>(sdw[0][k], sdw[1][k], sdw[2][k], sdw[3][k], sdw[4][k], sdw[5][k], sdw[6][k], rx, ry, rz, A.cover_sq, diam, A.clamp_c);
             if (h.m) part[j] += h.t * h.t;
             if (use_cov) {
                 const unsigned long long cm = __ballot(h.m);
                 if (lane == 0) cov[c] = cm;
             }
-        });
+        };
+        // four candidates per step: an evaluation is ONE dependent chain of ~60 instructions (exact division included), and a dense tile -- the
+        // reference's rendering_area 32: hundreds of candidates per share -- is paced by that latency with two waves per SIMD; four independent
+        // chains in flight, the sums still taken in candidate order (same bits).  (The compiler does not unroll a loop around a ballot itself.)
+        auto nu_quad = [&](int j, int k, int c) {
+            Hit h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                h[u] = disc_eval<ALT>(sdw[0][k + u], sdw[1][k + u], sdw[2][k + u], sdw[3][k + u], sdw[4][k + u], sdw[5][k + u], sdw[6][k + u], rx, ry, rz,
+                                      A.cover_sq, diam, A.clamp_c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (h[u].m) part[j] += h[u].t * h[u].t;
+            if (use_cov) {
+                unsigned long long cm[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cm[u] = __ballot(h[u].m);
+                if (lane == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cov[c + u] = cm[u];
+                }
+            }
+        };
+        for_each(nu_one, nu_quad);
         float nu2;
         if (PW > 1) {
             nured[wave][lane] = part[0];
@@ -470,7 +509,7 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
         acc[j].cs = 0.f; acc[j].c0 = 0.f; acc[j].c1 = 0.f; acc[j].c2 = 0.f; acc[j].dz = 0.f; acc[j].n0 = 0.f; acc[j].n1 = 0.f; acc[j].n2 = 0.f;
     }
     int ncov = 0;
-    for_each([&](int j, int k, int c) {
+    auto comp_one = [&](int j, int k, int c) {
         bool hit;
         float l;
         if (PRIM == 0) {
@@ -505,7 +544,8 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
             a.dz += e * sdw[2][k];
             a.n0 += e * ((sdw[3][k] + 1.f) / 2.f); a.n1 += e * ((sdw[4][k] + 1.f) / 2.f); a.n2 += e * ((sdw[5][k] + 1.f) / 2.f);
         }
-    });
+    };
+    for_each(comp_one, [&](int j, int k, int c) { comp_one(j, k, c); comp_one(j, k + 1, c + 1); comp_one(j, k + 2, c + 2); comp_one(j, k + 3, c + 3); });
     // merge the shares' partial states, in share order, into share 0
     SplatAcc& S = acc[0];
     if (PW > 1) {

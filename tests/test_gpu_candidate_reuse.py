@@ -309,15 +309,22 @@ def test_a_decoder_with_a_huge_lipschitz_bound_gets_a_full_pass_every_step_and_t
     assert reuse.br.creuse and reuse.br.lipschitz >= 5e4, reuse.br.lipschitz
     plain.set_crops(p0, target, [lidar] * B)
     reuse.set_crops(p0, target, [lidar] * B)
+    br, reused = reuse.br, 0
     for it in range(iters):
         plain.iteration()
         reuse.iteration()
-        _same_step(plain.br, reuse.br)
-        assert int(reuse.br.reuse_flag.sum()) == 0, it                  # no step may reuse
+        _same_step(plain.br, br)
+        # a crop may reuse its candidates only while the bound allows it: lip |z - z_ref| <= margin / 4, i.e. the (normalised) latent has moved
+        # less than ~5e-8 since its last full pass -- a step the solver skipped for that crop (optimizer.py:127-129,149-151), nothing else
+        flags = br.reuse_flag.bool()
+        moved = (br.inputs.view(B, br.G, br.NI)[:, 0, :br.L] - br.lat_ref).norm(dim=1)
+        assert bool((moved[flags] * br.lipschitz_plan <= br.margin / 4).all()) and bool((moved[flags] < 1e-7).all()), (it, moved, flags)
+        reused += int(flags.sum())
+    assert reused <= B * iters // 4, reused                               # (nearly) every step ran the whole grid
     assert int(plain.br.cnt.min()) > 200                                 # (the amplified decoder still has a shape)
     assert torch.equal(plain.results()[0], reuse.results()[0])          # results() -> check_overflow(): no exception
-    rep = reuse.br.prefilter_report()
-    assert rep["hard_violations"] == 0 and rep["full_grid_passes_per_crop"] == [iters] * B and rep["lipschitz_bound"] >= 5e4
+    rep = br.prefilter_report()
+    assert rep["hard_violations"] == 0 and sum(rep["full_grid_passes_per_crop"]) == B * iters - reused and rep["lipschitz_bound"] >= 5e4
 
 
 def test_a_kernel_error_beyond_the_margin_grows_the_margin_or_turns_reuse_off():

@@ -390,6 +390,7 @@ extern "C" int sdfr_mlp_jacobian(const sdfr_decoder* d, const float* inputs, int
     MlpParams P = d->proto;
     P.inputs = inputs; P.rows_per_crop = rows_per_crop; P.idx = idx; P.cnt = cnt; P.cap = cap; P.J = J; P.sdf_sel = sdf_sel;
     P.sdf_in = sdf_full; P.maskbuf = const_cast<uint32_t*>(mask_ws); P.trace = g_trace;      // (cycle stamps: trace builds only)
+    P.n_crops = B;                                                   // (the pool geometry of the half kernel walks the crops' live band tiles)
     const bool many_rows = (mask_from_f16 & SDFR_JAC_MANY_ROWS) != 0;       // hint: far more rows than 16 x the CU count (recomputing kernel on 32-row tiles)
     const bool half_tiles = (mask_from_f16 & SDFR_JAC_HALF_TILES) != 0;     // masks saved by a half-size-tile forward (sdfr_mlp_forward*_ragged, half_tiles = 1)
     const bool quarter_tiles = (mask_from_f16 & SDFR_JAC_QUARTER_TILES) != 0;

@@ -29,6 +29,10 @@ static int j16_geom() {
     }();
     return v;
 }
+static int j16_pool_crops() {            // (SDFR_J16_POOL_CROPS: A/B hook; a huge value turns the pool off)
+    static const int v = [] { const char* e = getenv("SDFR_J16_POOL_CROPS"); return e ? atoi(e) : 12; }();
+    return v;
+}
 static bool launch_j16_32(const MlpParams& P, int cap, int B, hipStream_t s) {
     int g = j16_geom();
     if (!g) return false;
@@ -63,6 +67,15 @@ void sdfr_launch_jac_f16_512_many(const MlpParams& P, int cap, int B, hipStream_
 #else
     // 16x16x32 products like the 16-row kernel -- every in-gradient is accumulated in the same order, so a crop's Jacobian has the same bits
     // whichever geometry the launch picked (batch-independent results) -- on 2 * NP point tiles of 16 per workgroup
+    // r06: from 8 crops (and at most 64, the pool's prefix table) a POOL of one workgroup per CU walks the live band tiles back to back -- the
+    // tiles take 130 KB of LDS, so a CU holds one workgroup, and as one-tile workgroups each of a CU's ~11 tiles paid its own dispatch
+    // (from two full rounds of tile slots: at 8 crops -- 344 live tiles -- the pool measured 119 us against 111)
+    const int64_t tiles = (int64_t)sdfr_cdiv(cap, 32 * SDFR_J16_MANY_NP) * B;
+    if (B >= j16_pool_crops() && B <= 64 && P.n_crops == B) {
+        hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 2 * SDFR_J16_MANY_NP, SDFR_J16_NW, SDFR_J16_MANY_PF, 3, 0, false, 2>),
+                           dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(64 * SDFR_J16_NW), 0, s, P);
+        return;
+    }
     hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 2 * SDFR_J16_MANY_NP, SDFR_J16_NW, SDFR_J16_MANY_PF, 3>), grid, dim3(64 * SDFR_J16_NW), 0, s, P);
 #endif
 }

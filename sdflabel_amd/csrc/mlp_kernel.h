@@ -219,7 +219,8 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     constexpr bool GMASK = MODE == 3;
     constexpr bool GATHER = (XF & 1) != 0;
     constexpr bool PERSIST = (XF & 2) != 0;
-    static_assert(XF == 0 || (MODE == 0 || MODE == 1), "GATHER / PERSIST are forward features");
+    static_assert(XF == 0 || (MODE == 0 || MODE == 1) || (MODE == 3 && XF == 2), "GATHER is a forward feature; PERSIST: forward modes and the mask-fed Jacobian");
+    constexpr bool JPOOL = JAC && PERSIST;                         // the mask-fed Jacobian as a pool over the crops' live band tiles (r06)
     static_assert(!SAVE || MS == 32, "mask layout assumes 32x32 forward tiles");
     static_assert(!SAVE || (FT * NP) % 2 == 0, "mask words: FT*NP*16 bits per thread and layer must fill whole words");
     static_assert(!HALF || !JAC || MODE == 3, "with half operands only the mask-fed Jacobian exists (MODE 3)");
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     // HBM at the start and atomicAdd-ed both parts: 24 lane-divergent global atomics in the last wave of the re-injecting layer held the
     // other seven waves at the barrier for 4-7 k cycles.)
     __shared__ float jinj[MLDS ? PT * 8 : 1];
+    __shared__ int jpfx[JPOOL ? 66 : 1];                          // JPOOL: inclusive prefix of the crops' live tiles (B <= 64), [64] = total
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -325,12 +327,28 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             for (int c = 0; c < P.n_crops; ++c) any = any || P.skip[c] == 0;
             if (!any) return;                               // nothing to evaluate in this launch: the common step of a reuse refinement
         }
+        if constexpr (JPOOL) {
+            // live tiles of crop c: ceil(min(cnt[c], cap) / PT); the pool walks them back to back (a workgroup per CU stays resident: no
+            // dispatch gap between a CU's tiles, and the last round is as full as the live tile count allows)
+            if (tid == 0) {
+                int acc_ = 0;
+                for (int c = 0; c < P.n_crops; ++c) { acc_ += (sdfr_count(P.cnt, c, P.cap) + PT - 1) / PT; jpfx[c] = acc_; }
+                jpfx[64] = acc_;
+            }
+            __syncthreads();
+            p_live = jpfx[64];
+            if ((int)blockIdx.x >= p_live) return;
+        }
     }
     do {
     int tile = blockIdx.x;
     if constexpr (PERSIST) {
         const int64_t j = (int64_t)blockIdx.x + (int64_t)p_iter * gridDim.x;
         ++p_iter;
+        if constexpr (JPOOL) {
+            if (j >= p_live) return;
+            tile = (int)j;                                  // (mapped to crop and band tile below)
+        } else
         if (p_compact) {
             if (j >= p_live) return;
             int lo = 0, hi = P.n_crops - 1;                 // first crop whose inclusive prefix exceeds j
@@ -355,10 +373,15 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
     }
     int n_valid;
     if (JAC) {
-        const int b = blockIdx.y;
+        int b = blockIdx.y, s0 = blockIdx.x * PT;
+        if constexpr (JPOOL) {
+            int lo = 0, hi = P.n_crops - 1;                 // first crop whose inclusive prefix exceeds the tile index
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (jpfx[mid] > tile) hi = mid; else lo = mid + 1; }
+            b = lo;
+            s0 = (tile - (lo > 0 ? jpfx[lo - 1] : 0)) * PT;
+        }
         const int count = sdfr_count(P.cnt, b, P.cap);
-        const int s0 = blockIdx.x * PT;
-        if (s0 >= count) return;
+        if (s0 >= count) { if constexpr (JPOOL) continue; else return; }
         n_valid = min(PT, count - s0);
         if (tid < PT) {
             const bool v = tid < n_valid;

@@ -2,7 +2,7 @@
 # One GPU-box session: parity tests, bench, rocprofv3 kernel trace + PMC passes.  Outputs under gpurun_out/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/pytest_$TAG.log
@@ -24,6 +24,13 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 bash $R/tools/sphere_pmc.sh $TAG > $O/pmcsph_$TAG.log 2>&1
 # kernel time table of the float16 + candidate-reuse refinement (256 crops x 60 iterations in chunks of 64)
 bash $R/tools/prof_refine.sh ${TAG}_f16reuse --crops 256 --chunk 64 --precision float16 --reuse > $O/prof_refine_${TAG}_f16reuse.txt 2>&1
+bash $R/tools/prof_refine.sh ${TAG}_f32reuse --crops 128 --chunk 64 --precision float32 --reuse > $O/prof_refine_${TAG}_f32reuse.txt 2>&1
+# the reference's shipped operating point (rendering_area 32, float16): per-annotation phases and a frame of 16 through optimize_many
+bash $R/tools/prof_area32.sh ${TAG}_one --only phases > $O/prof_area32_${TAG}_one.txt 2>&1
+bash $R/tools/prof_area32.sh ${TAG}_many16 --only many --frames 16 > $O/prof_area32_${TAG}_many16.txt 2>&1
+timeout 300 python $R/tools/area32_time.py > $O/area32_$TAG.log 2>&1
+# PMC passes over the float16 band Jacobian at 64 crops per launch (matrix-pipe busy, waits, L2, LDS)
+bash $R/tools/pmc_jac16.sh $TAG > $O/pmc_jac16_$TAG.txt 2>&1
 cd $R
 # gpurun merges at most 64 MiB back: the raw per-launch traces (60 MB for the full run) are not read by tools/summarize_profile.py -- only the
 # *_kernel_stats.csv of the trace runs and the *_counter_collection.csv of the PMC passes are

@@ -223,10 +223,16 @@ class BatchRenderer:
             self.max_dev = f(B)                 # (stays 0: this mode has no second arithmetic to deviate from; the plan kernel reads it)
             self.violations = i(B, 2)
             self.lipschitz = lipschitz
-            # the plan kernel reuses while  lip_plan |z1 - z0| <= margin / 4.  Here 2 e16 <= margin / 2 holds by calibration (margin >= 4 e16), so
-            # the latent's share of the margin may be 0.45 of it (|h(z1)| >= thr + margin - 0.45 margin - 0.5 margin > thr): the kernel is handed
-            # the bound scaled by 0.25 / 0.45 -- 1.8x the validity of a candidate set for the same proof
-            self.lipschitz_plan = self.lipschitz * (0.25 / 0.45)
+            # the plan kernel reuses while  lip_plan |z1 - z0| <= margin / 4.  A row outside the candidates had |h_sel(z0)| >= thr + margin at the
+            # selecting pass; with F the decoder in exact arithmetic (|F(z1) - F(z0)| <= Lip |z1 - z0|) the value consumed at z1 is
+            #   float16:        |h16(z1)| >= thr + margin - Lip |dz| - 2 e16
+            #   exact float32:  |h32(z1)| >= thr + margin - Lip |dz| - e_sel - e32
+            # so the latent may use  margin - (the kernel errors) ; 5 % of the margin stays unspent.  r05 gave the latent a flat 0.45 margin (the
+            # worst case margin = 4 e16); with the calibrated errors of the shipped decoder the share is 0.74 (float16) / 0.85 (float32): candidate
+            # sets stay valid 1.6-1.9x longer for the same proof.  The kernel is handed the bound scaled by 0.25 / share.
+            kernel_errors = 2.0 * self.f16_error if self.f16 else self.select_error + self.f16_error
+            self.latent_share = max(0.45, 0.95 - kernel_errors / self.margin)      # (>= 0.45 by calibration: margin >= 4 x the largest error)
+            self.lipschitz_plan = self.lipschitz * (0.25 / self.latent_share)
             self.reuse = True
             # (the bound is proven, so no full pass is forced for safety's sake inside a 60-iteration refinement, configs/config_refine.ini:15;
             # measured at 64 crops per launch: max_reuse 16 -> 64 and audit stride 16 -> 32 take a refinement iteration from 4.5 to 3.5 ms)
@@ -637,7 +643,7 @@ class BatchRenderer:
                "margin": float(self.margin_dev.max())}
         if self.creuse:
             rep.update({"candidate_reuse": True, "margin_grown_by_calibration": bool(self.margin_grown), "kernel_error_budget": self.select_error,
-                        "half_kernel_deviation_sampled": self.f16_deviation_sampled, "e32": self.e32, "lipschitz_bound": self.lipschitz,
+                        "half_kernel_deviation_sampled": self.f16_deviation_sampled, "e32": self.e32, "lipschitz_bound": self.lipschitz, "latent_share_of_margin": self.latent_share,
                         "full_grid_passes_per_crop": self.n_full.tolist()})
         if self.audit:
             rep["audit"] = {"stride": self.audit_stride, "rows_last_step": int(self.audit_n[0]), "steps": int(self.audit_phase[0]),

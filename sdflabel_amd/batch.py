@@ -241,7 +241,7 @@ class BatchRenderer:
             self.audit = bool(getattr(decoder, "candidate_audit", True))
             self.audit_stride = int(getattr(decoder, "candidate_audit_stride", 32))
             self.audit_split = (not self.f16) and str(getattr(decoder, "candidate_audit_arith", "split")) == "split"
-            self.audit_side = self.audit and B <= 4 and bool(getattr(decoder, "candidate_audit_side_stream", True))
+            self.audit_side = self.audit and B <= int(getattr(decoder, "candidate_audit_side_max_crops", 16)) and bool(getattr(decoder, "candidate_audit_side_stream", True))
             self._side = torch.cuda.Stream(device=dev) if self.audit_side else None
             self._side_pending = False
             self.half_tiles = self.f16 and B <= 2 and bool(getattr(decoder, "candidate_half_tiles", True))      # (a float16 option)

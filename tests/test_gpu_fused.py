@@ -159,3 +159,31 @@ def test_truncation_flags_are_sticky_across_graph_replays(reuse):
     rf.set_crops(small_p, target, [lidar] * B)                # new crops start clean
     rf.optimize(3)
     rf.results()
+
+
+def test_float16_jacobian_pool_with_empty_short_and_ragged_crops_gives_the_one_crop_bits():
+    """C ABI: sdfr_mlp_jacobian (mask-fed, half operands) at 16 crops per launch runs as a POOL of workgroups over the crops' LIVE band tiles (r06;
+    from 12 crops).  Per-crop counts of 0, 1, 63, 64, 65, a full band, ... must map every tile to its crop: each live row gets the bits it has in the launch with the crops' full
+    bands (which the B = 64 vs B = 1 refinement tests tie to the one-crop geometry), rows beyond a crop's count stay untouched, empty crops cost nothing"""
+    B, D = 16, 40
+    d = _dec(torch.float16, False, True)
+    br = sdflabel_amd.BatchRenderer(d, D, K_for(32, 32), (32, 32), B, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    lat = torch.tensor([[0.3, -0.5, 0.8]]) + 0.2 * (torch.rand(B, 3, generator=g) - 0.5)
+    br.forward(torch.full((B,), 0.7, device=DEV), torch.tensor([[0.05, 0.02, 3.3]], device=DEV).expand(B, 3).contiguous(), lat.to(DEV))
+    full = br.cnt.clone()
+    assert int(full.min()) > 500
+    want = br.J.clone()
+    L, P = _lib.lib(), _lib.ptr
+    counts = full.clone()
+    for b, c in enumerate([0, 1, 63, 64, 65, None, 0, 127, None, 129, 0, 0, None, 640, 2, None]):
+        if c is not None:
+            counts[b] = c
+    J = torch.full_like(br.J, -7.0)
+    sb = torch.full_like(br.sdf_band, -7.0)
+    _lib.check(L.sdfr_mlp_jacobian(br.handle.h, P(br.inputs), br.G, B, P(br.idx), br.cap, P(counts), P(J), P(sb), P(br.sdf), P(br.mask_ws), 2,
+                                   _lib.stream_ptr()), "sdfr_mlp_jacobian")
+    torch.cuda.synchronize()
+    live = torch.arange(br.cap, device=DEV).view(1, -1) < counts.view(-1, 1)
+    assert torch.equal(J[live], want[live]) and torch.equal(sb[live], br.sdf_band[live])
+    assert bool((J[~live] == -7.0).all()) and bool((sb[~live] == -7.0).all())

@@ -28,11 +28,22 @@ void sdfr_launch_jac_f32_512_recompute32(const MlpParams& P, int cap, int B, hip
     hipLaunchKernelGGL((sdfr_mlp_kernel<float, 32, 4, 1, 4, 2, 2>), dim3(sdfr_cdiv(cap, 32), B), dim3(256), 0, s, P);
 }
 
+#include <stdlib.h>
+static int jac_pool_crops() {            // (SDFR_JAC_POOL_CROPS: A/B hook; a huge value turns the pool off)
+    static const int v = [] { const char* e = getenv("SDFR_JAC_POOL_CROPS"); return e ? atoi(e) : 12; }();
+    return v;
+}
 void sdfr_launch_jac_f32_512(const MlpParams& P, int cap, int B, bool from_masks, hipStream_t s) {
     static_assert(SDFR_JAC_MS * SDFR_JAC_FT * SDFR_JAC_NW == 512 && 16 * SDFR_JAC_SMALL_FT * SDFR_JAC_SMALL_NW == 512, "padded width 512 = MS * FT * NW");
     if (!from_masks) {
         // recomputing Jacobian (no saved masks): 16-row tiles, 4 waves x 128 features (542 -> 511 us for 4371 rows against 8 waves x 64)
         hipLaunchKernelGGL((sdfr_mlp_kernel<float, 16, 8, 1, 4, 4, 2>), dim3(sdfr_cdiv(cap, 16), B), dim3(256), 0, s, P);
+    } else if (B >= jac_pool_crops() && B <= 64 && P.n_crops == B) {
+        // r06: a pool of two workgroups per CU (67 KB of LDS each) walks the crops' live band tiles back to back (mlp_kernel.h, JPOOL): no
+        // dispatch between a CU's ~21 tiles, no dead tile slots (a launch is sized for the capacity: 60 % of its slots are beyond the counts)
+        const int64_t tiles = (int64_t)sdfr_cdiv(cap, SDFR_JAC_MS * SDFR_JAC_NP) * B;
+        hipLaunchKernelGGL((sdfr_mlp_kernel<float, SDFR_JAC_MS, SDFR_JAC_FT, SDFR_JAC_NP, SDFR_JAC_NW, SDFR_JAC_PF, 3, 0, false, 2>),
+                           dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(64 * SDFR_JAC_NW), 0, s, P);
     } else if (B >= SDFR_JAC_SWITCH_ROWS) {
         hipLaunchKernelGGL((sdfr_mlp_kernel<float, SDFR_JAC_MS, SDFR_JAC_FT, SDFR_JAC_NP, SDFR_JAC_NW, SDFR_JAC_PF, 3>),
                            dim3(sdfr_cdiv(cap, SDFR_JAC_MS * SDFR_JAC_NP), B), dim3(64 * SDFR_JAC_NW), 0, s, P);

@@ -30,10 +30,10 @@
 #include <stdlib.h>
 #include <math.h>
 
-// LDS candidate-list capacity per tile (beyond it the tile walks EVERY surfel of the crop, twice, without coverage ballots).  4096 since r06: at the
+// LDS candidate-list capacity per tile (beyond it the tile walks EVERY surfel of the crop, twice, without coverage ballots).  3072 since r06 (6 KiB of 16-bit slots: the one-wave-per-tile geometry keeps its 16 tiles per CU): at the
 // reference's shipped rendering_area 32 (configs/config_refine.ini:13) a crop is ~18 tiles and its densest tile lists 1200-1600 of the crop's ~2700
 // surfels; with 1024 slots that tile took the walk-everything path and WAS the launch (142 us at one crop, 136 us at 16: tools/splat32_diag.py)
-#define SPL_LC 4096
+#define SPL_LC 3072
 #define SPL_SORT_MAX 1024      // binned tiles with more entries build their list by scanning the boxes (same list)
 #define SPL_LCOV 2048          // coverage ballots kept per tile by the wide geometry (16 KiB)
 #define SPL_BQ 128             // backward: covered-pixel queue per wave (drained whenever fewer than 64 slots are free)

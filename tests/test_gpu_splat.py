@@ -108,15 +108,16 @@ def _splat_any(prim, K, Kinv, p, n, attr, W, H, B, uv=None, znorm=None, bg=None,
     return outs[:2] + (outs[4],) if no_dn else outs
 
 
-@pytest.mark.parametrize("case", ["sparse", "dense", "list_overflow", "partial_tiles"])
+@pytest.mark.parametrize("case", ["sparse", "dense", "long_list", "list_overflow", "partial_tiles"])
 @pytest.mark.parametrize("bins", [0, BINS])
 def test_wave_per_tile_launch_is_bitwise_the_wave_per_share_launch(case, bins):
     """from 16384 tiles per launch the forward runs one wave per tile walking the 8 candidate shares in turn (many crops) instead of one wave
     per share: same share partition, same merge order -> the same bits.  sparse: <= 64 candidates per tile (kept resident); dense: hundreds
-    (staged share by share, two rounds); list_overflow: > 1024 candidates (every surfel walked, coverage re-evaluated); partial_tiles: image edges
+    (staged share by share, two rounds); long_list: 1300 candidates in a tile (r06: a list of 16-bit slots, the dense binned tile scans instead of
+    rank-sorting); list_overflow: > 3072 candidates (every surfel walked, coverage re-evaluated); partial_tiles: image edges
     that are no multiples of 8."""
     H, W, n, spread, z0, z1 = {"sparse": (256, 256, 3000, 0.9, 3.0, 4.0), "dense": (64, 64, 700, 0.05, 0.3, 0.4),
-                               "list_overflow": (64, 64, 1300, 0.01, 0.05, 0.06), "partial_tiles": (60, 100, 500, 0.8, 3.0, 4.0)}[case]
+                               "list_overflow": (64, 64, 3300, 0.01, 0.05, 0.06), "long_list": (64, 64, 1300, 0.01, 0.05, 0.06), "partial_tiles": (60, 100, 500, 0.8, 3.0, 4.0)}[case]
     tiles = ((W + 7) // 8) * ((H + 7) // 8)
     B = 16384 // tiles + 1
     rng = np.random.default_rng(21)

@@ -241,7 +241,7 @@ class BatchRenderer:
             self.audit = bool(getattr(decoder, "candidate_audit", True))
             self.audit_stride = int(getattr(decoder, "candidate_audit_stride", 32))
             self.audit_split = (not self.f16) and str(getattr(decoder, "candidate_audit_arith", "split")) == "split"
-            self.audit_side = self.audit and B <= int(getattr(decoder, "candidate_audit_side_max_crops", 16)) and bool(getattr(decoder, "candidate_audit_side_stream", True))
+            self.audit_side = self.audit and B <= int(getattr(decoder, "candidate_audit_side_max_crops", 64)) and bool(getattr(decoder, "candidate_audit_side_stream", True))
             self._side = torch.cuda.Stream(device=dev) if self.audit_side else None
             self._side_pending = False
             self.half_tiles = self.f16 and B <= 2 and bool(getattr(decoder, "candidate_half_tiles", True))      # (a float16 option)
@@ -444,7 +444,8 @@ class BatchRenderer:
                 # few crops per launch: every decoder pass of the step is ONE tile pass of latency with most CUs idle (25-50 tiles on 256 CUs), so
                 # the audit's pass runs BESIDE the candidates' on a side stream (fork here, join at the end of forward(); capturable: the side
                 # stream is forked from and joined into the capturing stream).  It reads rows OUTSIDE the candidates only; the main stream writes
-                # candidate rows.  Many crops per launch fill the chip: one stream.
+                # candidate rows.  r06: up to 64 crops per launch -- a full chip gains too (the audit's workgroups fill the CUs that the pool launches
+                # leave idle in their last, partial round: +1 % float16, +4 % exact float32 at 64 crops; tools/audit_side_ab.py).
                 ast = st
                 if self.audit_side:
                     self._side.wait_stream(torch.cuda.current_stream(self.dev))

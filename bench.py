@@ -606,33 +606,40 @@ def main():
             dist.all_gather(rows, mine)
         return {"rank_%d" % r: {k: float(v) for k, v in zip(keys, row.tolist())} for r, row in enumerate(rows)}
 
-    def sharded_section(label, precision, reuse, size, total, workload, render="splat"):
+    def sharded_section(label, precision, reuse, size, total, workload, render="splat", in_flight=1):
         chunk = max(1, min(64, (total + world - 1) // world))
         Kc = K_for(size, size)
+        # in_flight (r06): chunks refined at the same time, each on a refiner and a stream of its own (sdflabel_amd.parallel.refine_sharded with a
+        # list of refiners): the matrix-core-bound decoder passes of one chunk run beside the VALU-bound splat / loss kernels of the other.  Pays
+        # with the float16 decoder (+10 %); the exact-f32 iteration is 95 % decoder passes: one refiner
+        in_flight = max(1, min(in_flight, (((total + world - 1) // world) + chunk - 1) // chunk))
 
         def setup():
             d2, _ = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=precision)
             d2.prefilter_reuse = reuse
             d2.candidate_reuse = reuse                         # (float16 / exact float32: candidate rows only while the proven bound holds, r05)
             d2 = d2.to(dev)
-            rf = sdflabel_amd.BatchRefiner(d2, D, Kc, (size, size), chunk, lidar_cap=4096, device=dev, render=render)
             nocs1, lidar = synthetic_targets(dec, D, Kc, size, size, dev)      # targets from the exact-f32 rendering of the ground truth, all modes
-            rf.set_crops(crop_params(list(range(chunk))), nocs1.expand(chunk, 3, size, size), [lidar] * chunk)
-            rf.capture()
-            rf.optimize(2)                                     # warm-up (graph instantiation, allocator)
-            return [rf, crop_params(list(range(total))), nocs1, lidar]
+            rfs = []
+            for _ in range(in_flight):
+                rf = sdflabel_amd.BatchRefiner(d2, D, Kc, (size, size), chunk, lidar_cap=4096, device=dev, render=render)
+                rf.set_crops(crop_params(list(range(chunk))), nocs1.expand(chunk, 3, size, size), [lidar] * chunk)
+                rf.capture()
+                rf.optimize(2)                                 # warm-up (graph instantiation, allocator)
+                rfs.append(rf)
+            return [rfs, crop_params(list(range(total))), nocs1, lidar]
 
         def run(st):
-            rf, params, nocs1, lidar = st[:4]
+            rfs, params, nocs1, lidar = st[:4]
             tm = {}
-            st.append(refine_sharded(rf, params, nocs1, lidar, args.sharded_iters, rank, world, timing=tm))
+            st.append(refine_sharded(rfs if len(rfs) > 1 else rfs[0], params, nocs1, lidar, args.sharded_iters, rank, world, timing=tm))
             st.append(tm)
 
         res_, err_ = timed_section(setup, run)
         if res_ is None:
             return {"label": label, "error": err_}
         st, dt_s = res_
-        rf, table, tm = st[0], st[-2], st[-1]
+        rf, table, tm = st[0][0], st[-2], st[-1]
         ok = tuple(table.shape) == (total, 7 + rf.L) and bool(torch.isfinite(table).all())
         p_all = st[1]
         out = {"label": label, "workload": workload % (total, size, size, world, chunk), "decoder_precision": str(precision).replace("torch.", ""),
@@ -643,7 +650,7 @@ def main():
                "gathered_row": "yaw, trans(3), scale, latent(%d), weighted 2-D loss, weighted 3-D loss" % rf.L,
                "mean_weighted_losses_2d_3d_after": [float(table[:, -2].mean()), float(table[:, -1].mean())],
                "gathered_table_ok": ok, "scaling": "strong (total crops fixed): speed-up at N ranks = seconds(N=1) / seconds(N)",
-               "per_rank_phase_seconds": phase_table(tm)}
+               "chunks_in_flight_per_rank": in_flight, "per_rank_phase_seconds": phase_table(tm)}
         if render != "splat":
             out["renderer"] = "sphere tracer (BatchRefiner(render='trace'), surfel-semantics backward): not the reference's algorithm"
         if rf.br is not None and getattr(rf.br, "guarded", False):
@@ -670,33 +677,37 @@ def main():
             d2 = d2.to(dev)
             shapes, Ks, targets, lidars, starts = kitti_like_problems(dec, D, area, distinct, dev)
             pmax = max(1024, 1 << (max(h * w for h, w in shapes) - 1).bit_length())
-            rf = sdflabel_amd.BatchRefiner(d2, D, Ks[0], shapes[0], chunk, lidar_cap=max(1024, 1 << (max(l.shape[0] for l in lidars) - 1).bit_length()),
-                                           device=dev, max_pixels=pmax, candidate_reuse=True)
             ids = [i % distinct for i in range(total)]
             params = {k: np.stack([starts[j][k].reshape(-1) for j in ids]) for k in ("yaw", "trans", "scale", "latent")}
             params["yaw"] = params["yaw"] + 0.01 * (np.arange(total, dtype=np.float32) // distinct).reshape(-1, 1)      # (repeats start elsewhere)
             sel = list(range(chunk))
-            rf.set_crops({k: v[sel] for k, v in params.items()}, [targets[ids[i]] for i in sel], [lidars[ids[i]] for i in sel],
-                         K=np.stack([Ks[ids[i]] for i in sel]), crop_sizes=[shapes[ids[i]] for i in sel])
-            rf.capture()
-            rf.optimize(2)
-            return [rf, params, [targets[j] for j in ids], [lidars[j] for j in ids], np.stack([Ks[j] for j in ids]), [shapes[j] for j in ids], shapes]
+            rfs = []
+            for _ in range(2 if (total + world - 1) // world > chunk else 1):          # two chunks in flight per rank (see sharded_section)
+                rf = sdflabel_amd.BatchRefiner(d2, D, Ks[0], shapes[0], chunk, lidar_cap=max(1024, 1 << (max(l.shape[0] for l in lidars) - 1).bit_length()),
+                                               device=dev, max_pixels=pmax, candidate_reuse=True)
+                rf.set_crops({k: v[sel] for k, v in params.items()}, [targets[ids[i]] for i in sel], [lidars[ids[i]] for i in sel],
+                             K=np.stack([Ks[ids[i]] for i in sel]), crop_sizes=[shapes[ids[i]] for i in sel])
+                rf.capture()
+                rf.optimize(2)
+                rfs.append(rf)
+            return [rfs, params, [targets[j] for j in ids], [lidars[j] for j in ids], np.stack([Ks[j] for j in ids]), [shapes[j] for j in ids], shapes]
 
         def run(st):
-            rf, params, tg, li, Kall, sz = st[:6]
+            rfs, params, tg, li, Kall, sz = st[:6]
             tm = {}
-            st.append(refine_sharded(rf, params, tg, li, args.sharded_iters, rank, world, K=Kall, crop_sizes=sz, timing=tm))
+            st.append(refine_sharded(rfs if len(rfs) > 1 else rfs[0], params, tg, li, args.sharded_iters, rank, world, K=Kall, crop_sizes=sz, timing=tm))
             st.append(tm)
 
         res_, err_ = timed_section(setup, run)
         if res_ is None:
             return {"error": err_}
         st, dt_s = res_
-        rf, table, tm, shapes = st[0], st[-2], st[-1], st[6]
+        rf, table, tm, shapes = st[0][0], st[-2], st[-1], st[6]
+        n_flight = len(st[0])
         y0 = st[1]["yaw"].reshape(-1)
         out = {"label": "the reference's shipped operating point (configs/config_refine.ini:11-19), batched: float16 decoder, candidate reuse, ragged crops",
                "workload": "%d KITTI-like crops at rendering_area %d (own (H, W) and K per crop, %d distinct problems), 60 iterations, sharded crop i -> rank i mod %d, "
-                           "ragged chunks of %d through one BatchRefiner + one captured graph, one all_gather" % (total, area, distinct, world, chunk),
+                           "ragged chunks of %d through one BatchRefiner + one captured graph per chunk in flight (%d), one all_gather" % (total, area, distinct, world, chunk, n_flight),
                "total_crops": total, "iterations_per_crop": args.sharded_iters, "world_size": world, "seconds": dt_s, "crops_per_s": total / dt_s,
                "crop_sizes_h_w_min_max": [list(min(shapes)), list(max(shapes))], "rendering_area": area, "graph_captures": getattr(rf, "captures", None),
                "mean_abs_yaw_error_before_after": [float(np.abs(y0 - 0.6).mean()), float((table[:, 0] - 0.6).abs().mean())],
@@ -719,7 +730,7 @@ def main():
                                            max(64, args.total_crops // 8), wl)
         sharded16 = sharded_section("float16 decoder = the reference's shipped precision (config_refine.ini:19), f32 everything else; candidate reuse: "
                                     "the half decoder runs on the band candidates alone while a proven Lipschitz bound keeps them valid (bit-identical "
-                                    "to the full-grid evaluation, audited)", torch.float16, True, H, args.total_crops, wl)
+                                    "to the full-grid evaluation, audited); two chunks in flight per rank", torch.float16, True, H, args.total_crops, wl, in_flight=2)
         if world == 1:
             sharded16_full = sharded_section("float16 decoder, every grid row every iteration (the r04 figure)", torch.float16, False, H, args.total_crops, wl)
         if world == 1:
@@ -732,7 +743,7 @@ def main():
         if H == 256 and args.configs4_crops > 0 and world == 1:
             sharded_c4 = sharded_section("BASELINE configs[4] shape: 512x512 rays, float16 decoder on the f16 matrix cores, candidate reuse", torch.float16, True, 512,
                                          args.configs4_crops, "BASELINE configs[4]: %d crops of %dx%d rays, float16 DeepSDF decoder, sharded crop i -> rank "
-                                         "i mod %d, chunks of %d through BatchRefiner, one all_gather")
+                                         "i mod %d, chunks of %d through BatchRefiner, one all_gather", in_flight=2)
 
     # ---- labelled second line: pose-only refinement (BASELINE configs[1] says "pose-only refinement"; SURVEY.md 8d: "latent frozen -- MLP
     # result may be cached; state whether it was").  The HEADLINE above caches nothing.  Here the latent is fixed, so decoder, band and Jacobian

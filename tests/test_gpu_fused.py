@@ -187,3 +187,26 @@ def test_float16_jacobian_pool_with_empty_short_and_ragged_crops_gives_the_one_c
     live = torch.arange(br.cap, device=DEV).view(1, -1) < counts.view(-1, 1)
     assert torch.equal(J[live], want[live]) and torch.equal(sb[live], br.sdf_band[live])
     assert bool((J[~live] == -7.0).all()) and bool((sb[~live] == -7.0).all())
+
+
+@pytest.mark.parametrize("precision", [torch.float16, torch.float32])
+def test_two_chunks_in_flight_give_the_bits_of_one_refiner(precision):
+    """r06: sdflabel_amd.parallel.refine_sharded with a LIST of refiners refines that many chunks at the same time, each refiner's iterations replayed
+    on a stream of its own (the decoder passes of one chunk beside the splat / loss kernels of the other).  The chunks are independent: the
+    gathered table must equal the one-refiner table bit for bit -- 22 crops in chunks of 4 (a lone, padded last chunk), HIP-graph replay"""
+    from sdflabel_amd.parallel import refine_sharded
+    from sdflabel_amd.fixtures import crop_params
+    D, H, W, B, n = 40, 48, 48, 4, 22
+    K, _, target, lidar = _problem(D, H, W, 1)
+    d = _dec(precision, True, True)
+
+    def refiner():
+        rf = sdflabel_amd.BatchRefiner(d, D, K, (H, W), B, lidar_cap=4096, device=DEV)
+        rf.set_crops(crop_params(list(range(B))), target.expand(B, 3, H, W), [lidar] * B)
+        rf.capture()
+        return rf
+
+    one = refine_sharded(refiner(), crop_params(list(range(n))), target, lidar, 12)
+    tm = {}
+    two = refine_sharded([refiner(), refiner()], crop_params(list(range(n))), target, lidar, 12, timing=tm)
+    assert tuple(one.shape) == (n, 10) and torch.equal(one, two) and tm["chunks"] == 6 and tm["refiners_in_flight"] == 2

@@ -241,3 +241,17 @@ def test_refine_sharded_ragged_crops_and_phase_timing():
     assert torch.equal(table, _expected(n, 3))
     assert seen[0][0] == [0, 1, 2, 3] and seen[1][0] == [4, 5, 6, 6] and seen[1][1] == [sizes[4], sizes[5], sizes[6], sizes[6]]
     assert tm["chunks"] == 2 and all(tm[k] >= 0.0 for k in ("set_crops", "optimize", "all_gather"))
+
+
+def test_refine_sharded_with_two_refiners_in_flight_gives_the_same_table():
+    """r06: a LIST of refiners = that many chunks in flight (each on a stream of its own on the GPU; in turn on CPU stand-ins): same table, the
+    chunks dealt to the refiners in order, a lone last chunk handled by the first refiner"""
+    from sdflabel_amd.parallel import refine_sharded
+    a, b = _FakeRefiner(4), _FakeRefiner(4)
+    tm = {}
+    table = refine_sharded([a, b], _params(19), torch.zeros(19, 3, 4, 4), [torch.zeros(2, 3)] * 19, 3, timing=tm)
+    assert torch.equal(table, _expected(19, 3))
+    assert len(a.calls) == 3 and len(b.calls) == 2 and tm["chunks"] == 5 and tm["refiners_in_flight"] == 2
+    assert a.calls[0][0] == 0 and b.calls[0][0] == 4 and a.calls[1][0] == 8 and b.calls[1][0] == 12 and a.calls[2][0] == 16
+    with pytest.raises(ValueError, match="share batch size"):
+        refine_sharded([_FakeRefiner(4), _FakeRefiner(2)], _params(5), torch.zeros(1, 3, 4, 4), torch.zeros(2, 3), 1)

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--iters", type=int, default=60)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--precision", default="float32", choices=["float32", "float16", "float32_split", "float32_prefilter"])
+    ap.add_argument("--in-flight", type=int, default=1, help="chunks refined at the same time, each on a refiner and a stream of its own (r06; 2 pays "
+                    "with the float16 decoder: its decoder passes run beside the other chunk's splat / loss kernels)")
     ap.add_argument("--reuse", action="store_true", help="candidate reuse (float16: decoder.candidate_reuse; float32_prefilter: prefilter_reuse)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -52,9 +54,13 @@ def main():
     from sdflabel_amd.fixtures import crop_params
     from sdflabel_amd.parallel import refine_sharded
     chunk = max(1, min(args.chunk, (args.crops + world - 1) // world))
-    rf = sdflabel_amd.BatchRefiner(dec, D, K, (H, W), chunk, lidar_cap=4096, device=dev)
-    rf.set_crops(crop_params(list(range(chunk))), target.expand(chunk, 3, H, W), [lidar] * chunk)
-    rf.capture()
+    rfs = []
+    for _ in range(max(1, args.in_flight)):
+        rf = sdflabel_amd.BatchRefiner(dec, D, K, (H, W), chunk, lidar_cap=4096, device=dev)
+        rf.set_crops(crop_params(list(range(chunk))), target.expand(chunk, 3, H, W), [lidar] * chunk)
+        rf.capture()
+        rfs.append(rf)
+    rf = rfs if len(rfs) > 1 else rfs[0]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -23,8 +23,11 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 # the sphere march: HBM bytes and matrix-pipe counters (three --pmc passes)
 bash $R/tools/sphere_pmc.sh $TAG > $O/pmcsph_$TAG.log 2>&1
 # kernel time table of the float16 + candidate-reuse refinement (256 crops x 60 iterations in chunks of 64)
-bash $R/tools/prof_refine.sh ${TAG}_f16reuse --crops 256 --chunk 64 --precision float16 --reuse > $O/prof_refine_${TAG}_f16reuse.txt 2>&1
-bash $R/tools/prof_refine.sh ${TAG}_f32reuse --crops 128 --chunk 64 --precision float32 --reuse > $O/prof_refine_${TAG}_f32reuse.txt 2>&1
+# (--serial-audit: per-kernel durations are only meaningful when the kernels do not overlap; the product default runs the audit chain beside the
+# candidates' pass and the Jacobian, which stretches all three -- that run is the *_concurrent table)
+bash $R/tools/prof_refine.sh ${TAG}_f16reuse --crops 256 --chunk 64 --precision float16 --reuse --serial-audit > $O/prof_refine_${TAG}_f16reuse.txt 2>&1
+bash $R/tools/prof_refine.sh ${TAG}_f16reuse_concurrent --crops 256 --chunk 64 --precision float16 --reuse > $O/prof_refine_${TAG}_f16reuse_concurrent.txt 2>&1
+bash $R/tools/prof_refine.sh ${TAG}_f32reuse --crops 128 --chunk 64 --precision float32 --reuse --serial-audit > $O/prof_refine_${TAG}_f32reuse.txt 2>&1
 # the reference's shipped operating point (rendering_area 32, float16): per-annotation phases and a frame of 16 through optimize_many
 bash $R/tools/prof_area32.sh ${TAG}_one --only phases > $O/prof_area32_${TAG}_one.txt 2>&1
 bash $R/tools/prof_area32.sh ${TAG}_many16 --only many --frames 16 > $O/prof_area32_${TAG}_many16.txt 2>&1

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--precision", default="float32", choices=["float32", "float16", "float32_split", "float32_prefilter"])
     ap.add_argument("--in-flight", type=int, default=1, help="chunks refined at the same time, each on a refiner and a stream of its own (r06; 2 pays "
                     "with the float16 decoder: its decoder passes run beside the other chunk's splat / loss kernels)")
+    ap.add_argument("--serial-audit", action="store_true", help="the audit chain on the main stream at every batch size (for kernel time tables: "
+                    "beside the candidates' pass -- the default up to 64 crops -- the overlapping kernels stretch each other's durations)")
     ap.add_argument("--reuse", action="store_true", help="candidate reuse (float16: decoder.candidate_reuse; float32_prefilter: prefilter_reuse)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -42,6 +44,8 @@ def main():
     prec = {"float32": torch.float32, "float16": torch.float16}.get(args.precision, args.precision)
     dec, L = sdflabel_amd.setup_dsdf(ASSET + ".pt", precision=prec)
     dec.candidate_reuse = dec.prefilter_reuse = bool(args.reuse)
+    if args.serial_audit:
+        dec.candidate_audit_side_max_crops = 4
     dec = dec.to(dev)
     D, H, W = 40, args.size, args.size
     K = K_for(H, W)

@@ -278,8 +278,10 @@ int sdfr_project_dcm_bwd(const float* pose, const float* points, const float* no
  *   aux [B][H*W][4]: per-pixel state for the backward (nu, max logit, softmax denominator, clamp gates)
  */
 #define SDFR_JAC_MANY_ROWS 16
-#define SDFR_JAC_HALF_TILES 32  /* the masks were saved by a forward on half-size tiles (sdfr_mlp_forward_ragged / _f16_ragged with half_tiles = 1) */
-#define SDFR_JAC_QUARTER_TILES 64  /* ... on quarter-size tiles (sdfr_mlp_forward_candidates with half_tiles = 2: 32-row tiles, float16) */
+/* Since SDFR_VERSION 400 the mask workspace has ONE layout whatever launch saved it (64 bytes per row and layer, rows in blocks of 128:
+ * csrc/mlp_kernel.h sdfr_mask_dword), so the two flags below no longer select anything; they are accepted and ignored. */
+#define SDFR_JAC_HALF_TILES 32  /* (until version 300) the masks were saved by a forward on half-size tiles (sdfr_mlp_forward_ragged / _f16_ragged with half_tiles = 1) */
+#define SDFR_JAC_QUARTER_TILES 64  /* (until version 300) ... on quarter-size tiles (sdfr_mlp_forward_candidates with half_tiles = 2: 32-row tiles, float16) */
 #define SDFR_PRIM_BOXES_READY 256   /* OR into `primitive` of sdfr_splat_forward: bbox_ws already holds the surfels' screen boxes and tile lists */
 #define SDFR_PRIM_BINS 512          /* OR into `primitive`: bbox_ws is the LARGE workspace of sdfr_splat_ws_words() and per-tile surfel lists are
                                        built in it and used; without the flag bbox_ws only needs int32[B][cap][4] (boxes) and every 8x8 tile

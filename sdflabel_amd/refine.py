@@ -42,6 +42,7 @@ class BatchRefiner:
         self.w2 = float((weights or {}).get('2d', 0.3))          # configs/config_refine.ini:26-27
         self.w3 = float((weights or {}).get('3d', 0.5))
         self.optimize_latent = bool(optimize_latent)
+        self.unresolved_last = 0            # render='trace': rays unresolved at the step budget in the last checked iteration (check_overflow)
         if render not in ("splat", "trace"):
             raise ValueError("render must be 'splat' or 'trace'")
         if trace_grad not in ("surfel", "image"):

@@ -16,35 +16,14 @@
 #define SDFR_J16_SWITCH_CROPS 2       // 64-row tiles from this many crops per launch (tools/jac16_time.py, us per launch, 16-row / 64-row tiles:
 #endif                                // 1 crop 50 / 81, 2 crops 97 / 80, 4: 144 / 81, 8: 287 / 157, 64: 2148 / 1090)
 void sdfr_launch_jac_f16_512_many(const MlpParams& P, int cap, int B, hipStream_t s);
-// r06 experiment hook: SDFR_J16_GEOM = "32x1" | "32x2" | "32x4" | "32" (by crop count) takes 32x32x16 products on 32- / 64- / 128-row tiles
-static int j16_geom() {
-    static const int v = [] {
-        const char* e = getenv("SDFR_J16_GEOM");
-        if (!e) return 0;
-        if (!strcmp(e, "32x1")) return 1;
-        if (!strcmp(e, "32x2")) return 2;
-        if (!strcmp(e, "32x4")) return 4;
-        if (!strcmp(e, "32")) return 8;
-        return 0;
-    }();
-    return v;
-}
+// (r06: 32x32x16 products on 32- / 64- / 128-row tiles were measured for this kernel and rejected -- 1.2 / 1.1 / 2.1 ms at 64 crops against 0.98;
+// profiles/r06_notes.md section 2.  The hook that selected them is gone: they summed in another order, i.e. gave other bits.)
 static int j16_pool_crops() {            // (SDFR_J16_POOL_CROPS: A/B hook; a huge value turns the pool off)
     static const int v = [] { const char* e = getenv("SDFR_J16_POOL_CROPS"); return e ? atoi(e) : 12; }();
     return v;
 }
-static bool launch_j16_32(const MlpParams& P, int cap, int B, hipStream_t s) {
-    int g = j16_geom();
-    if (!g) return false;
-    if (g == 8) g = B >= 8 ? 4 : (B >= 2 ? 2 : 1);
-    if (g == 1) hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 1, 8, 4, 3, 2>), dim3(sdfr_cdiv(cap, 32), B), dim3(512), 0, s, P);
-    else if (g == 2) hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 2, 8, 2, 3, 2>), dim3(sdfr_cdiv(cap, 64), B), dim3(512), 0, s, P);
-    else hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, 4, 8, 2, 3, 2>), dim3(sdfr_cdiv(cap, 128), B), dim3(512), 0, s, P);
-    return true;
-}
 void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s) {
     static_assert(16 * SDFR_J16_FT * SDFR_J16_NW == 512, "padded width 512 = 16 * FT * NW");
-    if (launch_j16_32(P, cap, B, s)) return;
     if (B >= SDFR_J16_SWITCH_CROPS) { sdfr_launch_jac_f16_512_many(P, cap, B, s); return; }
     const dim3 grid(sdfr_cdiv(cap, 16), B);
     hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 16, SDFR_J16_FT, 1, SDFR_J16_NW, SDFR_J16_PF, 3>), grid, dim3(64 * SDFR_J16_NW), 0, s, P);
@@ -60,7 +39,6 @@ void sdfr_launch_jac_f16_512(const MlpParams& P, int cap, int B, hipStream_t s) 
 #define SDFR_J16_MANY_PF 2
 #endif
 void sdfr_launch_jac_f16_512_many(const MlpParams& P, int cap, int B, hipStream_t s) {
-    if (launch_j16_32(P, cap, B, s)) return;
     const dim3 grid(sdfr_cdiv(cap, 32 * SDFR_J16_MANY_NP), B);
 #ifdef SDFR_J16_MANY_32
     hipLaunchKernelGGL((sdfr_mlp_kernel<h16, 32, 2, SDFR_J16_MANY_NP, 8, 2, 3>), grid, dim3(512), 0, s, P);

@@ -870,3 +870,41 @@ def test_config3_sharded_flow_1024_crops_world_1():
         one.optimize(ITERS)
         r1, l2, l3 = one.results()
         assert torch.equal(r1[0], table[i, :8]) and float(l2[0]) == float(table[i, 8]) and float(l3[0]) == float(table[i, 9]), i
+
+
+@pytest.mark.parametrize("precision", [torch.float32, torch.float16])
+@pytest.mark.parametrize("kw", [dict(latent_in=[2, 4], xyz_in_all=False), dict(latent_in=[3], xyz_in_all=True)])
+def test_band_jacobian_pool_on_other_injection_patterns(kw, precision):
+    """r06: from 12 crops per launch the mask-fed band Jacobian runs as a POOL of workgroups over the live band tiles (float32: two workgroups per
+    CU; float16: one, masks in LDS, J rows assembled in LDS).  On 512-wide decoders with several latent_in layers / xyz_in_all and layers that are
+    not 512 wide, a crop's Jacobian and band values must have the bits of the one-crop launch (other tile geometry, no pool), and the float32
+    one must equal the oracle's input Jacobian"""
+    from oracle import sdf_oracle as O
+    torch.manual_seed(11)
+    dims = [300, 512, 512, 400, 512, 512]
+    d = sdflabel_amd.Decoder(3, dims=dims, norm_layers=(), weight_norm=False, **kw)
+    with torch.no_grad():
+        for p in d.parameters():
+            p.mul_(1.3)
+    d = d.to(DEV).eval()
+    d.mlp_precision = precision
+    D, B = 10, 13
+    G = D ** 3
+    rng = np.random.default_rng(4)
+    lats = rng.standard_normal((B, 3)).astype(np.float32)
+    yaws = np.zeros(B, np.float32); trans = np.tile(np.array([[0.0, 0.0, 3.5]], np.float32), (B, 1))
+    big = sdflabel_amd.BatchRenderer(d, D, K_for(16, 16), (16, 16), B, cap=G, threshold=1e9, device=DEV)       # every grid row is a band row
+    one = sdflabel_amd.BatchRenderer(d, D, K_for(16, 16), (16, 16), 1, cap=G, threshold=1e9, device=DEV)
+    big.forward(T(yaws), T(trans), T(lats))
+    assert int(big.cnt.min()) == G
+    for b in (0, 5, 12):
+        one.forward(T(yaws[b:b + 1]), T(trans[b:b + 1]), T(lats[b:b + 1]))
+        assert torch.equal(one.J[0], big.J[b]) and torch.equal(one.sdf_band[0], big.sdf_band[b]), b
+    if precision == torch.float32:
+        layers = [(W, b_, None) for W, b_ in d.effective_layers()]
+        spec = dict(dims=dims, latent_in=list(kw["latent_in"]), xyz_in_all=kw["xyz_in_all"])
+        inp = N(big.inputs.view(B, G, 6)[12])
+        ref, cache = O.decoder_forward(layers, spec, inp, want_cache=True)
+        Jref = O.decoder_backward_inputs(layers, spec, inp, cache, np.ones_like(ref))
+        err = np.abs(N(big.J[12]) - Jref)
+        assert np.quantile(err, 0.999) < 5e-6 and err.max() < 5e-3 and (err > 5e-5).sum() <= 40

@@ -137,7 +137,7 @@ extern "C" int sdfr_band_select_skip(const float* sdf, int64_t G, int B, float t
 // ... and with a STICKY truncation flag (r06): over[b] |= over_bit whenever crop b's selection holds more than `cap` rows.  cnt[b] is
 // overwritten by every selection, so a band that overflows in iterations 5-40 of a graph-replayed refinement and fits again at the end would
 // pass a check of the last count alone; the flag stays until the caller clears it (BatchRenderer.check_overflow / set_crops).  The reference
-// has no capacity (grid.py:64-66).  Launches of up to SDFR_BAND_ONE_WG_CROPS crops take the one-workgroup-per-crop kernel (one launch).
+// has no capacity (grid.py:64-66).  Launches of up to SDFR_BAND_ONE_WG_CROPS crops WITH skip flags take the one-workgroup-per-crop kernel (one launch).
 #define SDFR_BAND_ONE_WG_CROPS 8
 extern "C" int sdfr_band_select_ex(const float* sdf, int64_t G, int B, float thr, const float* thr_extra, const int32_t* skip, int32_t* idx,
                                    int cap, int32_t* cnt, int32_t* slot, int32_t* scratch, int32_t* over, int over_bit, void* stream) {
@@ -151,7 +151,10 @@ static int band_select_impl(const float* sdf, int64_t G, int B, float thr, const
     if (B == 0) return SDFR_OK;
     hipStream_t s = (hipStream_t)stream;
     if (G == 0) { SDFR_HIP_CHECK(sdfr_zero_async(cnt, sizeof(int32_t) * B, s)); return SDFR_OK; }
-    if (over && B <= SDFR_BAND_ONE_WG_CROPS) {
+    // (only where the selection is skipped on most steps -- the reuse modes' per-crop flags: one launch that usually has nothing to do.  A
+    // selection that really scans its 64 000 rows with one workgroup takes 47 us against 5 + 6 us for the two-kernel form: r06's first builds took
+    // this path in the headline step too and paid 36 us per step for it, profiles/r06_kernel_stats.csv)
+    if (over && skip && B <= SDFR_BAND_ONE_WG_CROPS) {
         hipLaunchKernelGGL(sdfr_band_select_crop_kernel, dim3(B), dim3(1024), 0, s, sdf, G, thr, thr_extra, idx, cap, cnt, slot, skip, over, over_bit);
         SDFR_LAUNCH_CHECK();
         return SDFR_OK;

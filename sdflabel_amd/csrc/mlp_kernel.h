@@ -953,6 +953,23 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
             // layout v2 (sdfr_mask_dword): this thread's 16 bits of (feature tile f, point tile p) -- bits ((f*NP + p)*4 + rg)*4 + i of its mask
             // words -- are one short of row tile*PT + p*32 + lp, dword (fbase >> 5) + f, half lg.  The 128-row block is uniform over the workgroup.
             const int64_t row0 = (int64_t)tile * PT;
+            if constexpr (FT == 2) {
+                // The wave's 64 features are dwords 2 wave, 2 wave + 1 of a row's line; lanes lp and lp + 32 (lg = 0 / 1) hold the two 16-bit halves
+                // of both.  One cross-lane exchange per point tile gives BOTH lanes the row's full 8 bytes, and lane group p & 1 stores them: NP / 2
+                // 8-byte stores per lane and layer, 32 lanes x 8 bytes per instruction.  (r06's first layout-v2 builds wrote FT NP 16-bit stores per
+                // lane -- 32 partial writes of 2 bytes per 64-byte line and layer: the half forward with masks lost 11-16 %, 93 -> 108 us at one crop.)
+                uint2* mb2 = reinterpret_cast<uint2*>(P.maskbuf) + (((row0 >> 7) * P.n_mfma + l) * 128) * (int64_t)(HP / 64);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const uint32_t h0 = (mw[p >> 1] >> ((p & 1) * 16)) & 0xffffu;                    // f = 0: field f * NP + p
+                    const uint32_t h1 = (mw[(NP + p) >> 1] >> (((NP + p) & 1) * 16)) & 0xffffu;      // f = 1
+                    const uint32_t mine = h0 | (h1 << 16);
+                    const uint32_t other = (uint32_t)__shfl_xor((int)mine, 32, 64);
+                    const uint32_t lo = lg == 0 ? mine : other, hi = lg == 0 ? other : mine;         // lane group 0's / 1's halves
+                    if (lg == (p & 1))
+                        mb2[((int)(row0 & 127) + p * MS + lp) * (HP / 64) + (fbase >> 6)] = make_uint2((lo & 0xffffu) | (hi << 16), (lo >> 16) | (hi & 0xffff0000u));
+                }
+            } else {
             uint16_t* mb = reinterpret_cast<uint16_t*>(P.maskbuf) + (((row0 >> 7) * P.n_mfma + l) * 128) * (int64_t)(HP / 32) * 2;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
@@ -962,6 +979,7 @@ __global__ __launch_bounds__(64 * NW, SDFR_MLP_WPE) void sdfr_mlp_kernel(const M
                     const int fi = f * NP + p;
                     mb[off + 2 * f] = (uint16_t)(mw[fi >> 1] >> ((fi & 1) * 16));
                 }
+            }
             }
         }
         SDFR_STAMP(l, 3);

@@ -472,11 +472,13 @@ int sdfr_losses_fused(const float* rend, const float* target, int B, int H, int 
                       const int32_t* ecnt, int ecap, const float* lidar, const int32_t* lcnt, int lcap, const float* scale, float threshold3d,
                       float weight3d, float* loss3d, float* g_est, float* g_scale, int32_t* npairs, float* scratch3, float* kscale,
                       void* stream);
-/* sdfr_splat_backward(_r) of the disc primitive for a colour gradient alone, scaled by kscale[2 b] on load (primitives.py:209-242 backward). */
+/* sdfr_splat_backward(_r) of the disc primitive for a colour gradient alone, scaled by kscale[2 b] on load (primitives.py:209-242 backward).
+ * bbox_ws (may be NULL): the splat workspace this step's sdfr_surfels_forward(_r) / sdfr_splat_forward(_r) filled -- the surfels' screen boxes at
+ * its head are then read instead of recomputed (same boxes, same results). */
 int sdfr_splat_backward_x(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr, int B, int cap,
                           const int32_t* cnt, int W, int H, const int32_t* wh, int pix_stride, float diam, float depth_constant, const float* aux,
                           const float* color, const float* g_color, const float* kscale, float* g_p_cam, float* g_n_cam, float* g_attr,
-                          void* stream);
+                          const int32_t* bbox_ws, void* stream);
 /* sdfr_pose_latent_backward (g_xyzf scaled by kscale[2 b + 1] on load) + sdfr_solver_step.  g_yaw / g_trans / g_latent are the sections of
  * `grads`, whose scale section the loss launch has written (optimizer.py:156 backward, :13-23 step). */
 int sdfr_pose_latent_solver(const float* pose, const float* points, const float* normals, const float* g_p_cam, const float* g_n_cam,

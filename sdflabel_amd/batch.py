@@ -610,7 +610,7 @@ class BatchRenderer:
             B, cap = self.B, self.cap
             ck(L.sdfr_splat_backward_x(P(self.K), P(self.Kinv), P(self.p_cam), P(self.n_cam), P(self.attr), B, cap, P(self.cnt), self.W, self.H,
                                        P(self.wh) if self.ragged else None, self.PS, _DIAM_DISC, _DEPTH_CONSTANT, P(self.aux), P(self.color),
-                                       P(g_color), P(kscale), P(self.g_p), P(self.g_n), P(self.g_a), st), "sdfr_splat_backward_x")
+                                       P(g_color), P(kscale), P(self.g_p), P(self.g_n), P(self.g_a), P(self.bbox), st), "sdfr_splat_backward_x")
             ck(L.sdfr_pose_latent_solver(P(self.pose), P(self.points), P(self.normals), P(self.g_p), P(self.g_n), P(self.g_a), B, cap, P(self.cnt),
                                          self.nocs_mode | 4, P(g_xyzf), P(self.fslot), P(kscale), None if self.freeze_shape else P(self.J), self.NI,
                                          self.L, P(self.yaw), P(self.latent), P(self.latnorm), P(self.g_pose), P(self.g_latn), P(sv["params"]),

@@ -626,9 +626,26 @@ __global__ __launch_bounds__(64 * PW) void sdfr_splat_fwd_kernel(const SplatArgs
 
 // ---- backward ---------------------------------------------------------------------------------------------------
 
+// Sum over the 64 lanes of a wave, the same value in every lane.  r06: DPP row shifts + row broadcasts (one v_add_f32_dpp per step, no LDS crossbar):
+// lane 63 ends up with  ((row0) + (row1)) + ((row2) + (row3)),  each row summed as a shifted prefix -- a fixed order, bit-repeatable, but not
+// r05's butterfly order (__shfl_xor: 6 ds_bpermute + 6 adds per value, 12 values per surfel = a sixth of the backward's instructions).
+// 1 / x to within an ulp: hardware reciprocal estimate + one Newton step (for gradient arithmetic only, see the chain below)
+__device__ __forceinline__ float fast_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.f), r, r);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add<0x111, 0xf>(v);        // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);        // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);        // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);        // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_add<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // DENSE: the upstream gradient is given per (surfel, pixel) weight -- gW [B][rows][P], rows = cap (+1 with a background row) -- together with
@@ -644,7 +661,8 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
                                                             const float* __restrict__ g_depth, const float* __restrict__ g_normals,
                                                             float* __restrict__ g_p, float* __restrict__ g_n, float* __restrict__ g_attr,
                                                             const float* __restrict__ gW = nullptr, const float* __restrict__ Sd = nullptr,
-                                                            int rows = 0, const float* __restrict__ kscale = nullptr) {
+                                                            int rows = 0, const float* __restrict__ kscale = nullptr,
+                                                            const int4* __restrict__ boxes = nullptr) {
     int xb, b;
     sdfr_xcd_crop_map(xb, b);          // a crop's surfels on one XCD: its pixel records (aux, images, upstream gradients) are fetched by one L2
     const float kc = KS ? kscale[2 * b] : 1.f;
@@ -690,7 +708,10 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
             q = (-ht) / nue + 1.f;
             logit = fmaxf(q, 0.f) * C;
         }
-        const float w = expf(logit - ax.y) / ax.z;
+        // (r06: the divisions of the GRADIENT chain -- softmax normalisation, d zeta / d t, d t / d a, d t / d b -- take v_rcp_f32 + one Newton step,
+        // within 1 ulp of the IEEE quotient; their results are compared against 1e-3 relative, never against a threshold.  Every division that
+        // feeds a DECISION -- the plane hit t behind the coverage test, q behind the clamp gate -- stays exact.)
+        const float w = expf(logit - ax.y) * fast_rcp(ax.z);
         // gated upstream gradients and S = sum_j w_j dL/dw_j = <gated grads, composited outputs>
         float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f, gm = 0.f, gd = 0.f, gn0 = 0.f, gn1 = 0.f, gn2 = 0.f, S = 0.f;
         if (DENSE) S = Sd[(int64_t)b * P + pix];
@@ -717,12 +738,13 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
         const float dl = w * (dLdw - S);
         if (PRIM == 0) {
             const float dq = (q >= 0.f) ? dl * C : 0.f;
-            const float dt = -(dq / nue);                           // zeta = -t * mask
-            sA += dt / hb;                                          // t = a / b
+            const float dt = -(dq * fast_rcp(nue));                 // zeta = -t * mask
+            const float ihb = fast_rcp(hb);
+            sA += dt * ihb;                                         // t = a / b
             if (hb != FLT_EPSILON) {                                // (|n.ray| < 0.01 was replaced by eps, :210: no gradient through b)
                 float rx, ry, rz;
                 pixel_ray(Ki, (float)x, (float)y, rx, ry, rz);
-                const float db = -dt * ht / hb;
+                const float db = -dt * ht * ihb;
                 sB0 += db * rx; sB1 += db * ry; sB2 += db * rz;
             }
         } else {
@@ -736,7 +758,15 @@ __global__ __launch_bounds__(256) void sdfr_splat_bwd_kernel(const SplatArgs A, 
             chain((int)(xy & 0xffffu), (int)(xy >> 16), en.y, en.z);
         }
     };
-    if (surfel_bbox<PRIM, ALT>(A, b, e1, x0, y0, x1, y1)) {
+    // (r06: the forward pass of the same step has written every surfel's conservative screen box into the splat workspace -- the same disc_bbox --;
+    // a caller that hands it over saves the ~80 instructions per surfel of recomputing it: two square roots, four divisions)
+    bool onscreen;
+    if (boxes) {
+        const int4 bb = boxes[e1];
+        x0 = max(bb.x, 0); y0 = max(bb.y, 0); x1 = min(bb.z, W - 1); y1 = min(bb.w, H - 1);      // (never beyond this crop's extent, whatever the workspace holds)
+        onscreen = x0 <= x1 && y0 <= y1;
+    } else onscreen = surfel_bbox<PRIM, ALT>(A, b, e1, x0, y0, x1, y1);
+    if (onscreen) {
         const int bw = x1 - x0 + 1, bh = y1 - y0 + 1, npx = bw * bh;
         int nq = 0;                                                  // wave-uniform fill of the queue
         for (int base = 0; base < npx; base += 64) {
@@ -1020,10 +1050,12 @@ extern "C" int sdfr_splat_backward_r(const float* K, const float* Kinv, const fl
 
 // The disc primitive's backward with a per-crop factor on the colour gradient (r06): g_color holds the un-normalised 2-D loss gradient and
 // kscale float[B][2] the factors sdfr_losses_fused published (kscale[2 b] applies).  wh == NULL: dense W x H images; else ragged extents.
+// bbox_ws (may be NULL): the splat workspace of this step's sdfr_surfels_forward(_r) / sdfr_splat_forward(_r) -- its head holds the surfels' screen
+// boxes [B][cap][4], which are then read instead of recomputed.
 extern "C" int sdfr_splat_backward_x(const float* K, const float* Kinv, const float* p_cam, const float* n_cam, const float* attr, int B, int cap,
                                      const int32_t* cnt, int W, int H, const int32_t* wh, int pix_stride, float diam, float depth_constant,
                                      const float* aux, const float* color, const float* g_color, const float* kscale, float* g_p_cam,
-                                     float* g_n_cam, float* g_attr, void* stream) {
+                                     float* g_n_cam, float* g_attr, const int32_t* bbox_ws, void* stream) {
     SplatArgs A;
     int rc = wh ? fill_args_r(A, "sdfr_splat_backward_x", K, Kinv, p_cam, n_cam, attr, B, cap, cnt, wh, pix_stride, 1, diam, depth_constant)
                 : fill_args(A, "sdfr_splat_backward_x", 0, K, Kinv, p_cam, n_cam, attr, nullptr, nullptr, nullptr, nullptr, B, cap, cnt, W, H, diam,
@@ -1033,7 +1065,8 @@ extern "C" int sdfr_splat_backward_x(const float* K, const float* Kinv, const fl
     if (B == 0 || cap == 0) return SDFR_OK;
     hipLaunchKernelGGL((sdfr_splat_bwd_kernel<0, false, false, true>), dim3(sdfr_cdiv(cap, 4), B), dim3(256), 0, (hipStream_t)stream, A, aux, color,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, g_color, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, g_p_cam, g_n_cam, g_attr, (const float*)nullptr, (const float*)nullptr, 0, kscale);
+                       (const float*)nullptr, g_p_cam, g_n_cam, g_attr, (const float*)nullptr, (const float*)nullptr, 0, kscale,
+                       reinterpret_cast<const int4*>(bbox_ws));
     SDFR_LAUNCH_CHECK();
     return SDFR_OK;
 }

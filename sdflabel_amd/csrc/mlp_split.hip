@@ -182,6 +182,20 @@ __global__ __launch_bounds__(64 * NW, 1) void sdfr_mlp_split_kernel(const MlpPar
         if (SAVE && P.maskbuf) {
             // mask layout v2 (mlp_kernel.h: sdfr_mask_dword): this thread's 16 bits of (feature tile f, point tile p) are one short of row
             // r0 + p*32 + lp, dword (fbase >> 5) + f, half lg
+            if constexpr (FT == 2) {
+                // (as in mlp_kernel.h: lanes lp and lp + 32 exchange their halves once per point tile; one of them stores the wave's 8 bytes of the row)
+                uint2* mb2 = reinterpret_cast<uint2*>(P.maskbuf) + (((r0 >> 7) * P.n_mfma + l) * 128) * (int64_t)(HP / 64);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const uint32_t h0 = (mw[p >> 1] >> ((p & 1) * 16)) & 0xffffu;
+                    const uint32_t h1 = (mw[(NP + p) >> 1] >> (((NP + p) & 1) * 16)) & 0xffffu;
+                    const uint32_t mine = h0 | (h1 << 16);
+                    const uint32_t other = (uint32_t)__shfl_xor((int)mine, 32, 64);
+                    const uint32_t lo = lg == 0 ? mine : other, hi = lg == 0 ? other : mine;
+                    if (lg == (p & 1))
+                        mb2[((int)(r0 & 127) + p * MS + lp) * (HP / 64) + (fbase >> 6)] = make_uint2((lo & 0xffffu) | (hi << 16), (lo >> 16) | (hi & 0xffff0000u));
+                }
+            } else {
             uint16_t* mb = reinterpret_cast<uint16_t*>(P.maskbuf) + (((r0 >> 7) * P.n_mfma + l) * 128) * (int64_t)(HP / 32) * 2;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
@@ -191,6 +205,7 @@ __global__ __launch_bounds__(64 * NW, 1) void sdfr_mlp_split_kernel(const MlpPar
                     const int fi = f * NP + p;
                     mb[off + 2 * f] = (uint16_t)(mw[fi >> 1] >> ((fi & 1) * 16));
                 }
+            }
             }
         }
         __syncthreads();
